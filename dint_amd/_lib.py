@@ -1,0 +1,94 @@
+"""ctypes binding of the C ABI (include/dint_abi.h) exported by dint_amd/libdint.so.
+
+There is deliberately no fallback: if the HIP extension is missing or fails to load,
+importing the engine raises -- the product path never runs on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdint.so")
+
+ABI_VERSION = 1
+MICRO_BATCH = 65536
+
+#: every symbol include/dint_abi.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "dint_engine_create", "dint_engine_destroy", "dint_msg_size", "dint_last_error", "dint_submit",
+    "dint_submit_device", "dint_sync", "dint_load_rows", "dint_populate", "dint_hash_size", "dint_dump_rows",
+    "dint_read_locks", "dint_read_log", "dint_get_stats", "dint_reset", "dint_snapshot", "dint_restore",
+    "dint_home_shard", "dint_bench_rand64", "dint_timing_enable", "dint_timing_read",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("workload", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
+        ("n_slots", C.c_uint64), ("n_rows", C.c_uint64), ("log_entries", C.c_uint32),
+        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("reserved", C.c_uint32 * 5),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("batches", C.c_uint64), ("requests", C.c_uint64), ("bad_requests", C.c_uint64),
+        ("missing_keys", C.c_uint64), ("foreign_requests", C.c_uint64), ("pool_exhausted", C.c_uint64),
+        ("reserved", C.c_uint64 * 2),
+    ]
+
+
+class DintError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libdint.so (built in-tree by dint_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DintError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -m dint_amd.build`); there is no CPU fallback"
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.c_int32
+    sig = {
+        "dint_engine_create": (C.c_int, [C.POINTER(Config), C.POINTER(vp)]),
+        "dint_engine_destroy": (None, [vp]),
+        "dint_msg_size": (C.c_int, [u32]),
+        "dint_last_error": (C.c_char_p, []),
+        "dint_submit": (C.c_int, [vp, vp, u32, vp]),
+        "dint_submit_device": (C.c_int, [vp, vp, u32, vp, vp]),
+        "dint_sync": (C.c_int, [vp]),
+        "dint_load_rows": (C.c_int, [vp, u32, vp, vp, vp, u64]),
+        "dint_populate": (C.c_int, [vp, u64]),
+        "dint_hash_size": (i64, [vp, u32]),
+        "dint_dump_rows": (i64, [vp, u32, vp, vp, vp, u64]),
+        "dint_read_locks": (i64, [vp, u32, vp, vp, u64]),
+        "dint_read_log": (i64, [vp, vp, u64]),
+        "dint_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "dint_reset": (C.c_int, [vp]),
+        "dint_snapshot": (C.c_int, [vp]),
+        "dint_restore": (C.c_int, [vp]),
+        "dint_home_shard": (C.c_int, [vp, vp, u32, vp, vp]),
+        "dint_bench_rand64": (C.c_int, [i32, u64, u64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "dint_timing_enable": (C.c_int, [vp, C.c_int]),
+        "dint_timing_read": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(u64), C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)  # AttributeError here = the .so does not export the ABI
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise DintError(f"dint error {rc}: {load().dint_last_error().decode(errors='replace')}")
+    return rc

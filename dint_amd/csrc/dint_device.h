@@ -1,0 +1,151 @@
+// dint_device.h -- device-side building blocks shared by every DINT kernel (gfx950 only).
+//
+// Hashing follows the reference bit for bit: fasthash64 with seed 0xdeadbeef over the
+// 4-byte lid (lock_fasst/udp/server.cc:81) or the 8-byte key (store/udp/kvs.h:33-35),
+// lock_fasst/udp/utils.h:16-53.  Everything else here is this engine's own machinery:
+// magic-multiply modulo, the batch record format, and the wave-level idx-ranking used to
+// restore request order inside a bin.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DINT_MICRO 65536u          // max requests per kernel pass (idx fits 16 bits)
+#define DINT_PMAX 1024u            // max bins per pass
+#define DINT_WCAP 512u             // records resolved per window inside one bin
+#define DINT_HSIZE 1024u           // LDS hash slots per window (2 x WCAP)
+#define DINT_EMPTY 0xFFFFFFFFu
+
+// ---- fasthash64 ------------------------------------------------------------------------
+__host__ __device__ static inline uint64_t dint_mix(uint64_t h) {
+  h ^= h >> 23;
+  h *= 0x2127599bf4325c37ULL;
+  h ^= h >> 47;
+  return h;
+}
+// fasthash64(&lid, 4, 0xdeadbeef): no 8-byte block, 4-byte tail  (utils.h:37-50, case 4)
+__host__ __device__ static inline uint64_t dint_hash_lid(uint32_t lid) {
+  const uint64_t m = 0x880355f21e6d1965ULL;
+  uint64_t h = 0xdeadbeefULL ^ (4ULL * m);
+  h ^= dint_mix((uint64_t)lid);
+  h *= m;
+  return dint_mix(h);
+}
+// fasthash64(&key, 8, 0xdeadbeef): one 8-byte block, no tail  (utils.h:31-35)
+__host__ __device__ static inline uint64_t dint_hash_key(uint64_t key) {
+  const uint64_t m = 0x880355f21e6d1965ULL;
+  uint64_t h = 0xdeadbeefULL ^ (8ULL * m);
+  h ^= dint_mix(key);
+  h *= m;
+  return dint_mix(h);
+}
+
+// ---- modulo by a run-time constant (36,000,000 / 9,000,000 / ... are not powers of 2) -----
+// m = floor(2^64 / d).  q' = mulhi(h, m) is floor(h/d) or one less, so one conditional
+// subtraction makes the remainder exact for every 64-bit h.
+struct dint_mod {
+  uint64_t d, m;
+};
+static inline dint_mod dint_make_mod(uint64_t d) {
+  dint_mod f;
+  f.d = d;
+  f.m = d > 1 ? (uint64_t)((((unsigned __int128)1) << 64) / d) : 0;
+  return f;
+}
+__host__ __device__ static inline uint64_t dint_fastmod(uint64_t h, dint_mod f) {
+  if (f.d <= 1) return 0;
+#ifdef __HIP_DEVICE_COMPILE__
+  uint64_t q = __umul64hi(h, f.m);
+#else
+  uint64_t q = (uint64_t)(((unsigned __int128)h * f.m) >> 64);
+#endif
+  uint64_t r = h - q * f.d;
+  if (r >= f.d) r -= f.d;
+  return r;
+}
+
+// ---- batch record: one 64-bit word per request --------------------------------------------
+//   bits  0..31  group key (local lock slot, or table_base + local bucket)
+//   bits 32..47  request index inside the micro-batch
+//   bits 48..55  op (workload-specific small integer)
+//   bits 56..63  aux (table id / lock quadrant)
+__device__ static inline uint64_t dint_rec(uint32_t gk, uint32_t idx, uint32_t op, uint32_t aux) {
+  return (uint64_t)gk | ((uint64_t)(idx & 0xFFFF) << 32) | ((uint64_t)(op & 0xFF) << 48) |
+         ((uint64_t)(aux & 0xFF) << 56);
+}
+__device__ static inline uint32_t rec_gk(uint64_t r) { return (uint32_t)r; }
+__device__ static inline uint32_t rec_idx(uint64_t r) { return (uint32_t)(r >> 32) & 0xFFFF; }
+__device__ static inline uint32_t rec_op(uint64_t r) { return (uint32_t)(r >> 48) & 0xFF; }
+__device__ static inline uint32_t rec_aux(uint64_t r) { return (uint32_t)(r >> 56) & 0xFF; }
+
+// ---- wave helpers (wave = 64 lanes) ----------------------------------------------------------
+__device__ static inline uint32_t lane_id() { return threadIdx.x & 63; }
+__device__ static inline uint64_t lanemask_lt() {
+  return (1ULL << lane_id()) - 1ULL;
+}
+__device__ static inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if ((int)lane_id() >= d) x += y;
+  }
+  *total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+// ---- idx ranking: restore request order inside a bin ---------------------------------------------
+// A bin receives its records in arbitrary order (atomic reservation), but every record carries
+// its request index.  The wave marks the indices present in a bitmap over [0, n), prefix-sums the
+// words, and rank(idx) = number of marked indices below idx.  LDS: bm[nwords], wpre[nwords] (u16),
+// lbase[64].  nwords = ceil(n/32) <= 2048.
+struct dint_rank_lds {
+  uint32_t bm[DINT_MICRO / 32];
+  uint16_t wpre[DINT_MICRO / 32];
+  uint32_t lbase[64];
+};
+
+__device__ static inline void rank_build(dint_rank_lds &L, const uint64_t *__restrict__ recs, uint32_t c,
+                                         uint32_t n) {
+  const uint32_t lane = lane_id();
+  const uint32_t nwords = (n + 31) >> 5;
+  const uint32_t wpl = (nwords + 63) >> 6;  // words per lane
+  for (uint32_t w = lane; w < nwords; w += 64) L.bm[w] = 0;
+  __syncthreads();
+  for (uint32_t k = lane; k < c; k += 64) {
+    uint32_t idx = rec_idx(recs[k]);
+    atomicOr(&L.bm[idx >> 5], 1u << (idx & 31));
+  }
+  __syncthreads();
+  uint32_t run = 0;
+  for (uint32_t j = 0; j < wpl; j++) {
+    uint32_t w = lane * wpl + j;
+    if (w < nwords) {
+      L.wpre[w] = (uint16_t)run;
+      run += __popc(L.bm[w]);
+    }
+  }
+  uint32_t tot;
+  uint32_t base = wave_excl_scan_u32(run, &tot);
+  L.lbase[lane] = base;
+  __syncthreads();
+}
+
+__device__ static inline uint32_t rank_of(const dint_rank_lds &L, uint32_t idx, uint32_t n) {
+  const uint32_t nwords = (n + 31) >> 5;
+  const uint32_t wpl = (nwords + 63) >> 6;
+  uint32_t w = idx >> 5;
+  return L.lbase[w / wpl] + L.wpre[w] + __popc(L.bm[w] & ((1u << (idx & 31)) - 1u));
+}
+
+// ---- LDS hash (group key -> dense entry) used for in-window grouping ----------------------------
+__device__ static inline uint32_t lds_hash_insert(uint32_t *keys, uint32_t gk, bool *is_new) {
+  uint32_t h = (gk * 0x9E3779B1u) >> (32 - 10);  // DINT_HSIZE = 1024
+  *is_new = false;
+  for (;;) {
+    uint32_t old = atomicCAS(&keys[h], DINT_EMPTY, gk);
+    if (old == DINT_EMPTY) { *is_new = true; return h; }
+    if (old == gk) return h;
+    h = (h + 1) & (DINT_HSIZE - 1);
+  }
+}
+static_assert(DINT_HSIZE == 1024, "lds_hash_insert assumes 1024 slots");

@@ -1,0 +1,472 @@
+// engine.hip -- host side of the C ABI (include/dint_abi.h): owns the HBM tables, the batch
+// scratch, the streams, and turns dint_submit* into kernel launches.  Product path: there is no
+// CPU fallback -- every entry point fails with DINT_ENODEV / DINT_EHIP when no gfx950 device works.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dint_abi.h"
+#include "dint_kernels.h"
+#include "dint_kv.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return fail(DINT_EHIP, "%s: %s", #expr, hipGetErrorString(_e));  \
+  } while (0)
+
+const int kMsgSize[DINT_WL_COUNT] = {9, 6, 53, 53, 55, 23};
+
+// kernel timing with HIP events on the stream the kernels run on
+struct KernelTimer {
+  static const int kMaxLaunch = 4096;
+  bool on = false;
+  int n_kernels = 0;             // kernels per pass (events per pass = n_kernels + 1)
+  const char *names[4] = {0, 0, 0, 0};
+  std::vector<hipEvent_t> ev;    // (n_kernels + 1) per recorded pass
+  int passes = 0;
+};
+
+}  // namespace
+
+struct dint_engine {
+  dint_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;  // dint_submit* is serialised per engine: submission order = serial order
+  uint32_t msg_size = 0;
+
+  // batch scratch
+  dint_scratch scratch{};
+  uint8_t *d_stage_req = nullptr, *d_stage_rep = nullptr;  // host path staging (DINT_MICRO msgs)
+  uint8_t *h_pinned = nullptr;                             // pinned bounce buffer
+
+  // lock tables (fasst / 2pl)
+  uint2 *d_lock_tbl = nullptr;
+  uint64_t n_slots = 0, n_local_slots = 0;
+  dint_mod slots_mod{};
+
+  // log
+  dint_log log{};
+
+  // kv workloads (store / tatp / smallbank)
+  dint_kv kv{};
+
+  // snapshot
+  std::vector<std::pair<void *, size_t>> regions;  // device regions making up the engine state
+  std::vector<void *> snap;
+
+  dint_shard shard{0, 1};
+  uint64_t batches = 0, requests = 0;
+  KernelTimer timer;
+};
+
+namespace {
+
+int dev_alloc(void **p, size_t bytes, bool zero = true) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+  if (e != hipSuccess) return fail(DINT_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  if (zero) {
+    e = hipMemset(*p, 0, bytes);
+    if (e != hipSuccess) return fail(DINT_EHIP, "hipMemset: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+void add_region(dint_engine *e, void *p, size_t bytes) { e->regions.push_back({p, bytes}); }
+
+hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names) {
+  KernelTimer &t = e->timer;
+  if (!t.on || t.passes >= KernelTimer::kMaxLaunch) return nullptr;
+  t.n_kernels = n_kernels;
+  for (int i = 0; i < n_kernels; i++) t.names[i] = names[i];
+  size_t need = (size_t)(t.passes + 1) * (n_kernels + 1);
+  while (t.ev.size() < need) {
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    t.ev.push_back(ev);
+  }
+  hipEvent_t *p = &t.ev[(size_t)t.passes * (n_kernels + 1)];
+  t.passes++;
+  return p;
+}
+
+// one micro-batch (n <= DINT_MICRO) on device buffers
+int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st) {
+  static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
+  static const char *const log_names[] = {"k_log_count", "k_log_write"};
+  static const char *const kv_names[] = {"k_kv_scatter", "k_kv_resolve"};
+  switch (e->cfg.workload) {
+    case DINT_WL_FASST:
+      dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
+                        timer_events(e, 2, lock_names));
+      break;
+    case DINT_WL_2PL:
+      dint_launch_2pl(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
+                      timer_events(e, 2, lock_names));
+      break;
+    case DINT_WL_LOG:
+      dint_launch_log(d_req, d_rep, n, e->log, e->scratch, st, timer_events(e, 2, log_names));
+      break;
+    case DINT_WL_STORE:
+    case DINT_WL_TATP:
+    case DINT_WL_SMALLBANK:
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->shard, e->scratch, st, timer_events(e, 2, kv_names));
+      break;
+    default:
+      return fail(DINT_EINVAL, "bad workload");
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  e->batches++;
+  e->requests += n;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dint_last_error(void) { return g_err.c_str(); }
+
+int dint_msg_size(uint32_t workload) { return workload < DINT_WL_COUNT ? kMsgSize[workload] : DINT_EINVAL; }
+
+int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
+  if (!cfg || !out) return fail(DINT_EINVAL, "null argument");
+  if (cfg->abi_version != DINT_ABI_VERSION) return fail(DINT_EINVAL, "abi_version %u != %u", cfg->abi_version, DINT_ABI_VERSION);
+  if (cfg->workload >= DINT_WL_COUNT) return fail(DINT_EINVAL, "unknown workload %u", cfg->workload);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DINT_ENODEV, "no HIP device");
+  int dev = cfg->device;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(DINT_ENODEV, "device %d of %d", dev, ndev);
+  HIP_TRY(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(DINT_ENODEV, "device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+
+  dint_engine *e = new dint_engine();
+  e->cfg = *cfg;
+  e->device = dev;
+  e->msg_size = kMsgSize[cfg->workload];
+  e->shard.count = cfg->shard_count ? cfg->shard_count : 1;
+  e->shard.index = cfg->shard_index;
+  int rc = 0;
+#define TRY(x) do { rc = (x); if (rc) { dint_engine_destroy(e); return rc; } } while (0)
+  if (e->shard.index >= e->shard.count || e->shard.count > 255) {
+    delete e;
+    return fail(DINT_EINVAL, "shard %u of %u", cfg->shard_index, cfg->shard_count);
+  }
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete e;
+    return fail(DINT_EHIP, "hipStreamCreate");
+  }
+  TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_PMAX * sizeof(uint32_t)));
+  TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_PMAX * DINT_MICRO * sizeof(uint64_t), false));
+  TRY(dev_alloc((void **)&e->scratch.stats, sizeof(dint_dev_stats)));
+  TRY(dev_alloc((void **)&e->scratch.blk_cnt, 256 * sizeof(uint32_t)));
+  add_region(e, e->scratch.stats, sizeof(dint_dev_stats));
+  TRY(dev_alloc((void **)&e->d_stage_req, (size_t)DINT_MICRO * e->msg_size + 64, false));
+  TRY(dev_alloc((void **)&e->d_stage_rep, (size_t)DINT_MICRO * e->msg_size + 64, false));
+  if (hipHostMalloc((void **)&e->h_pinned, (size_t)DINT_MICRO * e->msg_size + 64, hipHostMallocDefault) != hipSuccess) {
+    dint_engine_destroy(e);
+    return fail(DINT_ENOMEM, "hipHostMalloc");
+  }
+
+  const uint32_t wl = cfg->workload;
+  if (wl == DINT_WL_FASST || wl == DINT_WL_2PL) {
+    e->n_slots = cfg->n_slots ? cfg->n_slots : 36000000ull;  // lock_fasst/udp/utils.h:12
+    if (e->n_slots > 0xFFFFFFF0ull) { dint_engine_destroy(e); return fail(DINT_EINVAL, "n_slots too large"); }
+    e->slots_mod = dint_make_mod(e->n_slots);
+    e->n_local_slots = (e->n_slots + e->shard.count - 1) / e->shard.count;
+    TRY(dev_alloc((void **)&e->d_lock_tbl, e->n_local_slots * sizeof(uint2)));
+    add_region(e, e->d_lock_tbl, e->n_local_slots * sizeof(uint2));
+  }
+  if (wl == DINT_WL_LOG || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
+    e->log.cap = cfg->log_entries ? cfg->log_entries : 1000000u;  // log_server/udp/utils.h:16
+    TRY(dev_alloc((void **)&e->log.ring, (size_t)e->log.cap * 64));
+    TRY(dev_alloc((void **)&e->log.tail, 2 * sizeof(uint32_t)));
+    add_region(e, e->log.ring, (size_t)e->log.cap * 64);
+    add_region(e, e->log.tail, 2 * sizeof(uint32_t));
+  }
+  if (wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
+    rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard);
+    if (rc) { dint_engine_destroy(e); return fail(rc, "kv table allocation failed (%s)", g_err.c_str()); }
+    for (auto &r : dint_kv_regions(&e->kv)) add_region(e, r.first, r.second);
+  }
+#undef TRY
+  HIP_TRY(hipDeviceSynchronize());
+  *out = e;
+  return 0;
+}
+
+void dint_engine_destroy(dint_engine_t *e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  for (hipEvent_t ev : e->timer.ev) hipEventDestroy(ev);
+  for (void *p : e->snap) hipFree(p);
+  hipFree(e->scratch.bin_cnt);
+  hipFree(e->scratch.bins);
+  hipFree(e->scratch.stats);
+  hipFree(e->scratch.blk_cnt);
+  hipFree(e->d_stage_req);
+  hipFree(e->d_stage_rep);
+  if (e->h_pinned) hipHostFree(e->h_pinned);
+  hipFree(e->d_lock_tbl);
+  hipFree(e->log.ring);
+  hipFree(e->log.tail);
+  dint_kv_destroy(&e->kv);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, void *stream) {
+  if (!e || (n && (!d_reqs || !d_replies))) return fail(DINT_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  const uint8_t *rq = (const uint8_t *)d_reqs;
+  uint8_t *rp = (uint8_t *)d_replies;
+  for (uint32_t off = 0; off < n; off += DINT_MICRO) {
+    uint32_t m = std::min<uint32_t>(DINT_MICRO, n - off);
+    int rc = run_pass(e, rq + (size_t)off * e->msg_size, m, rp + (size_t)off * e->msg_size, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies) {
+  if (!e || (n && (!reqs || !replies))) return fail(DINT_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  const uint8_t *rq = (const uint8_t *)reqs;
+  uint8_t *rp = (uint8_t *)replies;
+  for (uint32_t off = 0; off < n; off += DINT_MICRO) {
+    uint32_t m = std::min<uint32_t>(DINT_MICRO, n - off);
+    size_t bytes = (size_t)m * e->msg_size;
+    memcpy(e->h_pinned, rq + (size_t)off * e->msg_size, bytes);
+    HIP_TRY(hipMemcpyAsync(e->d_stage_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
+    int rc = run_pass(e, e->d_stage_req, m, e->d_stage_rep, e->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_stage_rep, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(rp + (size_t)off * e->msg_size, e->h_pinned, bytes);
+  }
+  return 0;
+}
+
+int dint_sync(dint_engine_t *e) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int64_t dint_read_locks(dint_engine_t *e, uint32_t table, uint32_t *a, uint32_t *b, uint64_t cap) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL) {
+    uint64_t n = std::min<uint64_t>(cap, e->n_local_slots);
+    std::vector<uint2> h(n);
+    HIP_TRY(hipMemcpy(h.data(), e->d_lock_tbl, n * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; i++) {
+      if (a) a[i] = h[i].x;
+      if (b) b[i] = h[i].y;
+    }
+    return (int64_t)e->n_local_slots;
+  }
+  if (e->cfg.workload == DINT_WL_TATP || e->cfg.workload == DINT_WL_SMALLBANK) {
+    int64_t r = dint_kv_read_locks(&e->kv, table, a, b, cap);
+    if (r < 0) return fail((int)r, "bad table %u", table);
+    return r;
+  }
+  return fail(DINT_ESTATE, "workload has no lock table");
+}
+
+int64_t dint_read_log(dint_engine_t *e, void *records, uint64_t cap) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  if (!e->log.ring) return fail(DINT_ESTATE, "workload has no log");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint64_t n = std::min<uint64_t>(cap, e->log.cap);
+  if (records && n) HIP_TRY(hipMemcpy(records, e->log.ring, n * 64, hipMemcpyDeviceToHost));
+  uint32_t t[2];
+  HIP_TRY(hipMemcpy(t, e->log.tail, sizeof t, hipMemcpyDeviceToHost));
+  return (int64_t)t[1];
+}
+
+int dint_get_stats(dint_engine_t *e, dint_stats *out) {
+  if (!e || !out) return fail(DINT_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  dint_dev_stats d;
+  HIP_TRY(hipMemcpy(&d, e->scratch.stats, sizeof d, hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof *out);
+  out->batches = e->batches;
+  out->requests = e->requests;
+  out->bad_requests = d.bad_requests;
+  out->missing_keys = d.missing_keys;
+  out->foreign_requests = d.foreign_requests;
+  out->pool_exhausted = d.pool_exhausted;
+  return 0;
+}
+
+int dint_reset(dint_engine_t *e) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (auto &r : e->regions) HIP_TRY(hipMemset(r.first, 0, r.second));
+  dint_kv_reset(&e->kv);
+  e->batches = e->requests = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+int dint_snapshot(dint_engine_t *e) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (e->snap.empty()) {
+    for (auto &r : e->regions) {
+      void *p = nullptr;
+      int rc = dev_alloc(&p, r.second, false);
+      if (rc) return rc;
+      e->snap.push_back(p);
+    }
+  }
+  for (size_t i = 0; i < e->regions.size(); i++)
+    HIP_TRY(hipMemcpy(e->snap[i], e->regions[i].first, e->regions[i].second, hipMemcpyDeviceToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+int dint_restore(dint_engine_t *e) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (e->snap.empty()) return fail(DINT_ESTATE, "no snapshot taken");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  for (size_t i = 0; i < e->regions.size(); i++)
+    HIP_TRY(hipMemcpy(e->regions[i].first, e->snap[i], e->regions[i].second, hipMemcpyDeviceToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+int dint_load_rows(dint_engine_t *e, uint32_t table, const uint64_t *keys, const uint32_t *vers, const void *vals,
+                   uint64_t n) {
+  if (!e || (n && (!keys || !vals))) return fail(DINT_EINVAL, "null argument");
+  if (!e->kv.n_tables) return fail(DINT_ESTATE, "workload has no kv table");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = dint_kv_load_rows(&e->kv, table, keys, vers, (const uint8_t *)vals, n, e->scratch, e->stream);
+  if (rc) return fail(rc, "load_rows failed: %s", g_err.c_str());
+  return 0;
+}
+
+int dint_populate(dint_engine_t *e, uint64_t populate_n) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  if (!e->kv.n_tables) return fail(DINT_ESTATE, "workload has no kv table");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = dint_kv_populate(&e->kv, e->cfg.workload, populate_n, e->scratch, e->stream);
+  if (rc) return fail(rc, "populate failed: %s", g_err.c_str());
+  return 0;
+}
+
+int64_t dint_hash_size(dint_engine_t *e, uint32_t table) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  if (table >= e->kv.n_tables) return fail(DINT_EINVAL, "bad table %u", table);
+  return (int64_t)e->kv.tab[table].hash_size;
+}
+
+int64_t dint_dump_rows(dint_engine_t *e, uint32_t table, uint64_t *keys, uint32_t *vers, void *vals, uint64_t cap) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  if (table >= e->kv.n_tables) return fail(DINT_EINVAL, "bad table %u", table);
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  return dint_kv_dump_rows(&e->kv, table, keys, vers, (uint8_t *)vals, cap);
+}
+
+int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d_home, void *stream) {
+  if (!e || (n && (!d_reqs || !d_home))) return fail(DINT_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  switch (e->cfg.workload) {
+    case DINT_WL_FASST:
+    case DINT_WL_2PL:
+      dint_launch_home_lid(d_reqs, e->msg_size, n, e->slots_mod, e->shard.count, d_home, st);
+      break;
+    case DINT_WL_STORE:
+    case DINT_WL_TATP:
+    case DINT_WL_SMALLBANK:
+      dint_launch_home_kv(d_reqs, n, e->kv, e->shard.count, d_home, st);
+      break;
+    default:
+      return fail(DINT_ESTATE, "workload is not sharded by key");
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  return 0;
+}
+
+int dint_timing_enable(dint_engine_t *e, int on) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  e->timer.on = on != 0;
+  e->timer.passes = 0;
+  return 0;
+}
+
+int dint_timing_read(dint_engine_t *e, const char **names, double *avg_us, uint64_t *launches, int cap) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  KernelTimer &t = e->timer;
+  int nk = std::min(t.n_kernels, cap);
+  for (int k = 0; k < nk; k++) {
+    double sum = 0;
+    for (int p = 0; p < t.passes; p++) {
+      float ms = 0;
+      hipEvent_t *ev = &t.ev[(size_t)p * (t.n_kernels + 1)];
+      if (hipEventElapsedTime(&ms, ev[k], ev[k + 1]) == hipSuccess) sum += ms;
+    }
+    names[k] = t.names[k];
+    avg_us[k] = t.passes ? sum * 1000.0 / t.passes : 0.0;
+    launches[k] = (uint64_t)t.passes;
+  }
+  t.passes = 0;
+  return nk;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""Host-side mirror of the reference servers over the C ABI.
+
+One :class:`Engine` plays the role of one reference server process
+(``lock_fasst/udp/server``, ``tatp/udp/server_shard`` ...): it owns the tables and
+answers batches of wire messages.  ``submit`` takes/returns numpy arrays of the packed
+wire structs (:mod:`dint_amd.wire`); ``submit_device`` works on HBM-resident buffers
+(torch uint8 tensors or raw device pointers) without any host copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .wire import LOG_REC, MSG_DTYPE, Workload
+
+
+def _ptr(x):
+    """Device pointer of a torch tensor / int."""
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+class Engine:
+    def __init__(self, workload: Workload, *, n_slots: int = 0, n_rows: int = 0, log_entries: int = 0,
+                 device: int = -1, shard_index: int = 0, shard_count: int = 1):
+        self._L = _lib.load()
+        self.workload = Workload(workload)
+        self.msg_dtype = MSG_DTYPE[self.workload]
+        self.msg_size = self.msg_dtype.itemsize
+        cfg = _lib.Config(abi_version=_lib.ABI_VERSION, workload=int(workload), device=device, n_slots=n_slots,
+                          n_rows=n_rows, log_entries=log_entries, shard_index=shard_index, shard_count=shard_count)
+        h = C.c_void_p()
+        _lib.check(self._L.dint_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.shard_index, self.shard_count = shard_index, max(1, shard_count)
+        self.val_size = 8 if self.workload == Workload.SMALLBANK else 40
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dint_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- hot path ---------------------------------------------------------
+    def submit(self, reqs: np.ndarray) -> np.ndarray:
+        """Process a batch held in host memory; returns the reply array (same dtype)."""
+        reqs = np.ascontiguousarray(reqs)
+        assert reqs.dtype.itemsize in (1, self.msg_size)
+        n = reqs.nbytes // self.msg_size
+        out = np.empty_like(reqs)
+        _lib.check(self._L.dint_submit(self._h, reqs.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def submit_device(self, d_reqs, n: int, d_replies=None, stream: int = 0) -> None:
+        """Enqueue a batch that already lives in HBM (asynchronous)."""
+        d_replies = d_reqs if d_replies is None else d_replies
+        _lib.check(self._L.dint_submit_device(self._h, _ptr(d_reqs), n, _ptr(d_replies), stream))
+
+    def sync(self):
+        _lib.check(self._L.dint_sync(self._h))
+
+    def home_shard(self, d_reqs, n: int, d_home, stream: int = 0) -> None:
+        _lib.check(self._L.dint_home_shard(self._h, _ptr(d_reqs), n, _ptr(d_home), stream))
+
+    # ---- population / state ---------------------------------------------------
+    def populate(self, populate_n: int):
+        _lib.check(self._L.dint_populate(self._h, populate_n))
+
+    def load_rows(self, table: int, keys, vers, vals):
+        keys = np.ascontiguousarray(keys, "<u8")
+        vals = np.ascontiguousarray(vals, "u1").reshape(len(keys), self.val_size)
+        vp = None
+        if vers is not None:
+            vers = np.ascontiguousarray(vers, "<u4")
+            vp = vers.ctypes.data
+        _lib.check(self._L.dint_load_rows(self._h, table, keys.ctypes.data, vp, vals.ctypes.data, len(keys)))
+
+    def hash_size(self, table: int) -> int:
+        return _lib.check(self._L.dint_hash_size(self._h, table))
+
+    def dump_rows(self, table: int):
+        n = _lib.check(self._L.dint_dump_rows(self._h, table, None, None, None, 0))
+        keys = np.zeros(n, "<u8"); vers = np.zeros(n, "<u4"); vals = np.zeros((n, self.val_size), "u1")
+        got = _lib.check(self._L.dint_dump_rows(self._h, table, keys.ctypes.data, vers.ctypes.data, vals.ctypes.data, n))
+        assert got == n
+        return keys, vers, vals
+
+    def read_locks(self, table: int = 0):
+        n = _lib.check(self._L.dint_read_locks(self._h, table, None, None, 0))
+        a = np.zeros(n, "<u4"); b = np.zeros(n, "<u4")
+        _lib.check(self._L.dint_read_locks(self._h, table, a.ctypes.data, b.ctypes.data, n))
+        return a, b
+
+    def read_log(self, cap: int):
+        rec = np.zeros(cap, LOG_REC)
+        tail = _lib.check(self._L.dint_read_log(self._h, rec.ctypes.data, cap))
+        return rec, tail
+
+    def stats(self) -> dict:
+        s = _lib.Stats()
+        _lib.check(self._L.dint_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+
+    def reset(self): _lib.check(self._L.dint_reset(self._h))
+    def snapshot(self): _lib.check(self._L.dint_snapshot(self._h))
+    def restore(self): _lib.check(self._L.dint_restore(self._h))
+
+    # ---- measurement -----------------------------------------------------------
+    def timing_enable(self, on: bool = True):
+        _lib.check(self._L.dint_timing_enable(self._h, int(on)))
+
+    def timing_read(self) -> dict:
+        names = (C.c_char_p * 4)(); us = (C.c_double * 4)(); cnt = (C.c_uint64 * 4)()
+        k = _lib.check(self._L.dint_timing_read(self._h, names, us, cnt, 4))
+        return {names[i].decode(): {"avg_us": us[i], "launches": cnt[i]} for i in range(k)}
+
+
+def bench_rand64(bytes_: int, n_access: int, write_back: bool = False, device: int = -1):
+    """Random 64-byte gather microbenchmark (roofline denominator); returns (accesses/s, seconds)."""
+    L = _lib.load()
+    aps = C.c_double(); sec = C.c_double()
+    _lib.check(L.dint_bench_rand64(device, bytes_, n_access, int(write_back), C.byref(aps), C.byref(sec)))
+    return aps.value, sec.value

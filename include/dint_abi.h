@@ -1,0 +1,173 @@
+/*
+ * dint_abi.h -- C ABI of the MI355X batched transaction-certification engine.
+ *
+ * This is the drop-in boundary for ONE path of DINT: the per-packet server state
+ * machine (lock_fasst / lock_2pl lock tables, store KV, log append, TATP and
+ * SmallBank shard servers).  The reference has no function API for this path --
+ * its boundary is the UDP wire protocol (one packed request struct per datagram,
+ * the reply is the same struct mutated in place) -- so the ABI is the *batched form
+ * of the reference's handler loop*:
+ *
+ *   reference (one message at a time)                      this ABI (N messages)
+ *   -----------------------------------------------------  ----------------------------
+ *   lock_fasst/udp/server.cc:78-119   server_loop body     dint_submit(workload FASST)
+ *   lock_2pl/udp/server.cc:70-122     server_loop body     dint_submit(workload 2PL)
+ *   log_server/udp/server.cc:73-88    server_handler body  dint_submit(workload LOG)
+ *   store/udp/server.cc:72-98         server_handler body  dint_submit(workload STORE)
+ *   tatp/udp/server_shard.cc:113-210  server_handler body  dint_submit(workload TATP)
+ *   smallbank/udp/server_shard.cc:107-189                  dint_submit(workload SMALLBANK)
+ *   (eBPF flavour: lock_fasst/ebpf/ls_kern.c:32-100 ls_xdp_main and siblings)
+ *
+ * Contract (SURVEY.md 8 "parity target"): for a request array R[0..n) the reply
+ * array and the final table/log state equal those of the reference udp/ server
+ * processing R in index order on one thread.  reqs/replies are arrays of the exact
+ * `#pragma pack(1)` wire structs (9 / 6 / 53 / 53 / 55 / 23 bytes, see dint_msg_size);
+ * replies[i] answers reqs[i]; every byte the reference does not overwrite is echoed.
+ * Per-request errors never abort a batch: an unknown type/table leaves the reply
+ * equal to the request and is counted in dint_stats (the reference would panic()).
+ *
+ * No torch/HIP types appear in any signature: device pointers and the stream are
+ * passed as void*.  All functions return 0 or a negative DINT_E* code.
+ */
+#ifndef DINT_ABI_H
+#define DINT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINT_ABI_VERSION 1
+
+/* workloads (dint_config.workload) */
+enum {
+  DINT_WL_FASST = 0,     /* lock_fasst: 9-byte {u8 type; u32 lid; u32 ver}            net.h:23-29 */
+  DINT_WL_2PL = 1,       /* lock_2pl:   6-byte {u8 action; u32 lid; u8 type}          net.h:25-31 */
+  DINT_WL_LOG = 2,       /* log_server: 53-byte {u8 type; u64 key; u8 val[40]; u32 ver}           */
+  DINT_WL_STORE = 3,     /* store:      53-byte, same layout                                      */
+  DINT_WL_TATP = 4,      /* tatp:       55-byte {u8 ord,type,table; u64 key; u8 val[40]; u32 ver} */
+  DINT_WL_SMALLBANK = 5, /* smallbank:  23-byte {u8 ord,type,table; u64 key; u8 val[8]; u32 ver}  */
+  DINT_WL_COUNT = 6
+};
+
+/* error codes */
+enum {
+  DINT_OK = 0,
+  DINT_EINVAL = -1,   /* bad argument / unsupported configuration */
+  DINT_ENOMEM = -2,   /* host or device allocation failed */
+  DINT_EHIP = -3,     /* a HIP runtime call failed (see dint_last_error) */
+  DINT_ENODEV = -4,   /* no usable gfx950 device */
+  DINT_ESTATE = -5    /* call not valid for this engine's workload */
+};
+
+/* The largest request count one kernel pass handles; dint_submit splits larger
+ * arrays into consecutive micro-batches (correct by the serial-order contract). */
+#define DINT_MICRO_BATCH 65536u
+
+typedef struct dint_config {
+  uint32_t abi_version;  /* DINT_ABI_VERSION */
+  uint32_t workload;     /* DINT_WL_* */
+  int32_t device;        /* HIP device ordinal; -1 = current device */
+  uint32_t flags;        /* reserved, 0 */
+  /* FASST / 2PL: number of lock slots; slot = fasthash64(lid,4,0xdeadbeef) % n_slots.
+   * 0 = the reference's 36,000,000 (lock_fasst/udp/utils.h:12). */
+  uint64_t n_slots;
+  /* STORE: subscribers (buckets = n_rows*18/4, store/udp/server.cc:112-114; 0 = 2,000,000)
+   * TATP : subscribers (bucket counts per tatp/udp/server_shard.cc:75-79; 0 = 7,000,000)
+   * SMALLBANK: accounts (buckets = n_rows*3/2/4, smallbank/udp/server_shard.cc:75-76; 0 = 24,000,000) */
+  uint64_t n_rows;
+  /* log ring entries (LOG/TATP/SMALLBANK); 0 = the reference's 1,000,000 */
+  uint32_t log_entries;
+  /* multi-GPU hash sharding: this engine owns global slots/buckets g
+   * with g % shard_count == shard_index and stores them at g / shard_count.  Requests
+   * handed to dint_submit must already be routed to their home shard (dint_home_shard).
+   * shard_count 0 or 1 = unsharded. */
+  uint32_t shard_index;
+  uint32_t shard_count;
+  uint32_t reserved[5];
+} dint_config;
+
+typedef struct dint_stats {
+  uint64_t batches;        /* micro-batches processed */
+  uint64_t requests;       /* requests processed */
+  uint64_t bad_requests;   /* unknown type / table: reply left equal to request */
+  uint64_t missing_keys;   /* SET/COMMIT/DELETE (tatp) or lock+read (smallbank) on a missing key:
+                              the reference panics (tatp/udp/kvs.h:91,152); ack still sent */
+  uint64_t foreign_requests; /* request whose home shard is not this engine: left untouched */
+  uint64_t pool_exhausted; /* INSERT dropped because the overflow-entry pool is full */
+  uint64_t reserved[2];
+} dint_stats;
+
+typedef struct dint_engine dint_engine_t;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int dint_engine_create(const dint_config *cfg, dint_engine_t **out);
+void dint_engine_destroy(dint_engine_t *e);
+/* bytes of one wire message of `workload` (9/6/53/53/55/23), or DINT_EINVAL */
+int dint_msg_size(uint32_t workload);
+/* human-readable text of the last failure on this thread */
+const char *dint_last_error(void);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Host buffers: copies reqs to the GPU, runs the batch, copies replies back;
+ * returns when replies are complete.  reqs == replies (in place) is allowed. */
+int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies);
+/* Device buffers (HBM-resident, e.g. torch tensors): enqueues the batch on `stream`
+ * (a hipStream_t, NULL = the engine's own stream) and returns immediately; in-place
+ * allowed.  Buffers must stay valid until the stream reaches the end of the batch. */
+int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, void *stream);
+/* wait for everything enqueued on the engine's own stream */
+int dint_sync(dint_engine_t *e);
+
+/* ---- population / state (parity + checkpointing) -------------------------- */
+/* KV workloads: bulk-insert rows in order with kvs_insert semantics (ver given, or 0 if
+ * vers == NULL).  val_size is 40 (store/tatp) or 8 (smallbank).  Host pointers. */
+int dint_load_rows(dint_engine_t *e, uint32_t table, const uint64_t *keys, const uint32_t *vers,
+                   const void *vals, uint64_t n);
+/* generate and load the reference's initial population for the first `populate_n`
+ * subscribers/accounts (store/udp/tatp.h:44-66, tatp/udp/tatp.h:283-412,
+ * smallbank/udp/smallbank.h:105-127); value structs are zero-initialised first. */
+int dint_populate(dint_engine_t *e, uint64_t populate_n);
+/* number of buckets of `table` (global, before sharding) */
+int64_t dint_hash_size(dint_engine_t *e, uint32_t table);
+/* dump all valid rows of `table` (bucket order, chain order inside a bucket);
+ * returns the row count (also when it exceeds cap; only cap rows are written). */
+int64_t dint_dump_rows(dint_engine_t *e, uint32_t table, uint64_t *keys, uint32_t *vers, void *vals,
+                       uint64_t cap);
+/* lock-word state, one u32 per LOCAL slot (n_local = ceil((n_slots - shard_index)/shard_count)):
+ *   FASST: a=lock (0/1), b=version        2PL/SMALLBANK: a=num_ex, b=num_sh
+ *   TATP : a=txn lock (0/1), b unused (may be NULL)
+ * `table` selects the tatp/smallbank table (0 for fasst/2pl).  Returns n_local. */
+int64_t dint_read_locks(dint_engine_t *e, uint32_t table, uint32_t *a, uint32_t *b, uint64_t cap);
+/* log ring: copies up to cap canonical 64-byte records
+ * {u64 key; u8 val[40]; u32 ver; u8 is_del; u8 table; u8 pad[10]} and returns the tail index */
+int64_t dint_read_log(dint_engine_t *e, void *records, uint64_t cap);
+int dint_get_stats(dint_engine_t *e, dint_stats *out);
+/* reset tables, locks, log and stats to the freshly-created (unpopulated) state */
+int dint_reset(dint_engine_t *e);
+/* snapshot / restore the whole engine state in HBM (used to replay a recorded trace) */
+int dint_snapshot(dint_engine_t *e);
+int dint_restore(dint_engine_t *e);
+
+/* ---- multi-GPU routing helper ------------------------------ */
+/* d_home[i] = home shard (0..shard_count-1) of d_reqs[i], computed on the GPU with the
+ * same hash/modulus the engine uses; 0xFF for requests that have no home (bad table). */
+int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d_home, void *stream);
+
+/* ---- measurement helpers -------------------------------------------------- */
+/* Random 64-byte gather microbenchmark over `bytes` of HBM (roofline denominator,
+ * SURVEY.md 8d): returns accesses per second via *out_aps, elapsed seconds via *out_s. */
+int dint_bench_rand64(int32_t device, uint64_t bytes, uint64_t n_access, int write_back,
+                      double *out_aps, double *out_s);
+/* Per-kernel launch time of the most recent dint_submit_device micro-batch sequence, measured
+ * with HIP events on the stream the kernels ran on.  Call dint_timing_enable(e,1) first. */
+int dint_timing_enable(dint_engine_t *e, int on);
+/* returns number of kernels written; names[i] points to a static string */
+int dint_timing_read(dint_engine_t *e, const char **names, double *avg_us, uint64_t *launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINT_ABI_H */

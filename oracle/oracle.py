@@ -1,0 +1,263 @@
+"""ctypes binding of the CPU parity oracle (oracle/libdint_oracle.so) and a runner
+for the unmodified-reference replay binaries under oracle/_ref/.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of bench.py.  Nothing under dint_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdint_oracle.so")
+REF_DIR = os.path.join(HERE, "_ref")
+
+
+def build(force: bool = False) -> None:
+    """Compile the C restatement (and, where /root/reference exists, the _ref binaries)."""
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
+        os.path.join(HERE, "dint_oracle.c")
+    ):
+        subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    if os.path.isdir("/root/reference/lock_fasst/udp"):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+        sig = {
+            "orc_fasthash64": (u64, [vp, u64, u64]),
+            "orc_fasst_create": (vp, [u32]), "orc_fasst_destroy": (None, [vp]),
+            "orc_fasst_replay": (u64, [vp, vp, sz]),
+            "orc_fasst_locks": (vp, [vp]), "orc_fasst_vers": (vp, [vp]),
+            "orc_2pl_create": (vp, [u32]), "orc_2pl_destroy": (None, [vp]),
+            "orc_2pl_replay": (u64, [vp, vp, sz]),
+            "orc_2pl_num_ex": (vp, [vp]), "orc_2pl_num_sh": (vp, [vp]),
+            "orc_log_create": (vp, [u32]), "orc_log_destroy": (None, [vp]),
+            "orc_log_replay": (u64, [vp, vp, sz]),
+            "orc_log_ring": (vp, [vp]), "orc_log_tail": (u32, [vp]),
+            "orc_kvs_count": (u64, [vp]),
+            "orc_kvs_dump": (u64, [vp, vp, vp, vp, u64]),
+            "orc_kvs_load": (None, [vp, vp, vp, vp, u64]),
+            "orc_store_create": (vp, [u32, u32]), "orc_store_destroy": (None, [vp]),
+            "orc_store_replay": (u64, [vp, vp, sz]), "orc_store_table": (vp, [vp]),
+            "orc_tatp_create": (vp, [u32, u32, u32]), "orc_tatp_destroy": (None, [vp]),
+            "orc_tatp_replay": (u64, [vp, vp, sz]),
+            "orc_tatp_table": (vp, [vp, C.c_int]), "orc_tatp_hash_size": (u32, [vp, C.c_int]),
+            "orc_tatp_locks": (vp, [vp, C.c_int]),
+            "orc_tatp_log_ring": (vp, [vp]), "orc_tatp_log_tail": (u32, [vp]),
+            "orc_sb_create": (vp, [u32, u32, u32]), "orc_sb_destroy": (None, [vp]),
+            "orc_sb_replay": (u64, [vp, vp, sz]),
+            "orc_sb_table": (vp, [vp, C.c_int]), "orc_sb_hash_size": (u32, [vp, C.c_int]),
+            "orc_sb_num_ex": (vp, [vp, C.c_int]), "orc_sb_num_sh": (vp, [vp, C.c_int]),
+            "orc_sb_log_ring": (vp, [vp]), "orc_sb_log_tail": (u32, [vp]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def fasthash64(data: bytes, seed: int = 0xDEADBEEF) -> int:
+    buf = C.create_string_buffer(data, len(data))
+    return lib().orc_fasthash64(C.cast(buf, C.c_void_p), len(data), seed)
+
+
+def _view(ptr: int, n: int, dtype) -> np.ndarray:
+    dt = np.dtype(dtype)
+    buf = (C.c_uint8 * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n)
+
+
+def _bytes_inplace(msgs: np.ndarray, itemsize: int):
+    assert msgs.flags["C_CONTIGUOUS"] and msgs.dtype.itemsize in (1, itemsize)
+    n = msgs.nbytes // itemsize
+    return msgs.ctypes.data, n
+
+
+def _dump_kvs(kvs_ptr: int, val_size: int):
+    L = lib()
+    n = L.orc_kvs_count(kvs_ptr)
+    keys = np.zeros(n, "<u8"); vers = np.zeros(n, "<u4"); vals = np.zeros((n, val_size), "u1")
+    got = L.orc_kvs_dump(kvs_ptr, keys.ctypes.data, vers.ctypes.data, vals.ctypes.data, n)
+    assert got == n
+    return keys, vers, vals
+
+
+class _Base:
+    _destroy = None
+    ITEM = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(lib(), self._destroy)(self.h)
+            self.h = None
+
+    def replay(self, msgs: np.ndarray) -> np.ndarray:
+        """Serially process a batch (copy); returns the reply array; self.errors accumulates."""
+        out = np.ascontiguousarray(msgs).copy()
+        ptr, n = _bytes_inplace(out, self.ITEM)
+        self.errors = getattr(self, "errors", 0) + getattr(lib(), self._replay)(self.h, ptr, n)
+        return out
+
+
+class FasstOracle(_Base):
+    _destroy, _replay, ITEM = "orc_fasst_destroy", "orc_fasst_replay", 9
+
+    def __init__(self, nslots: int):
+        self.n = nslots
+        self.h = lib().orc_fasst_create(nslots)
+
+    @property
+    def locks(self): return _view(lib().orc_fasst_locks(self.h), self.n, "<u4")
+
+    @property
+    def vers(self): return _view(lib().orc_fasst_vers(self.h), self.n, "<u4")
+
+
+class TplOracle(_Base):
+    _destroy, _replay, ITEM = "orc_2pl_destroy", "orc_2pl_replay", 6
+
+    def __init__(self, nslots: int):
+        self.n = nslots
+        self.h = lib().orc_2pl_create(nslots)
+
+    @property
+    def num_ex(self): return _view(lib().orc_2pl_num_ex(self.h), self.n, "<u4")
+
+    @property
+    def num_sh(self): return _view(lib().orc_2pl_num_sh(self.h), self.n, "<u4")
+
+
+class LogOracle(_Base):
+    _destroy, _replay, ITEM = "orc_log_destroy", "orc_log_replay", 53
+
+    def __init__(self, ring_entries: int = 1_000_000):
+        self.cap = ring_entries
+        self.h = lib().orc_log_create(ring_entries)
+
+    @property
+    def ring(self): return _view(lib().orc_log_ring(self.h), self.cap * 64, "u1").reshape(self.cap, 64)
+
+    @property
+    def tail(self): return lib().orc_log_tail(self.h)
+
+
+class StoreOracle(_Base):
+    _destroy, _replay, ITEM = "orc_store_destroy", "orc_store_replay", 53
+
+    def __init__(self, hash_size: int, populate_n: int = 0):
+        """hash_size buckets; rows of the first `populate_n` subscribers (store/udp/tatp.h:44-66)."""
+        self.h = lib().orc_store_create(hash_size, populate_n)
+
+    def dump(self):
+        return _dump_kvs(lib().orc_store_table(self.h), 40)
+
+    def load(self, keys, vers, vals):
+        keys = np.ascontiguousarray(keys, "<u8"); vers = np.ascontiguousarray(vers, "<u4")
+        vals = np.ascontiguousarray(vals, "u1")
+        lib().orc_kvs_load(lib().orc_store_table(self.h), keys.ctypes.data, vers.ctypes.data,
+                           vals.ctypes.data, len(keys))
+
+
+class TatpOracle(_Base):
+    _destroy, _replay, ITEM = "orc_tatp_destroy", "orc_tatp_replay", 55
+
+    def __init__(self, n_sub: int, log_entries: int = 1_000_000, populate_n: int | None = None):
+        """`n_sub` sizes the tables; rows of the first `populate_n` (default all) subscribers."""
+        self.cap = log_entries
+        self.h = lib().orc_tatp_create(n_sub, log_entries, n_sub if populate_n is None else populate_n)
+
+    def hash_size(self, t: int) -> int: return lib().orc_tatp_hash_size(self.h, t)
+
+    def dump(self, t: int): return _dump_kvs(lib().orc_tatp_table(self.h, t), 40)
+
+    def load(self, t: int, keys, vers, vals):
+        keys = np.ascontiguousarray(keys, "<u8"); vers = np.ascontiguousarray(vers, "<u4")
+        vals = np.ascontiguousarray(vals, "u1")
+        lib().orc_kvs_load(lib().orc_tatp_table(self.h, t), keys.ctypes.data, vers.ctypes.data,
+                           vals.ctypes.data, len(keys))
+
+    def locks(self, t: int): return _view(lib().orc_tatp_locks(self.h, t), 4 * self.hash_size(t), "u1")
+
+    @property
+    def ring(self): return _view(lib().orc_tatp_log_ring(self.h), self.cap * 64, "u1").reshape(self.cap, 64)
+
+    @property
+    def tail(self): return lib().orc_tatp_log_tail(self.h)
+
+
+class SmallbankOracle(_Base):
+    _destroy, _replay, ITEM = "orc_sb_destroy", "orc_sb_replay", 23
+
+    def __init__(self, n_acct: int, log_entries: int = 1_000_000, populate_n: int | None = None):
+        self.cap = log_entries
+        self.h = lib().orc_sb_create(n_acct, log_entries, n_acct if populate_n is None else populate_n)
+
+    def hash_size(self, t: int) -> int: return lib().orc_sb_hash_size(self.h, t)
+
+    def dump(self, t: int): return _dump_kvs(lib().orc_sb_table(self.h, t), 8)
+
+    def load(self, t: int, keys, vers, vals):
+        keys = np.ascontiguousarray(keys, "<u8"); vers = np.ascontiguousarray(vers, "<u4")
+        vals = np.ascontiguousarray(vals, "u1")
+        lib().orc_kvs_load(lib().orc_sb_table(self.h, t), keys.ctypes.data, vers.ctypes.data,
+                           vals.ctypes.data, len(keys))
+
+    def num_ex(self, t: int): return _view(lib().orc_sb_num_ex(self.h, t), 4 * self.hash_size(t), "<u4")
+
+    def num_sh(self, t: int): return _view(lib().orc_sb_num_sh(self.h, t), 4 * self.hash_size(t), "<u4")
+
+    @property
+    def ring(self): return _view(lib().orc_sb_log_ring(self.h), self.cap * 64, "u1").reshape(self.cap, 64)
+
+    @property
+    def tail(self): return lib().orc_sb_log_tail(self.h)
+
+
+# --------------------------------------------------------------------------- #
+# unmodified reference, replayed through the socket-interposing harness
+REF_BIN = {
+    "lock_fasst": "ref_lock_fasst", "lock_2pl": "ref_lock_2pl", "log_server": "ref_log_server",
+    "store": "ref_store", "tatp": "ref_tatp", "smallbank": "ref_smallbank",
+}
+
+
+def ref_available(workload: str) -> bool:
+    return os.access(os.path.join(REF_DIR, REF_BIN[workload]), os.X_OK)
+
+
+def ref_replay(workload: str, msgs: np.ndarray, dump: bool = False, timeout: float = 3600):
+    """Run the unmodified reference server over `msgs` (one thread, serial).
+
+    Returns (replies ndarray of msgs.dtype, stats dict[, dump bytes]).
+    """
+    exe = os.path.join(REF_DIR, REF_BIN[workload])
+    msgs = np.ascontiguousarray(msgs)
+    with tempfile.TemporaryDirectory(prefix="dint_ref_") as td:
+        tp, rp, dp = (os.path.join(td, x) for x in ("trace.bin", "replies.bin", "dump.bin"))
+        msgs.tofile(tp)
+        cmd = [exe, tp, rp] + ([dp] if dump else [])
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        if res.returncode != 0:
+            raise RuntimeError(f"{exe} failed rc={res.returncode}: {res.stderr[-2000:]}")
+        stats = json.loads(res.stdout.strip().splitlines()[-1])
+        replies = np.fromfile(rp, dtype=msgs.dtype)
+        if dump:
+            with open(dp, "rb") as f:
+                return replies, stats, f.read()
+        return replies, stats
