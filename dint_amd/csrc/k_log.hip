@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(256)
 k_log_write(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const uint32_t *__restrict__ blk_cnt,
             dint_log log, dint_dev_stats *__restrict__ stats) {
   __shared__ uint32_t red[4];
+  __shared__ uint32_t redall[4];
   __shared__ uint32_t wbase[4];
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -42,6 +43,9 @@ k_log_write(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const uin
   uint32_t tot;
   wave_excl_scan_u32(part, &tot);
   if (lane == 0) red[wv] = tot;
+  // batch total: if the batch alone overflows the ring only its last `cap` records survive
+  wave_excl_scan_u32((threadIdx.x < gridDim.x) ? blk_cnt[threadIdx.x] : 0, &tot);
+  if (lane == 0) redall[wv] = tot;
   log_msg m;
   bool valid = false;
   if (i < n) {
@@ -52,10 +56,13 @@ k_log_write(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const uin
   if (lane == 0) wbase[wv] = (uint32_t)__popcll(vm);
   __syncthreads();
   uint32_t base = red[0] + red[1] + red[2] + red[3];
+  const uint32_t total_all = redall[0] + redall[1] + redall[2] + redall[3];
   for (uint32_t w = 0; w < wv; w++) base += wbase[w];
   const uint32_t pos_in_batch = base + (uint32_t)__popcll(vm & lanemask_lt());
   if (i < n) {
-    if (valid) {
+    if (valid && pos_in_batch + log.cap < total_all) {
+      m.type = 1;  // overwritten later in this same batch by a record one ring-lap ahead
+    } else if (valid) {
       const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
       uint4 *e = (uint4 *)(log.ring + (size_t)pos * 64);
       uint32_t w[16];

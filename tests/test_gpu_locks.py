@@ -1,0 +1,153 @@
+"""GPU parity: lock_fasst / lock_2pl / log_server through the C ABI vs the CPU oracle and
+the golden fixtures recorded from the unmodified reference.  Bit-exact (integer work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import tracegen
+from dint_amd import wire
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _engine(*a, **k):
+    from dint_amd.engine import Engine
+
+    return Engine(*a, **k)
+
+
+def _golden(name, dtype):
+    z = np.load(os.path.join(G, name + ".npz"))
+    return z, json.loads(str(z["meta"])), np.frombuffer(z["req"].tobytes(), dtype), np.frombuffer(z["rep"].tobytes(), dtype)
+
+
+def test_fasst_golden_reference_sizes():
+    z, meta, req, rep = _golden("lock_fasst", wire.FASST_MSG)
+    eng = _engine(wire.Workload.FASST, n_slots=meta["nslots"])
+    got = eng.submit(req)
+    assert got.tobytes() == rep.tobytes()
+    lock, ver = eng.read_locks()
+    d = np.frombuffer(z["dump"].tobytes()[4:], "<u4").reshape(-1, 3)
+    nz = np.nonzero(lock | ver)[0]
+    assert (d[:, 0] == nz).all() and (d[:, 1] == lock[nz]).all() and (d[:, 2] == ver[nz]).all()
+
+
+def test_fasst_kat2():
+    F = wire.Fasst
+    ops = [F.ACQUIRE_LOCK, F.ACQUIRE_LOCK, F.READ, F.COMMIT, F.READ, F.ACQUIRE_LOCK, F.ABORT, F.ACQUIRE_LOCK]
+    m = np.zeros(len(ops), wire.FASST_MSG)
+    m["type"], m["lid"] = ops, 7
+    r = _engine(wire.Workload.FASST).submit(m)
+    assert r["type"].tolist() == [5, 6, 4, 8, 4, 5, 7, 5] and r["ver"][2] == 0 and r["ver"][4] == 1
+
+
+@pytest.mark.parametrize("n,nslots,n_hot,p_hot", [
+    (1, 1 << 20, 4, 0.5), (63, 1 << 20, 4, 0.9), (64, 97, 4, 0.5), (65, 1 << 20, 1, 1.0),
+    (4096, 1 << 20, 16, 0.8), (65536, 1 << 20, 64, 0.7), (65536, 36_000_000, 3, 0.95),
+    (65536, 1 << 20, 1, 1.0), (200_000, 4800, 64, 0.3), (65537, 1, 2, 0.5),
+])
+def test_fasst_vs_oracle(n, nslots, n_hot, p_hot):
+    req = tracegen.fasst_random(n, seed=n + nslots, n_hot=n_hot, p_hot=p_hot)
+    eng = _engine(wire.Workload.FASST, n_slots=nslots)
+    o = orc.FasstOracle(nslots)
+    got = eng.submit(req)
+    want = o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    lock, ver = eng.read_locks()
+    assert (lock == o.locks).all() and (ver == o.vers).all()
+
+
+def test_fasst_batch_split_invariance():
+    """The reply stream must not depend on how the trace is cut into batches."""
+    req = tracegen.fasst_random(50_000, seed=3, n_hot=32, p_hot=0.8)
+    want = orc.FasstOracle(1 << 20).replay(req)
+    for bs in (1, 64, 4096, 65536):
+        if bs == 1:
+            sub = req[:300]
+            eng = _engine(wire.Workload.FASST, n_slots=1 << 20)
+            got = np.concatenate([eng.submit(sub[i:i + 1]) for i in range(len(sub))])
+            assert got.tobytes() == want[:300].tobytes()
+            continue
+        eng = _engine(wire.Workload.FASST, n_slots=1 << 20)
+        got = np.concatenate([eng.submit(req[i:i + bs]) for i in range(0, len(req), bs)])
+        assert got.tobytes() == want.tobytes(), bs
+
+
+def test_fasst_bad_types_are_echoed_and_counted():
+    req = tracegen.fasst_random(5000, seed=9)
+    req["type"][::7] = 200
+    eng = _engine(wire.Workload.FASST, n_slots=1 << 16)
+    o = orc.FasstOracle(1 << 16)
+    got, want = eng.submit(req), o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    assert eng.stats()["bad_requests"] == o.errors == len(req[::7])
+
+
+def test_fasst_device_inplace_and_empty():
+    import torch
+
+    eng = _engine(wire.Workload.FASST, n_slots=1 << 20)
+    assert len(eng.submit(np.zeros(0, wire.FASST_MSG))) == 0
+    req = tracegen.fasst_random(70_000, seed=21, n_hot=8, p_hot=0.6)
+    d = torch.from_numpy(np.frombuffer(req.tobytes(), np.uint8).copy()).cuda()
+    eng.submit_device(d, len(req), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = np.frombuffer(d.cpu().numpy().tobytes(), wire.FASST_MSG)
+    assert got.tobytes() == orc.FasstOracle(1 << 20).replay(req).tobytes()
+
+
+def test_tpl_golden_reference_sizes():
+    z, meta, req, rep = _golden("lock_2pl", wire.TPL_MSG)
+    eng = _engine(wire.Workload.TPL, n_slots=meta["nslots"])
+    assert eng.submit(req).tobytes() == rep.tobytes()
+    ex, sh = eng.read_locks()
+    d = np.frombuffer(z["dump"].tobytes()[4:], "<u4").reshape(-1, 3)
+    nz = np.nonzero(ex | sh)[0]
+    assert (d[:, 0] == nz).all() and (d[:, 1] == ex[nz]).all() and (d[:, 2] == sh[nz]).all()
+
+
+@pytest.mark.parametrize("n,nslots,n_hot,p_hot", [
+    (1, 1 << 20, 4, 0.5), (100, 7, 4, 0.5), (4096, 1 << 20, 16, 0.8), (65536, 36_000_000, 64, 0.7),
+    (65536, 1 << 20, 1, 1.0), (150_000, 1 << 20, 200, 0.9),
+])
+def test_tpl_vs_oracle(n, nslots, n_hot, p_hot):
+    req = tracegen.tpl_random(n, seed=n + nslots, n_hot=n_hot, p_hot=p_hot)
+    req["type"][5::11] = 9  # unknown lock types: acquire -> bad request, release -> ack only
+    eng = _engine(wire.Workload.TPL, n_slots=nslots)
+    o = orc.TplOracle(nslots)
+    got, want = eng.submit(req), o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    ex, sh = eng.read_locks()
+    assert (ex == o.num_ex).all() and (sh == o.num_sh).all()
+    assert eng.stats()["bad_requests"] == o.errors
+
+
+def test_log_golden():
+    z, meta, req, rep = _golden("log_server", wire.LOG_MSG)
+    eng = _engine(wire.Workload.LOG, log_entries=meta["ring"])
+    assert eng.submit(req).tobytes() == rep.tobytes()
+    dump = z["dump"].tobytes()
+    tail, n = np.frombuffer(dump, "<u4", 2)
+    recs = np.frombuffer(dump, "u1", offset=8).reshape(n, 64)
+    ring, t = eng.read_log(int(n))
+    assert t == tail
+    assert (np.frombuffer(ring.tobytes(), "u1").reshape(n, 64)[:, :52] == recs[:, :52]).all()
+
+
+@pytest.mark.parametrize("n,cap", [(1, 1000), (999, 1000), (1000, 1000), (70_000, 1000), (70_000, 1_000_000), (200_001, 65_537)])
+def test_log_vs_oracle_with_wrap(n, cap):
+    req = tracegen.log_random(n, seed=n)
+    req["type"][3::17] = 5  # not a COMMIT: the reference panics; we echo and count
+    eng = _engine(wire.Workload.LOG, log_entries=cap)
+    o = orc.LogOracle(cap)
+    for lo in range(0, n, 50_000):  # several submits: the tail carries over
+        got = eng.submit(req[lo:lo + 50_000])
+        want = o.replay(req[lo:lo + 50_000])
+        assert got.tobytes() == want.tobytes()
+    ring, t = eng.read_log(cap)
+    assert t == o.tail
+    assert (np.frombuffer(ring.tobytes(), "u1").reshape(cap, 64) == o.ring).all()
