@@ -4,33 +4,46 @@
 #include <vector>
 
 #include "dint_kernels.h"
+#include "dint_kv_core.h"
 
-struct dint_kv_table {
-  uint64_t hash_size = 0;     // global bucket count (before sharding)
-  uint64_t n_local = 0;       // buckets stored on this shard
-  dint_mod mod{};             // % hash_size
-  dint_mod lock_mod{};        // % (4 * hash_size)   (tatp/udp/tatp.h:12-14)
-  uint8_t *entries = nullptr; // n_local inline entries + overflow pool
-  uint32_t gk_base = 0;       // first group key of this table
+#define DINT_KV_MAX_TABLES 5
+#define DINT_KV_LOAD_OP 0xF0u  // internal request type: insert a row with the version carried in msg.ver
+
+// everything the kernels need about the tables; lives in device memory (d_dev) and in a host mirror
+struct kv_dev {
+  kv_tab tab[DINT_KV_MAX_TABLES];
+  dint_mod mod[DINT_KV_MAX_TABLES];      // % hash_size (global bucket)
+  dint_mod lockmod[DINT_KV_MAX_TABLES];  // % (4 * hash_size)  (tatp/udp/tatp.h:12-14)
+  uint32_t gk_base[DINT_KV_MAX_TABLES];  // group key of local bucket 0 of each table
+  uint32_t n_tables;
+  uint32_t shard_index, shard_count;
 };
 
 struct dint_kv {
   uint32_t workload = 0;
   uint32_t n_tables = 0;
   uint32_t val_size = 0;
-  dint_kv_table tab[5];
+  uint64_t hash_size[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};  // global bucket counts
+  kv_dev h{};                // host mirror (device pointers inside)
+  kv_dev *d_dev = nullptr;   // device copy
+  uint8_t *d_ctl = nullptr;  // pool_top / free_head / pend_head words of all tables
+  size_t entry_bytes[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
 };
 
 int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard);
 void dint_kv_destroy(dint_kv *kv);
-void dint_kv_reset(dint_kv *kv);
 std::vector<std::pair<void *, size_t>> dint_kv_regions(dint_kv *kv);
-int dint_kv_load_rows(dint_kv *kv, uint32_t table, const uint64_t *keys, const uint32_t *vers, const uint8_t *vals,
-                      uint64_t n, dint_scratch s, hipStream_t st);
-int dint_kv_populate(dint_kv *kv, uint32_t workload, uint64_t populate_n, dint_scratch s, hipStream_t st);
+// valid rows of `table` in bucket order, chain order inside a bucket; returns the row count
 int64_t dint_kv_dump_rows(dint_kv *kv, uint32_t table, uint64_t *keys, uint32_t *vers, uint8_t *vals, uint64_t cap);
+// lock words, index = q * n_local + local bucket  (== lock_hash when unsharded)
 int64_t dint_kv_read_locks(dint_kv *kv, uint32_t table, uint32_t *a, uint32_t *b, uint64_t cap);
-void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, dint_kv kv, dint_log log, dint_shard shard,
-                    dint_scratch s, hipStream_t st, hipEvent_t *ev);
-void dint_launch_home_kv(const void *d_req, uint32_t n, dint_kv kv, uint32_t shard_count, uint8_t *d_home,
-                         hipStream_t st);
+// one pass (n <= DINT_MICRO and, when a log is attached, n <= log.cap).  load_mode: accept DINT_KV_LOAD_OP
+// rows and ignore rows of other shards silently.
+void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
+                    int load_mode, hipStream_t st, hipEvent_t *ev);
+void dint_launch_home_kv(const void *d_req, uint32_t n, const dint_kv &kv, uint8_t *d_home, hipStream_t st);
+// wire message size / field offsets of a kv workload
+struct dint_kv_fmt {
+  uint32_t msg, type, table, key, val, ver, val_size;  // table == 0xFFFFFFFF: no table field
+};
+dint_kv_fmt dint_kv_format(uint32_t workload);

@@ -15,6 +15,7 @@
 #include "../../include/dint_abi.h"
 #include "dint_kernels.h"
 #include "dint_kv.h"
+#include "dint_populate.h"
 
 namespace {
 
@@ -52,6 +53,7 @@ struct KernelTimer {
 
 struct dint_engine {
   dint_config cfg;
+  uint32_t pass_max = DINT_MICRO;  // requests per kernel pass (<= the log ring size when a log is attached)
   int device = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;  // dint_submit* is serialised per engine: submission order = serial order
@@ -113,7 +115,7 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 }
 
 // one micro-batch (n <= DINT_MICRO) on device buffers
-int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st) {
+int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0) {
   static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
   static const char *const kv_names[] = {"k_kv_scatter", "k_kv_resolve"};
@@ -132,7 +134,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->shard, e->scratch, st, timer_events(e, 2, kv_names));
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 2, kv_names));
       break;
     default:
       return fail(DINT_EINVAL, "bad workload");
@@ -141,6 +143,33 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
   e->batches++;
   e->requests += n;
+  return 0;
+}
+
+// bulk load (kvs_insert semantics, explicit version) = passes of internal LOAD requests through the
+// same scatter/resolve kernels, so rows land in request order exactly like wire INSERTs
+int load_rows_locked(dint_engine *e, uint32_t table, const uint64_t *keys, const uint32_t *vers, const uint8_t *vals,
+                     uint64_t n) {
+  const dint_kv_fmt f = dint_kv_format(e->cfg.workload);
+  for (uint64_t off = 0; off < n; off += e->pass_max) {
+    const uint32_t m = (uint32_t)std::min<uint64_t>(e->pass_max, n - off);
+    const size_t bytes = (size_t)m * f.msg;
+    memset(e->h_pinned, 0, bytes);
+    for (uint32_t i = 0; i < m; i++) {
+      uint8_t *msg = e->h_pinned + (size_t)i * f.msg;
+      msg[f.type] = (uint8_t)DINT_KV_LOAD_OP;
+      if (f.table != 0xFFFFFFFFu) msg[f.table] = (uint8_t)table;
+      memcpy(msg + f.key, &keys[off + i], 8);
+      memcpy(msg + f.val, vals + (off + i) * f.val_size, f.val_size);
+      const uint32_t ver = vers ? vers[off + i] : 0;
+      memcpy(msg + f.ver, &ver, 4);
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_stage_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
+    dint_launch_kv(e->d_stage_req, e->d_stage_req, m, e->kv, e->log, e->scratch, 1, e->stream, nullptr);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   return 0;
 }
 
@@ -210,6 +239,9 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     TRY(dev_alloc((void **)&e->log.tail, 2 * sizeof(uint32_t)));
     add_region(e, e->log.ring, (size_t)e->log.cap * 64);
     add_region(e, e->log.tail, 2 * sizeof(uint32_t));
+    // tatp / smallbank: a pass never laps the ring, so a DELETE_LOG record keeps the val bytes of the
+    // record it overwrites exactly as in the serial reference
+    if (wl != DINT_WL_LOG) e->pass_max = std::min<uint32_t>(DINT_MICRO, e->log.cap);
   }
   if (wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
     rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard);
@@ -250,8 +282,8 @@ int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d
   hipStream_t st = stream ? (hipStream_t)stream : e->stream;
   const uint8_t *rq = (const uint8_t *)d_reqs;
   uint8_t *rp = (uint8_t *)d_replies;
-  for (uint32_t off = 0; off < n; off += DINT_MICRO) {
-    uint32_t m = std::min<uint32_t>(DINT_MICRO, n - off);
+  for (uint32_t off = 0; off < n; off += e->pass_max) {
+    uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
     int rc = run_pass(e, rq + (size_t)off * e->msg_size, m, rp + (size_t)off * e->msg_size, st);
     if (rc) return rc;
   }
@@ -264,8 +296,8 @@ int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies) {
   HIP_TRY(hipSetDevice(e->device));
   const uint8_t *rq = (const uint8_t *)reqs;
   uint8_t *rp = (uint8_t *)replies;
-  for (uint32_t off = 0; off < n; off += DINT_MICRO) {
-    uint32_t m = std::min<uint32_t>(DINT_MICRO, n - off);
+  for (uint32_t off = 0; off < n; off += e->pass_max) {
+    uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
     size_t bytes = (size_t)m * e->msg_size;
     memcpy(e->h_pinned, rq + (size_t)off * e->msg_size, bytes);
     HIP_TRY(hipMemcpyAsync(e->d_stage_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
@@ -344,7 +376,6 @@ int dint_reset(dint_engine_t *e) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
   for (auto &r : e->regions) HIP_TRY(hipMemset(r.first, 0, r.second));
-  dint_kv_reset(&e->kv);
   e->batches = e->requests = 0;
   HIP_TRY(hipDeviceSynchronize());
   return 0;
@@ -385,11 +416,10 @@ int dint_load_rows(dint_engine_t *e, uint32_t table, const uint64_t *keys, const
                    uint64_t n) {
   if (!e || (n && (!keys || !vals))) return fail(DINT_EINVAL, "null argument");
   if (!e->kv.n_tables) return fail(DINT_ESTATE, "workload has no kv table");
+  if (table >= e->kv.n_tables) return fail(DINT_EINVAL, "bad table %u", table);
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
-  int rc = dint_kv_load_rows(&e->kv, table, keys, vers, (const uint8_t *)vals, n, e->scratch, e->stream);
-  if (rc) return fail(rc, "load_rows failed: %s", g_err.c_str());
-  return 0;
+  return load_rows_locked(e, table, keys, vers, (const uint8_t *)vals, n);
 }
 
 int dint_populate(dint_engine_t *e, uint64_t populate_n) {
@@ -397,15 +427,16 @@ int dint_populate(dint_engine_t *e, uint64_t populate_n) {
   if (!e->kv.n_tables) return fail(DINT_ESTATE, "workload has no kv table");
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
-  int rc = dint_kv_populate(&e->kv, e->cfg.workload, populate_n, e->scratch, e->stream);
-  if (rc) return fail(rc, "populate failed: %s", g_err.c_str());
-  return 0;
+  return dint_pop::generate(e->cfg.workload, populate_n,
+                            [e](uint32_t table, const uint64_t *keys, const uint8_t *vals, uint64_t n) {
+                              return load_rows_locked(e, table, keys, nullptr, vals, n);
+                            });
 }
 
 int64_t dint_hash_size(dint_engine_t *e, uint32_t table) {
   if (!e) return fail(DINT_EINVAL, "null engine");
   if (table >= e->kv.n_tables) return fail(DINT_EINVAL, "bad table %u", table);
-  return (int64_t)e->kv.tab[table].hash_size;
+  return (int64_t)e->kv.hash_size[table];
 }
 
 int64_t dint_dump_rows(dint_engine_t *e, uint32_t table, uint64_t *keys, uint32_t *vers, void *vals, uint64_t cap) {
@@ -429,7 +460,7 @@ int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_home_kv(d_reqs, n, e->kv, e->shard.count, d_home, st);
+      dint_launch_home_kv(d_reqs, n, e->kv, d_home, st);
       break;
     default:
       return fail(DINT_ESTATE, "workload is not sharded by key");

@@ -1,13 +1,621 @@
-// k_kv.hip -- placeholder until the KV kernels land (store / tatp / smallbank).
-#include "dint_kv.h"
+// k_kv.hip -- store / tatp / smallbank shard servers on gfx950.
+//
+// Reference semantics (serial, one message at a time):
+//   store/udp/server.cc:75-97            READ / SET on one kvs  (INSERT as store/ebpf/store_kern.c:226-297)
+//   tatp/udp/server_shard.cc:113-210     13 request types over 5 kvs tables + txn_locks[5][] + log ring
+//   smallbank/udp/server_shard.cc:107-189  9 request types over 2 tables + num_ex/num_sh counters + log ring
+// Every request touches exactly one bucket of one table (lock_hash % hash_size == kvs bucket), or only
+// the log ring.  Requests on different buckets commute; requests on one bucket apply in request order.
+//
+// One pass (n <= 65,536 requests) = up to three kernels:
+//   k_kv_prepass (tatp / smallbank): per-block count of log requests, publishes the ring tail.
+//   k_kv_scatter : one thread per request -- copy the message to the reply array, classify, hash, and
+//                  either append the canonical 64-byte log record at ring position
+//                  tail + (#log requests below i)   [deterministic: an exclusive scan, not an atomic], or
+//                  append a {bucket group, idx, type, table|quadrant} record to bin = group & (P-1).
+//   k_kv_resolve : one wave per bin -- restore request order (bitmap rank over idx), group the window's
+//                  records by bucket in an LDS hash, then walk them 64 at a time in request order.  Lanes
+//                  whose bucket is unique in their chunk run in round 0; the k-th request of a bucket that
+//                  several lanes of the chunk hit runs in round k, with a workgroup fence between rounds, so
+//                  every request sees the table exactly as the serial reference would.  The table itself is
+//                  the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
 #include "../../include/dint_abi.h"
-int dint_kv_create(dint_kv *, uint32_t, uint64_t, dint_shard) { return DINT_EINVAL; }
-void dint_kv_destroy(dint_kv *) {}
-void dint_kv_reset(dint_kv *) {}
-std::vector<std::pair<void *, size_t>> dint_kv_regions(dint_kv *) { return {}; }
-int dint_kv_load_rows(dint_kv *, uint32_t, const uint64_t *, const uint32_t *, const uint8_t *, uint64_t, dint_scratch, hipStream_t) { return DINT_ESTATE; }
-int dint_kv_populate(dint_kv *, uint32_t, uint64_t, dint_scratch, hipStream_t) { return DINT_ESTATE; }
-int64_t dint_kv_dump_rows(dint_kv *, uint32_t, uint64_t *, uint32_t *, uint8_t *, uint64_t) { return DINT_ESTATE; }
-int64_t dint_kv_read_locks(dint_kv *, uint32_t, uint32_t *, uint32_t *, uint64_t) { return DINT_ESTATE; }
-void dint_launch_kv(const void *, void *, uint32_t, dint_kv, dint_log, dint_shard, dint_scratch, hipStream_t, hipEvent_t *) {}
-void dint_launch_home_kv(const void *, uint32_t, dint_kv, uint32_t, uint8_t *, hipStream_t) {}
+#include "dint_kv.h"
+
+// ---- wire formats ------------------------------------------------------------------------------------
+template <int WL> struct Fmt;
+template <> struct Fmt<DINT_WL_STORE> {  // store/udp/net.h:34-41
+  static constexpr uint32_t MSG = 53, TYPE = 0, KEY = 1, VAL = 9, VER = 49, VS = 40;
+  static constexpr bool HAS_TABLE = false;
+  static constexpr uint32_t TABLE = 0;
+};
+template <> struct Fmt<DINT_WL_TATP> {  // tatp/udp/net.h:57-66
+  static constexpr uint32_t MSG = 55, TYPE = 1, KEY = 3, VAL = 11, VER = 51, VS = 40;
+  static constexpr bool HAS_TABLE = true;
+  static constexpr uint32_t TABLE = 2;
+};
+template <> struct Fmt<DINT_WL_SMALLBANK> {  // smallbank/udp/net.h:41-50
+  static constexpr uint32_t MSG = 23, TYPE = 1, KEY = 3, VAL = 11, VER = 19, VS = 8;
+  static constexpr bool HAS_TABLE = true;
+  static constexpr uint32_t TABLE = 2;
+};
+
+dint_kv_fmt dint_kv_format(uint32_t workload) {
+  switch (workload) {
+    case DINT_WL_STORE: return {53, 0, 0xFFFFFFFFu, 1, 9, 49, 40};
+    case DINT_WL_TATP: return {55, 1, 2, 3, 11, 51, 40};
+    default: return {23, 1, 2, 3, 11, 19, 8};
+  }
+}
+
+// request classes: 0 = unknown (reply untouched, counted), 1 = table op, 2 = log op
+template <int WL>
+__device__ static inline uint32_t kv_class(uint32_t type, int load_mode) {
+  if (load_mode && type == DINT_KV_LOAD_OP) return 1;
+  if (WL == DINT_WL_STORE) return type <= 2 ? 1 : 0;
+  if (WL == DINT_WL_TATP) {
+    switch (type) {
+      case 0: case 1: case 2: case 12: case 13: case 18: case 19: case 22: case 23: return 1;
+      case 14: case 24: return 2;
+      default: return 0;
+    }
+  }
+  return type <= 5 ? 1 : (type == 6 ? 2 : 0);
+}
+
+__device__ static inline uint64_t ld_u64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ static inline uint32_t ld_u32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ static inline void st_u32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// ---- memory policy of the device build: pool words are only ever touched with device-scope RMWs ------
+struct kv_dev_mem {
+  __device__ static inline uint32_t fetch_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+  __device__ static inline uint32_t load32(uint32_t *p) { return atomicAdd(p, 0u); }
+  __device__ static inline void store32(uint32_t *p, uint32_t v) { atomicExch(p, v); }
+  __device__ static inline unsigned long long load64(unsigned long long *p) { return atomicAdd(p, 0ull); }
+  __device__ static inline bool cas64(unsigned long long *p, unsigned long long exp, unsigned long long des) {
+    return atomicCAS(p, exp, des) == exp;
+  }
+};
+
+// ---- k_kv_prepass ------------------------------------------------------------------------------------
+template <int WL>
+__global__ void __launch_bounds__(256)
+k_kv_prepass(const uint8_t *__restrict__ req, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *__restrict__ blk_cnt,
+             uint32_t *tail) {
+  using F = Fmt<WL>;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) tail[0] = tail[1];
+  bool is_log = false;
+  if (i < n) {
+    const uint8_t *m = req + (size_t)i * F::MSG;
+    is_log = kv_class<WL>(m[F::TYPE], 0) == 2 && m[F::TABLE] < kv->n_tables;
+  }
+  const uint32_t cnt = __syncthreads_count(is_log);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = cnt;
+}
+
+// ---- k_kv_scatter ------------------------------------------------------------------------------------
+template <int WL>
+__global__ void __launch_bounds__(256)
+k_kv_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
+             const uint32_t *__restrict__ blk_cnt, uint32_t pmask, uint32_t *__restrict__ bin_cnt,
+             uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int load_mode) {
+  using F = Fmt<WL>;
+  __shared__ uint32_t red[4];
+  __shared__ uint32_t wcnt[4];
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+  if (blockIdx.x == 0 && threadIdx.x == 0)  // entries freed by earlier passes become reusable
+    for (uint32_t t = 0; t < kv->n_tables; t++) kv_pool_rotate<kv_dev_mem>(kv->tab[t]);
+
+  // copy this block's messages to the reply array (replies are the request mutated in place)
+  if (rep != req) {
+    const size_t lo = (size_t)blockIdx.x * 256u * F::MSG;
+    const size_t hi = min((size_t)n * F::MSG, lo + (size_t)256u * F::MSG);
+    if ((((uintptr_t)req | (uintptr_t)rep) & 15) == 0) {
+      const size_t nv = (hi - lo) / 16;
+      const uint4 *s = (const uint4 *)(req + lo);
+      uint4 *d = (uint4 *)(rep + lo);
+      for (size_t k = threadIdx.x; k < nv; k += 256) d[k] = s[k];
+      for (size_t k = lo + nv * 16 + threadIdx.x; k < hi; k += 256) rep[k] = req[k];
+    } else {
+      for (size_t k = lo + threadIdx.x; k < hi; k += 256) rep[k] = req[k];
+    }
+  }
+
+  uint32_t type = 0, table = 0, cls = 0;
+  uint64_t key = 0;
+  const uint8_t *m = req + (size_t)i * F::MSG;
+  if (i < n) {
+    type = m[F::TYPE];
+    table = F::HAS_TABLE ? m[F::TABLE] : 0;
+    cls = kv_class<WL>(type, load_mode);
+    if (table >= kv->n_tables) cls = 0;  // the reference indexes tables[] out of bounds
+    if (cls) key = ld_u64(m + F::KEY);
+    else atomicAdd(&stats->bad_requests, 1ULL);
+  }
+
+  // ---- log requests: ring position = tail + exclusive count of log requests below i ----
+  if (WL != DINT_WL_STORE) {
+    uint32_t part = (threadIdx.x < blockIdx.x) ? blk_cnt[threadIdx.x] : 0, tot;
+    wave_excl_scan_u32(part, &tot);
+    if (lane == 0) red[wv] = tot;
+    const uint64_t lm = __ballot(cls == 2);
+    if (lane == 0) wcnt[wv] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    uint32_t base = red[0] + red[1] + red[2] + red[3];
+    for (uint32_t w = 0; w < wv; w++) base += wcnt[w];
+    const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
+    if (cls == 2) {
+      const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
+      uint8_t *e = log.ring + (size_t)pos * 64;
+      const uint32_t ver = ld_u32(m + F::VER);
+      uint8_t *r = rep + (size_t)i * F::MSG;
+      if (WL == DINT_WL_TATP && type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
+        *(uint64_t *)e = key;
+        *(uint2 *)(e + 48) = make_uint2(ver, 1u | (table << 8));
+        r[F::TYPE] = 27;
+      } else {  // kCommitLog  (tatp server_shard.cc:182-194, smallbank server_shard.cc:175-186)
+        uint32_t w[16];
+        __builtin_memcpy(&w[0], &key, 8);
+#pragma unroll
+        for (uint32_t k = 0; k < F::VS / 4; k++) w[2 + k] = ld_u32(m + F::VAL + 4 * k);
+        uint4 *e4 = (uint4 *)e;
+        e4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (F::VS == 40) {
+          e4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+          e4[2] = make_uint4(w[8], w[9], w[10], w[11]);
+        }
+        *(uint2 *)(e + 48) = make_uint2(ver, table << 8);
+        r[F::TYPE] = (WL == DINT_WL_TATP) ? 17 : 15;
+      }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+      const uint32_t total = pos_in_batch + (cls == 2 ? 1u : 0u);
+      log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
+    }
+  }
+
+  // ---- table requests: record -> bin ----
+  if (cls == 1) {
+    const uint64_t h = dint_hash_key(key);
+    const uint64_t g = dint_fastmod(h, kv->mod[table]);
+    uint32_t local = (uint32_t)g;
+    if (kv->shard_count > 1) {
+      if ((uint32_t)(g % kv->shard_count) != kv->shard_index) {
+        if (!load_mode) atomicAdd(&stats->foreign_requests, 1ULL);
+        return;
+      }
+      local = (uint32_t)(g / kv->shard_count);
+    }
+    // lock quadrant: lock_hash / hash_size, lock_hash = h % (4 * hash_size)
+    const uint64_t hs = kv->mod[table].d, dq = dint_fastmod(h, kv->lockmod[table]) - g;  // 0, hs, 2hs or 3hs
+    const uint32_t q = dq >= 2 * hs ? (dq >= 3 * hs ? 3u : 2u) : (dq >= hs ? 1u : 0u);
+    const uint32_t gk = kv->gk_base[table] + local;
+    const uint32_t bin = gk & pmask;
+    const uint32_t pos = atomicAdd(&bin_cnt[bin], 1u);
+    bins[(size_t)bin * DINT_MICRO + pos] = dint_rec(gk, i, type, table | (q << 4));
+  }
+}
+
+// ---- one request against the table ---------------------------------------------------------------------
+template <int WL>
+__device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_t table, uint32_t q, uint64_t bucket,
+                                            const kv_dev *__restrict__ kv, dint_dev_stats *__restrict__ stats) {
+  using F = Fmt<WL>;
+  const kv_tab t = kv->tab[table];
+  const uint64_t key = ld_u64(msg + F::KEY);
+  uint8_t *val = msg + F::VAL;
+  uint32_t ver;
+  if (type == DINT_KV_LOAD_OP) {  // bulk load: kvs_insert with the version carried in the message
+    if (!kv_insert<kv_dev_mem>(t, bucket, key, val, ld_u32(msg + F::VER))) atomicAdd(&stats->pool_exhausted, 1ULL);
+    return;
+  }
+  if (WL == DINT_WL_STORE) {
+    switch (type) {
+      case 0:  // kRead  store/udp/server.cc:77-82
+        if (kv_get(t, bucket, key, val, &ver)) { st_u32(msg + F::VER, ver); msg[F::TYPE] = 3; }
+        else msg[F::TYPE] = 7;
+        break;
+      case 1:  // kSet  :84-89
+        msg[F::TYPE] = kv_set(t, bucket, key, val) ? 5 : 7;
+        break;
+      default:  // kInsert (eBPF store)
+        if (!kv_insert<kv_dev_mem>(t, bucket, key, val, 0)) atomicAdd(&stats->pool_exhausted, 1ULL);
+        msg[F::TYPE] = 8;
+        break;
+    }
+  } else if (WL == DINT_WL_TATP) {
+    uint8_t *lk = &kv_entry_hdr(t, bucket, KV_INLINE)->lockb[q];
+    switch (type) {
+      case 0:  // kRead  tatp/udp/server_shard.cc:116-121
+        if (kv_get(t, bucket, key, val, &ver)) { st_u32(msg + F::VER, ver); msg[F::TYPE] = 4; }
+        else msg[F::TYPE] = 6;
+        break;
+      case 1:  // kAcquireLock  :123-132
+        if (*lk == 0) { *lk = 1; msg[F::TYPE] = 7; } else msg[F::TYPE] = 8;
+        break;
+      case 2:  // kAbort  :134-138
+        *lk = 0;
+        msg[F::TYPE] = 9;
+        break;
+      case 12:  // kCommitPrim: set + unlock  :140-146
+        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
+        *lk = 0;
+        msg[F::TYPE] = 15;
+        break;
+      case 18:  // kInsertPrim  :148-154
+        if (!kv_insert<kv_dev_mem>(t, bucket, key, val, 0)) atomicAdd(&stats->pool_exhausted, 1ULL);
+        *lk = 0;
+        msg[F::TYPE] = 20;
+        break;
+      case 22:  // kDeletePrim  :156-162
+        if (!kv_delete<kv_dev_mem>(t, bucket, key)) atomicAdd(&stats->missing_keys, 1ULL);
+        *lk = 0;
+        msg[F::TYPE] = 25;
+        break;
+      case 13:  // kCommitBck  :164-168
+        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
+        msg[F::TYPE] = 16;
+        break;
+      case 19:  // kInsertBck  :170-174
+        if (!kv_insert<kv_dev_mem>(t, bucket, key, val, 0)) atomicAdd(&stats->pool_exhausted, 1ULL);
+        msg[F::TYPE] = 21;
+        break;
+      default:  // 23 kDeleteBck  :176-180
+        if (!kv_delete<kv_dev_mem>(t, bucket, key)) atomicAdd(&stats->missing_keys, 1ULL);
+        msg[F::TYPE] = 26;
+        break;
+    }
+  } else {
+    uint32_t *cnt = (uint32_t *)(kv_entry_ptr(t, bucket, KV_INLINE) + KV_SB_LOCK_OFF) + 2 * q;  // {num_ex, num_sh}
+    switch (type) {
+      case 0:  // kAcquireShared  smallbank/udp/server_shard.cc:121-133
+        if (cnt[0] == 0) {
+          cnt[1]++;
+          if (kv_get(t, bucket, key, val, &ver)) st_u32(msg + F::VER, ver);
+          else atomicAdd(&stats->missing_keys, 1ULL);
+          msg[F::TYPE] = 7;
+        } else msg[F::TYPE] = 8;
+        break;
+      case 1:  // kAcquireExclusive  :135-147
+        if (cnt[0] == 0 && cnt[1] == 0) {
+          cnt[0]++;
+          if (kv_get(t, bucket, key, val, &ver)) st_u32(msg + F::VER, ver);
+          else atomicAdd(&stats->missing_keys, 1ULL);
+          msg[F::TYPE] = 9;
+        } else msg[F::TYPE] = 10;
+        break;
+      case 2: cnt[1]--; msg[F::TYPE] = 11; break;  // kReleaseShared  :149-154
+      case 3: cnt[0]--; msg[F::TYPE] = 12; break;  // kReleaseExclusive  :156-161
+      case 4:  // kCommitPrim  :163-167
+        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
+        msg[F::TYPE] = 13;
+        break;
+      default:  // 5 kCommitBck  :169-173
+        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
+        msg[F::TYPE] = 14;
+        break;
+    }
+  }
+}
+
+// ---- k_kv_resolve ----------------------------------------------------------------------------------------
+template <int WL>
+__global__ void __launch_bounds__(64)
+k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats) {
+  using F = Fmt<WL>;
+  __shared__ dint_rank_lds R;
+  __shared__ uint32_t Srec[DINT_WCAP];  // idx | hash entry << 16, in request order
+  __shared__ uint16_t Sop[DINT_WCAP];   // type | table << 8 | quadrant << 12
+  __shared__ uint32_t Hk[DINT_HSIZE];   // bucket group of each hash entry
+  __shared__ uint32_t Hfl[DINT_HSIZE];  // lanes of the current chunk on it
+  const uint32_t bin = blockIdx.x, lane = threadIdx.x;
+  const uint32_t c = bin_cnt[bin];
+  if (c == 0) return;
+  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
+  rank_build(R, recs, c, n);
+
+  for (uint32_t lo = 0; lo < c; lo += DINT_WCAP) {
+    const uint32_t wn = min(DINT_WCAP, c - lo);
+    for (uint32_t h = lane; h < DINT_HSIZE; h += 64) { Hk[h] = DINT_EMPTY; Hfl[h] = 0; }
+    __syncthreads();
+    for (uint32_t k = lane; k < c; k += 64) {
+      const uint64_t r = recs[k];
+      const uint32_t rk = rank_of(R, rec_idx(r), n) - lo;
+      if (rk < wn) {
+        bool nw;
+        const uint32_t e = lds_hash_insert(Hk, rec_gk(r), &nw);
+        Srec[rk] = rec_idx(r) | (e << 16);
+        const uint32_t aux = rec_aux(r);
+        Sop[rk] = (uint16_t)(rec_op(r) | ((aux & 15u) << 8) | ((aux >> 4) << 12));
+      }
+    }
+    __syncthreads();
+
+    for (uint32_t ch = 0; ch < wn; ch += 64) {
+      const uint32_t j = ch + lane;
+      const bool valid = j < wn;
+      const uint32_t sr = valid ? Srec[j] : 0;
+      const uint32_t so = valid ? Sop[j] : 0;
+      const uint32_t idx = sr & 0xFFFF, e = (sr >> 16) & (DINT_HSIZE - 1);
+      const uint32_t type = so & 0xFF, table = (so >> 8) & 15u, q = so >> 12;
+      if (valid) atomicAdd(&Hfl[e], 1u);
+      __syncthreads();
+      const uint32_t cnt = valid ? Hfl[e] : 0;
+      // position of this lane among the chunk's requests on the same bucket, in request (= lane) order
+      uint32_t pos = 0, maxpos = 0;
+      uint64_t conf = __ballot(valid && cnt > 1);
+      while (conf) {
+        const int leader = __ffsll((unsigned long long)conf) - 1;
+        const uint32_t se = __builtin_amdgcn_readlane(e, leader);
+        const bool mine = valid && e == se;
+        const uint64_t same = __ballot(mine);
+        if (mine) pos = (uint32_t)__popcll(same & lanemask_lt());
+        maxpos = max(maxpos, (uint32_t)__popcll(same) - 1u);
+        conf &= ~same;
+      }
+      const uint64_t bucket = valid ? (uint64_t)(Hk[e] - kv->gk_base[table]) : 0;
+      for (uint32_t r = 0; r <= maxpos; r++) {
+        if (valid && pos == r) kv_do_request<WL>(rep + (size_t)idx * F::MSG, type, table, q, bucket, kv, stats);
+        // the next round (and the next chunk) must see this round's stores
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+      __syncthreads();
+      if (valid) Hfl[e] = 0;
+      __syncthreads();
+    }
+  }
+  if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
+}
+
+// ---- launch -------------------------------------------------------------------------------------------
+template <int WL>
+static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
+                      int load_mode, hipStream_t st, hipEvent_t *ev) {
+  const uint32_t P = dint_pick_bins(n);
+  const uint32_t nb = (n + 255) / 256;
+  if (ev) hipEventRecord(ev[0], st);
+  if (WL != DINT_WL_STORE)
+    hipLaunchKernelGGL((k_kv_prepass<WL>), dim3(nb), dim3(256), 0, st, (const uint8_t *)d_req, n, kv.d_dev, s.blk_cnt,
+                       log.tail);
+  hipLaunchKernelGGL((k_kv_scatter<WL>), dim3(nb), dim3(256), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n,
+                     kv.d_dev, log, (const uint32_t *)s.blk_cnt, P - 1, s.bin_cnt, s.bins, s.stats, load_mode);
+  if (ev) hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
+                     (const uint64_t *)s.bins, s.stats);
+  if (ev) hipEventRecord(ev[2], st);
+}
+
+void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
+                    int load_mode, hipStream_t st, hipEvent_t *ev) {
+  if (n == 0) return;
+  switch (kv.workload) {
+    case DINT_WL_STORE: launch_kv<DINT_WL_STORE>(d_req, d_rep, n, kv, log, s, load_mode, st, ev); break;
+    case DINT_WL_TATP: launch_kv<DINT_WL_TATP>(d_req, d_rep, n, kv, log, s, load_mode, st, ev); break;
+    default: launch_kv<DINT_WL_SMALLBANK>(d_req, d_rep, n, kv, log, s, load_mode, st, ev); break;
+  }
+}
+
+// ---- home shard of each request (multi-GPU routing): global bucket % shard_count -------------------------
+__global__ void __launch_bounds__(256)
+k_home_kv(const uint8_t *__restrict__ req, uint32_t n, const kv_dev *__restrict__ kv, dint_kv_fmt f,
+          uint8_t *__restrict__ home) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *m = req + (size_t)i * f.msg;
+  const uint32_t table = f.table == 0xFFFFFFFFu ? 0 : m[f.table];
+  if (table >= kv->n_tables) { home[i] = 0xFF; return; }
+  const uint64_t g = dint_fastmod(dint_hash_key(ld_u64(m + f.key)), kv->mod[table]);
+  home[i] = (uint8_t)(g % (kv->shard_count ? kv->shard_count : 1));
+}
+void dint_launch_home_kv(const void *d_req, uint32_t n, const dint_kv &kv, uint8_t *d_home, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_home_kv, dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t *)d_req, n, kv.d_dev,
+                     dint_kv_format(kv.workload), d_home);
+}
+
+// ---- table management (host) ------------------------------------------------------------------------------
+int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard) {
+  *kv = dint_kv();
+  kv->workload = workload;
+  uint64_t hs[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
+  if (workload == DINT_WL_STORE) {
+    const uint64_t n = n_rows ? n_rows : 2000000ull;  // store/udp/tatp.h:10
+    kv->n_tables = 1;
+    kv->val_size = 40;
+    hs[0] = n * 18 / 4;  // store/udp/server.cc:112-114: 12 rows per subscriber * 3/2 / 4 slots
+  } else if (workload == DINT_WL_TATP) {
+    const uint64_t n = n_rows ? n_rows : 7000000ull;  // tatp/udp/tatp.h:28
+    kv->n_tables = 5;
+    kv->val_size = 40;
+    hs[0] = hs[1] = n * 3 / 2 / 4;   // tatp/udp/server_shard.cc:75-76
+    hs[2] = hs[3] = n * 15 / 4 / 4;  // :77-78
+    hs[4] = n * 45 / 8 / 4;          // :79
+  } else {
+    const uint64_t n = n_rows ? n_rows : 24000000ull;  // smallbank/udp/smallbank.h:17
+    kv->n_tables = 2;
+    kv->val_size = 8;
+    hs[0] = hs[1] = n * 3 / 2 / 4;  // smallbank/udp/server_shard.cc:75-76
+  }
+  const uint32_t stride = kv->val_size == 40 ? 256u : 128u;
+  const uint32_t count = shard.count ? shard.count : 1;
+  kv->h.n_tables = kv->n_tables;
+  kv->h.shard_index = shard.index;
+  kv->h.shard_count = count;
+  if (hipMalloc((void **)&kv->d_ctl, 64 * DINT_KV_MAX_TABLES) != hipSuccess) return DINT_ENOMEM;
+  hipMemset(kv->d_ctl, 0, 64 * DINT_KV_MAX_TABLES);
+  uint64_t gk = 0;
+  for (uint32_t t = 0; t < kv->n_tables; t++) {
+    if (hs[t] == 0) hs[t] = 1;
+    kv->hash_size[t] = hs[t];
+    kv_tab &tb = kv->h.tab[t];
+    tb.n_local = (hs[t] + count - 1) / count;
+    const uint64_t pool = tb.n_local / 4 + 4096;  // expected overflow at the reference's 2.67 rows/bucket: 0.14/bucket
+    if (pool > 0xFFFFFFF0ull || gk + tb.n_local > 0xFFFFFFF0ull) return DINT_EINVAL;
+    tb.pool_cap = (uint32_t)pool;
+    tb.stride = stride;
+    tb.val_size = kv->val_size;
+    kv->entry_bytes[t] = (size_t)(tb.n_local + tb.pool_cap) * stride;
+    if (hipMalloc((void **)&tb.entries, kv->entry_bytes[t]) != hipSuccess) return DINT_ENOMEM;
+    if (hipMemset(tb.entries, 0, kv->entry_bytes[t]) != hipSuccess) return DINT_EHIP;
+    if (hipMalloc((void **)&tb.pool_next, (size_t)tb.pool_cap * 4) != hipSuccess) return DINT_ENOMEM;
+    hipMemset(tb.pool_next, 0, (size_t)tb.pool_cap * 4);
+    uint8_t *ctl = kv->d_ctl + 64 * t;
+    tb.pool_top = (uint32_t *)ctl;
+    tb.free_head = (unsigned long long *)(ctl + 8);
+    tb.pend_head = (unsigned long long *)(ctl + 16);
+    kv->h.mod[t] = dint_make_mod(hs[t]);
+    kv->h.lockmod[t] = dint_make_mod(4 * hs[t]);
+    kv->h.gk_base[t] = (uint32_t)gk;
+    gk += tb.n_local;
+  }
+  if (hipMalloc((void **)&kv->d_dev, sizeof(kv_dev)) != hipSuccess) return DINT_ENOMEM;
+  if (hipMemcpy(kv->d_dev, &kv->h, sizeof(kv_dev), hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;
+  return 0;
+}
+
+void dint_kv_destroy(dint_kv *kv) {
+  for (uint32_t t = 0; t < DINT_KV_MAX_TABLES; t++) {
+    if (kv->h.tab[t].entries) hipFree(kv->h.tab[t].entries);
+    if (kv->h.tab[t].pool_next) hipFree(kv->h.tab[t].pool_next);
+  }
+  if (kv->d_ctl) hipFree(kv->d_ctl);
+  if (kv->d_dev) hipFree(kv->d_dev);
+  *kv = dint_kv();
+}
+
+std::vector<std::pair<void *, size_t>> dint_kv_regions(dint_kv *kv) {
+  std::vector<std::pair<void *, size_t>> r;
+  for (uint32_t t = 0; t < kv->n_tables; t++) {
+    r.push_back({kv->h.tab[t].entries, kv->entry_bytes[t]});
+    r.push_back({kv->h.tab[t].pool_next, (size_t)kv->h.tab[t].pool_cap * 4});
+  }
+  if (kv->d_ctl) r.push_back({kv->d_ctl, (size_t)64 * DINT_KV_MAX_TABLES});
+  return r;
+}
+
+// ---- dumps (parity tooling; not on the hot path) -------------------------------------------------------------
+// rows of a bucket in chain order
+__device__ static inline uint32_t bucket_rows(const kv_tab &t, uint64_t b, uint64_t *keys, uint32_t *vers, uint8_t *vals) {
+  uint32_t cur = kv_entry_hdr(t, b, KV_INLINE)->head, nrow = 0;
+  for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
+    const uint8_t *e = kv_entry_ptr(t, b, cur);
+    const kv_hdr *h = (const kv_hdr *)e;
+    for (uint32_t i = 0; i < 4; i++)
+      if (h->valid[i]) {
+        if (keys) {
+          keys[nrow] = h->key[i];
+          vers[nrow] = h->ver[i];
+          for (uint32_t o = 0; o < t.val_size; o++) vals[(size_t)nrow * t.val_size + o] = e[KV_VAL_OFF + i * t.val_size + o];
+        }
+        nrow++;
+      }
+    cur = h->next;
+  }
+  return nrow;
+}
+// pass 1: rows per 256-bucket block
+__global__ void __launch_bounds__(256) k_kv_dump_count(kv_tab t, uint32_t *__restrict__ blk_rows) {
+  __shared__ uint32_t red[4];
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t nrow = b < t.n_local ? bucket_rows(t, b, nullptr, nullptr, nullptr) : 0, tot;
+  wave_excl_scan_u32(nrow, &tot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_rows[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// pass 2: write rows at blk_off[block] + in-block exclusive offset
+__global__ void __launch_bounds__(256) k_kv_dump_write(kv_tab t, const uint64_t *__restrict__ blk_off, uint64_t *keys,
+                                                       uint32_t *vers, uint8_t *vals, uint64_t cap) {
+  __shared__ uint32_t red[4];
+  const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t nrow = b < t.n_local ? bucket_rows(t, b, nullptr, nullptr, nullptr) : 0;
+  uint32_t tot;
+  uint32_t off = wave_excl_scan_u32(nrow, &tot);
+  if ((threadIdx.x & 63) == 0) red[wv] = tot;
+  __syncthreads();
+  for (uint32_t w = 0; w < wv; w++) off += red[w];
+  const uint64_t at = blk_off[blockIdx.x] + off;
+  if (nrow && at + nrow <= cap) bucket_rows(t, b, keys + at, vers + at, vals + at * t.val_size);
+}
+
+int64_t dint_kv_dump_rows(dint_kv *kv, uint32_t table, uint64_t *keys, uint32_t *vers, uint8_t *vals, uint64_t cap) {
+  if (table >= kv->n_tables) return DINT_EINVAL;
+  const kv_tab t = kv->h.tab[table];
+  const uint32_t nb = (uint32_t)((t.n_local + 255) / 256);
+  uint32_t *d_cnt = nullptr;
+  if (hipMalloc((void **)&d_cnt, (size_t)nb * 4) != hipSuccess) return DINT_ENOMEM;
+  hipLaunchKernelGGL(k_kv_dump_count, dim3(nb), dim3(256), 0, 0, t, d_cnt);
+  std::vector<uint32_t> cnt(nb);
+  hipMemcpy(cnt.data(), d_cnt, (size_t)nb * 4, hipMemcpyDeviceToHost);
+  hipFree(d_cnt);
+  std::vector<uint64_t> off(nb);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < nb; i++) { off[i] = total; total += cnt[i]; }
+  if (!keys || !vers || !vals || cap == 0 || total == 0) return (int64_t)total;
+  const uint64_t m = std::min<uint64_t>(cap, total);
+  uint64_t *d_off = nullptr, *d_keys = nullptr;
+  uint32_t *d_vers = nullptr;
+  uint8_t *d_vals = nullptr;
+  int64_t rc = (int64_t)total;
+  if (hipMalloc((void **)&d_off, (size_t)nb * 8) != hipSuccess || hipMalloc((void **)&d_keys, m * 8) != hipSuccess ||
+      hipMalloc((void **)&d_vers, m * 4) != hipSuccess || hipMalloc((void **)&d_vals, m * t.val_size) != hipSuccess) {
+    rc = DINT_ENOMEM;
+  } else {
+    hipMemcpy(d_off, off.data(), (size_t)nb * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_kv_dump_write, dim3(nb), dim3(256), 0, 0, t, (const uint64_t *)d_off, d_keys, d_vers, d_vals, m);
+    hipMemcpy(keys, d_keys, m * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(vers, d_vers, m * 4, hipMemcpyDeviceToHost);
+    if (hipMemcpy(vals, d_vals, m * t.val_size, hipMemcpyDeviceToHost) != hipSuccess) rc = DINT_EHIP;
+  }
+  hipFree(d_off); hipFree(d_keys); hipFree(d_vers); hipFree(d_vals);
+  return rc;
+}
+
+// lock words -> a[q * n_local + local], b[...]   tatp: a = txn lock; smallbank: a = num_ex, b = num_sh
+__global__ void __launch_bounds__(256) k_kv_read_locks(kv_tab t, int is_sb, uint32_t *a, uint32_t *b, uint64_t cap) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= t.n_local) return;
+  const uint8_t *e = kv_entry_ptr(t, i, KV_INLINE);
+  for (uint32_t q = 0; q < 4; q++) {
+    const uint64_t at = (uint64_t)q * t.n_local + i;
+    if (at >= cap) continue;
+    if (is_sb) {
+      const uint32_t *c = (const uint32_t *)(e + KV_SB_LOCK_OFF) + 2 * q;
+      a[at] = c[0];
+      if (b) b[at] = c[1];
+    } else {
+      a[at] = ((const kv_hdr *)e)->lockb[q];
+      if (b) b[at] = 0;
+    }
+  }
+}
+
+int64_t dint_kv_read_locks(dint_kv *kv, uint32_t table, uint32_t *a, uint32_t *b, uint64_t cap) {
+  if (table >= kv->n_tables || kv->workload == DINT_WL_STORE) return DINT_EINVAL;
+  const kv_tab t = kv->h.tab[table];
+  const uint64_t total = 4 * t.n_local;
+  if (!a || cap == 0) return (int64_t)total;
+  const uint64_t m = std::min<uint64_t>(cap, total);
+  uint32_t *d_a = nullptr, *d_b = nullptr;
+  if (hipMalloc((void **)&d_a, m * 4) != hipSuccess || hipMalloc((void **)&d_b, m * 4) != hipSuccess) {
+    hipFree(d_a);
+    return DINT_ENOMEM;
+  }
+  hipLaunchKernelGGL(k_kv_read_locks, dim3((uint32_t)((t.n_local + 255) / 256)), dim3(256), 0, 0, t,
+                     kv->workload == DINT_WL_SMALLBANK ? 1 : 0, d_a, d_b, m);
+  hipMemcpy(a, d_a, m * 4, hipMemcpyDeviceToHost);
+  if (b) hipMemcpy(b, d_b, m * 4, hipMemcpyDeviceToHost);
+  hipFree(d_a);
+  hipFree(d_b);
+  return (int64_t)total;
+}

@@ -136,10 +136,13 @@ int64_t dint_hash_size(dint_engine_t *e, uint32_t table);
  * returns the row count (also when it exceeds cap; only cap rows are written). */
 int64_t dint_dump_rows(dint_engine_t *e, uint32_t table, uint64_t *keys, uint32_t *vers, void *vals,
                        uint64_t cap);
-/* lock-word state, one u32 per LOCAL slot (n_local = ceil((n_slots - shard_index)/shard_count)):
+/* lock-word state, one u32 per LOCAL lock slot:
  *   FASST: a=lock (0/1), b=version        2PL/SMALLBANK: a=num_ex, b=num_sh
- *   TATP : a=txn lock (0/1), b unused (may be NULL)
- * `table` selects the tatp/smallbank table (0 for fasst/2pl).  Returns n_local. */
+ *   TATP : a=txn lock (0/1), b=0 (b may be NULL)
+ * FASST/2PL: n = ceil(n_slots / shard_count) words, index = global slot / shard_count.
+ * TATP/SMALLBANK (`table` selects the table): n = 4 * local buckets, index = q * n_local + local bucket with
+ * q = lock_hash / hash_size -- i.e. exactly lock_hash (tatp/udp/tatp.h:12-14) when unsharded.
+ * Returns n (also when cap is smaller; only cap words are written). */
 int64_t dint_read_locks(dint_engine_t *e, uint32_t table, uint32_t *a, uint32_t *b, uint64_t cap);
 /* log ring: copies up to cap canonical 64-byte records
  * {u64 key; u8 val[40]; u32 ver; u8 is_del; u8 table; u8 pad[10]} and returns the tail index */

@@ -49,6 +49,9 @@ def lib() -> C.CDLL:
             "orc_log_create": (vp, [u32]), "orc_log_destroy": (None, [vp]),
             "orc_log_replay": (u64, [vp, vp, sz]),
             "orc_log_ring": (vp, [vp]), "orc_log_tail": (u32, [vp]),
+            "orc_kvs_create": (vp, [u32, u32]), "orc_kvs_destroy": (None, [vp]),
+            "orc_kvs_get": (C.c_int, [vp, u64, vp, vp]), "orc_kvs_set": (C.c_int, [vp, u64, vp]),
+            "orc_kvs_insert": (None, [vp, u64, vp]), "orc_kvs_delete": (C.c_int, [vp, u64]),
             "orc_kvs_count": (u64, [vp]),
             "orc_kvs_dump": (u64, [vp, vp, vp, vp, u64]),
             "orc_kvs_load": (None, [vp, vp, vp, vp, u64]),
@@ -96,6 +99,36 @@ def _dump_kvs(kvs_ptr: int, val_size: int):
     got = L.orc_kvs_dump(kvs_ptr, keys.ctypes.data, vers.ctypes.data, vals.ctypes.data, n)
     assert got == n
     return keys, vers, vals
+
+
+class KvsOracle:
+    """One chained 4-way table (store/udp/kvs.h) on its own -- used to pin the engine's HBM layout."""
+
+    def __init__(self, hash_size: int, val_size: int):
+        self.vs = val_size
+        self.h = lib().orc_kvs_create(hash_size, val_size)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_kvs_destroy(self.h)
+            self.h = None
+
+    def get(self, key: int):
+        val = np.zeros(self.vs, "u1"); ver = C.c_uint32()
+        rc = lib().orc_kvs_get(self.h, key, val.ctypes.data, C.addressof(ver))
+        return (None, None) if rc else (val, ver.value)
+
+    def set(self, key: int, val: np.ndarray) -> int:
+        return lib().orc_kvs_set(self.h, key, np.ascontiguousarray(val, "u1").ctypes.data)
+
+    def insert(self, key: int, val: np.ndarray) -> None:
+        lib().orc_kvs_insert(self.h, key, np.ascontiguousarray(val, "u1").ctypes.data)
+
+    def delete(self, key: int) -> int:
+        return lib().orc_kvs_delete(self.h, key)
+
+    def dump(self):
+        return _dump_kvs(self.h, self.vs)
 
 
 class _Base:

@@ -1,0 +1,317 @@
+"""GPU parity: store / tatp / smallbank shard servers through the C ABI vs the CPU oracle and the
+golden fixtures recorded from the unmodified reference udp/ servers.  Bit-exact: reply streams,
+final rows (bucket order, chain order), lock words and log rings."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import tracegen
+from dint_amd import wire
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+W = wire.Workload
+
+
+def _engine(*a, **k):
+    from dint_amd.engine import Engine
+
+    return Engine(*a, **k)
+
+
+def _golden(name, dtype):
+    z = np.load(os.path.join(G, name + ".npz"))
+    return z, json.loads(str(z["meta"])), np.frombuffer(z["req"].tobytes(), dtype), np.frombuffer(z["rep"].tobytes(), dtype)
+
+
+def _same_rows(a, b):
+    return all(x.shape == y.shape and (x == y).all() for x, y in zip(a, b))
+
+
+# ---------------------------------------------------------------- store
+def test_store_golden_reference_sizes():
+    z, meta, req, rep = _golden("store", wire.STORE_MSG)
+    eng = _engine(W.STORE, n_rows=meta["n_sub"])
+    assert eng.hash_size(0) == meta["hash_size"]
+    eng.populate(meta["touch"])
+    got = eng.submit(req)
+    a = tracegen.mask_populate_garbage("store", got)
+    b = tracegen.mask_populate_garbage("store", rep)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_store_kat3():
+    """SURVEY.md 8(c) KAT-3, recorded from the unmodified store/udp/server.cc."""
+    S = wire.Store
+    eng = _engine(W.STORE, n_rows=1000)
+    eng.populate(1)
+    key = 1 << 32  # s_id 0, sf_type 1, start_time 0
+
+    def one(t, k, v0=None):
+        m = np.zeros(1, wire.STORE_MSG)
+        m["type"], m["key"], m["ver"] = t, k, 0x11223344
+        m["val"] = 0xEE
+        if v0 is not None:
+            m["val"][0, 0] = v0
+        return eng.submit(m)[0]
+
+    r = one(S.READ, key)
+    assert r["type"] == 3 and r["val"][0] == 21 and r["val"][1] == 0x5A and r["ver"] == 0
+    r = one(S.SET, key, 7)
+    assert r["type"] == 5 and r["ver"] == 0x11223344 and r["val"][0] == 7 and r["val"][1] == 0xEE
+    r = one(S.READ, key)
+    assert r["val"][0] == 7 and r["val"][2] == 0xEE and r["ver"] == 1
+    assert one(S.SET, key, 9)["type"] == 5
+    r = one(S.READ, key)
+    assert r["val"][0] == 9 and r["ver"] == 2
+    r = one(S.READ, 0xDEAD << 48)
+    assert r["type"] == 7 and r["ver"] == 0x11223344 and (r["val"] == 0xEE).all()
+    assert one(S.SET, 0xDEAD << 48)["type"] == 7
+
+
+@pytest.mark.parametrize("n,n_sub,touch,p_set,p_ins", [
+    (1, 1000, 50, 0.4, 0.0), (64, 1000, 3, 0.5, 0.0), (5000, 1000, 50, 0.4, 0.05), (65536, 50_000, 2000, 0.3, 0.02),
+    (150_000, 2000, 40, 0.5, 0.1), (65536, 1000, 1, 0.6, 0.0),
+])
+def test_store_vs_oracle(n, n_sub, touch, p_set, p_ins):
+    hs = n_sub * 18 // 4
+    req = tracegen.store_random(n, seed=n + touch, n_sub_touch=touch, p_set=p_set, p_insert=p_ins)
+    eng = _engine(W.STORE, n_rows=n_sub)
+    eng.populate(min(touch * 2, n_sub))
+    o = orc.StoreOracle(hs, min(touch * 2, n_sub))
+    assert _same_rows(eng.dump_rows(0), o.dump())
+    got, want = eng.submit(req), o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    assert _same_rows(eng.dump_rows(0), o.dump())
+    st = eng.stats()
+    assert st["bad_requests"] == o.errors == 0 and st["pool_exhausted"] == 0
+
+
+def test_store_bad_types_batch_split_and_device_path():
+    import torch
+
+    req = tracegen.store_random(40_000, seed=77, n_sub_touch=30, p_set=0.5, p_insert=0.05)
+    req["type"][::13] = 99
+    want_o = orc.StoreOracle(4500, 60)
+    want = want_o.replay(req)
+    for bs in (64, 4096, 65536):
+        eng = _engine(W.STORE, n_rows=1000)
+        eng.populate(60)
+        got = np.concatenate([eng.submit(req[i:i + bs]) for i in range(0, len(req), bs)])
+        assert got.tobytes() == want.tobytes(), bs
+        assert eng.stats()["bad_requests"] == want_o.errors
+    eng = _engine(W.STORE, n_rows=1000)
+    eng.populate(60)
+    d = torch.from_numpy(np.frombuffer(req.tobytes(), np.uint8).copy()).cuda()
+    out = torch.empty_like(d)
+    eng.submit_device(d, len(req), out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == want.tobytes()
+    assert d.cpu().numpy().tobytes() == req.tobytes()  # out-of-place: requests untouched
+
+
+def test_store_full_population_matches_oracle_dump():
+    """Every row of a 100k-subscriber store (1.2M rows): same rows, same bucket/chain order."""
+    n = 100_000
+    eng = _engine(W.STORE, n_rows=n)
+    eng.populate(n)
+    o = orc.StoreOracle(n * 18 // 4, n)
+    a, b = eng.dump_rows(0), o.dump()
+    assert len(a[0]) == 12 * n and _same_rows(a, b)
+    assert eng.stats()["pool_exhausted"] == 0
+
+
+# ---------------------------------------------------------------- tatp
+def _tatp_locks(eng, o):
+    for t in range(5):
+        lk, _ = eng.read_locks(t)
+        assert (lk == o.locks(t)).all(), t
+
+
+def test_tatp_golden_reference_sizes():
+    z, meta, req, rep = _golden("tatp", wire.TATP_MSG)
+    eng = _engine(W.TATP, n_rows=meta["n_sub"])
+    eng.populate(meta["touch"])
+    got = eng.submit(req)
+    a = tracegen.mask_populate_garbage("tatp", got)
+    b = tracegen.mask_populate_garbage("tatp", rep)
+    assert a.tobytes() == b.tobytes()
+    st = eng.stats()
+    assert st["bad_requests"] == 0 and st["missing_keys"] == 0
+    tail_dump = z["dump_tail"].tobytes()
+    off = 0
+    for t in range(5):
+        cnt = int(np.frombuffer(tail_dump, "<u4", 1, off)[0]); off += 4
+        held = np.frombuffer(tail_dump, "<u4", cnt, off); off += 4 * cnt
+        lk, _ = eng.read_locks(t)
+        assert (np.nonzero(lk)[0] == held).all()
+    tail, n = np.frombuffer(tail_dump, "<u4", 2, off); off += 8
+    recs = np.frombuffer(tail_dump, "u1", n * 64, off).reshape(n, 64)
+    ring, t_eng = eng.read_log(int(n))
+    ring = np.frombuffer(ring.tobytes(), "u1").reshape(n, 64)
+    assert t_eng == tail
+    is_del = recs[:, 52] == 1
+    assert (ring[:, :8] == recs[:, :8]).all() and (ring[:, 48:54] == recs[:, 48:54]).all()
+    assert (ring[~is_del, 8:48] == recs[~is_del, 8:48]).all()
+
+
+@pytest.mark.parametrize("n,n_sub,touch,well", [
+    (1, 2000, 40, True), (4096, 2000, 40, True), (65536, 2000, 40, True), (70_000, 100_000, 3000, True),
+    (30_000, 2000, 6, False), (100_000, 2000, 2, True),
+])
+def test_tatp_vs_oracle(n, n_sub, touch, well):
+    o = orc.TatpOracle(n_sub, log_entries=100_000, populate_n=touch)
+    existing = [o.dump(t)[0] for t in range(5)]
+    req = tracegen.tatp_random(n, existing, seed=n + touch, n_sub_touch=touch, well_formed=well)
+    if not well:
+        req["type"][7::41] = 3      # kCommit is never handled by the reference servers
+        req["table"][11::53] = 9    # out-of-range table
+    eng = _engine(W.TATP, n_rows=n_sub, log_entries=100_000)
+    eng.populate(touch)
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+    got, want = eng.submit(req), o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+    _tatp_locks(eng, o)
+    ring, tail = eng.read_log(100_000)
+    assert tail == o.tail
+    assert (np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64) == o.ring).all()
+    st = eng.stats()
+    assert st["bad_requests"] + st["missing_keys"] == o.errors and st["pool_exhausted"] == 0
+    if well:
+        assert o.errors == 0
+
+
+def test_tatp_log_ring_wrap_and_small_ring():
+    """A ring smaller than a micro-batch: passes are clamped to the ring size, so DELETE_LOG records
+    (which keep the val bytes of the slot they overwrite) still match the serial reference."""
+    o = orc.TatpOracle(2000, log_entries=777, populate_n=20)
+    existing = [o.dump(t)[0] for t in range(5)]
+    req = tracegen.tatp_random(30_000, existing, seed=5, n_sub_touch=20)
+    eng = _engine(W.TATP, n_rows=2000, log_entries=777)
+    eng.populate(20)
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    ring, tail = eng.read_log(777)
+    assert tail == o.tail and (np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64) == o.ring).all()
+
+
+def test_tatp_full_population_1m_subscribers():
+    """BASELINE.json configs[3] size: 1M subscribers -- every row of all five tables equals the oracle's
+    restatement of tatp/udp/tatp.h:283-412, in bucket and chain order; then a 3x64k trace over it."""
+    n_sub = 1_000_000
+    eng = _engine(W.TATP, n_rows=n_sub)
+    eng.populate(n_sub)
+    o = orc.TatpOracle(n_sub)
+    existing = []
+    for t in range(5):
+        a, b = eng.dump_rows(t), o.dump(t)
+        assert _same_rows(a, b), t
+        existing.append(b[0][:4000])
+    assert eng.stats()["pool_exhausted"] == 0
+    rng = np.random.default_rng(1)
+    n = 3 * 65536
+    req = np.zeros(n, wire.TATP_MSG)
+    T = wire.Tatp
+    tb = rng.integers(0, 5, n)
+    for t in range(5):
+        sel = tb == t
+        pool = o.dump(t)[0]
+        req["key"][sel] = pool[rng.integers(0, len(pool), int(sel.sum()))]
+    req["table"] = tb
+    req["type"] = rng.choice([T.READ, T.ACQUIRE_LOCK, T.ABORT, T.COMMIT_PRIM, T.COMMIT_BCK, T.COMMIT_LOG], n,
+                             p=[0.5, 0.15, 0.05, 0.1, 0.1, 0.1])
+    req["val"] = rng.integers(0, 256, (n, 40), dtype=np.uint8)
+    req["ver"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype("<u4")
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    _tatp_locks(eng, o)
+
+
+# ---------------------------------------------------------------- smallbank
+def _sb_state(eng, o):
+    for t in range(2):
+        ex, sh = eng.read_locks(t)
+        assert (ex == o.num_ex(t)).all() and (sh == o.num_sh(t)).all()
+        assert _same_rows(eng.dump_rows(t), o.dump(t))
+
+
+def test_smallbank_golden_reference_sizes():
+    z, meta, req, rep = _golden("smallbank", wire.SB_MSG)
+    eng = _engine(W.SMALLBANK, n_rows=meta["n_acct"])
+    eng.populate(meta["touch"])
+    assert eng.submit(req).tobytes() == rep.tobytes()
+    tail_dump = z["dump_tail"].tobytes()
+    off = 0
+    for t in range(2):
+        cnt = int(np.frombuffer(tail_dump, "<u4", 1, off)[0]); off += 4
+        d = np.frombuffer(tail_dump, "<u4", cnt * 3, off).reshape(cnt, 3); off += 12 * cnt
+        ex, sh = eng.read_locks(t)
+        nz = np.nonzero(ex | sh)[0]
+        assert (d[:, 0] == nz).all() and (d[:, 1] == ex[nz]).all() and (d[:, 2] == sh[nz]).all()
+
+
+@pytest.mark.parametrize("n,n_acct,touch", [(1, 10_000, 40), (5000, 10_000, 40), (65536, 10_000, 3),
+                                            (200_000, 1_000_000, 5000), (65536, 10_000, 1)])
+def test_smallbank_vs_oracle(n, n_acct, touch):
+    req = tracegen.sb_random(n, seed=n + touch, n_acct_touch=touch)
+    req["type"][9::31] = 17  # WARMUP_READ: the udp server has no handler (Appendix B.6) -> counted, echoed
+    if n > 100:
+        req["key"][5::97] = 10**9  # lock + read of a missing account: the reference panics; counted
+    eng = _engine(W.SMALLBANK, n_rows=n_acct, log_entries=70_000)
+    eng.populate(touch)
+    o = orc.SmallbankOracle(n_acct, log_entries=70_000, populate_n=touch)
+    got, want = eng.submit(req), o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    _sb_state(eng, o)
+    ring, tail = eng.read_log(70_000)
+    assert tail == o.tail and (np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64) == o.ring).all()
+    st = eng.stats()
+    assert st["bad_requests"] + st["missing_keys"] == o.errors
+
+
+# ---------------------------------------------------------------- sharding on one GPU
+@pytest.mark.parametrize("wl", ["store", "tatp", "smallbank"])
+def test_two_shards_on_one_gpu_equal_one_server(wl):
+    """Two engines (shard 0/2 and 1/2) fed the requests they are home to, in order, answer exactly
+    like one unsharded server; requests sent to the wrong shard are left untouched and counted."""
+    import torch
+
+    if wl == "store":
+        req = tracegen.store_random(40_000, seed=3, n_sub_touch=200, p_set=0.4, p_insert=0.05)
+        mk = lambda **k: _engine(W.STORE, n_rows=5000, **k)
+        o = orc.StoreOracle(5000 * 18 // 4, 400); pop = 400
+    elif wl == "tatp":
+        o = orc.TatpOracle(5000, populate_n=300); pop = 300
+        req = tracegen.tatp_random(40_000, [o.dump(t)[0] for t in range(5)], seed=4, n_sub_touch=300)
+        T = wire.Tatp
+        req = req[(req["type"] != T.COMMIT_LOG) & (req["type"] != T.DELETE_LOG)]  # logs are per-shard rings
+        mk = lambda **k: _engine(W.TATP, n_rows=5000, **k)
+    else:
+        req = tracegen.sb_random(40_000, seed=5, n_acct_touch=300)
+        req = req[req["type"] != wire.Sb.COMMIT_LOG]
+        mk = lambda **k: _engine(W.SMALLBANK, n_rows=5000, **k)
+        o = orc.SmallbankOracle(5000, populate_n=300); pop = 300
+    want = o.replay(req)
+    shards = [mk(shard_index=i, shard_count=2) for i in range(2)]
+    for s in shards:
+        s.populate(pop)
+    d = torch.from_numpy(np.frombuffer(req.tobytes(), np.uint8).copy()).cuda()
+    home = torch.empty(len(req), dtype=torch.uint8, device="cuda")
+    shards[0].home_shard(d, len(req), home)
+    torch.cuda.synchronize()
+    home = home.cpu().numpy()
+    assert set(np.unique(home)) <= {0, 1} and 0.3 < home.mean() < 0.7
+    got = req.copy()
+    for i, s in enumerate(shards):
+        sel = home == i
+        got[sel] = s.submit(req[sel])
+        assert s.stats()["foreign_requests"] == 0
+    assert got.tobytes() == want.tobytes()
+    # wrong shard: untouched + counted
+    wrong = shards[0].submit(req[home == 1][:100])
+    assert wrong.tobytes() == req[home == 1][:100].tobytes()
+    assert shards[0].stats()["foreign_requests"] == 100
