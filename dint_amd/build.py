@@ -11,15 +11,18 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdint.so")
-SOURCES = ["engine.hip", "k_locks.hip", "k_log.hip", "k_kv.hip", "k_bench.hip"]
+SOURCES = ["engine.hip", "k_locks.hip", "k_log.hip", "k_kv.hip", "k_bench.hip", "txn_driver.cc"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SHIM = os.path.join(HERE, "dint_udp_server")
+ROCM_LIB = os.environ.get("ROCM_LIB", "/opt/rocm/lib")
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(SHIM):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "dint_abi.h")]
+    inc = os.path.join(HERE, "..", "include")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(inc, f) for f in os.listdir(inc)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -31,6 +34,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # the UDP host shim (plain C) links against the library it sits next to
+    shim = [os.environ.get("CC", "gcc"), "-std=gnu11", "-O2", "-Wall", "-o", SHIM, os.path.join(CSRC, "udp_shim.c"),
+            "-L" + HERE, "-ldint", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + ROCM_LIB, "-lpthread"]
+    if verbose:
+        print(" ".join(shim))
+    subprocess.check_call(shim)
     return LIB
 
 

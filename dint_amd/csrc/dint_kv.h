@@ -23,6 +23,7 @@ struct dint_kv {
   uint32_t workload = 0;
   uint32_t n_tables = 0;
   uint32_t val_size = 0;
+  int force_rounds = 0;  // DINT_FLAG_KV_ROUNDS: never use the closed-form same-key path (A/B and parity testing)
   uint64_t hash_size[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};  // global bucket counts
   kv_dev h{};                // host mirror (device pointers inside)
   kv_dev *d_dev = nullptr;   // device copy

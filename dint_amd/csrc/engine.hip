@@ -246,6 +246,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   if (wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
     rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard);
     if (rc) { dint_engine_destroy(e); return fail(rc, "kv table allocation failed (%s)", g_err.c_str()); }
+    e->kv.force_rounds = (cfg->flags & DINT_FLAG_KV_ROUNDS) ? 1 : 0;
     for (auto &r : dint_kv_regions(&e->kv)) add_region(e, r.first, r.second);
   }
 #undef TRY

@@ -306,11 +306,123 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
   }
 }
 
+
+// ---- same-key conflict group of one 64-chunk, resolved in closed form ------------------------------------
+// All lanes in `same` address ONE key (hence one bucket, one lock word) with ops that never change the chain
+// (no INSERT / DELETE).  The group's serial outcome depends only on a few words of state -- exists, version,
+// last writer, lock word -- so it is walked once in lane (= request) order with wave-uniform registers
+// (readlane of each member's op, ~15 instructions per request) instead of one memory round trip per request;
+// afterwards every lane fills its reply in parallel (a read takes its value from the message of the last
+// writer below it, or from the table) and the leader writes the final row / lock word back once.
+// Semantics per op: the same reference lines as kv_do_request.
+template <int WL>
+__device__ static inline bool kv_simple_op(uint32_t type) {
+  if (WL == DINT_WL_STORE) return type <= 1;                                   // READ, SET
+  if (WL == DINT_WL_TATP) return type <= 2 || type == 12 || type == 13;        // READ, ACQUIRE, ABORT, COMMIT_PRIM/BCK
+  return type <= 5;                                                            // every smallbank table op
+}
+
+template <int WL>
+__device__ static inline void kv_fast_group(uint64_t same, bool mine, int leader, uint8_t *rep, uint32_t idx,
+                                            uint32_t type, uint32_t table, uint32_t q, uint64_t bucket, uint64_t key,
+                                            const kv_dev *__restrict__ kv, dint_dev_stats *__restrict__ stats) {
+  using F = Fmt<WL>;
+  const uint32_t lane = lane_id();
+  // ---- leader: locate the row, read version and lock word
+  uint32_t found = 0, link = 0, slot = 0, ver0 = 0, la0 = 0, lb0 = 0;
+  const uint32_t ltable = __builtin_amdgcn_readlane(table, leader);
+  const kv_tab t = kv->tab[ltable];
+  const uint64_t lbucket = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bucket >> 32), leader) << 32) |
+                           __builtin_amdgcn_readlane((uint32_t)bucket, leader);
+  const uint32_t lq = __builtin_amdgcn_readlane(q, leader);
+  if ((int)lane == leader) {
+    kv_loc l;
+    if (kv_find(t, lbucket, key, &l)) {
+      found = 1; link = l.link; slot = l.slot;
+      ver0 = kv_entry_hdr(t, lbucket, l.link)->ver[l.slot];
+    }
+    if (WL == DINT_WL_TATP) la0 = kv_entry_hdr(t, lbucket, KV_INLINE)->lockb[lq];
+    if (WL == DINT_WL_SMALLBANK) {
+      const uint32_t *c = (const uint32_t *)(kv_entry_ptr(t, lbucket, KV_INLINE) + KV_SB_LOCK_OFF) + 2 * lq;
+      la0 = c[0]; lb0 = c[1];
+    }
+  }
+  found = __builtin_amdgcn_readlane(found, leader);
+  link = __builtin_amdgcn_readlane(link, leader);
+  slot = __builtin_amdgcn_readlane(slot, leader);
+  ver0 = __builtin_amdgcn_readlane(ver0, leader);
+  la0 = __builtin_amdgcn_readlane(la0, leader);
+  lb0 = __builtin_amdgcn_readlane(lb0, leader);
+
+  // ---- walk the group in request order; all state is wave-uniform
+  uint32_t ver = ver0, la = la0, lb = lb0, nmiss = 0;
+  int src = -1;                                  // lane of the last writer so far (-1: the table)
+  uint32_t my_code = 0, my_ver = 0, my_get = 0;  // my_get: this lane's reply carries val + ver
+  int my_src = -1;
+  for (uint64_t m = same; m; m &= m - 1) {
+    const int l = __ffsll((unsigned long long)m) - 1;
+    const uint32_t op = __builtin_amdgcn_readlane(type, l);
+    uint32_t code = 0, get = 0;
+    const uint32_t ver_seen = ver;
+    const int src_seen = src;
+    if (WL == DINT_WL_STORE) {
+      if (op == 0) { code = found ? 3 : 7; get = found; }
+      else { code = found ? 5 : 7; if (found) { ver++; src = l; } }
+    } else if (WL == DINT_WL_TATP) {
+      switch (op) {
+        case 0: code = found ? 4 : 6; get = found; break;
+        case 1: if (la == 0) { la = 1; code = 7; } else code = 8; break;
+        case 2: la = 0; code = 9; break;
+        case 12: if (found) { ver++; src = l; } else nmiss++; la = 0; code = 15; break;
+        default: if (found) { ver++; src = l; } else nmiss++; code = 16; break;  // 13 kCommitBck
+      }
+    } else {
+      switch (op) {  // la = num_ex, lb = num_sh
+        case 0: if (la == 0) { lb++; code = 7; get = found; if (!found) nmiss++; } else code = 8; break;
+        case 1: if (la == 0 && lb == 0) { la++; code = 9; get = found; if (!found) nmiss++; } else code = 10; break;
+        case 2: lb--; code = 11; break;
+        case 3: la--; code = 12; break;
+        case 4: if (found) { ver++; src = l; } else nmiss++; code = 13; break;
+        default: if (found) { ver++; src = l; } else nmiss++; code = 14; break;  // 5 kCommitBck
+      }
+    }
+    if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
+  }
+
+  // ---- replies, all lanes in parallel
+  const uint32_t src_idx = __shfl(idx, my_src >= 0 ? my_src : (int)lane, 64);
+  const uint32_t fin_idx = __shfl(idx, src >= 0 ? src : (int)lane, 64);
+  uint8_t *row = kv_entry_ptr(t, lbucket, link) + KV_VAL_OFF + slot * F::VS;
+  if (mine) {
+    uint8_t *msg = rep + (size_t)idx * F::MSG;
+    if (my_get) {
+      const uint8_t *from = my_src >= 0 ? rep + (size_t)src_idx * F::MSG + F::VAL : row;
+      kv_copy_words(msg + F::VAL, from, F::VS);
+      st_u32(msg + F::VER, my_ver);
+    }
+    msg[F::TYPE] = (uint8_t)my_code;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the table reads above precede the write-back below
+  // ---- final state, written once by the leader
+  if ((int)lane == leader) {
+    if (src >= 0) {
+      kv_copy_words(row, rep + (size_t)fin_idx * F::MSG + F::VAL, F::VS);
+      kv_entry_hdr(t, lbucket, link)->ver[slot] = ver;
+    }
+    if (WL == DINT_WL_TATP && la != la0) kv_entry_hdr(t, lbucket, KV_INLINE)->lockb[lq] = (uint8_t)la;
+    if (WL == DINT_WL_SMALLBANK && (la != la0 || lb != lb0)) {
+      uint32_t *c = (uint32_t *)(kv_entry_ptr(t, lbucket, KV_INLINE) + KV_SB_LOCK_OFF) + 2 * lq;
+      c[0] = la; c[1] = lb;
+    }
+    if (nmiss) atomicAdd(&stats->missing_keys, (unsigned long long)nmiss);
+  }
+}
+
 // ---- k_kv_resolve ----------------------------------------------------------------------------------------
 template <int WL>
 __global__ void __launch_bounds__(64)
 k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats) {
+             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int kv_force_rounds) {
   using F = Fmt<WL>;
   __shared__ dint_rank_lds R;
   __shared__ uint32_t Srec[DINT_WCAP];  // idx | hash entry << 16, in request order
@@ -350,21 +462,32 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *
       if (valid) atomicAdd(&Hfl[e], 1u);
       __syncthreads();
       const uint32_t cnt = valid ? Hfl[e] : 0;
-      // position of this lane among the chunk's requests on the same bucket, in request (= lane) order
+      const uint64_t bucket = valid ? (uint64_t)(Hk[e] - kv->gk_base[table]) : 0;
+      const uint64_t key = valid ? ld_u64(rep + (size_t)idx * F::MSG + F::KEY) : 0;
+      // Buckets hit by several lanes of the chunk.  A group whose lanes all address one key with
+      // chain-preserving ops is resolved in closed form (kv_fast_group); any other group runs in rounds:
+      // its k-th request, in request (= lane) order, executes in round k.
       uint32_t pos = 0, maxpos = 0;
+      bool rounds = valid && cnt == 1;  // the only request of the chunk on its bucket: round 0
       uint64_t conf = __ballot(valid && cnt > 1);
       while (conf) {
         const int leader = __ffsll((unsigned long long)conf) - 1;
         const uint32_t se = __builtin_amdgcn_readlane(e, leader);
         const bool mine = valid && e == se;
         const uint64_t same = __ballot(mine);
-        if (mine) pos = (uint32_t)__popcll(same & lanemask_lt());
-        maxpos = max(maxpos, (uint32_t)__popcll(same) - 1u);
+        const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(key >> 32), leader) << 32) |
+                            __builtin_amdgcn_readlane((uint32_t)key, leader);
+        const bool simple = __ballot(mine && !(key == k0 && kv_simple_op<WL>(type))) == 0 && !kv_force_rounds;
+        if (simple) {
+          kv_fast_group<WL>(same, mine, leader, rep, idx, type, table, q, bucket, key, kv, stats);
+        } else {
+          if (mine) { pos = (uint32_t)__popcll(same & lanemask_lt()); rounds = true; }
+          maxpos = max(maxpos, (uint32_t)__popcll(same) - 1u);
+        }
         conf &= ~same;
       }
-      const uint64_t bucket = valid ? (uint64_t)(Hk[e] - kv->gk_base[table]) : 0;
       for (uint32_t r = 0; r <= maxpos; r++) {
-        if (valid && pos == r) kv_do_request<WL>(rep + (size_t)idx * F::MSG, type, table, q, bucket, kv, stats);
+        if (rounds && pos == r) kv_do_request<WL>(rep + (size_t)idx * F::MSG, type, table, q, bucket, kv, stats);
         // the next round (and the next chunk) must see this round's stores
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       }
@@ -390,7 +513,7 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
                      kv.d_dev, log, (const uint32_t *)s.blk_cnt, P - 1, s.bin_cnt, s.bins, s.stats, load_mode);
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
-                     (const uint64_t *)s.bins, s.stats);
+                     (const uint64_t *)s.bins, s.stats, kv.force_rounds);
   if (ev) hipEventRecord(ev[2], st);
 }
 

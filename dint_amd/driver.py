@@ -1,0 +1,105 @@
+"""ctypes binding of the closed-loop transaction drivers (include/dint_driver.h, csrc/txn_driver.cc).
+
+A :class:`Driver` plays W reference clients in lock step: ``next()`` returns the three per-shard
+request batches of one epoch (numpy arrays of packed wire structs), ``consume(replies)`` feeds the
+servers' replies back.  :func:`run_epochs` wires a driver to three servers (GPU engines, or any
+object with ``submit``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .wire import MSG_DTYPE, Workload
+
+N_SHARDS = 3
+
+
+class DriverConfig(C.Structure):
+    _fields_ = [("workload", C.c_uint32), ("n_clients", C.c_uint32), ("n_rows", C.c_uint64),
+                ("first_client", C.c_uint32), ("key_dist", C.c_uint32), ("zipf_theta", C.c_double),
+                ("reserved", C.c_uint32 * 8)]
+
+
+class DriverStats(C.Structure):
+    _fields_ = [("txns", C.c_uint64), ("committed", C.c_uint64), ("messages", C.c_uint64),
+                ("by_type", C.c_uint64 * 8), ("committed_by_type", C.c_uint64 * 8), ("epochs", C.c_uint64)]
+
+
+def _bind():
+    L = _lib.load()
+    if getattr(L, "_driver_bound", False):
+        return L
+    vp, u32 = C.c_void_p, C.c_uint32
+    L.dint_driver_create.restype, L.dint_driver_create.argtypes = C.c_int, [C.POINTER(DriverConfig), C.POINTER(vp)]
+    L.dint_driver_destroy.restype, L.dint_driver_destroy.argtypes = None, [vp]
+    L.dint_driver_msg_size.restype, L.dint_driver_msg_size.argtypes = C.c_int, [vp]
+    L.dint_driver_next.restype, L.dint_driver_next.argtypes = C.c_int, [vp, C.POINTER(u32 * N_SHARDS)]
+    L.dint_driver_batch.restype, L.dint_driver_batch.argtypes = vp, [vp, u32]
+    L.dint_driver_consume.restype, L.dint_driver_consume.argtypes = C.c_int, [vp, C.POINTER(vp * N_SHARDS)]
+    L.dint_driver_get_stats.restype, L.dint_driver_get_stats.argtypes = C.c_int, [vp, C.POINTER(DriverStats)]
+    L._driver_bound = True
+    return L
+
+
+class Driver:
+    def __init__(self, workload: Workload, n_clients: int, n_rows: int, *, first_client: int = 0,
+                 zipf_theta: float | None = None):
+        self._L = _bind()
+        self.workload = Workload(workload)
+        self.dtype = MSG_DTYPE[self.workload]
+        cfg = DriverConfig(workload=int(workload), n_clients=n_clients, n_rows=n_rows, first_client=first_client,
+                           key_dist=0 if zipf_theta is None else 1, zipf_theta=zipf_theta or 0.0)
+        h = C.c_void_p()
+        rc = self._L.dint_driver_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise _lib.DintError(f"dint_driver_create failed: {rc}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dint_driver_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def next(self):
+        """Requests of the next epoch: list of 3 numpy arrays (copies) of packed wire structs."""
+        cnt = (C.c_uint32 * N_SHARDS)()
+        _lib.check(self._L.dint_driver_next(self._h, C.byref(cnt)))
+        out = []
+        for s in range(N_SHARDS):
+            n = cnt[s]
+            if n == 0:
+                out.append(np.zeros(0, self.dtype))
+                continue
+            p = self._L.dint_driver_batch(self._h, s)
+            buf = (C.c_uint8 * (n * self.dtype.itemsize)).from_address(p)
+            out.append(np.frombuffer(buf, self.dtype, n).copy())
+        return out
+
+    def consume(self, replies):
+        keep = [np.ascontiguousarray(r) for r in replies]
+        ptrs = (C.c_void_p * N_SHARDS)(*[r.ctypes.data if len(r) else None for r in keep])
+        _lib.check(self._L.dint_driver_consume(self._h, C.byref(ptrs)))
+
+    def stats(self) -> dict:
+        s = DriverStats()
+        _lib.check(self._L.dint_driver_get_stats(self._h, C.byref(s)))
+        return {"txns": s.txns, "committed": s.committed, "messages": s.messages, "epochs": s.epochs,
+                "by_type": list(s.by_type), "committed_by_type": list(s.committed_by_type)}
+
+
+def run_epochs(driver: Driver, servers, n_epochs: int, record: bool = False):
+    """Closed loop: `servers` = 3 objects with submit(ndarray) -> ndarray (one per shard).
+    Returns the recorded [(requests[3], replies[3])] per epoch when record=True."""
+    trace = []
+    for _ in range(n_epochs):
+        req = driver.next()
+        rep = [servers[s].submit(req[s]) if len(req[s]) else req[s] for s in range(N_SHARDS)]
+        driver.consume(rep)
+        if record:
+            trace.append((req, rep))
+    return trace

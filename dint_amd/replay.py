@@ -1,0 +1,121 @@
+"""Record / replay of closed-loop transaction traffic against a group of three shard servers.
+
+The reference deployment is three `server_shard <id>` processes (tatp/udp/server_shard.cc:279-285),
+3-way replicated.  A :class:`ShardGroup` is those three servers on one GPU (three engines, each on
+its own HIP stream so their kernel chains overlap) -- or, with world > 1, on N GPUs: every logical
+shard server is hash-partitioned over the ranks and fronted by a :class:`ShardedEngine`.
+
+`record()` runs a :class:`Driver` closed loop through the group and keeps every epoch's per-shard
+request and reply batches; `Replay` uploads them to HBM and re-submits them without any host work,
+which is what bench.py times (inputs resident in HBM when the timed region starts).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .driver import N_SHARDS, Driver
+from .engine import Engine
+from .sharded import ShardedEngine
+from .wire import Workload
+
+
+class ShardGroup:
+    def __init__(self, workload: Workload, n_rows: int, *, device: int = -1, rank: int = 0, world: int = 1,
+                 log_entries: int = 0, populate: Optional[int] = None):
+        self.workload, self.world, self.rank = Workload(workload), world, rank
+        self.engines = [Engine(workload, n_rows=n_rows, device=device, shard_index=rank, shard_count=world,
+                               log_entries=log_entries) for _ in range(N_SHARDS)]
+        self.msg = self.engines[0].msg_size
+        self.sharded = [ShardedEngine(e, world, rank) for e in self.engines] if world > 1 else None
+        for e in self.engines:  # every server holds every row (tatp/udp/server_shard.cc:71-85)
+            e.populate(n_rows if populate is None else populate)
+
+    # ---- host path (recording) ----------------------------------------------------------------------
+    def submit(self, reqs: List[np.ndarray]) -> List[np.ndarray]:
+        if self.sharded is None:
+            return [self.engines[s].submit(reqs[s]) if len(reqs[s]) else reqs[s] for s in range(N_SHARDS)]
+        out = []
+        for s in range(N_SHARDS):  # every rank must enter the collectives, also with an empty batch
+            n = len(reqs[s])
+            d = torch.from_numpy(np.frombuffer(reqs[s].tobytes(), np.uint8).copy()).cuda()
+            r = torch.empty_like(d)
+            self.sharded[s].submit_device(d, n, r)
+            out.append(np.frombuffer(r.cpu().numpy().tobytes(), reqs[s].dtype))
+        return out
+
+    # ---- device path (replay) --------------------------------------------------------------------------
+    def submit_device(self, d_reqs, counts, d_reps) -> None:
+        """d_reqs / d_reps: per shard uint8 tensors; asynchronous.  Single GPU: each engine runs on its own
+        stream (the three shard servers are independent).  Multi GPU: routed on torch's current stream."""
+        if self.sharded is None:
+            for s in range(N_SHARDS):
+                if counts[s]:
+                    self.engines[s].submit_device(d_reqs[s], counts[s], d_reps[s], 0)
+        else:
+            for s in range(N_SHARDS):
+                self.sharded[s].submit_device(d_reqs[s], counts[s], d_reps[s])
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+        torch.cuda.synchronize()
+
+    def snapshot(self):
+        for e in self.engines:
+            e.snapshot()
+
+    def restore(self):
+        for e in self.engines:
+            e.restore()
+
+
+def record(driver: Driver, group, n_epochs: int):
+    """Closed loop for n_epochs; returns (trace, finished_txns_per_epoch) with
+    trace[e] = (requests[3], replies[3]) as numpy arrays."""
+    trace, done = [], []
+    last = driver.stats()["txns"]
+    for _ in range(n_epochs):
+        req = driver.next()
+        rep = group.submit(req)
+        driver.consume(rep)
+        trace.append((req, rep))
+        now = driver.stats()["txns"]  # transactions whose last reply arrived in this epoch
+        done.append(now - last)
+        last = now
+    return trace, done
+
+
+class Replay:
+    """A recorded trace resident in HBM."""
+
+    def __init__(self, trace, msg_size: int):
+        self.msg = msg_size
+        self.counts = [[len(req[s]) for s in range(N_SHARDS)] for req, _ in trace]
+        self.d_req, self.d_rep, self.want = [], [], []
+        for req, rep in trace:
+            self.d_req.append([torch.from_numpy(np.frombuffer(req[s].tobytes(), np.uint8).copy()).cuda()
+                               for s in range(N_SHARDS)])
+            self.d_rep.append([torch.empty(len(req[s]) * msg_size, dtype=torch.uint8, device="cuda")
+                               for s in range(N_SHARDS)])
+            self.want.append([rep[s].tobytes() for s in range(N_SHARDS)])
+
+    def __len__(self):
+        return len(self.counts)
+
+    def run(self, group: ShardGroup, lo: int, hi: int) -> None:
+        for e in range(lo, hi):
+            group.submit_device(self.d_req[e], self.counts[e], self.d_rep[e])
+
+    def check(self, lo: int, hi: int) -> None:
+        """The replayed replies must equal the recorded ones byte for byte."""
+        for e in range(lo, hi):
+            for s in range(N_SHARDS):
+                got = self.d_rep[e][s].cpu().numpy().tobytes()
+                if got != self.want[e][s]:
+                    raise AssertionError(f"replay diverged from the recorded run at epoch {e}, shard {s}")
+
+    def ops(self, lo: int, hi: int) -> int:
+        return sum(sum(c) for c in self.counts[lo:hi])

@@ -41,6 +41,10 @@ extern "C" {
 
 #define DINT_ABI_VERSION 1
 
+/* dint_config.flags */
+#define DINT_FLAG_KV_ROUNDS 1u /* kv workloads: resolve same-key conflicts request by request instead of in
+                                  closed form (slow; identical results -- used for A/B runs and parity tests) */
+
 /* workloads (dint_config.workload) */
 enum {
   DINT_WL_FASST = 0,     /* lock_fasst: 9-byte {u8 type; u32 lid; u32 ver}            net.h:23-29 */
@@ -70,7 +74,7 @@ typedef struct dint_config {
   uint32_t abi_version;  /* DINT_ABI_VERSION */
   uint32_t workload;     /* DINT_WL_* */
   int32_t device;        /* HIP device ordinal; -1 = current device */
-  uint32_t flags;        /* reserved, 0 */
+  uint32_t flags;        /* DINT_FLAG_* */
   /* FASST / 2PL: number of lock slots; slot = fasthash64(lid,4,0xdeadbeef) % n_slots.
    * 0 = the reference's 36,000,000 (lock_fasst/udp/utils.h:12). */
   uint64_t n_slots;

@@ -1,0 +1,72 @@
+/*
+ * dint_driver.h -- C ABI of the closed-loop transaction drivers (the CALLER of the hot path).
+ *
+ * The reference's load generators are Caladan programs, one uthread per client, each running
+ * complete OCC / 2PL transactions against three replicated shard servers
+ * (tatp/caladan/client_udp_shard.cc:177-1185, smallbank/caladan/client_udp_shard.cc:169-1240).
+ * They cannot be built here (DPDK / rdma-core / SPDK submodules are not vendored), and no NIC can
+ * offer the > 100 M requests/s one MI355X absorbs, so the same transaction state machines are
+ * restated here as a deterministic, epoch-synchronous driver:
+ *
+ *   - W virtual clients, client g seeded 0xdeadbeef + g exactly as ClientLoop does (:1122);
+ *   - a transaction is a sequence of PHASES; the messages of one phase are sent together (the
+ *     reference sends them from one uthread per shard and joins) and all replies are awaited;
+ *   - one EPOCH = every client emits the messages of its current phase; the messages addressed to
+ *     shard s (s = key % 3 for reads / locks / primary ops, (s+1)%3 and (s+2)%3 for backups, all three
+ *     for logs -- client_udp_shard.cc:187,493-531) form batch s, ordered by client id then send order;
+ *     the three shard servers answer; every client consumes its replies and moves on.
+ *
+ * The driver owns no sockets and no GPU state: the caller carries the batches to the servers
+ * (dint_submit of three engines, or the CPU oracle in tests) and hands the replies back.
+ */
+#ifndef DINT_DRIVER_H
+#define DINT_DRIVER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINT_N_SHARDS 3 /* the reference's deployment: 3 servers, 3-way replication */
+
+typedef struct dint_driver dint_driver_t;
+
+typedef struct dint_driver_config {
+  uint32_t workload;      /* DINT_WL_TATP or DINT_WL_SMALLBANK */
+  uint32_t n_clients;     /* W */
+  uint64_t n_rows;        /* subscribers (tatp) / accounts (smallbank) the keys are drawn from */
+  uint32_t first_client;  /* global id of client 0 (seed = 0xdeadbeef + first_client + i) */
+  /* key distribution: 0 = the reference's own (tatp_nurand, tatp/caladan/tatp.h:40-43; smallbank hot/cold
+   * picker, smallbank.h:30-50); 1 = Zipf(theta) over the rows (BASELINE.json's stress distribution) */
+  uint32_t key_dist;
+  double zipf_theta;
+  uint32_t reserved[8];
+} dint_driver_config;
+
+typedef struct dint_driver_stats {
+  uint64_t txns;          /* finished transactions (committed or not) = the reference's "throughput" count */
+  uint64_t committed;     /* = "goodput" */
+  uint64_t messages;      /* requests emitted */
+  uint64_t by_type[8];    /* finished, per transaction type */
+  uint64_t committed_by_type[8];
+  uint64_t epochs;
+} dint_driver_stats;
+
+int dint_driver_create(const dint_driver_config *cfg, dint_driver_t **out);
+void dint_driver_destroy(dint_driver_t *d);
+/* wire message size of the driver's workload (55 / 23) */
+int dint_driver_msg_size(const dint_driver_t *d);
+/* Emit the next epoch.  counts[s] receives the number of messages for shard s; the messages stay in
+ * driver-owned buffers returned by dint_driver_batch.  Must alternate with dint_driver_consume. */
+int dint_driver_next(dint_driver_t *d, uint32_t counts[DINT_N_SHARDS]);
+/* request batch of shard s for the current epoch (valid until the next dint_driver_next) */
+const void *dint_driver_batch(dint_driver_t *d, uint32_t shard);
+/* hand back the replies (same order, same count as the batches) and advance every client */
+int dint_driver_consume(dint_driver_t *d, const void *const replies[DINT_N_SHARDS]);
+int dint_driver_get_stats(const dint_driver_t *d, dint_driver_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINT_DRIVER_H */

@@ -315,3 +315,33 @@ def test_two_shards_on_one_gpu_equal_one_server(wl):
     wrong = shards[0].submit(req[home == 1][:100])
     assert wrong.tobytes() == req[home == 1][:100].tobytes()
     assert shards[0].stats()["foreign_requests"] == 100
+
+
+# ---------------------------------------------------------------- closed-form vs request-by-request resolution
+@pytest.mark.parametrize("flags", [0, 1])  # 1 = DINT_FLAG_KV_ROUNDS
+def test_hot_key_paths_agree_with_oracle(flags):
+    """Zipf-like traffic puts hundreds of requests of a pass on one key.  Both resolution strategies of the
+    resolve kernel (closed-form same-key groups; one round per request) must give the serial answer."""
+    # store: 12 keys, 70% SET
+    req = tracegen.store_random(30_000, seed=31, n_sub_touch=1, p_set=0.7, p_missing=0.05)
+    eng = _engine(W.STORE, n_rows=1000, flags=flags)
+    eng.populate(2)
+    o = orc.StoreOracle(4500, 2)
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    assert _same_rows(eng.dump_rows(0), o.dump())
+    # tatp: 3 subscribers, every request type incl. insert/delete (which force the round path for their bucket)
+    o = orc.TatpOracle(2000, log_entries=100_000, populate_n=3)
+    req = tracegen.tatp_random(40_000, [o.dump(t)[0] for t in range(5)], seed=32, n_sub_touch=3)
+    eng = _engine(W.TATP, n_rows=2000, log_entries=100_000, flags=flags)
+    eng.populate(3)
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t))
+    _tatp_locks(eng, o)
+    # smallbank: 2 accounts
+    req = tracegen.sb_random(40_000, seed=33, n_acct_touch=2)
+    eng = _engine(W.SMALLBANK, n_rows=10_000, log_entries=100_000, flags=flags)
+    eng.populate(2)
+    o = orc.SmallbankOracle(10_000, log_entries=100_000, populate_n=2)
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    _sb_state(eng, o)

@@ -1,0 +1,103 @@
+"""The UDP host shim (dint_amd/csrc/udp_shim.c) end to end on the GPU box: real datagrams in the
+reference's wire format over loopback, replies compared with the CPU oracle; plus the port+1
+CPU-usage echo the reference clients query at the end of a run."""
+import os
+import signal
+import socket
+import struct
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+import tracegen
+from dint_amd import wire
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SERVER = os.path.join(ROOT, "dint_amd", "dint_udp_server")
+
+
+def _free_udp_port():
+    while True:
+        s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s.close()
+        if p % 2 == 0 and p < 65000:
+            return p
+
+
+class Server:
+    def __init__(self, *args):
+        self.port = _free_udp_port()
+        self.p = subprocess.Popen([SERVER, "--bind", "127.0.0.1", "--port", str(self.port), *args],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        line = self.p.stdout.readline()
+        assert "ready" in line, (line, self.p.stderr.read() if self.p.poll() is not None else "")
+
+    def stop(self):
+        self.p.send_signal(signal.SIGTERM)
+        out, _ = self.p.communicate(timeout=20)
+        return out
+
+
+def _exchange(port, req, window):
+    """Closed loop over one socket: `window` datagrams out, `window` replies back, in order."""
+    c = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    c.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 8 << 20)
+    c.settimeout(10)
+    size = req.dtype.itemsize
+    raw = req.tobytes()
+    out = bytearray()
+    for lo in range(0, len(req), window):
+        hi = min(len(req), lo + window)
+        for i in range(lo, hi):
+            c.sendto(raw[i * size:(i + 1) * size], ("127.0.0.1", port))
+        for _ in range(lo, hi):
+            d, _ = c.recvfrom(256)
+            assert len(d) == size
+            out += d
+    c.close()
+    return np.frombuffer(bytes(out), req.dtype)
+
+
+def test_shim_lock_fasst_over_loopback():
+    srv = Server("--workload", "fasst", "--slots", str(1 << 20), "--batch", "512", "--deadline-us", "200")
+    try:
+        req = tracegen.fasst_random(20_000, seed=41, n_hot=8, p_hot=0.8)
+        got = _exchange(srv.port, req, 300)
+        assert got.tobytes() == orc.FasstOracle(1 << 20).replay(req).tobytes()
+        # a datagram of the wrong size is dropped, the server keeps serving
+        c = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        c.sendto(b"\x00" * 5, ("127.0.0.1", srv.port))
+        c.close()
+        more = tracegen.fasst_random(100, seed=42)
+        o = orc.FasstOracle(1 << 20)
+        o.replay(req)
+        assert _exchange(srv.port, more, 50).tobytes() == o.replay(more).tobytes()
+    finally:
+        out = srv.stop()
+    assert "requests=20100" in out and "dropped=1" in out
+
+
+def test_shim_tatp_over_loopback_and_cpu_monitor():
+    n_sub, touch = 2000, 40
+    srv = Server("--workload", "tatp", "--rows", str(n_sub), "--populate", str(touch), "--batch", "1024")
+    try:
+        o = orc.TatpOracle(n_sub, populate_n=touch)
+        req = tracegen.tatp_random(15_000, [o.dump(t)[0] for t in range(5)], seed=43, n_sub_touch=touch)
+        got = _exchange(srv.port, req, 500)
+        assert got.tobytes() == o.replay(req).tobytes()
+        # port + 1: 16 bytes in, {double ucores, double kcores} out (tatp/caladan/client_udp_shard.cc:75-92)
+        c = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        c.settimeout(5)
+        c.sendto(b"\x00" * 16, ("127.0.0.1", srv.port + 1))
+        d, _ = c.recvfrom(64)
+        c.close()
+        u, k = struct.unpack("<dd", d)
+        assert len(d) == 16 and 0 <= u < 256 and 0 <= k < 256
+    finally:
+        srv.stop()
