@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #define DINT_MICRO 65536u          // max requests per kernel pass (idx fits 16 bits)
-#define DINT_PMAX 1024u            // max bins per pass
+#define DINT_PMAX 2048u            // max bins per pass
 #define DINT_WCAP 512u             // records resolved per window inside one bin
 #define DINT_HSIZE 1024u           // LDS hash slots per window (2 x WCAP)
 #define DINT_EMPTY 0xFFFFFFFFu

@@ -26,9 +26,10 @@ struct dint_shard {
 };
 
 static inline uint32_t dint_pick_bins(uint32_t n) {
-  // ~64 records per bin (one wave resolves one bin), power of two, <= DINT_PMAX
+  // ~32 records per bin on average, so that almost every bin fits one 64-lane chunk (one wave resolves one
+  // bin); power of two, <= DINT_PMAX
   uint32_t p = 1;
-  while (p < DINT_PMAX && p * 64u < n) p <<= 1;
+  while (p < DINT_PMAX && p * 32u < n) p <<= 1;
   return p;
 }
 

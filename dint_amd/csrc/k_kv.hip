@@ -13,12 +13,15 @@
 //                  either append the canonical 64-byte log record at ring position
 //                  tail + (#log requests below i)   [deterministic: an exclusive scan, not an atomic], or
 //                  append a {bucket group, idx, type, table|quadrant} record to bin = group & (P-1).
-//   k_kv_resolve : one wave per bin -- restore request order (bitmap rank over idx), group the window's
-//                  records by bucket in an LDS hash, then walk them 64 at a time in request order.  Lanes
-//                  whose bucket is unique in their chunk run in round 0; the k-th request of a bucket that
-//                  several lanes of the chunk hit runs in round k, with a workgroup fence between rounds, so
-//                  every request sees the table exactly as the serial reference would.  The table itself is
-//                  the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
+//   k_kv_resolve : one wave per bin.  A bin of <= 64 records (the common case: ~32 per bin) is sorted by
+//                  (bucket group, idx) in registers and handled as one chunk.  Larger bins (hot keys) restore
+//                  request order with a bitmap rank over idx, group each window of 512 records by bucket in
+//                  an LDS hash and walk it 64 at a time.  Inside a chunk, lanes whose bucket is unique run at
+//                  once; several requests on ONE key are resolved in closed form (ballots: version = v0 +
+//                  #writers below, value = message of the last writer below, lock = last lock op below); any
+//                  other same-bucket group runs in rounds (k-th request in round k, workgroup fence between
+//                  rounds), so every request sees the table exactly as the serial reference would.  The table
+//                  is the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -310,8 +313,8 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
 // ---- same-key conflict group of one 64-chunk, resolved in closed form ------------------------------------
 // All lanes in `same` address ONE key (hence one bucket, one lock word) with ops that never change the chain
 // (no INSERT / DELETE).  The group's serial outcome depends only on a few words of state -- exists, version,
-// last writer, lock word -- so it is walked once in lane (= request) order with wave-uniform registers
-// (readlane of each member's op, ~15 instructions per request) instead of one memory round trip per request;
+// last writer, lock word -- which every lane derives for its own position from ballots (store / tatp) or from
+// one wave-uniform walk over the group (smallbank counters) instead of one memory round trip per request;
 // afterwards every lane fills its reply in parallel (a read takes its value from the message of the last
 // writer below it, or from the table) and the leader writes the final row / lock word back once.
 // Semantics per op: the same reference lines as kv_do_request.
@@ -354,29 +357,51 @@ __device__ static inline void kv_fast_group(uint64_t same, bool mine, int leader
   la0 = __builtin_amdgcn_readlane(la0, leader);
   lb0 = __builtin_amdgcn_readlane(lb0, leader);
 
-  // ---- walk the group in request order; all state is wave-uniform
+  // ---- outcome of every request of the group
   uint32_t ver = ver0, la = la0, lb = lb0, nmiss = 0;
-  int src = -1;                                  // lane of the last writer so far (-1: the table)
+  int src = -1;                                  // lane of the group's last writer (-1: none, the table stands)
   uint32_t my_code = 0, my_ver = 0, my_get = 0;  // my_get: this lane's reply carries val + ver
   int my_src = -1;
-  for (uint64_t m = same; m; m &= m - 1) {
-    const int l = __ffsll((unsigned long long)m) - 1;
-    const uint32_t op = __builtin_amdgcn_readlane(type, l);
-    uint32_t code = 0, get = 0;
-    const uint32_t ver_seen = ver;
-    const int src_seen = src;
+  if (WL != DINT_WL_SMALLBANK) {
+    // store / tatp: closed form with ballots.  A row is rewritten by every SET / COMMIT_* (found rows only), so
+    //   version seen by lane l = ver0 + #writers below l,   value seen = message of the last writer below l;
+    // the tatp lock byte is rewritten by ACQUIRE (to 1, granted or not), ABORT and COMMIT_PRIM (to 0), so
+    //   lock seen by lane l = what the last of those below l wrote, else the stored byte.
+    const bool writer = mine && (WL == DINT_WL_STORE ? type == 1 : (type == 12 || type == 13));
+    const uint64_t m_wr = found ? __ballot(writer) : 0;
+    const uint64_t lt = lanemask_lt();
+    const uint64_t wr_below = m_wr & lt;
+    my_ver = ver0 + (uint32_t)__popcll(wr_below);
+    my_src = wr_below ? 63 - __clzll(wr_below) : -1;
+    ver = ver0 + (uint32_t)__popcll(m_wr);
+    src = m_wr ? 63 - __clzll(m_wr) : -1;
     if (WL == DINT_WL_STORE) {
-      if (op == 0) { code = found ? 3 : 7; get = found; }
-      else { code = found ? 5 : 7; if (found) { ver++; src = l; } }
-    } else if (WL == DINT_WL_TATP) {
-      switch (op) {
-        case 0: code = found ? 4 : 6; get = found; break;
-        case 1: if (la == 0) { la = 1; code = 7; } else code = 8; break;
-        case 2: la = 0; code = 9; break;
-        case 12: if (found) { ver++; src = l; } else nmiss++; la = 0; code = 15; break;
-        default: if (found) { ver++; src = l; } else nmiss++; code = 16; break;  // 13 kCommitBck
-      }
+      my_code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
+      my_get = (type == 0 && found) ? 1 : 0;
     } else {
+      const uint64_t m_lk = __ballot(mine && (type == 1 || type == 2 || type == 12));
+      const uint64_t m_acq = __ballot(mine && type == 1);
+      const uint64_t lk_below = m_lk & lt;
+      const uint32_t lock_seen = lk_below ? (uint32_t)((m_acq >> (63 - __clzll(lk_below))) & 1ull) : la0;
+      if (m_lk) la = (uint32_t)((m_acq >> (63 - __clzll(m_lk))) & 1ull);
+      if (!found) nmiss = (uint32_t)__popcll(__ballot(writer));
+      switch (type) {
+        case 0: my_code = found ? 4 : 6; my_get = found; break;
+        case 1: my_code = lock_seen ? 8 : 7; break;
+        case 2: my_code = 9; break;
+        case 12: my_code = 15; break;
+        default: my_code = 16; break;  // 13 kCommitBck
+      }
+    }
+  } else {
+    // smallbank: the shared / exclusive counters have no closed form (a grant depends on both running
+    // counts), so the group is walked once in request order with wave-uniform registers
+    for (uint64_t m = same; m; m &= m - 1) {
+      const int l = __ffsll((unsigned long long)m) - 1;
+      const uint32_t op = __builtin_amdgcn_readlane(type, l);
+      uint32_t code = 0, get = 0;
+      const uint32_t ver_seen = ver;
+      const int src_seen = src;
       switch (op) {  // la = num_ex, lb = num_sh
         case 0: if (la == 0) { lb++; code = 7; get = found; if (!found) nmiss++; } else code = 8; break;
         case 1: if (la == 0 && lb == 0) { la++; code = 9; get = found; if (!found) nmiss++; } else code = 10; break;
@@ -385,8 +410,8 @@ __device__ static inline void kv_fast_group(uint64_t same, bool mine, int leader
         case 4: if (found) { ver++; src = l; } else nmiss++; code = 13; break;
         default: if (found) { ver++; src = l; } else nmiss++; code = 14; break;  // 5 kCommitBck
       }
+      if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
     }
-    if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
   }
 
   // ---- replies, all lanes in parallel
@@ -418,12 +443,66 @@ __device__ static inline void kv_fast_group(uint64_t same, bool mine, int leader
   }
 }
 
+// ---- one 64-chunk of a bin's requests, in request order ---------------------------------------------------
+// grp identifies the bucket group of a lane within this chunk (equal grp <=> same bucket); `shared` says that
+// another lane of the chunk has the same grp.  A shared group whose lanes all address one key with
+// chain-preserving ops is resolved in closed form (kv_fast_group); any other shared group runs in rounds:
+// its k-th request, in request (= lane) order, executes in round k.  Unshared lanes run in round 0.
+template <int WL>
+__device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t grp, bool shared, uint32_t gk,
+                                       uint32_t type, uint32_t table, uint32_t q, const kv_dev *__restrict__ kv,
+                                       dint_dev_stats *__restrict__ stats, int force_rounds) {
+  using F = Fmt<WL>;
+  const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
+  const uint64_t key = valid ? ld_u64(rep + (size_t)idx * F::MSG + F::KEY) : 0;
+  uint32_t pos = 0, maxpos = 0;
+  bool rounds = valid && !shared;
+  uint64_t conf = __ballot(valid && shared);
+  while (conf) {
+    const int leader = __ffsll((unsigned long long)conf) - 1;
+    const uint32_t sg = __builtin_amdgcn_readlane(grp, leader);
+    const bool mine = valid && shared && grp == sg;
+    const uint64_t same = __ballot(mine);
+    const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(key >> 32), leader) << 32) |
+                        __builtin_amdgcn_readlane((uint32_t)key, leader);
+    const bool simple = __ballot(mine && !(key == k0 && kv_simple_op<WL>(type))) == 0 && !force_rounds;
+    if (simple) {
+      kv_fast_group<WL>(same, mine, leader, rep, idx, type, table, q, bucket, key, kv, stats);
+    } else {
+      if (mine) { pos = (uint32_t)__popcll(same & lanemask_lt()); rounds = true; }
+      maxpos = max(maxpos, (uint32_t)__popcll(same) - 1u);
+    }
+    conf &= ~same;
+  }
+  for (uint32_t r = 0; r <= maxpos; r++) {
+    if (rounds && pos == r) kv_do_request<WL>(rep + (size_t)idx * F::MSG, type, table, q, bucket, kv, stats);
+    // the next round (and the next chunk) must see this round's stores
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
+}
+
+// 64 keys, one per lane, ascending (bitonic network over the wave, 21 compare-exchange steps)
+__device__ static inline uint64_t wave_sort_u64(uint64_t w) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)w, (int)j, 64), hi = __shfl_xor((uint32_t)(w >> 32), (int)j, 64);
+      const uint64_t o = ((uint64_t)hi << 32) | lo;
+      const bool up = (lane & k) == 0;           // this k-block sorts ascending
+      const bool low = (lane & j) == 0;          // lower lane of the pair
+      w = (low == up) ? (w < o ? w : o) : (w < o ? o : w);
+    }
+  }
+  return w;
+}
+
 // ---- k_kv_resolve ----------------------------------------------------------------------------------------
 template <int WL>
 __global__ void __launch_bounds__(64)
 k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *__restrict__ bin_cnt,
              const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int kv_force_rounds) {
-  using F = Fmt<WL>;
   __shared__ dint_rank_lds R;
   __shared__ uint32_t Srec[DINT_WCAP];  // idx | hash entry << 16, in request order
   __shared__ uint16_t Sop[DINT_WCAP];   // type | table << 8 | quadrant << 12
@@ -433,8 +512,28 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *
   const uint32_t c = bin_cnt[bin];
   if (c == 0) return;
   const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
-  rank_build(R, recs, c, n);
+  if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
 
+  if (c <= 64) {
+    // The common case: the whole bin is one chunk.  Sort the records by (bucket group, idx) in registers:
+    // groups commute, so any order that keeps each group's requests in idx order is serial-equivalent, and
+    // after the sort the requests of a group sit in adjacent lanes -- no LDS, no rank bitmap, no hash.
+    uint64_t w = ~0ull;  // empty lanes sort last
+    if (lane < c) {
+      const uint64_t r = recs[lane];
+      w = ((uint64_t)rec_gk(r) << 32) | ((uint64_t)rec_idx(r) << 16) | ((uint64_t)rec_op(r) << 8) | rec_aux(r);
+    }
+    w = wave_sort_u64(w);
+    const bool valid = lane < c;
+    const uint32_t gk = (uint32_t)(w >> 32), idx = (uint32_t)(w >> 16) & 0xFFFF;
+    const uint32_t type = (uint32_t)(w >> 8) & 0xFF, aux = (uint32_t)w & 0xFF;
+    const uint32_t up = __shfl_up(gk, 1, 64), dn = __shfl_down(gk, 1, 64);
+    const bool shared = valid && ((lane > 0 && up == gk) || (lane + 1 < c && dn == gk));
+    kv_chunk<WL>(rep, valid, idx, gk, shared, gk, type, aux & 15u, aux >> 4, kv, stats, kv_force_rounds);
+    return;
+  }
+
+  rank_build(R, recs, c, n);
   for (uint32_t lo = 0; lo < c; lo += DINT_WCAP) {
     const uint32_t wn = min(DINT_WCAP, c - lo);
     for (uint32_t h = lane; h < DINT_HSIZE; h += 64) { Hk[h] = DINT_EMPTY; Hfl[h] = 0; }
@@ -458,45 +557,16 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *
       const uint32_t sr = valid ? Srec[j] : 0;
       const uint32_t so = valid ? Sop[j] : 0;
       const uint32_t idx = sr & 0xFFFF, e = (sr >> 16) & (DINT_HSIZE - 1);
-      const uint32_t type = so & 0xFF, table = (so >> 8) & 15u, q = so >> 12;
       if (valid) atomicAdd(&Hfl[e], 1u);
       __syncthreads();
-      const uint32_t cnt = valid ? Hfl[e] : 0;
-      const uint64_t bucket = valid ? (uint64_t)(Hk[e] - kv->gk_base[table]) : 0;
-      const uint64_t key = valid ? ld_u64(rep + (size_t)idx * F::MSG + F::KEY) : 0;
-      // Buckets hit by several lanes of the chunk.  A group whose lanes all address one key with
-      // chain-preserving ops is resolved in closed form (kv_fast_group); any other group runs in rounds:
-      // its k-th request, in request (= lane) order, executes in round k.
-      uint32_t pos = 0, maxpos = 0;
-      bool rounds = valid && cnt == 1;  // the only request of the chunk on its bucket: round 0
-      uint64_t conf = __ballot(valid && cnt > 1);
-      while (conf) {
-        const int leader = __ffsll((unsigned long long)conf) - 1;
-        const uint32_t se = __builtin_amdgcn_readlane(e, leader);
-        const bool mine = valid && e == se;
-        const uint64_t same = __ballot(mine);
-        const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(key >> 32), leader) << 32) |
-                            __builtin_amdgcn_readlane((uint32_t)key, leader);
-        const bool simple = __ballot(mine && !(key == k0 && kv_simple_op<WL>(type))) == 0 && !kv_force_rounds;
-        if (simple) {
-          kv_fast_group<WL>(same, mine, leader, rep, idx, type, table, q, bucket, key, kv, stats);
-        } else {
-          if (mine) { pos = (uint32_t)__popcll(same & lanemask_lt()); rounds = true; }
-          maxpos = max(maxpos, (uint32_t)__popcll(same) - 1u);
-        }
-        conf &= ~same;
-      }
-      for (uint32_t r = 0; r <= maxpos; r++) {
-        if (rounds && pos == r) kv_do_request<WL>(rep + (size_t)idx * F::MSG, type, table, q, bucket, kv, stats);
-        // the next round (and the next chunk) must see this round's stores
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      }
+      const bool shared = valid && Hfl[e] > 1;
+      kv_chunk<WL>(rep, valid, idx, e, shared, valid ? Hk[e] : 0, so & 0xFF, (so >> 8) & 15u, so >> 12, kv, stats,
+                   kv_force_rounds);
       __syncthreads();
       if (valid) Hfl[e] = 0;
       __syncthreads();
     }
   }
-  if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
