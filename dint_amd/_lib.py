@@ -19,7 +19,7 @@ SYMBOLS = [
     "dint_engine_create", "dint_engine_destroy", "dint_msg_size", "dint_last_error", "dint_submit",
     "dint_submit_device", "dint_sync", "dint_load_rows", "dint_populate", "dint_hash_size", "dint_dump_rows",
     "dint_read_locks", "dint_read_log", "dint_get_stats", "dint_reset", "dint_snapshot", "dint_restore",
-    "dint_home_shard", "dint_bench_rand64", "dint_timing_enable", "dint_timing_read",
+    "dint_home_shard", "dint_bench_rand64", "dint_timing_enable", "dint_timing_read", "dint_kv_trace_read",
 ]
 
 
@@ -78,6 +78,7 @@ def load() -> C.CDLL:
         "dint_restore": (C.c_int, [vp]),
         "dint_home_shard": (C.c_int, [vp, vp, u32, vp, vp]),
         "dint_bench_rand64": (C.c_int, [i32, u64, u64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "dint_kv_trace_read": (C.c_int, [vp, vp, u64]),
         "dint_timing_enable": (C.c_int, [vp, C.c_int]),
         "dint_timing_read": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(u64), C.c_int]),
     }

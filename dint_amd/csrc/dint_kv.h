@@ -28,6 +28,7 @@ struct dint_kv {
   kv_dev h{};                // host mirror (device pointers inside)
   kv_dev *d_dev = nullptr;   // device copy
   uint8_t *d_ctl = nullptr;  // pool_top / free_head / pend_head words of all tables
+  uint64_t *d_trace = nullptr;  // DINT_KV_TRACE=1: [DINT_PMAX][16] per-wave s_memtime stamps of the last resolve launch
   size_t entry_bytes[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
 };
 

@@ -11,7 +11,7 @@
 //
 //   entries[]  = n_local INLINE entries (one per local bucket, at index = local bucket)
 //              + pool_cap OVERFLOW entries (bump allocated, recycled through a deferred free list)
-//   entry      = 64-byte header sector {key[4], ver[4], valid[4], next, head, lockb[4]}
+//   entry      = 64-byte header sector {key[4], ver[4], validw, next, head, lockw}
 //              + 4 values (val_size bytes each) + (smallbank) 4 x {num_ex, num_sh}
 //     stride 256 B for 40-byte values (store / tatp), 128 B for 8-byte values (smallbank).
 //   A link is 0 = end of chain, 1 = the bucket's own inline entry, k >= 2 = pool entry k-2.
@@ -21,7 +21,7 @@
 //   ordinary chain node: it is used for the first entry the reference would `new`, and again whenever
 //   it is not linked at the time the reference would allocate.
 //   The per-bucket lock words of the shard servers live in the same inline entry:
-//     tatp      txn_locks[table][lock_hash]          -> hdr.lockb[q]     (q = lock_hash / hash_size, 0..3)
+//     tatp      txn_locks[table][lock_hash]          -> byte q of hdr.lockw (q = lock_hash / hash_size, 0..3)
 //     smallbank num_ex/num_sh[table][lock_hash]      -> u32 pair at byte 96 + 8 q
 //   because lock_hash % hash_size == bucket (tatp/udp/tatp.h:12-14 vs kvs.h:51-53).
 //
@@ -44,14 +44,16 @@
 struct kv_hdr {
   uint64_t key[4];
   uint32_t ver[4];
-  uint8_t valid[4];
+  uint32_t validw;   // valid flags of the 4 slots: slot i in bits 8i..8i+7 (byte i in memory), 0 or 1
   uint32_t next;     // successor of this entry in its chain
   uint32_t head;     // inline entries only: first entry of the bucket's chain
-  uint8_t lockb[4];  // inline entries only: tatp txn lock per quadrant
+  uint32_t lockw;    // inline entries only: tatp txn lock bytes, quadrant q in bits 8q..8q+7 (byte q in memory)
 };
 static_assert(sizeof(kv_hdr) == 64, "header must be one 64-byte sector");
 
 #define KV_VAL_OFF 64u
+#define KV_VALID_OFF 48u     // byte offset of validw in a header
+#define KV_LOCKB_OFF 60u     // byte offset of lockw in the inline header
 #define KV_SB_LOCK_OFF 96u  // smallbank: 4 x {u32 num_ex, u32 num_sh}
 
 // device view of one table (plain pointers, passed to kernels by value)
@@ -76,12 +78,14 @@ KV_HD static inline uint8_t *kv_entry_ptr(const kv_tab &t, uint64_t bucket, uint
 KV_HD static inline kv_hdr *kv_entry_hdr(const kv_tab &t, uint64_t bucket, uint32_t link) {
   return (kv_hdr *)kv_entry_ptr(t, bucket, link);
 }
+// field-wise copy: keeps headers in registers (an aggregate copy is lowered through stack memory on the GPU)
+KV_HD static inline void kv_hdr_copy(kv_hdr &d, const kv_hdr &s) {
+  d.key[0] = s.key[0]; d.key[1] = s.key[1]; d.key[2] = s.key[2]; d.key[3] = s.key[3];
+  d.ver[0] = s.ver[0]; d.ver[1] = s.ver[1]; d.ver[2] = s.ver[2]; d.ver[3] = s.ver[3];
+  d.validw = s.validw; d.next = s.next; d.head = s.head; d.lockw = s.lockw;
+}
+KV_HD static inline bool kv_valid(const kv_hdr &h, uint32_t slot) { return (h.validw >> (8 * slot)) & 0xFFu; }
 
-struct kv_loc {
-  uint32_t link;  // entry holding the key
-  uint32_t slot;  // 0..3
-  uint32_t prev;  // predecessor entry in the chain (KV_NULL = the entry is the chain head)
-};
 
 // ---- memory policy of the host build (single thread, plain memory) ---------------------------------
 struct kv_host_mem {
@@ -132,107 +136,179 @@ KV_HD static inline void kv_pool_rotate(const kv_tab &t) {
   }
 }
 
-// ---- lookups ---------------------------------------------------------------------------------------------
-// kvs_get / kvs_set / kvs_delete all start with the same walk (kvs.h:59-70)
+// ---- the one table operation -------------------------------------------------------------------------------
+// Every request does at most one of: GET (kvs_get), SET (kvs_set), INS (kvs_insert), DEL (kvs_delete).  They all
+// start with the same chain walk (kvs.h:59-70 / 97-110 / 127-150), so they are one function: a single walk that
+// records the first matching slot and the first invalid slot, then a short action.  On the GPU this matters:
+// the lanes of a wave run different request types, and one shared load phase (the caller passes the bucket's
+// inline header H, already loaded) costs one memory round trip instead of one per request type.
+enum : uint32_t { KV_ACT_NONE = 0, KV_ACT_GET = 1, KV_ACT_SET = 2, KV_ACT_INS = 3, KV_ACT_DEL = 4 };
+
+struct kv_res {
+  bool ok;       // GET / SET / DEL: the key was found.  INS: the row was stored (false = pool exhausted)
+  uint32_t ver;  // GET: the row's version
+};
+
+// Copy one value (40 or 8 bytes).  All loads are issued before the first store: source and destination may
+// alias as far as the compiler knows, and a load/store/load/store chain would cost one memory round trip per
+// word on the GPU.  Entry values are 4-byte aligned; message values are not (packed wire structs) -> memcpy.
+KV_HD static inline void kv_copy_words(uint8_t *dst, const uint8_t *src, uint32_t bytes) {
+  uint32_t w[10];
+  if (bytes == 40) {
+#pragma unroll
+    for (uint32_t k = 0; k < 10; k++) __builtin_memcpy(&w[k], src + 4 * k, 4);
+#pragma unroll
+    for (uint32_t k = 0; k < 10; k++) __builtin_memcpy(dst + 4 * k, &w[k], 4);
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) __builtin_memcpy(&w[k], src + 4 * k, 4);
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) __builtin_memcpy(dst + 4 * k, &w[k], 4);
+  }
+}
+
+// `H` = a copy of the bucket's inline header as it is in memory now.  val: output of GET, input of SET / INS
+// (may be unaligned).  ins_ver: version of an inserted row (0 for the wire INSERT ops).
+template <class M>
+KV_HD static inline kv_res kv_apply(const kv_tab &t, uint64_t bucket, const kv_hdr &H, uint32_t act, uint64_t key,
+                                    uint8_t *val, uint32_t ins_ver) {
+  kv_res res = {false, 0};
+  if (act == KV_ACT_NONE) return res;
+  const bool want_match = act != KV_ACT_INS;
+  bool matched = false, have_free = false, inline_linked = false;
+  uint32_t m_link = 0, m_slot = 0, m_prev = 0, m_next = 0, m_ver = 0, m_valid = 0;  // m_valid: valid[0..3] packed
+  uint32_t f_link = 0, f_slot = 0;
+  uint32_t cur = H.head, prev = KV_NULL;
+  for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
+    // the inline entry's header is already in registers (it does not change between the caller's load and here)
+    kv_hdr h;
+    if (cur == KV_INLINE) { kv_hdr_copy(h, H); inline_linked = true; }
+    else kv_hdr_copy(h, *kv_entry_hdr(t, bucket, cur));
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      if (want_match && !matched && kv_valid(h, i) && h.key[i] == key) {
+        matched = true; m_link = cur; m_slot = i; m_prev = prev; m_next = h.next; m_ver = h.ver[i];
+        m_valid = h.validw;
+      }
+      if (!want_match && !have_free && !kv_valid(h, i)) { have_free = true; f_link = cur; f_slot = i; }
+    }
+    if (matched || have_free) break;
+    prev = cur;
+    cur = h.next;
+  }
+  switch (act) {
+    case KV_ACT_GET:  // kvs.h:55-73
+      if (matched) {
+        kv_copy_words(val, kv_entry_ptr(t, bucket, m_link) + KV_VAL_OFF + m_slot * t.val_size, t.val_size);
+        res.ok = true;
+        res.ver = m_ver;
+      }
+      break;
+    case KV_ACT_SET:  // kvs.h:75-92
+      if (matched) {
+        uint8_t *e = kv_entry_ptr(t, bucket, m_link);
+        kv_copy_words(e + KV_VAL_OFF + m_slot * t.val_size, val, t.val_size);
+        ((kv_hdr *)e)->ver[m_slot] = m_ver + 1;
+        res.ok = true;
+      }
+      break;
+    case KV_ACT_INS: {  // kvs.h:94-121
+      uint32_t link = f_link, slot = f_slot;
+      if (!have_free) {  // every slot of the chain is taken: a new entry, prepended (kvs.h:112-119)
+        link = inline_linked ? kv_pool_alloc<M>(t) : KV_INLINE;
+        if (link == KV_NULL) break;
+        slot = 0;
+      }
+      uint8_t *e = kv_entry_ptr(t, bucket, link);
+      kv_hdr *h = (kv_hdr *)e;
+      h->key[slot] = key;
+      h->ver[slot] = ins_ver;
+      kv_copy_words(e + KV_VAL_OFF + slot * t.val_size, val, t.val_size);
+      if (have_free) {
+        e[KV_VALID_OFF + slot] = 1;
+      } else {
+        h->key[1] = h->key[2] = h->key[3] = 0;
+        h->ver[1] = h->ver[2] = h->ver[3] = 0;
+        h->validw = 1;  // slot 0 valid, 1..3 invalid
+        h->next = H.head;
+        kv_entry_hdr(t, bucket, KV_INLINE)->head = link;  // for link == KV_INLINE the same header: lock words stay
+      }
+      res.ok = true;
+      break;
+    }
+    default:  // KV_ACT_DEL  kvs.h:123-153
+      if (matched) {
+        kv_hdr *h = kv_entry_hdr(t, bucket, m_link);
+        ((uint8_t *)h)[KV_VALID_OFF + m_slot] = 0;
+        if ((m_valid & ~(0xFFu << (8 * m_slot))) == 0) {  // the entry is empty now: unlink it and free it
+          if (m_prev == KV_NULL) kv_entry_hdr(t, bucket, KV_INLINE)->head = m_next;
+          else kv_entry_hdr(t, bucket, m_prev)->next = m_next;
+          if (m_link != KV_INLINE) kv_pool_free<M>(t, m_link);
+        }
+        res.ok = true;
+      }
+      break;
+  }
+  return res;
+}
+
+// ---- the reference's four functions, as thin wrappers (host tests, dumps, non-hot paths) -----------------------
+KV_HD static inline bool kv_get(const kv_tab &t, uint64_t bucket, uint64_t key, uint8_t *val_out, uint32_t *ver_out) {
+  const kv_hdr H = *kv_entry_hdr(t, bucket, KV_INLINE);
+  const kv_res r = kv_apply<kv_host_mem>(t, bucket, H, KV_ACT_GET, key, val_out, 0);  // GET never touches the pool
+  if (r.ok) *ver_out = r.ver;
+  return r.ok;
+}
+KV_HD static inline bool kv_set(const kv_tab &t, uint64_t bucket, uint64_t key, const uint8_t *val) {
+  const kv_hdr H = *kv_entry_hdr(t, bucket, KV_INLINE);
+  return kv_apply<kv_host_mem>(t, bucket, H, KV_ACT_SET, key, (uint8_t *)val, 0).ok;
+}
+template <class M>
+KV_HD static inline bool kv_insert(const kv_tab &t, uint64_t bucket, uint64_t key, const uint8_t *val, uint32_t ver) {
+  const kv_hdr H = *kv_entry_hdr(t, bucket, KV_INLINE);
+  return kv_apply<M>(t, bucket, H, KV_ACT_INS, key, (uint8_t *)val, ver).ok;
+}
+template <class M>
+KV_HD static inline bool kv_delete(const kv_tab &t, uint64_t bucket, uint64_t key) {
+  const kv_hdr H = *kv_entry_hdr(t, bucket, KV_INLINE);
+  return kv_apply<M>(t, bucket, H, KV_ACT_DEL, key, nullptr, 0).ok;
+}
+// where a key lives (closed-form group resolution, k_kv.hip)
+struct kv_loc {
+  uint32_t link;  // entry holding the key
+  uint32_t slot;  // 0..3
+};
+struct kv_where {
+  uint32_t found, link, slot, ver;
+};
+// the lookup walk alone, from the preloaded inline header H
+KV_HD static inline kv_where kv_locate(const kv_tab &t, uint64_t bucket, const kv_hdr &H, uint64_t key) {
+  kv_where w = {0, 0, 0, 0};
+  uint32_t cur = H.head;
+  for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
+    kv_hdr h;
+    if (cur == KV_INLINE) kv_hdr_copy(h, H);
+    else kv_hdr_copy(h, *kv_entry_hdr(t, bucket, cur));
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+      if (!w.found && kv_valid(h, i) && h.key[i] == key) { w.found = 1; w.link = cur; w.slot = i; w.ver = h.ver[i]; }
+    if (w.found) break;
+    cur = h.next;
+  }
+  return w;
+}
 KV_HD static inline bool kv_find(const kv_tab &t, uint64_t bucket, uint64_t key, kv_loc *loc) {
-  uint32_t cur = kv_entry_hdr(t, bucket, KV_INLINE)->head, prev = KV_NULL;
+  uint32_t cur = kv_entry_hdr(t, bucket, KV_INLINE)->head;
   for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
     const kv_hdr *h = kv_entry_hdr(t, bucket, cur);
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++)
-      if (h->key[i] == key && h->valid[i]) {
+      if (h->key[i] == key && kv_valid(*h, i)) {
         loc->link = cur;
         loc->slot = i;
-        loc->prev = prev;
         return true;
       }
-    prev = cur;
     cur = h->next;
   }
   return false;
-}
-
-KV_HD static inline void kv_copy_words(uint8_t *dst, const uint8_t *src, uint32_t bytes) {
-  // entry values are 4-byte aligned; message values are not (packed wire structs) -> memcpy per word
-  for (uint32_t o = 0; o < bytes; o += 4) {
-    uint32_t w;
-    __builtin_memcpy(&w, src + o, 4);
-    __builtin_memcpy(dst + o, &w, 4);
-  }
-}
-
-// kvs_get (kvs.h:55-73): true = found; val_out may be unaligned
-KV_HD static inline bool kv_get(const kv_tab &t, uint64_t bucket, uint64_t key, uint8_t *val_out, uint32_t *ver_out) {
-  kv_loc l;
-  if (!kv_find(t, bucket, key, &l)) return false;
-  const uint8_t *e = kv_entry_ptr(t, bucket, l.link);
-  kv_copy_words(val_out, e + KV_VAL_OFF + l.slot * t.val_size, t.val_size);
-  *ver_out = ((const kv_hdr *)e)->ver[l.slot];
-  return true;
-}
-
-// kvs_set (kvs.h:75-92): true = found (the reference panics otherwise)
-KV_HD static inline bool kv_set(const kv_tab &t, uint64_t bucket, uint64_t key, const uint8_t *val) {
-  kv_loc l;
-  if (!kv_find(t, bucket, key, &l)) return false;
-  uint8_t *e = kv_entry_ptr(t, bucket, l.link);
-  kv_copy_words(e + KV_VAL_OFF + l.slot * t.val_size, val, t.val_size);
-  ((kv_hdr *)e)->ver[l.slot]++;
-  return true;
-}
-
-// kvs_insert (kvs.h:94-121) with an explicit initial version (0 for the wire INSERT ops).
-// false = the overflow pool is exhausted and the row was dropped.
-template <class M>
-KV_HD static inline bool kv_insert(const kv_tab &t, uint64_t bucket, uint64_t key, const uint8_t *val, uint32_t ver) {
-  kv_hdr *ih = kv_entry_hdr(t, bucket, KV_INLINE);
-  const uint32_t head = ih->head;
-  uint32_t cur = head;
-  bool inline_linked = false;
-  for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
-    uint8_t *e = kv_entry_ptr(t, bucket, cur);
-    kv_hdr *h = (kv_hdr *)e;
-    if (cur == KV_INLINE) inline_linked = true;
-#pragma unroll
-    for (uint32_t i = 0; i < 4; i++)
-      if (!h->valid[i]) {
-        h->key[i] = key;
-        kv_copy_words(e + KV_VAL_OFF + i * t.val_size, val, t.val_size);
-        h->ver[i] = ver;
-        h->valid[i] = 1;
-        return true;
-      }
-    cur = h->next;
-  }
-  // every slot of the chain is taken: new entry, prepended (kvs.h:112-119)
-  const uint32_t nl = inline_linked ? kv_pool_alloc<M>(t) : KV_INLINE;
-  if (nl == KV_NULL) return false;
-  uint8_t *e = kv_entry_ptr(t, bucket, nl);
-  kv_hdr *h = (kv_hdr *)e;
-  h->key[0] = key;
-  h->key[1] = h->key[2] = h->key[3] = 0;
-  h->ver[0] = ver;
-  h->ver[1] = h->ver[2] = h->ver[3] = 0;
-  h->valid[0] = 1;
-  h->valid[1] = h->valid[2] = h->valid[3] = 0;
-  kv_copy_words(e + KV_VAL_OFF, val, t.val_size);
-  h->next = head;
-  ih->head = nl;  // for nl == KV_INLINE this is the same header: head and lock words are preserved
-  return true;
-}
-
-// kvs_delete (kvs.h:123-153): true = found (the reference panics otherwise)
-template <class M>
-KV_HD static inline bool kv_delete(const kv_tab &t, uint64_t bucket, uint64_t key) {
-  kv_loc l;
-  if (!kv_find(t, bucket, key, &l)) return false;
-  kv_hdr *h = kv_entry_hdr(t, bucket, l.link);
-  h->valid[l.slot] = 0;
-  if (!(h->valid[0] | h->valid[1] | h->valid[2] | h->valid[3])) {  // unlink and free the empty entry
-    const uint32_t nxt = h->next;
-    if (l.prev == KV_NULL) kv_entry_hdr(t, bucket, KV_INLINE)->head = nxt;
-    else kv_entry_hdr(t, bucket, l.prev)->next = nxt;
-    if (l.link != KV_INLINE) kv_pool_free<M>(t, l.link);
-  }
-  return true;
 }

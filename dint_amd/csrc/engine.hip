@@ -471,6 +471,17 @@ int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d
   return 0;
 }
 
+int dint_kv_trace_read(dint_engine_t *e, uint64_t *out, uint64_t cap) {
+  if (!e || !out) return fail(DINT_EINVAL, "null argument");
+  if (!e->kv.d_trace) return fail(DINT_ESTATE, "tracing is off (set DINT_KV_TRACE=1 before creating the engine)");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const uint64_t words = std::min<uint64_t>(cap, (uint64_t)DINT_PMAX * 16);
+  HIP_TRY(hipMemcpy(out, e->kv.d_trace, words * 8, hipMemcpyDeviceToHost));
+  return (int)DINT_PMAX;
+}
+
 int dint_timing_enable(dint_engine_t *e, int on) {
   if (!e) return fail(DINT_EINVAL, "null engine");
   std::lock_guard<std::mutex> lk(e->mu);

@@ -23,6 +23,7 @@
 //                  rounds), so every request sees the table exactly as the serial reference would.  The table
 //                  is the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -207,116 +208,111 @@ k_kv_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv
   }
 }
 
-// ---- one request against the table ---------------------------------------------------------------------
-template <int WL>
-__device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_t table, uint32_t q, uint64_t bucket,
-                                            const kv_dev *__restrict__ kv, dint_dev_stats *__restrict__ stats) {
-  using F = Fmt<WL>;
-  const kv_tab t = kv->tab[table];
-  const uint64_t key = ld_u64(msg + F::KEY);
-  uint8_t *val = msg + F::VAL;
-  uint32_t ver;
-  if (type == DINT_KV_LOAD_OP) {  // bulk load: kvs_insert with the version carried in the message
-    if (!kv_insert<kv_dev_mem>(t, bucket, key, val, ld_u32(msg + F::VER))) atomicAdd(&stats->pool_exhausted, 1ULL);
-    return;
-  }
-  if (WL == DINT_WL_STORE) {
-    switch (type) {
-      case 0:  // kRead  store/udp/server.cc:77-82
-        if (kv_get(t, bucket, key, val, &ver)) { st_u32(msg + F::VER, ver); msg[F::TYPE] = 3; }
-        else msg[F::TYPE] = 7;
-        break;
-      case 1:  // kSet  :84-89
-        msg[F::TYPE] = kv_set(t, bucket, key, val) ? 5 : 7;
-        break;
-      default:  // kInsert (eBPF store)
-        if (!kv_insert<kv_dev_mem>(t, bucket, key, val, 0)) atomicAdd(&stats->pool_exhausted, 1ULL);
-        msg[F::TYPE] = 8;
-        break;
-    }
-  } else if (WL == DINT_WL_TATP) {
-    uint8_t *lk = &kv_entry_hdr(t, bucket, KV_INLINE)->lockb[q];
-    switch (type) {
-      case 0:  // kRead  tatp/udp/server_shard.cc:116-121
-        if (kv_get(t, bucket, key, val, &ver)) { st_u32(msg + F::VER, ver); msg[F::TYPE] = 4; }
-        else msg[F::TYPE] = 6;
-        break;
-      case 1:  // kAcquireLock  :123-132
-        if (*lk == 0) { *lk = 1; msg[F::TYPE] = 7; } else msg[F::TYPE] = 8;
-        break;
-      case 2:  // kAbort  :134-138
-        *lk = 0;
-        msg[F::TYPE] = 9;
-        break;
-      case 12:  // kCommitPrim: set + unlock  :140-146
-        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
-        *lk = 0;
-        msg[F::TYPE] = 15;
-        break;
-      case 18:  // kInsertPrim  :148-154
-        if (!kv_insert<kv_dev_mem>(t, bucket, key, val, 0)) atomicAdd(&stats->pool_exhausted, 1ULL);
-        *lk = 0;
-        msg[F::TYPE] = 20;
-        break;
-      case 22:  // kDeletePrim  :156-162
-        if (!kv_delete<kv_dev_mem>(t, bucket, key)) atomicAdd(&stats->missing_keys, 1ULL);
-        *lk = 0;
-        msg[F::TYPE] = 25;
-        break;
-      case 13:  // kCommitBck  :164-168
-        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
-        msg[F::TYPE] = 16;
-        break;
-      case 19:  // kInsertBck  :170-174
-        if (!kv_insert<kv_dev_mem>(t, bucket, key, val, 0)) atomicAdd(&stats->pool_exhausted, 1ULL);
-        msg[F::TYPE] = 21;
-        break;
-      default:  // 23 kDeleteBck  :176-180
-        if (!kv_delete<kv_dev_mem>(t, bucket, key)) atomicAdd(&stats->missing_keys, 1ULL);
-        msg[F::TYPE] = 26;
-        break;
-    }
-  } else {
-    uint32_t *cnt = (uint32_t *)(kv_entry_ptr(t, bucket, KV_INLINE) + KV_SB_LOCK_OFF) + 2 * q;  // {num_ex, num_sh}
-    switch (type) {
-      case 0:  // kAcquireShared  smallbank/udp/server_shard.cc:121-133
-        if (cnt[0] == 0) {
-          cnt[1]++;
-          if (kv_get(t, bucket, key, val, &ver)) st_u32(msg + F::VER, ver);
-          else atomicAdd(&stats->missing_keys, 1ULL);
-          msg[F::TYPE] = 7;
-        } else msg[F::TYPE] = 8;
-        break;
-      case 1:  // kAcquireExclusive  :135-147
-        if (cnt[0] == 0 && cnt[1] == 0) {
-          cnt[0]++;
-          if (kv_get(t, bucket, key, val, &ver)) st_u32(msg + F::VER, ver);
-          else atomicAdd(&stats->missing_keys, 1ULL);
-          msg[F::TYPE] = 9;
-        } else msg[F::TYPE] = 10;
-        break;
-      case 2: cnt[1]--; msg[F::TYPE] = 11; break;  // kReleaseShared  :149-154
-      case 3: cnt[0]--; msg[F::TYPE] = 12; break;  // kReleaseExclusive  :156-161
-      case 4:  // kCommitPrim  :163-167
-        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
-        msg[F::TYPE] = 13;
-        break;
-      default:  // 5 kCommitBck  :169-173
-        if (!kv_set(t, bucket, key, val)) atomicAdd(&stats->missing_keys, 1ULL);
-        msg[F::TYPE] = 14;
-        break;
-    }
+// ---- optional per-wave timeline (DINT_KV_TRACE=1): lane 0 of every resolve wave stamps s_memtime at fixed
+// points into trace[bin * 16 + k]; with tracing on, each stamp first drains the wave's memory queue so the
+// difference of two stamps is the latency of what lies between them.  Off (nullptr) in normal runs.
+__device__ static inline void kv_stamp(uint64_t *tr, uint32_t k) {
+  if (tr) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (lane_id() == 0) tr[k] = __builtin_amdgcn_s_memtime();
   }
 }
 
+// ---- one request against the table ---------------------------------------------------------------------
+// Written so that the lanes of a wave, which run different request types, share their memory round trips:
+//   load phase   : the bucket's inline header sector (probe keys, versions, valid bits, chain head AND the tatp lock
+//                  bytes), the request's key, and the smallbank counter pair -- three independent loads, one wait;
+//   decide phase : registers only -- which table action (GET / SET / INS / DEL / none), the lock transition, the
+//                  reply code;
+//   act phase    : kv_apply (value copy, row / header stores) and the lock-word store.
+template <int WL>
+__device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_t table, uint32_t q, uint64_t bucket,
+                                            const kv_dev *kv, dint_dev_stats *__restrict__ stats, uint64_t *tr = nullptr) {
+  using F = Fmt<WL>;
+  const kv_tab t = kv->tab[table];
+  uint8_t *ie = kv_entry_ptr(t, bucket, KV_INLINE);
+  // ---- load phase
+  kv_hdr H;
+  kv_hdr_copy(H, *(const kv_hdr *)ie);
+  uint2 cnt = make_uint2(0, 0);
+  if (WL == DINT_WL_SMALLBANK) cnt = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);  // {num_ex, num_sh}
+  const uint64_t key = ld_u64(msg + F::KEY);
+  uint8_t *val = msg + F::VAL;
+  kv_stamp(tr, 6);
 
-// ---- same-key conflict group of one 64-chunk, resolved in closed form ------------------------------------
-// All lanes in `same` address ONE key (hence one bucket, one lock word) with ops that never change the chain
-// (no INSERT / DELETE).  The group's serial outcome depends only on a few words of state -- exists, version,
-// last writer, lock word -- which every lane derives for its own position from ballots (store / tatp) or from
-// one wave-uniform walk over the group (smallbank counters) instead of one memory round trip per request;
-// afterwards every lane fills its reply in parallel (a read takes its value from the message of the last
-// writer below it, or from the table) and the leader writes the final row / lock word back once.
+  // ---- decide phase
+  uint32_t act = KV_ACT_NONE, code = 0, ins_ver = 0;
+  bool miss_counts = false;   // a miss of this action is an event the reference panics on
+  int lock_store = -1;        // tatp: byte to store into lock byte q (-1 = none)
+  bool cnt_store = false;     // smallbank: store the counter pair back
+  if (type == DINT_KV_LOAD_OP) {  // bulk load: kvs_insert with the version carried in the message
+    act = KV_ACT_INS;
+    ins_ver = ld_u32(msg + F::VER);
+  } else if (WL == DINT_WL_STORE) {
+    switch (type) {
+      case 0: act = KV_ACT_GET; break;   // kRead  store/udp/server.cc:77-82
+      case 1: act = KV_ACT_SET; break;   // kSet   :84-89
+      default: act = KV_ACT_INS; code = 8; break;  // kInsert (eBPF store)
+    }
+  } else if (WL == DINT_WL_TATP) {
+    const uint32_t lk = (H.lockw >> (8 * q)) & 0xFFu;
+    switch (type) {
+      case 0: act = KV_ACT_GET; break;                                                    // kRead  server_shard.cc:116-121
+      case 1: if (lk == 0) { lock_store = 1; code = 7; } else code = 8; break;           // kAcquireLock  :123-132
+      case 2: lock_store = 0; code = 9; break;                                            // kAbort  :134-138
+      case 12: act = KV_ACT_SET; miss_counts = true; lock_store = 0; code = 15; break;    // kCommitPrim  :140-146
+      case 18: act = KV_ACT_INS; lock_store = 0; code = 20; break;                        // kInsertPrim  :148-154
+      case 22: act = KV_ACT_DEL; miss_counts = true; lock_store = 0; code = 25; break;    // kDeletePrim  :156-162
+      case 13: act = KV_ACT_SET; miss_counts = true; code = 16; break;                    // kCommitBck   :164-168
+      case 19: act = KV_ACT_INS; code = 21; break;                                        // kInsertBck   :170-174
+      default: act = KV_ACT_DEL; miss_counts = true; code = 26; break;                    // 23 kDeleteBck  :176-180
+    }
+    if (lock_store >= 0 && (uint32_t)lock_store == lk) lock_store = -1;  // unchanged byte: no store
+  } else {
+    switch (type) {  // cnt.x = num_ex, cnt.y = num_sh   smallbank/udp/server_shard.cc:121-173
+      case 0: if (cnt.x == 0) { cnt.y++; cnt_store = true; act = KV_ACT_GET; miss_counts = true; code = 7; } else code = 8; break;
+      case 1: if (cnt.x == 0 && cnt.y == 0) { cnt.x++; cnt_store = true; act = KV_ACT_GET; miss_counts = true; code = 9; } else code = 10; break;
+      case 2: cnt.y--; cnt_store = true; code = 11; break;
+      case 3: cnt.x--; cnt_store = true; code = 12; break;
+      case 4: act = KV_ACT_SET; miss_counts = true; code = 13; break;
+      default: act = KV_ACT_SET; miss_counts = true; code = 14; break;  // 5 kCommitBck
+    }
+  }
+
+  // ---- act phase
+  const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, act, key, val, ins_ver);
+  kv_stamp(tr, 7);
+  if (WL == DINT_WL_TATP && lock_store >= 0) ie[KV_LOCKB_OFF + q] = (uint8_t)lock_store;
+  if (WL == DINT_WL_SMALLBANK && cnt_store) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = cnt;
+  if (act == KV_ACT_GET && r.ok) st_u32(msg + F::VER, r.ver);
+  if (act != KV_ACT_NONE && !r.ok) {
+    if (act == KV_ACT_INS) atomicAdd(&stats->pool_exhausted, 1ULL);
+    else if (miss_counts) atomicAdd(&stats->missing_keys, 1ULL);
+  }
+  if (type == DINT_KV_LOAD_OP) return;  // internal request: no reply
+  if (WL == DINT_WL_STORE && type <= 1) code = r.ok ? (type == 0 ? 3 : 5) : 7;  // GRANT_READ / SET_ACK / NOT_EXIST
+  if (WL == DINT_WL_TATP && type == 0) code = r.ok ? 4 : 6;                      // GRANT_READ / NOT_EXIST
+  msg[F::TYPE] = (uint8_t)code;
+}
+
+// ---- one 64-chunk of a bin's requests ----------------------------------------------------------------------
+// Precondition: the chunk's lanes are sorted by (bucket group, idx), so the requests of one bucket sit in
+// adjacent lanes, in request order (valid lanes first).  Such a run is a SEGMENT; segments commute.
+//
+// A segment is "simple" when all its requests address ONE key with ops that never change the chain (no INSERT /
+// DELETE): READ, SET / COMMIT_*, lock ops.  Its serial outcome then depends on a few words of state -- row found?,
+// version, last writer, lock word -- and ALL simple segments of the chunk (single requests included) are
+// resolved together:
+//   1. every segment head loads its bucket's inline header (and smallbank counters) and locates the row;
+//   2. every lane derives its own reply from ballots restricted to its segment's lane mask (store / tatp):
+//        version seen = ver0 + #writers below in the segment, value seen = message of the last writer below,
+//        lock seen    = what the last ACQUIRE (-> 1) / ABORT / COMMIT_PRIM (-> 0) below wrote, else the stored byte;
+//      smallbank's shared / exclusive counters have no closed form: single requests apply their op directly,
+//      longer segments are walked once each with wave-uniform registers (no memory inside the walk);
+//   3. replies are written, reads copy their value from the last writer's message or from the table row;
+//   4. after a fence the segment heads write the final row / version / lock word once.
+// Four memory round trips per chunk however many requests collide.  Any other segment (several keys of one
+// bucket, inserts, deletes) runs in rounds: its k-th request executes in round k through kv_do_request.
 // Semantics per op: the same reference lines as kv_do_request.
 template <int WL>
 __device__ static inline bool kv_simple_op(uint32_t type) {
@@ -325,101 +321,152 @@ __device__ static inline bool kv_simple_op(uint32_t type) {
   return type <= 5;                                                            // every smallbank table op
 }
 
+__device__ static inline uint64_t shfl_u64(uint64_t v, int src) {
+  const uint32_t hi = (uint32_t)__shfl((uint32_t)(v >> 32), src, 64), lo = (uint32_t)__shfl((uint32_t)v, src, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ static inline uint64_t readlane_u64(uint64_t v, int l) {
+  // the builtin returns int: without the casts the low word would be sign-extended over the high one
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(v >> 32), l);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)v, l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 template <int WL>
-__device__ static inline void kv_fast_group(uint64_t same, bool mine, int leader, uint8_t *rep, uint32_t idx,
-                                            uint32_t type, uint32_t table, uint32_t q, uint64_t bucket, uint64_t key,
-                                            const kv_dev *__restrict__ kv, dint_dev_stats *__restrict__ stats) {
+__device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t gk, uint32_t type, uint32_t table,
+                                       uint32_t q, const kv_dev *kv, dint_dev_stats *__restrict__ stats, int force_rounds,
+                                       uint64_t *tr = nullptr) {
   using F = Fmt<WL>;
-  const uint32_t lane = lane_id();
-  // ---- leader: locate the row, read version and lock word
+  const int lane = (int)lane_id();
+  const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
+  uint8_t *msg = rep + (size_t)idx * F::MSG;
+  const uint64_t key = valid ? ld_u64(msg + F::KEY) : 0;
+  const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
+
+  // ---- segments
+  const uint32_t gk_up = __shfl_up(gk, 1, 64);
+  const bool head = valid && (lane == 0 || gk_up != gk);
+  const uint64_t hm = __ballot(head);
+  const uint64_t vm = __ballot(valid);
+  const int hl = valid ? 63 - __clzll(hm & le) : lane;                       // my segment's head lane
+  // lanes of my segment = [hl, next head) ; valid lanes are lanes 0..nvalid-1, so without a head above me the
+  // segment ends at the first invalid lane: bit nvalid = vm + 1 (0 when all 64 lanes are valid -> mask of all ones)
+  const uint64_t above = hm & ~le;
+  const uint64_t next = above ? (above & (~above + 1ull)) : vm + 1ull;
+  const uint64_t seg = valid ? ((next - 1ull) & ~((1ull << hl) - 1ull)) : 0;
+  const uint64_t hkey = shfl_u64(key, hl);
+  const uint64_t m_bad = __ballot(valid && !(key == hkey && kv_simple_op<WL>(type)));
+  const bool simple = valid && (m_bad & seg) == 0 && !force_rounds;
+  kv_stamp(tr, 4);
+
+  // ---- 1. segment heads: load + locate
+  const bool leader = head && simple;
   uint32_t found = 0, link = 0, slot = 0, ver0 = 0, la0 = 0, lb0 = 0;
-  const uint32_t ltable = __builtin_amdgcn_readlane(table, leader);
-  const kv_tab t = kv->tab[ltable];
-  const uint64_t lbucket = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(bucket >> 32), leader) << 32) |
-                           __builtin_amdgcn_readlane((uint32_t)bucket, leader);
-  const uint32_t lq = __builtin_amdgcn_readlane(q, leader);
-  if ((int)lane == leader) {
-    kv_loc l;
-    if (kv_find(t, lbucket, key, &l)) {
-      found = 1; link = l.link; slot = l.slot;
-      ver0 = kv_entry_hdr(t, lbucket, l.link)->ver[l.slot];
-    }
-    if (WL == DINT_WL_TATP) la0 = kv_entry_hdr(t, lbucket, KV_INLINE)->lockb[lq];
+  kv_tab t;
+  uint8_t *ie = nullptr;
+  if (valid) {
+    t = kv->tab[table];
+    ie = kv_entry_ptr(t, bucket, KV_INLINE);
+  }
+  if (leader) {
+    kv_hdr H;
+    kv_hdr_copy(H, *(const kv_hdr *)ie);
     if (WL == DINT_WL_SMALLBANK) {
-      const uint32_t *c = (const uint32_t *)(kv_entry_ptr(t, lbucket, KV_INLINE) + KV_SB_LOCK_OFF) + 2 * lq;
-      la0 = c[0]; lb0 = c[1];
+      const uint2 c = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);
+      la0 = c.x; lb0 = c.y;
     }
+    if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
+    const kv_where w = kv_locate(t, bucket, H, key);
+    found = w.found; link = w.link; slot = w.slot; ver0 = w.ver;
   }
-  found = __builtin_amdgcn_readlane(found, leader);
-  link = __builtin_amdgcn_readlane(link, leader);
-  slot = __builtin_amdgcn_readlane(slot, leader);
-  ver0 = __builtin_amdgcn_readlane(ver0, leader);
-  la0 = __builtin_amdgcn_readlane(la0, leader);
-  lb0 = __builtin_amdgcn_readlane(lb0, leader);
+  found = __shfl(found, hl, 64); link = __shfl(link, hl, 64); slot = __shfl(slot, hl, 64);
+  ver0 = __shfl(ver0, hl, 64); la0 = __shfl(la0, hl, 64); lb0 = __shfl(lb0, hl, 64);
+  kv_stamp(tr, 5);
 
-  // ---- outcome of every request of the group
-  uint32_t ver = ver0, la = la0, lb = lb0, nmiss = 0;
-  int src = -1;                                  // lane of the group's last writer (-1: none, the table stands)
-  uint32_t my_code = 0, my_ver = 0, my_get = 0;  // my_get: this lane's reply carries val + ver
-  int my_src = -1;
-  if (WL != DINT_WL_SMALLBANK) {
-    // store / tatp: closed form with ballots.  A row is rewritten by every SET / COMMIT_* (found rows only), so
-    //   version seen by lane l = ver0 + #writers below l,   value seen = message of the last writer below l;
-    // the tatp lock byte is rewritten by ACQUIRE (to 1, granted or not), ABORT and COMMIT_PRIM (to 0), so
-    //   lock seen by lane l = what the last of those below l wrote, else the stored byte.
-    const bool writer = mine && (WL == DINT_WL_STORE ? type == 1 : (type == 12 || type == 13));
-    const uint64_t m_wr = found ? __ballot(writer) : 0;
-    const uint64_t lt = lanemask_lt();
-    const uint64_t wr_below = m_wr & lt;
-    my_ver = ver0 + (uint32_t)__popcll(wr_below);
-    my_src = wr_below ? 63 - __clzll(wr_below) : -1;
-    ver = ver0 + (uint32_t)__popcll(m_wr);
-    src = m_wr ? 63 - __clzll(m_wr) : -1;
-    if (WL == DINT_WL_STORE) {
-      my_code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
-      my_get = (type == 0 && found) ? 1 : 0;
+  // ---- 2. outcome of every request of a simple segment
+  uint32_t my_code = 0, my_ver = 0, my_get = 0;   // my_get: the reply carries val + ver
+  int my_src = -1;                                // lane whose message holds the value this lane reads (-1: the table)
+  uint32_t fin_ver = ver0, fin_la = la0, fin_lb = lb0, nmiss = 0;  // segment totals (meaningful on the head lane)
+  int fin_src = -1;
+  {
+    const bool writer = simple && (WL == DINT_WL_STORE ? type == 1 : WL == DINT_WL_TATP ? (type == 12 || type == 13)
+                                                                                       : (type == 4 || type == 5));
+    const uint64_t m_wr = __ballot(writer && found) & seg;
+    if (WL != DINT_WL_SMALLBANK) {
+      const uint64_t wr_below = m_wr & lt;
+      my_ver = ver0 + (uint32_t)__popcll(wr_below);
+      my_src = wr_below ? 63 - __clzll(wr_below) : -1;
+      fin_ver = ver0 + (uint32_t)__popcll(m_wr);
+      fin_src = m_wr ? 63 - __clzll(m_wr) : -1;
+      if (WL == DINT_WL_STORE) {
+        my_code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
+        my_get = (type == 0 && found) ? 1 : 0;
+      } else {
+        const uint64_t m_lk = __ballot(simple && (type == 1 || type == 2 || type == 12)) & seg;
+        const uint64_t m_acq = __ballot(simple && type == 1);
+        const uint64_t lk_below = m_lk & lt;
+        const uint32_t lock_seen = lk_below ? (uint32_t)((m_acq >> (63 - __clzll(lk_below))) & 1ull) : la0;
+        if (m_lk) fin_la = (uint32_t)((m_acq >> (63 - __clzll(m_lk))) & 1ull);
+        nmiss = found ? 0 : (uint32_t)__popcll(__ballot(writer) & seg);
+        switch (type) {
+          case 0: my_code = found ? 4 : 6; my_get = found; break;
+          case 1: my_code = lock_seen ? 8 : 7; break;
+          case 2: my_code = 9; break;
+          case 12: my_code = 15; break;
+          default: my_code = 16; break;  // 13 kCommitBck
+        }
+      }
     } else {
-      const uint64_t m_lk = __ballot(mine && (type == 1 || type == 2 || type == 12));
-      const uint64_t m_acq = __ballot(mine && type == 1);
-      const uint64_t lk_below = m_lk & lt;
-      const uint32_t lock_seen = lk_below ? (uint32_t)((m_acq >> (63 - __clzll(lk_below))) & 1ull) : la0;
-      if (m_lk) la = (uint32_t)((m_acq >> (63 - __clzll(m_lk))) & 1ull);
-      if (!found) nmiss = (uint32_t)__popcll(__ballot(writer));
-      switch (type) {
-        case 0: my_code = found ? 4 : 6; my_get = found; break;
-        case 1: my_code = lock_seen ? 8 : 7; break;
-        case 2: my_code = 9; break;
-        case 12: my_code = 15; break;
-        default: my_code = 16; break;  // 13 kCommitBck
+      // smallbank.  cnt = {la: num_ex, lb: num_sh}
+      auto sb_step = [](uint32_t op, uint32_t fnd, uint32_t &la, uint32_t &lb, uint32_t &get, uint32_t &miss,
+                        bool &wr) -> uint32_t {
+        switch (op) {
+          case 0: if (la == 0) { lb++; get = fnd; miss += !fnd; return 7; } return 8;
+          case 1: if (la == 0 && lb == 0) { la++; get = fnd; miss += !fnd; return 9; } return 10;
+          case 2: lb--; return 11;
+          case 3: la--; return 12;
+          case 4: wr = fnd; miss += !fnd; return 13;
+          default: wr = fnd; miss += !fnd; return 14;  // 5 kCommitBck
+        }
+      };
+      const bool single = simple && seg == (1ull << lane);
+      if (single) {  // one request on its bucket: apply it directly
+        bool wr = false;
+        my_code = sb_step(type, found, fin_la, fin_lb, my_get, nmiss, wr);
+        my_ver = ver0;
+        if (wr) { fin_ver = ver0 + 1; fin_src = lane; }
       }
-    }
-  } else {
-    // smallbank: the shared / exclusive counters have no closed form (a grant depends on both running
-    // counts), so the group is walked once in request order with wave-uniform registers
-    for (uint64_t m = same; m; m &= m - 1) {
-      const int l = __ffsll((unsigned long long)m) - 1;
-      const uint32_t op = __builtin_amdgcn_readlane(type, l);
-      uint32_t code = 0, get = 0;
-      const uint32_t ver_seen = ver;
-      const int src_seen = src;
-      switch (op) {  // la = num_ex, lb = num_sh
-        case 0: if (la == 0) { lb++; code = 7; get = found; if (!found) nmiss++; } else code = 8; break;
-        case 1: if (la == 0 && lb == 0) { la++; code = 9; get = found; if (!found) nmiss++; } else code = 10; break;
-        case 2: lb--; code = 11; break;
-        case 3: la--; code = 12; break;
-        case 4: if (found) { ver++; src = l; } else nmiss++; code = 13; break;
-        default: if (found) { ver++; src = l; } else nmiss++; code = 14; break;  // 5 kCommitBck
+      uint64_t multi = __ballot(leader && !single);
+      while (multi) {  // longer segments: one wave-uniform walk each, registers only
+        const int L = __ffsll((unsigned long long)multi) - 1;
+        multi &= multi - 1;
+        const uint64_t sm = readlane_u64(seg, L);
+        const uint32_t fnd = __builtin_amdgcn_readlane(found, L);
+        uint32_t la = __builtin_amdgcn_readlane(la0, L), lb = __builtin_amdgcn_readlane(lb0, L);
+        uint32_t ver = __builtin_amdgcn_readlane(ver0, L), miss = 0;
+        int src = -1;
+        for (uint64_t m = sm; m; m &= m - 1) {
+          const int l = __ffsll((unsigned long long)m) - 1;
+          const uint32_t op = __builtin_amdgcn_readlane(type, l);
+          uint32_t get = 0;
+          bool wr = false;
+          const uint32_t ver_seen = ver;
+          const int src_seen = src;
+          const uint32_t code = sb_step(op, fnd, la, lb, get, miss, wr);
+          if (wr) { ver++; src = l; }
+          if (lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
+        }
+        if (lane == L) { fin_la = la; fin_lb = lb; fin_ver = ver; fin_src = src; nmiss = miss; }
       }
-      if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
     }
   }
 
-  // ---- replies, all lanes in parallel
-  const uint32_t src_idx = __shfl(idx, my_src >= 0 ? my_src : (int)lane, 64);
-  const uint32_t fin_idx = __shfl(idx, src >= 0 ? src : (int)lane, 64);
-  uint8_t *row = kv_entry_ptr(t, lbucket, link) + KV_VAL_OFF + slot * F::VS;
-  if (mine) {
-    uint8_t *msg = rep + (size_t)idx * F::MSG;
+  // ---- 3. replies of the simple segments, all lanes in parallel
+  const uint32_t src_idx = __shfl(idx, my_src >= 0 ? my_src : lane, 64);
+  const uint32_t fin_idx = __shfl(idx, fin_src >= 0 ? fin_src : lane, 64);
+  uint8_t *row = nullptr;
+  if (simple) {
+    row = kv_entry_ptr(t, bucket, link) + KV_VAL_OFF + slot * F::VS;
     if (my_get) {
       const uint8_t *from = my_src >= 0 ? rep + (size_t)src_idx * F::MSG + F::VAL : row;
       kv_copy_words(msg + F::VAL, from, F::VS);
@@ -427,58 +474,40 @@ __device__ static inline void kv_fast_group(uint64_t same, bool mine, int leader
     }
     msg[F::TYPE] = (uint8_t)my_code;
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the table reads above precede the write-back below
-  // ---- final state, written once by the leader
-  if ((int)lane == leader) {
-    if (src >= 0) {
+  kv_stamp(tr, 6);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the table reads above precede the write-backs below
+  // ---- 4. final state of each simple segment, written once by its head
+  if (leader) {
+    if (fin_src >= 0) {
       kv_copy_words(row, rep + (size_t)fin_idx * F::MSG + F::VAL, F::VS);
-      kv_entry_hdr(t, lbucket, link)->ver[slot] = ver;
+      kv_entry_hdr(t, bucket, link)->ver[slot] = fin_ver;
     }
-    if (WL == DINT_WL_TATP && la != la0) kv_entry_hdr(t, lbucket, KV_INLINE)->lockb[lq] = (uint8_t)la;
-    if (WL == DINT_WL_SMALLBANK && (la != la0 || lb != lb0)) {
-      uint32_t *c = (uint32_t *)(kv_entry_ptr(t, lbucket, KV_INLINE) + KV_SB_LOCK_OFF) + 2 * lq;
-      c[0] = la; c[1] = lb;
-    }
+    if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
+    if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = make_uint2(fin_la, fin_lb);
     if (nmiss) atomicAdd(&stats->missing_keys, (unsigned long long)nmiss);
   }
-}
+  kv_stamp(tr, 7);
 
-// ---- one 64-chunk of a bin's requests, in request order ---------------------------------------------------
-// grp identifies the bucket group of a lane within this chunk (equal grp <=> same bucket); `shared` says that
-// another lane of the chunk has the same grp.  A shared group whose lanes all address one key with
-// chain-preserving ops is resolved in closed form (kv_fast_group); any other shared group runs in rounds:
-// its k-th request, in request (= lane) order, executes in round k.  Unshared lanes run in round 0.
-template <int WL>
-__device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t grp, bool shared, uint32_t gk,
-                                       uint32_t type, uint32_t table, uint32_t q, const kv_dev *__restrict__ kv,
-                                       dint_dev_stats *__restrict__ stats, int force_rounds) {
-  using F = Fmt<WL>;
-  const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
-  const uint64_t key = valid ? ld_u64(rep + (size_t)idx * F::MSG + F::KEY) : 0;
-  uint32_t pos = 0, maxpos = 0;
-  bool rounds = valid && !shared;
-  uint64_t conf = __ballot(valid && shared);
-  while (conf) {
-    const int leader = __ffsll((unsigned long long)conf) - 1;
-    const uint32_t sg = __builtin_amdgcn_readlane(grp, leader);
-    const bool mine = valid && shared && grp == sg;
-    const uint64_t same = __ballot(mine);
-    const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(key >> 32), leader) << 32) |
-                        __builtin_amdgcn_readlane((uint32_t)key, leader);
-    const bool simple = __ballot(mine && !(key == k0 && kv_simple_op<WL>(type))) == 0 && !force_rounds;
-    if (simple) {
-      kv_fast_group<WL>(same, mine, leader, rep, idx, type, table, q, bucket, key, kv, stats);
-    } else {
-      if (mine) { pos = (uint32_t)__popcll(same & lanemask_lt()); rounds = true; }
-      maxpos = max(maxpos, (uint32_t)__popcll(same) - 1u);
+  // ---- everything else: rounds
+  const bool rounds = valid && !simple;
+  const uint32_t pos = (uint32_t)(lane - hl);
+  const uint64_t rm = __ballot(rounds);
+  uint32_t maxpos = 0;
+  if (rm) {
+    // longest non-simple segment
+    uint64_t heads = rm & hm;
+    while (heads) {
+      const int L = __ffsll((unsigned long long)heads) - 1;
+      heads &= heads - 1;
+      maxpos = max(maxpos, (uint32_t)__popcll(readlane_u64(seg, L)) - 1u);
     }
-    conf &= ~same;
+    for (uint32_t r = 0; r <= maxpos; r++) {
+      if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the next round must see this round's stores
+    }
   }
-  for (uint32_t r = 0; r <= maxpos; r++) {
-    if (rounds && pos == r) kv_do_request<WL>(rep + (size_t)idx * F::MSG, type, table, q, bucket, kv, stats);
-    // the next round (and the next chunk) must see this round's stores
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ... and the next chunk this chunk's
+  kv_stamp(tr, 8);
 }
 
 // 64 keys, one per lane, ascending (bitonic network over the wave, 21 compare-exchange steps)
@@ -501,18 +530,26 @@ __device__ static inline uint64_t wave_sort_u64(uint64_t w) {
 // ---- k_kv_resolve ----------------------------------------------------------------------------------------
 template <int WL>
 __global__ void __launch_bounds__(64)
-k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int kv_force_rounds) {
+k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int kv_force_rounds,
+             uint64_t *trace) {
   __shared__ dint_rank_lds R;
   __shared__ uint32_t Srec[DINT_WCAP];  // idx | hash entry << 16, in request order
   __shared__ uint16_t Sop[DINT_WCAP];   // type | table << 8 | quadrant << 12
   __shared__ uint32_t Hk[DINT_HSIZE];   // bucket group of each hash entry
-  __shared__ uint32_t Hfl[DINT_HSIZE];  // lanes of the current chunk on it
+  __shared__ kv_dev Skv;                // table descriptors: per-lane lookups by table id become LDS reads
   const uint32_t bin = blockIdx.x, lane = threadIdx.x;
+  uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
+  kv_stamp(tr, 0);
   const uint32_t c = bin_cnt[bin];
+  if (tr && lane == 0) tr[15] = c;
   if (c == 0) return;
   const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
   if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
+  for (uint32_t k = lane; k < sizeof(kv_dev) / 4; k += 64) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
+  __syncthreads();
+  const kv_dev *kv = &Skv;
+  kv_stamp(tr, 1);
 
   if (c <= 64) {
     // The common case: the whole bin is one chunk.  Sort the records by (bucket group, idx) in registers:
@@ -523,20 +560,21 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *
       const uint64_t r = recs[lane];
       w = ((uint64_t)rec_gk(r) << 32) | ((uint64_t)rec_idx(r) << 16) | ((uint64_t)rec_op(r) << 8) | rec_aux(r);
     }
+    kv_stamp(tr, 2);
     w = wave_sort_u64(w);
+    kv_stamp(tr, 3);
     const bool valid = lane < c;
     const uint32_t gk = (uint32_t)(w >> 32), idx = (uint32_t)(w >> 16) & 0xFFFF;
     const uint32_t type = (uint32_t)(w >> 8) & 0xFF, aux = (uint32_t)w & 0xFF;
-    const uint32_t up = __shfl_up(gk, 1, 64), dn = __shfl_down(gk, 1, 64);
-    const bool shared = valid && ((lane > 0 && up == gk) || (lane + 1 < c && dn == gk));
-    kv_chunk<WL>(rep, valid, idx, gk, shared, gk, type, aux & 15u, aux >> 4, kv, stats, kv_force_rounds);
+    kv_chunk<WL>(rep, valid, idx, gk, type, aux & 15u, aux >> 4, kv, stats, kv_force_rounds, tr);
+    kv_stamp(tr, 9);
     return;
   }
 
   rank_build(R, recs, c, n);
   for (uint32_t lo = 0; lo < c; lo += DINT_WCAP) {
     const uint32_t wn = min(DINT_WCAP, c - lo);
-    for (uint32_t h = lane; h < DINT_HSIZE; h += 64) { Hk[h] = DINT_EMPTY; Hfl[h] = 0; }
+    for (uint32_t h = lane; h < DINT_HSIZE; h += 64) Hk[h] = DINT_EMPTY;
     __syncthreads();
     for (uint32_t k = lane; k < c; k += 64) {
       const uint64_t r = recs[k];
@@ -552,20 +590,21 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *
     __syncthreads();
 
     for (uint32_t ch = 0; ch < wn; ch += 64) {
+      // 64 consecutive requests of the window; sorted by (hash entry, idx) so that each bucket's requests are
+      // adjacent and in request order, as kv_chunk expects
       const uint32_t j = ch + lane;
-      const bool valid = j < wn;
-      const uint32_t sr = valid ? Srec[j] : 0;
-      const uint32_t so = valid ? Sop[j] : 0;
-      const uint32_t idx = sr & 0xFFFF, e = (sr >> 16) & (DINT_HSIZE - 1);
-      if (valid) atomicAdd(&Hfl[e], 1u);
-      __syncthreads();
-      const bool shared = valid && Hfl[e] > 1;
-      kv_chunk<WL>(rep, valid, idx, e, shared, valid ? Hk[e] : 0, so & 0xFF, (so >> 8) & 15u, so >> 12, kv, stats,
+      uint64_t w = ~0ull;
+      if (j < wn) {
+        const uint32_t sr = Srec[j];
+        w = ((uint64_t)(sr >> 16) << 32) | ((uint64_t)(sr & 0xFFFF) << 16) | Sop[j];
+      }
+      w = wave_sort_u64(w);
+      const bool valid = w != ~0ull;
+      const uint32_t e = (uint32_t)(w >> 32) & (DINT_HSIZE - 1), idx = (uint32_t)(w >> 16) & 0xFFFF, so = (uint32_t)w & 0xFFFF;
+      kv_chunk<WL>(rep, valid, idx, valid ? Hk[e] : 0xFFFFFFFFu, so & 0xFF, (so >> 8) & 15u, so >> 12, kv, stats,
                    kv_force_rounds);
-      __syncthreads();
-      if (valid) Hfl[e] = 0;
-      __syncthreads();
     }
+    __syncthreads();
   }
 }
 
@@ -583,7 +622,7 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
                      kv.d_dev, log, (const uint32_t *)s.blk_cnt, P - 1, s.bin_cnt, s.bins, s.stats, load_mode);
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
-                     (const uint64_t *)s.bins, s.stats, kv.force_rounds);
+                     (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace);
   if (ev) hipEventRecord(ev[2], st);
 }
 
@@ -670,6 +709,10 @@ int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard s
     kv->h.gk_base[t] = (uint32_t)gk;
     gk += tb.n_local;
   }
+  if (getenv("DINT_KV_TRACE")) {
+    if (hipMalloc((void **)&kv->d_trace, (size_t)DINT_PMAX * 16 * 8) != hipSuccess) return DINT_ENOMEM;
+    hipMemset(kv->d_trace, 0, (size_t)DINT_PMAX * 16 * 8);
+  }
   if (hipMalloc((void **)&kv->d_dev, sizeof(kv_dev)) != hipSuccess) return DINT_ENOMEM;
   if (hipMemcpy(kv->d_dev, &kv->h, sizeof(kv_dev), hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;
   return 0;
@@ -682,6 +725,7 @@ void dint_kv_destroy(dint_kv *kv) {
   }
   if (kv->d_ctl) hipFree(kv->d_ctl);
   if (kv->d_dev) hipFree(kv->d_dev);
+  if (kv->d_trace) hipFree(kv->d_trace);
   *kv = dint_kv();
 }
 
@@ -703,7 +747,7 @@ __device__ static inline uint32_t bucket_rows(const kv_tab &t, uint64_t b, uint6
     const uint8_t *e = kv_entry_ptr(t, b, cur);
     const kv_hdr *h = (const kv_hdr *)e;
     for (uint32_t i = 0; i < 4; i++)
-      if (h->valid[i]) {
+      if (kv_valid(*h, i)) {
         if (keys) {
           keys[nrow] = h->key[i];
           vers[nrow] = h->ver[i];
@@ -787,7 +831,7 @@ __global__ void __launch_bounds__(256) k_kv_read_locks(kv_tab t, int is_sb, uint
       a[at] = c[0];
       if (b) b[at] = c[1];
     } else {
-      a[at] = ((const kv_hdr *)e)->lockb[q];
+      a[at] = e[KV_LOCKB_OFF + q];
       if (b) b[at] = 0;
     }
   }

@@ -113,6 +113,12 @@ class Engine:
     def timing_enable(self, on: bool = True):
         _lib.check(self._L.dint_timing_enable(self._h, int(on)))
 
+    def kv_trace(self) -> np.ndarray:
+        """[2048, 16] u64 per-wave timeline of the last resolve launch (needs DINT_KV_TRACE=1)."""
+        out = np.zeros((2048, 16), "<u8")
+        _lib.check(self._L.dint_kv_trace_read(self._h, out.ctypes.data, out.size))
+        return out
+
     def timing_read(self) -> dict:
         names = (C.c_char_p * 4)(); us = (C.c_double * 4)(); cnt = (C.c_uint64 * 4)()
         k = _lib.check(self._L.dint_timing_read(self._h, names, us, cnt, 4))

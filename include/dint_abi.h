@@ -174,6 +174,11 @@ int dint_timing_enable(dint_engine_t *e, int on);
 /* returns number of kernels written; names[i] points to a static string */
 int dint_timing_read(dint_engine_t *e, const char **names, double *avg_us, uint64_t *launches, int cap);
 
+/* Debug (kv workloads, engine created with DINT_KV_TRACE=1 in the environment): per-wave timeline of the most
+ * recent resolve launch, 16 u64 per bin: [0..9] s_memtime stamps (see k_kv.hip kv_stamp), [15] records in the bin.
+ * Copies min(cap, 2048 * 16) words; returns the number of bins traced or DINT_ESTATE when tracing is off. */
+int dint_kv_trace_read(dint_engine_t *e, uint64_t *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,11 +43,11 @@ void kvh_rotate(kvh *h) { kv_pool_rotate<kv_host_mem>(h->t); }
 uint32_t kvh_pool_top(kvh *h) { return h->pool_top; }
 // lock words share the inline entry with the rows: poke them to prove row ops never clobber them
 void kvh_set_lock_bytes(kvh *h, uint64_t bucket, uint32_t v) {
-  memcpy(kv_entry_hdr(h->t, bucket, KV_INLINE)->lockb, &v, 4);
+  kv_entry_hdr(h->t, bucket, KV_INLINE)->lockw = v;
 }
 uint32_t kvh_get_lock_bytes(kvh *h, uint64_t bucket) {
   uint32_t v;
-  memcpy(&v, kv_entry_hdr(h->t, bucket, KV_INLINE)->lockb, 4);
+  v = kv_entry_hdr(h->t, bucket, KV_INLINE)->lockw;
   return v;
 }
 // valid rows in bucket order, chain order inside a bucket
@@ -59,7 +59,7 @@ uint64_t kvh_dump(kvh *h, uint64_t *keys, uint32_t *vers, uint8_t *vals, uint64_
       const uint8_t *e = kv_entry_ptr(h->t, b, cur);
       const kv_hdr *hd = (const kv_hdr *)e;
       for (int i = 0; i < 4; i++)
-        if (hd->valid[i]) {
+        if (kv_valid(*hd, i)) {
           if (n < cap) {
             keys[n] = hd->key[i];
             vers[n] = hd->ver[i];

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of k_kv_resolve for one tatp pass (DINT_KV_TRACE=1): where a wave's time goes."""
+import os
+import sys
+
+os.environ["DINT_KV_TRACE"] = "1"
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dint_amd import wire  # noqa: E402
+from dint_amd.driver import Driver  # noqa: E402
+from dint_amd.replay import Replay, ShardGroup, record  # noqa: E402
+
+theta = float(sys.argv[1]) if len(sys.argv) > 1 else 0.8
+n_sub, C, E = 1_000_000, 131072, 30
+grp = ShardGroup(wire.Workload.TATP, n_sub)
+grp.sync(); grp.snapshot()
+d = Driver(wire.Workload.TATP, C, n_sub, zipf_theta=theta if theta > 0 else None)
+trace, done = record(d, grp, E)
+grp.sync(); grp.restore()
+rp = Replay(trace, grp.msg)
+torch.cuda.synchronize()
+eng = grp.engines[0]
+for e in range(E):
+    eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
+grp.sync()
+t = eng.kv_trace().astype(np.int64)
+c = t[:, 15]
+live = c > 0
+t0 = t[live, 0].min()
+names = ["entry->c,Skv", "recs", "sort", "msg key+segments", "heads: hdr+locate", "outcomes+replies", "fence+write-back", "rounds+fence", "exit"]
+small = live & (c <= 64)
+print(f"theta={theta} bins live={live.sum()} small={small.sum()} big={(live & (c > 64)).sum()} max c={c.max()} n={rp.counts[E-1][0]}")
+ts = t[small][:, :10]
+d_ = np.diff(ts, axis=1)
+print("small bins: mean cycles per phase (s_memtime ticks; 100 MHz => x10 ns)")
+for k, nm in enumerate(names):
+    print(f"  {nm:18s} mean {d_[:, k].mean():9.1f}  p50 {np.median(d_[:, k]):9.1f}  p99 {np.percentile(d_[:, k], 99):9.1f}")
+print(f"  wave total        mean {(ts[:, 9] - ts[:, 0]).mean():9.1f}")
+start = t[live, 0] - t0
+end_small = ts[:, 9] - t0
+print(f"wave start (ticks after first): p50 {np.median(start):.0f} p99 {np.percentile(start, 99):.0f} max {start.max()}")
+print(f"small-wave end: p50 {np.median(end_small):.0f} p99 {np.percentile(end_small, 99):.0f} max {end_small.max()}")
+big = live & (c > 64)
+if big.any():
+    # big bins only stamp 0,1 and the per-chunk stamps get overwritten; report count and start
+    print("big bins c:", sorted(c[big].tolist())[-10:])
