@@ -7,6 +7,7 @@
 #include "dint_kv_core.h"
 
 #define DINT_KV_MAX_TABLES 5
+#define DINT_KV_CTL_BYTES (64 + 16 * KV_NLISTS)  // per table: pool_top, free_head[], pend_head[]
 #define DINT_KV_LOAD_OP 0xF0u  // internal request type: insert a row with the version carried in msg.ver
 
 // everything the kernels need about the tables; lives in device memory (d_dev) and in a host mirror

@@ -40,6 +40,7 @@
 #define KV_NULL 0u
 #define KV_INLINE 1u
 #define KV_MAX_CHAIN 4096u  // walk bound: a corrupt chain must never hang a GPU
+#define KV_NLISTS 64u        // free lists per table
 
 struct kv_hdr {
   uint64_t key[4];
@@ -65,10 +66,11 @@ struct kv_tab {
   uint32_t val_size;
   uint32_t *pool_top;    // bump allocator (entries handed out so far)
   uint32_t *pool_next;   // [pool_cap] free-list links, touched with atomics only
-  // {tag:32, link:32}; frees go to `pend`; `pend` becomes poppable at the next pass boundary, when the
-  // freeing workgroup's dirty lines are known to have left its XCD's L2 (see kv_pool_rotate)
-  unsigned long long *free_head;
-  unsigned long long *pend_head;
+  // KV_NLISTS free lists, each {tag:32, link:32}; a workgroup uses list (its bin & (KV_NLISTS-1)), so concurrent
+  // inserts / deletes rarely CAS the same word.  Frees go to `pend`; `pend` becomes poppable at the next pass
+  // boundary, when the freeing workgroup's dirty lines are known to have left its XCD's L2 (see kv_pool_rotate)
+  unsigned long long *free_head;  // [KV_NLISTS]
+  unsigned long long *pend_head;  // [KV_NLISTS]
 };
 
 KV_HD static inline uint8_t *kv_entry_ptr(const kv_tab &t, uint64_t bucket, uint32_t link) {
@@ -102,13 +104,14 @@ struct kv_host_mem {
 
 // ---- overflow-entry pool -------------------------------------------------------------------------------
 template <class M>
-KV_HD static inline uint32_t kv_pool_alloc(const kv_tab &t) {
+KV_HD static inline uint32_t kv_pool_alloc(const kv_tab &t, uint32_t lst) {
+  unsigned long long *fh = t.free_head + (lst & (KV_NLISTS - 1));
   for (uint32_t spin = 0; spin < 1024; spin++) {  // recycled entries first
-    const unsigned long long old = M::load64(t.free_head);
+    const unsigned long long old = M::load64(fh);
     const uint32_t link = (uint32_t)old;
     if (link == KV_NULL) break;
     const uint32_t nxt = M::load32(&t.pool_next[link - 2u]);
-    if (M::cas64(t.free_head, old, ((old >> 32) + 1ull) << 32 | nxt)) return link;
+    if (M::cas64(fh, old, ((old >> 32) + 1ull) << 32 | nxt)) return link;
   }
   const uint32_t p = M::fetch_add(t.pool_top, 1u);
   if (p >= t.pool_cap) {
@@ -118,21 +121,23 @@ KV_HD static inline uint32_t kv_pool_alloc(const kv_tab &t) {
   return p + 2u;
 }
 template <class M>
-KV_HD static inline void kv_pool_free(const kv_tab &t, uint32_t link) {
+KV_HD static inline void kv_pool_free(const kv_tab &t, uint32_t link, uint32_t lst) {
+  unsigned long long *ph = t.pend_head + (lst & (KV_NLISTS - 1));
   for (uint32_t spin = 0; spin < 65536; spin++) {
-    const unsigned long long old = M::load64(t.pend_head);
+    const unsigned long long old = M::load64(ph);
     M::store32(&t.pool_next[link - 2u], (uint32_t)old);
-    if (M::cas64(t.pend_head, old, ((old >> 32) + 1ull) << 32 | link)) return;
+    if (M::cas64(ph, old, ((old >> 32) + 1ull) << 32 | link)) return;
   }
   // give up: the entry leaks (bounded spin, never reached in practice)
 }
-// pass boundary (single thread, no pass in flight): entries freed during earlier passes become poppable
+// pass boundary (one thread per list, no pass in flight): entries freed during earlier passes become poppable
 template <class M>
-KV_HD static inline void kv_pool_rotate(const kv_tab &t) {
-  const unsigned long long f = M::load64(t.free_head), p = M::load64(t.pend_head);
+KV_HD static inline void kv_pool_rotate(const kv_tab &t, uint32_t lst) {
+  unsigned long long *fh = t.free_head + lst, *ph = t.pend_head + lst;
+  const unsigned long long f = *fh, p = *ph;
   if ((uint32_t)f == KV_NULL && (uint32_t)p != KV_NULL) {
-    *t.free_head = ((f >> 32) + 1ull) << 32 | (uint32_t)p;
-    *t.pend_head = ((p >> 32) + 1ull) << 32;
+    *fh = ((f >> 32) + 1ull) << 32 | (uint32_t)p;
+    *ph = ((p >> 32) + 1ull) << 32;
   }
 }
 
@@ -171,7 +176,7 @@ KV_HD static inline void kv_copy_words(uint8_t *dst, const uint8_t *src, uint32_
 // (may be unaligned).  ins_ver: version of an inserted row (0 for the wire INSERT ops).
 template <class M>
 KV_HD static inline kv_res kv_apply(const kv_tab &t, uint64_t bucket, const kv_hdr &H, uint32_t act, uint64_t key,
-                                    uint8_t *val, uint32_t ins_ver) {
+                                    uint8_t *val, uint32_t ins_ver, uint32_t lst = 0) {
   kv_res res = {false, 0};
   if (act == KV_ACT_NONE) return res;
   const bool want_match = act != KV_ACT_INS;
@@ -215,7 +220,7 @@ KV_HD static inline kv_res kv_apply(const kv_tab &t, uint64_t bucket, const kv_h
     case KV_ACT_INS: {  // kvs.h:94-121
       uint32_t link = f_link, slot = f_slot;
       if (!have_free) {  // every slot of the chain is taken: a new entry, prepended (kvs.h:112-119)
-        link = inline_linked ? kv_pool_alloc<M>(t) : KV_INLINE;
+        link = inline_linked ? kv_pool_alloc<M>(t, lst) : KV_INLINE;
         if (link == KV_NULL) break;
         slot = 0;
       }
@@ -243,7 +248,7 @@ KV_HD static inline kv_res kv_apply(const kv_tab &t, uint64_t bucket, const kv_h
         if ((m_valid & ~(0xFFu << (8 * m_slot))) == 0) {  // the entry is empty now: unlink it and free it
           if (m_prev == KV_NULL) kv_entry_hdr(t, bucket, KV_INLINE)->head = m_next;
           else kv_entry_hdr(t, bucket, m_prev)->next = m_next;
-          if (m_link != KV_INLINE) kv_pool_free<M>(t, m_link);
+          if (m_link != KV_INLINE) kv_pool_free<M>(t, m_link, lst);
         }
         res.ok = true;
       }

@@ -115,19 +115,25 @@ k_kv_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
-  if (blockIdx.x == 0 && threadIdx.x == 0)  // entries freed by earlier passes become reusable
-    for (uint32_t t = 0; t < kv->n_tables; t++) kv_pool_rotate<kv_dev_mem>(kv->tab[t]);
+  if (blockIdx.x == 0 && threadIdx.x < KV_NLISTS)  // entries freed by earlier passes become reusable
+    for (uint32_t t = 0; t < kv->n_tables; t++) kv_pool_rotate<kv_dev_mem>(kv->tab[t], threadIdx.x);
 
-  // copy this block's messages to the reply array (replies are the request mutated in place)
+  // copy this block's messages to the reply array (replies are the request mutated in place).  All loads of a
+  // thread are issued before its first store: one memory round trip for the 256 * MSG <= 16 KiB of the block.
   if (rep != req) {
     const size_t lo = (size_t)blockIdx.x * 256u * F::MSG;
     const size_t hi = min((size_t)n * F::MSG, lo + (size_t)256u * F::MSG);
     if ((((uintptr_t)req | (uintptr_t)rep) & 15) == 0) {
-      const size_t nv = (hi - lo) / 16;
+      const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 880 vectors
       const uint4 *s = (const uint4 *)(req + lo);
       uint4 *d = (uint4 *)(rep + lo);
-      for (size_t k = threadIdx.x; k < nv; k += 256) d[k] = s[k];
-      for (size_t k = lo + nv * 16 + threadIdx.x; k < hi; k += 256) rep[k] = req[k];
+      // unconditional loads at clamped indices (branch-free, so the four loads stay in flight together; nv >= 1)
+      const uint32_t a0 = min(threadIdx.x, nv - 1), a1 = min(threadIdx.x + 256u, nv - 1);
+      const uint32_t a2 = min(threadIdx.x + 512u, nv - 1), a3 = min(threadIdx.x + 768u, nv - 1);
+      const uint4 v0 = s[a0], v1 = s[a1], v2 = s[a2], v3 = s[a3];
+      // ... and unconditional stores: a clamped lane rewrites vector nv-1 with the same bytes
+      d[a0] = v0; d[a1] = v1; d[a2] = v2; d[a3] = v3;
+      for (size_t k = lo + (size_t)nv * 16 + threadIdx.x; k < hi; k += 256) rep[k] = req[k];
     } else {
       for (size_t k = lo + threadIdx.x; k < hi; k += 256) rep[k] = req[k];
     }
@@ -217,6 +223,10 @@ __device__ static inline void kv_stamp(uint64_t *tr, uint32_t k) {
     if (lane_id() == 0) tr[k] = __builtin_amdgcn_s_memtime();
   }
 }
+// device-wide constant-rate clock (100 MHz), comparable across waves: [10] = wave start, [11] = wave end
+__device__ static inline void kv_stamp_real(uint64_t *tr, uint32_t k) {
+  if (tr && lane_id() == 0) tr[k] = __builtin_amdgcn_s_memrealtime();
+}
 
 // ---- one request against the table ---------------------------------------------------------------------
 // Written so that the lanes of a wave, which run different request types, share their memory round trips:
@@ -238,7 +248,7 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
   if (WL == DINT_WL_SMALLBANK) cnt = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);  // {num_ex, num_sh}
   const uint64_t key = ld_u64(msg + F::KEY);
   uint8_t *val = msg + F::VAL;
-  kv_stamp(tr, 6);
+  if (tr) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[12] = __builtin_amdgcn_s_memtime(); tr[14] = type; }
 
   // ---- decide phase
   uint32_t act = KV_ACT_NONE, code = 0, ins_ver = 0;
@@ -280,8 +290,8 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
   }
 
   // ---- act phase
-  const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, act, key, val, ins_ver);
-  kv_stamp(tr, 7);
+  const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, act, key, val, ins_ver, blockIdx.x);
+  if (tr) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[13] = __builtin_amdgcn_s_memtime(); }
   if (WL == DINT_WL_TATP && lock_store >= 0) ie[KV_LOCKB_OFF + q] = (uint8_t)lock_store;
   if (WL == DINT_WL_SMALLBANK && cnt_store) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = cnt;
   if (act == KV_ACT_GET && r.ok) st_u32(msg + F::VER, r.ver);
@@ -335,7 +345,7 @@ __device__ static inline uint64_t readlane_u64(uint64_t v, int l) {
 template <int WL>
 __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t gk, uint32_t type, uint32_t table,
                                        uint32_t q, const kv_dev *kv, dint_dev_stats *__restrict__ stats, int force_rounds,
-                                       uint64_t *tr = nullptr) {
+                                       bool last_chunk, uint64_t *tr = nullptr) {
   using F = Fmt<WL>;
   const int lane = (int)lane_id();
   const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
@@ -354,27 +364,29 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   const uint64_t above = hm & ~le;
   const uint64_t next = above ? (above & (~above + 1ull)) : vm + 1ull;
   const uint64_t seg = valid ? ((next - 1ull) & ~((1ull << hl) - 1ull)) : 0;
-  const uint64_t hkey = shfl_u64(key, hl);
-  const uint64_t m_bad = __ballot(valid && !(key == hkey && kv_simple_op<WL>(type)));
-  const bool simple = valid && (m_bad & seg) == 0 && !force_rounds;
-  kv_stamp(tr, 4);
-
-  // ---- 1. segment heads: load + locate
-  const bool leader = head && simple;
+  // ---- 1. segment heads: load the bucket's inline header (and smallbank counters) -- issued before the keys
+  // are compared, so the header round trip overlaps the key round trip -- then locate the row
   uint32_t found = 0, link = 0, slot = 0, ver0 = 0, la0 = 0, lb0 = 0;
   kv_tab t;
   uint8_t *ie = nullptr;
+  kv_hdr H;
   if (valid) {
     t = kv->tab[table];
     ie = kv_entry_ptr(t, bucket, KV_INLINE);
   }
-  if (leader) {
-    kv_hdr H;
+  if (head) {
     kv_hdr_copy(H, *(const kv_hdr *)ie);
     if (WL == DINT_WL_SMALLBANK) {
       const uint2 c = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);
       la0 = c.x; lb0 = c.y;
     }
+  }
+  const uint64_t hkey = shfl_u64(key, hl);
+  const uint64_t m_bad = __ballot(valid && !(key == hkey && kv_simple_op<WL>(type)));
+  const bool simple = valid && (m_bad & seg) == 0 && !force_rounds;
+  kv_stamp(tr, 4);
+  const bool leader = head && simple;
+  if (leader) {
     if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
     const kv_where w = kv_locate(t, bucket, H, key);
     found = w.found; link = w.link; slot = w.slot; ver0 = w.ver;
@@ -502,11 +514,11 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
       maxpos = max(maxpos, (uint32_t)__popcll(readlane_u64(seg, L)) - 1u);
     }
     for (uint32_t r = 0; r <= maxpos; r++) {
-      if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats);
+      if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats, r == 0 ? tr : nullptr);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the next round must see this round's stores
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ... and the next chunk this chunk's
+  if (!last_chunk) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ... and the next chunk this chunk's
   kv_stamp(tr, 8);
 }
 
@@ -540,11 +552,13 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t
   __shared__ kv_dev Skv;                // table descriptors: per-lane lookups by table id become LDS reads
   const uint32_t bin = blockIdx.x, lane = threadIdx.x;
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
+  kv_stamp_real(tr, 10);
   kv_stamp(tr, 0);
+  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
+  const uint64_t r0 = recs[lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
   if (tr && lane == 0) tr[15] = c;
   if (c == 0) return;
-  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
   if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
   for (uint32_t k = lane; k < sizeof(kv_dev) / 4; k += 64) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
@@ -557,7 +571,7 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t
     // after the sort the requests of a group sit in adjacent lanes -- no LDS, no rank bitmap, no hash.
     uint64_t w = ~0ull;  // empty lanes sort last
     if (lane < c) {
-      const uint64_t r = recs[lane];
+      const uint64_t r = r0;
       w = ((uint64_t)rec_gk(r) << 32) | ((uint64_t)rec_idx(r) << 16) | ((uint64_t)rec_op(r) << 8) | rec_aux(r);
     }
     kv_stamp(tr, 2);
@@ -566,8 +580,9 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t
     const bool valid = lane < c;
     const uint32_t gk = (uint32_t)(w >> 32), idx = (uint32_t)(w >> 16) & 0xFFFF;
     const uint32_t type = (uint32_t)(w >> 8) & 0xFF, aux = (uint32_t)w & 0xFF;
-    kv_chunk<WL>(rep, valid, idx, gk, type, aux & 15u, aux >> 4, kv, stats, kv_force_rounds, tr);
+    kv_chunk<WL>(rep, valid, idx, gk, type, aux & 15u, aux >> 4, kv, stats, kv_force_rounds, true, tr);
     kv_stamp(tr, 9);
+    kv_stamp_real(tr, 11);
     return;
   }
 
@@ -602,10 +617,11 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t
       const bool valid = w != ~0ull;
       const uint32_t e = (uint32_t)(w >> 32) & (DINT_HSIZE - 1), idx = (uint32_t)(w >> 16) & 0xFFFF, so = (uint32_t)w & 0xFFFF;
       kv_chunk<WL>(rep, valid, idx, valid ? Hk[e] : 0xFFFFFFFFu, so & 0xFF, (so >> 8) & 15u, so >> 12, kv, stats,
-                   kv_force_rounds);
+                   kv_force_rounds, false);
     }
     __syncthreads();
   }
+  kv_stamp_real(tr, 11);
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
@@ -682,8 +698,8 @@ int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard s
   kv->h.n_tables = kv->n_tables;
   kv->h.shard_index = shard.index;
   kv->h.shard_count = count;
-  if (hipMalloc((void **)&kv->d_ctl, 64 * DINT_KV_MAX_TABLES) != hipSuccess) return DINT_ENOMEM;
-  hipMemset(kv->d_ctl, 0, 64 * DINT_KV_MAX_TABLES);
+  if (hipMalloc((void **)&kv->d_ctl, DINT_KV_CTL_BYTES * DINT_KV_MAX_TABLES) != hipSuccess) return DINT_ENOMEM;
+  hipMemset(kv->d_ctl, 0, DINT_KV_CTL_BYTES * DINT_KV_MAX_TABLES);
   uint64_t gk = 0;
   for (uint32_t t = 0; t < kv->n_tables; t++) {
     if (hs[t] == 0) hs[t] = 1;
@@ -700,10 +716,10 @@ int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard s
     if (hipMemset(tb.entries, 0, kv->entry_bytes[t]) != hipSuccess) return DINT_EHIP;
     if (hipMalloc((void **)&tb.pool_next, (size_t)tb.pool_cap * 4) != hipSuccess) return DINT_ENOMEM;
     hipMemset(tb.pool_next, 0, (size_t)tb.pool_cap * 4);
-    uint8_t *ctl = kv->d_ctl + 64 * t;
+    uint8_t *ctl = kv->d_ctl + DINT_KV_CTL_BYTES * t;
     tb.pool_top = (uint32_t *)ctl;
-    tb.free_head = (unsigned long long *)(ctl + 8);
-    tb.pend_head = (unsigned long long *)(ctl + 16);
+    tb.free_head = (unsigned long long *)(ctl + 64);
+    tb.pend_head = (unsigned long long *)(ctl + 64 + 8 * KV_NLISTS);
     kv->h.mod[t] = dint_make_mod(hs[t]);
     kv->h.lockmod[t] = dint_make_mod(4 * hs[t]);
     kv->h.gk_base[t] = (uint32_t)gk;
@@ -735,7 +751,7 @@ std::vector<std::pair<void *, size_t>> dint_kv_regions(dint_kv *kv) {
     r.push_back({kv->h.tab[t].entries, kv->entry_bytes[t]});
     r.push_back({kv->h.tab[t].pool_next, (size_t)kv->h.tab[t].pool_cap * 4});
   }
-  if (kv->d_ctl) r.push_back({kv->d_ctl, (size_t)64 * DINT_KV_MAX_TABLES});
+  if (kv->d_ctl) r.push_back({kv->d_ctl, (size_t)DINT_KV_CTL_BYTES * DINT_KV_MAX_TABLES});
   return r;
 }
 

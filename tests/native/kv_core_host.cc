@@ -10,7 +10,7 @@
 struct kvh {
   kv_tab t;
   uint32_t pool_top;
-  unsigned long long free_head, pend_head;
+  unsigned long long free_head[KV_NLISTS], pend_head[KV_NLISTS];
 };
 
 extern "C" {
@@ -24,8 +24,8 @@ kvh *kvh_create(uint64_t n_buckets, uint32_t pool_cap, uint32_t val_size) {
   h->t.entries = (uint8_t *)calloc(n_buckets + pool_cap, h->t.stride);
   h->t.pool_next = (uint32_t *)calloc(pool_cap ? pool_cap : 1, 4);
   h->t.pool_top = &h->pool_top;
-  h->t.free_head = &h->free_head;
-  h->t.pend_head = &h->pend_head;
+  h->t.free_head = h->free_head;
+  h->t.pend_head = h->pend_head;
   return h;
 }
 void kvh_destroy(kvh *h) {
@@ -39,7 +39,7 @@ int kvh_insert(kvh *h, uint64_t bucket, uint64_t key, const uint8_t *val, uint32
   return kv_insert<kv_host_mem>(h->t, bucket, key, val, ver) ? 0 : 1;
 }
 int kvh_delete(kvh *h, uint64_t bucket, uint64_t key) { return kv_delete<kv_host_mem>(h->t, bucket, key) ? 0 : 1; }
-void kvh_rotate(kvh *h) { kv_pool_rotate<kv_host_mem>(h->t); }
+void kvh_rotate(kvh *h) { for (uint32_t l = 0; l < KV_NLISTS; l++) kv_pool_rotate<kv_host_mem>(h->t, l); }
 uint32_t kvh_pool_top(kvh *h) { return h->pool_top; }
 // lock words share the inline entry with the rows: poke them to prove row ops never clobber them
 void kvh_set_lock_bytes(kvh *h, uint64_t bucket, uint32_t v) {

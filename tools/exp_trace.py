@@ -38,6 +38,19 @@ print("small bins: mean cycles per phase (s_memtime ticks; 100 MHz => x10 ns)")
 for k, nm in enumerate(names):
     print(f"  {nm:18s} mean {d_[:, k].mean():9.1f}  p50 {np.median(d_[:, k]):9.1f}  p99 {np.percentile(d_[:, k], 99):9.1f}")
 print(f"  wave total        mean {(ts[:, 9] - ts[:, 0]).mean():9.1f}")
+rs, re = t[live, 10], t[live, 11]
+r0 = rs.min()
+print(f"realtime (10 ns ticks): wave start p50 {np.median(rs - r0):.0f} p99 {np.percentile(rs - r0, 99):.0f} max {(rs - r0).max()};  "
+      f"wave end p50 {np.median(re - r0):.0f} p90 {np.percentile(re - r0, 90):.0f} p99 {np.percentile(re - r0, 99):.0f} max {(re - r0).max()}")
+order = np.argsort(re)[-8:]
+print("last waves to finish: (c, start, end)", [(int(c[live][i]), int(rs[i] - r0), int(re[i] - r0)) for i in order])
+tl = t[live]
+for i in order[-5:]:
+    print("   slow wave c=%d phases(cycles):" % tl[i, 15], np.diff(tl[i, :10]).tolist(), "dur_10ns", int(re[i] - rs[i]),
+          "| do_request: type", int(tl[i, 14]), "t7->loads", int(tl[i, 12] - tl[i, 7]), "apply", int(tl[i, 13] - tl[i, 12]), "->t8", int(tl[i, 8] - tl[i, 13]))
+dur = re - rs
+sm = tl[:, 15] <= 64
+print("small-wave duration (10ns): p50 %d p90 %d p99 %d max %d" % tuple(np.percentile(dur[sm], [50, 90, 99, 100])))
 start = t[live, 0] - t0
 end_small = ts[:, 9] - t0
 print(f"wave start (ticks after first): p50 {np.median(start):.0f} p99 {np.percentile(start, 99):.0f} max {start.max()}")
