@@ -93,6 +93,23 @@ __device__ static inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total
   return x - v;
 }
 
+// 64 keys, one per lane, ascending (bitonic network over the wave, 21 compare-exchange steps)
+__device__ static inline uint64_t wave_sort_u64(uint64_t w) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)w, (int)j, 64), hi = __shfl_xor((uint32_t)(w >> 32), (int)j, 64);
+      const uint64_t o = ((uint64_t)hi << 32) | lo;
+      const bool up = (lane & k) == 0;           // this k-block sorts ascending
+      const bool low = (lane & j) == 0;          // lower lane of the pair
+      w = (low == up) ? (w < o ? w : o) : (w < o ? o : w);
+    }
+  }
+  return w;
+}
+
 // ---- idx ranking: restore request order inside a bin ---------------------------------------------
 // A bin receives its records in arbitrary order (atomic reservation), but every record carries
 // its request index.  The wave marks the indices present in a bitmap over [0, n), prefix-sums the

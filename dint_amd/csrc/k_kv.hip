@@ -71,6 +71,15 @@ __device__ static inline uint32_t kv_class(uint32_t type, int load_mode) {
   return type <= 5 ? 1 : (type == 6 ? 2 : 0);
 }
 
+// 16-bit request descriptor carried from the scatter kernel to the resolve kernels
+__device__ static inline uint32_t kv_pay(uint32_t type, uint32_t table, uint32_t q, uint32_t kh) {
+  return (type == DINT_KV_LOAD_OP ? 31u : type) | (table << 5) | (q << 8) | (kh << 10);
+}
+__device__ static inline uint32_t pay_type(uint32_t p) { const uint32_t t = p & 31u; return t == 31u ? DINT_KV_LOAD_OP : t; }
+__device__ static inline uint32_t pay_table(uint32_t p) { return (p >> 5) & 7u; }
+__device__ static inline uint32_t pay_q(uint32_t p) { return (p >> 8) & 3u; }
+__device__ static inline uint32_t pay_kh(uint32_t p) { return (p >> 10) & 63u; }
+
 __device__ static inline uint64_t ld_u64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ static inline uint32_t ld_u32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ static inline void st_u32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
@@ -210,7 +219,9 @@ k_kv_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv
     const uint32_t gk = kv->gk_base[table] + local;
     const uint32_t bin = gk & pmask;
     const uint32_t pos = atomicAdd(&bin_cnt[bin], 1u);
-    bins[(size_t)bin * DINT_MICRO + pos] = dint_rec(gk, i, type, table | (q << 4));
+    // record payload (16 bits): type (5 bits, LOAD -> 31) | table << 5 | lock quadrant << 8 | 6 key-hash bits << 10
+    const uint32_t pay = kv_pay(type, table, q, (uint32_t)(h >> 40) & 63u);
+    bins[(size_t)bin * DINT_MICRO + pos] = dint_rec(gk, i, pay & 0xFF, pay >> 8);
   }
 }
 
@@ -306,14 +317,16 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
 }
 
 // ---- one 64-chunk of a bin's requests ----------------------------------------------------------------------
-// Precondition: the chunk's lanes are sorted by (bucket group, idx), so the requests of one bucket sit in
-// adjacent lanes, in request order (valid lanes first).  Such a run is a SEGMENT; segments commute.
-//
-// A segment is "simple" when all its requests address ONE key with ops that never change the chain (no INSERT /
-// DELETE): READ, SET / COMMIT_*, lock ops.  Its serial outcome then depends on a few words of state -- row found?,
-// version, last writer, lock word -- and ALL simple segments of the chunk (single requests included) are
-// resolved together:
-//   1. every segment head loads its bucket's inline header (and smallbank counters) and locates the row;
+// Precondition: the chunk's lanes are sorted by (bucket group, key-hash bits, idx): the requests of one bucket sit
+// in adjacent lanes (a BUCKET RUN), inside it the requests of one key sit in adjacent lanes, in request order (a
+// KEY SEGMENT; valid lanes first).  Runs of different buckets commute.  Inside a bucket:
+//   - rows of different keys are independent (GET / SET touch one row);
+//   - the lock word (tatp lock byte, smallbank counters) is shared by the keys that map to the same quadrant;
+//   - INSERT / DELETE change the chain the other keys are found through.
+// So a bucket run is "simple" when every request is a chain-preserving op, every key segment really holds one
+// key, and at most one of its key segments carries lock ops.  Every key segment of a simple run is then
+// resolved on its own and ALL of them at once:
+//   1. every segment head loads the bucket's inline header (and smallbank counters) and locates its row;
 //   2. every lane derives its own reply from ballots restricted to its segment's lane mask (store / tatp):
 //        version seen = ver0 + #writers below in the segment, value seen = message of the last writer below,
 //        lock seen    = what the last ACQUIRE (-> 1) / ABORT / COMMIT_PRIM (-> 0) below wrote, else the stored byte;
@@ -321,14 +334,20 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
 //      longer segments are walked once each with wave-uniform registers (no memory inside the walk);
 //   3. replies are written, reads copy their value from the last writer's message or from the table row;
 //   4. after a fence the segment heads write the final row / version / lock word once.
-// Four memory round trips per chunk however many requests collide.  Any other segment (several keys of one
-// bucket, inserts, deletes) runs in rounds: its k-th request executes in round k through kv_do_request.
+// Four memory round trips per chunk however many requests collide.  Any other bucket run (inserts, deletes,
+// lock ops on two keys, key-hash collisions) executes request by request in rounds, in idx order.
 // Semantics per op: the same reference lines as kv_do_request.
 template <int WL>
 __device__ static inline bool kv_simple_op(uint32_t type) {
   if (WL == DINT_WL_STORE) return type <= 1;                                   // READ, SET
   if (WL == DINT_WL_TATP) return type <= 2 || type == 12 || type == 13;        // READ, ACQUIRE, ABORT, COMMIT_PRIM/BCK
   return type <= 5;                                                            // every smallbank table op
+}
+template <int WL>
+__device__ static inline bool kv_lock_op(uint32_t type) {  // touches the bucket's lock word
+  if (WL == DINT_WL_STORE) return false;
+  if (WL == DINT_WL_TATP) return type == 1 || type == 2 || type == 12;
+  return type <= 3;
 }
 
 __device__ static inline uint64_t shfl_u64(uint64_t v, int src) {
@@ -341,11 +360,19 @@ __device__ static inline uint64_t readlane_u64(uint64_t v, int l) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)v, l);
   return ((uint64_t)hi << 32) | lo;
 }
+// lanes [my run's head, next head): heads = ballot of run heads, le = lanes <= me, vm = ballot(valid)
+__device__ static inline uint64_t run_mask(uint64_t heads, uint64_t le, uint64_t vm, int *head_lane) {
+  const int hl = 63 - __clzll(heads & le);
+  const uint64_t above = heads & ~le;
+  const uint64_t next = above ? (above & (~above + 1ull)) : vm + 1ull;  // first invalid lane = bit nvalid = vm + 1
+  *head_lane = hl;
+  return (next - 1ull) & ~((1ull << hl) - 1ull);
+}
 
 template <int WL>
-__device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t gk, uint32_t type, uint32_t table,
-                                       uint32_t q, const kv_dev *kv, dint_dev_stats *__restrict__ stats, int force_rounds,
-                                       bool last_chunk, uint64_t *tr = nullptr) {
+__device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t gk, uint32_t kh, uint32_t type,
+                                       uint32_t table, uint32_t q, const kv_dev *kv, dint_dev_stats *__restrict__ stats,
+                                       int force_rounds, bool last_chunk, uint64_t *tr = nullptr) {
   using F = Fmt<WL>;
   const int lane = (int)lane_id();
   const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
@@ -353,17 +380,16 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   const uint64_t key = valid ? ld_u64(msg + F::KEY) : 0;
   const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
 
-  // ---- segments
-  const uint32_t gk_up = __shfl_up(gk, 1, 64);
-  const bool head = valid && (lane == 0 || gk_up != gk);
-  const uint64_t hm = __ballot(head);
+  // ---- bucket runs and key segments
+  const uint32_t gk_up = __shfl_up(gk, 1, 64), kh_up = __shfl_up(kh, 1, 64);
+  const bool bhead = valid && (lane == 0 || gk_up != gk);
+  const bool head = valid && (bhead || kh_up != kh);
   const uint64_t vm = __ballot(valid);
-  const int hl = valid ? 63 - __clzll(hm & le) : lane;                       // my segment's head lane
-  // lanes of my segment = [hl, next head) ; valid lanes are lanes 0..nvalid-1, so without a head above me the
-  // segment ends at the first invalid lane: bit nvalid = vm + 1 (0 when all 64 lanes are valid -> mask of all ones)
-  const uint64_t above = hm & ~le;
-  const uint64_t next = above ? (above & (~above + 1ull)) : vm + 1ull;
-  const uint64_t seg = valid ? ((next - 1ull) & ~((1ull << hl) - 1ull)) : 0;
+  const uint64_t bhm = __ballot(bhead), hm = __ballot(head);
+  int hl = lane, bhl = lane;
+  const uint64_t seg = valid ? run_mask(hm, le, vm, &hl) : 0;   // my key segment
+  const uint64_t run = valid ? run_mask(bhm, le, vm, &bhl) : 0; // my bucket run
+
   // ---- 1. segment heads: load the bucket's inline header (and smallbank counters) -- issued before the keys
   // are compared, so the header round trip overlaps the key round trip -- then locate the row
   uint32_t found = 0, link = 0, slot = 0, ver0 = 0, la0 = 0, lb0 = 0;
@@ -383,7 +409,9 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   }
   const uint64_t hkey = shfl_u64(key, hl);
   const uint64_t m_bad = __ballot(valid && !(key == hkey && kv_simple_op<WL>(type)));
-  const bool simple = valid && (m_bad & seg) == 0 && !force_rounds;
+  const uint64_t m_lockop = __ballot(valid && kv_lock_op<WL>(type));
+  const uint64_t m_lkseg = __ballot(head && (m_lockop & seg) != 0);  // key segments that carry lock ops
+  const bool simple = valid && (m_bad & run) == 0 && __popcll(m_lkseg & run) <= 1 && !force_rounds;
   kv_stamp(tr, 4);
   const bool leader = head && simple;
   if (leader) {
@@ -442,7 +470,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         }
       };
       const bool single = simple && seg == (1ull << lane);
-      if (single) {  // one request on its bucket: apply it directly
+      if (single) {  // one request on its key: apply it directly
         bool wr = false;
         my_code = sb_step(type, found, fin_la, fin_lb, my_get, nmiss, wr);
         my_ver = ver0;
@@ -453,13 +481,13 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         const int L = __ffsll((unsigned long long)multi) - 1;
         multi &= multi - 1;
         const uint64_t sm = readlane_u64(seg, L);
-        const uint32_t fnd = __builtin_amdgcn_readlane(found, L);
-        uint32_t la = __builtin_amdgcn_readlane(la0, L), lb = __builtin_amdgcn_readlane(lb0, L);
-        uint32_t ver = __builtin_amdgcn_readlane(ver0, L), miss = 0;
+        const uint32_t fnd = (uint32_t)__builtin_amdgcn_readlane(found, L);
+        uint32_t la = (uint32_t)__builtin_amdgcn_readlane(la0, L), lb = (uint32_t)__builtin_amdgcn_readlane(lb0, L);
+        uint32_t ver = (uint32_t)__builtin_amdgcn_readlane(ver0, L), miss = 0;
         int src = -1;
         for (uint64_t m = sm; m; m &= m - 1) {
           const int l = __ffsll((unsigned long long)m) - 1;
-          const uint32_t op = __builtin_amdgcn_readlane(type, l);
+          const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
           uint32_t get = 0;
           bool wr = false;
           const uint32_t ver_seen = ver;
@@ -488,7 +516,8 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   }
   kv_stamp(tr, 6);
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the table reads above precede the write-backs below
-  // ---- 4. final state of each simple segment, written once by its head
+  // ---- 4. final state of each simple segment, written once by its head.  The lock word belongs to the one
+  // segment of the bucket that carries lock ops (fin_la / fin_lb differ from la0 / lb0 only there).
   if (leader) {
     if (fin_src >= 0) {
       kv_copy_words(row, rep + (size_t)fin_idx * F::MSG + F::VAL, F::VS);
@@ -500,21 +529,26 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   }
   kv_stamp(tr, 7);
 
-  // ---- everything else: rounds
+  // ---- every other bucket run: request by request.  Position of a request inside its run = number of the run's
+  // requests with a smaller idx (the run is sorted by key first); the k-th request executes in round k.
   const bool rounds = valid && !simple;
-  const uint32_t pos = (uint32_t)(lane - hl);
-  const uint64_t rm = __ballot(rounds);
-  uint32_t maxpos = 0;
-  if (rm) {
-    // longest non-simple segment
-    uint64_t heads = rm & hm;
-    while (heads) {
-      const int L = __ffsll((unsigned long long)heads) - 1;
-      heads &= heads - 1;
-      maxpos = max(maxpos, (uint32_t)__popcll(readlane_u64(seg, L)) - 1u);
+  uint64_t rheads = __ballot(rounds && bhead);
+  if (rheads) {
+    uint32_t pos = 0, maxlen = 0;
+    while (rheads) {
+      const int L = __ffsll((unsigned long long)rheads) - 1;
+      rheads &= rheads - 1;
+      const uint64_t rmask = readlane_u64(run, L);
+      maxlen = max(maxlen, (uint32_t)__popcll(rmask));
+      const bool mine = (rmask >> lane) & 1ull;
+      for (uint64_t m = rmask; m; m &= m - 1) {
+        const int l = __ffsll((unsigned long long)m) - 1;
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane(idx, l);
+        if (mine && oi < idx) pos++;
+      }
     }
-    for (uint32_t r = 0; r <= maxpos; r++) {
-      if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats, r == 0 ? tr : nullptr);
+    for (uint32_t r = 0; r < maxlen; r++) {
+      if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the next round must see this round's stores
     }
   }
@@ -522,34 +556,13 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   kv_stamp(tr, 8);
 }
 
-// 64 keys, one per lane, ascending (bitonic network over the wave, 21 compare-exchange steps)
-__device__ static inline uint64_t wave_sort_u64(uint64_t w) {
-  const uint32_t lane = lane_id();
-#pragma unroll
-  for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t lo = __shfl_xor((uint32_t)w, (int)j, 64), hi = __shfl_xor((uint32_t)(w >> 32), (int)j, 64);
-      const uint64_t o = ((uint64_t)hi << 32) | lo;
-      const bool up = (lane & k) == 0;           // this k-block sorts ascending
-      const bool low = (lane & j) == 0;          // lower lane of the pair
-      w = (low == up) ? (w < o ? w : o) : (w < o ? o : w);
-    }
-  }
-  return w;
-}
-
-// ---- k_kv_resolve ----------------------------------------------------------------------------------------
+// ---- k_kv_resolve: bins of <= 64 records, one wave each ---------------------------------------------------
 template <int WL>
 __global__ void __launch_bounds__(64)
 k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
              const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int kv_force_rounds,
              uint64_t *trace) {
-  __shared__ dint_rank_lds R;
-  __shared__ uint32_t Srec[DINT_WCAP];  // idx | hash entry << 16, in request order
-  __shared__ uint16_t Sop[DINT_WCAP];   // type | table << 8 | quadrant << 12
-  __shared__ uint32_t Hk[DINT_HSIZE];   // bucket group of each hash entry
-  __shared__ kv_dev Skv;                // table descriptors: per-lane lookups by table id become LDS reads
+  __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   const uint32_t bin = blockIdx.x, lane = threadIdx.x;
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
   kv_stamp_real(tr, 10);
@@ -557,71 +570,372 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t
   const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
   const uint64_t r0 = recs[lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
-  if (tr && lane == 0) tr[15] = c;
-  if (c == 0) return;
+  if (tr && lane == 0 && c) { tr[15] = c; tr[14] = 0; }
+  if (c == 0 || c > 64) return;    // larger bins belong to k_kv_resolve_big
   if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
   for (uint32_t k = lane; k < sizeof(kv_dev) / 4; k += 64) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
   const kv_dev *kv = &Skv;
   kv_stamp(tr, 1);
-
-  if (c <= 64) {
-    // The common case: the whole bin is one chunk.  Sort the records by (bucket group, idx) in registers:
-    // groups commute, so any order that keeps each group's requests in idx order is serial-equivalent, and
-    // after the sort the requests of a group sit in adjacent lanes -- no LDS, no rank bitmap, no hash.
-    uint64_t w = ~0ull;  // empty lanes sort last
-    if (lane < c) {
-      const uint64_t r = r0;
-      w = ((uint64_t)rec_gk(r) << 32) | ((uint64_t)rec_idx(r) << 16) | ((uint64_t)rec_op(r) << 8) | rec_aux(r);
-    }
-    kv_stamp(tr, 2);
-    w = wave_sort_u64(w);
-    kv_stamp(tr, 3);
-    const bool valid = lane < c;
-    const uint32_t gk = (uint32_t)(w >> 32), idx = (uint32_t)(w >> 16) & 0xFFFF;
-    const uint32_t type = (uint32_t)(w >> 8) & 0xFF, aux = (uint32_t)w & 0xFF;
-    kv_chunk<WL>(rep, valid, idx, gk, type, aux & 15u, aux >> 4, kv, stats, kv_force_rounds, true, tr);
-    kv_stamp(tr, 9);
-    kv_stamp_real(tr, 11);
-    return;
+  // Sort the records by (bucket group, idx) in registers: groups commute, so any order that keeps each group's
+  // requests in idx order is serial-equivalent, and after the sort the requests of a group sit in adjacent
+  // lanes -- no LDS, no rank bitmap, no hash.
+  uint64_t w = ~0ull;  // empty lanes sort last
+  if (lane < c) {
+    const uint32_t pay = rec_op(r0) | (rec_aux(r0) << 8);
+    w = ((uint64_t)rec_gk(r0) << 32) | ((uint64_t)pay_kh(pay) << 26) | ((uint64_t)rec_idx(r0) << 10) | (pay & 0x3FFu);
   }
+  kv_stamp(tr, 2);
+  w = wave_sort_u64(w);
+  kv_stamp(tr, 3);
+  const bool valid = lane < c;
+  const uint32_t gk = (uint32_t)(w >> 32), kh = (uint32_t)(w >> 26) & 63u, idx = (uint32_t)(w >> 10) & 0xFFFF;
+  const uint32_t pay = (uint32_t)w & 0x3FFu;
+  kv_chunk<WL>(rep, valid, idx, gk, kh, pay_type(pay), pay_table(pay), pay_q(pay), kv, stats, kv_force_rounds, true, tr);
+  kv_stamp(tr, 9);
+  kv_stamp_real(tr, 11);
+}
 
-  rank_build(R, recs, c, n);
-  for (uint32_t lo = 0; lo < c; lo += DINT_WCAP) {
-    const uint32_t wn = min(DINT_WCAP, c - lo);
-    for (uint32_t h = lane; h < DINT_HSIZE; h += 64) Hk[h] = DINT_EMPTY;
+// ---- k_kv_resolve_big: bins of > 64 records (hot keys), one 512-thread workgroup each ------------------------
+// The same algorithm as kv_chunk, over a window of 512 requests at a time and 8 waves:
+//   restore request order (bitmap rank over idx, built by the whole workgroup), take the next 512 requests, group
+//   them by bucket in an LDS hash, sort the window by (bucket group, request order) with a 512-wide bitonic network
+//   (in-wave steps by shuffle, the 6 wide steps through LDS), and resolve every segment of the sorted window at
+//   once: per-wave ballot masks go to LDS, and "writers below me in my segment" / "last writer below" / "last lock
+//   op below" become popcounts and find-last-bit over the mask words the segment spans.  A hot key's 500 requests
+//   therefore cost the same handful of memory round trips as 5.  smallbank's counters are walked wave by wave with
+//   the running state carried through LDS.  Segments with several keys / inserts / deletes run in rounds.
+#define KVB_T 512u
+#define KVB_W (KVB_T / 64u)
+struct kvb_lead { uint32_t found_link, slot, ver0, la0, lb0; };   // found_link: found << 31 | link
+struct kvb_carry { uint32_t la, lb, ver; int src; uint32_t miss; };
+
+__device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, uint32_t b) {  // bits set in [a, b)
+  uint32_t cnt = 0;
+  for (uint32_t w = a >> 6; w <= ((b - 1) >> 6) && a < b; w++) {
+    uint64_t m = M[w];
+    if (w == (a >> 6)) m &= ~0ull << (a & 63);
+    if (w == ((b - 1) >> 6) && (b & 63)) m &= (1ull << (b & 63)) - 1ull;
+    cnt += (uint32_t)__popcll(m);
+  }
+  return cnt;
+}
+__device__ static inline int kvb_range_last(const uint64_t *M, uint32_t a, uint32_t b) {  // highest set bit in [a, b) or -1
+  if (a >= b) return -1;
+  for (int w = (int)((b - 1) >> 6); w >= (int)(a >> 6); w--) {
+    uint64_t m = M[w];
+    if ((uint32_t)w == (a >> 6)) m &= ~0ull << (a & 63);
+    if ((uint32_t)w == ((b - 1) >> 6) && (b & 63)) m &= (1ull << (b & 63)) - 1ull;
+    if (m) return w * 64 + 63 - __clzll(m);
+  }
+  return -1;
+}
+__device__ static inline int kvb_range_first(const uint64_t *M, uint32_t a) {  // lowest set bit at or above a, or -1
+  for (uint32_t w = a >> 6; w < KVB_W && a < KVB_T; w++) {
+    uint64_t m = M[w];
+    if (w == (a >> 6)) m &= ~0ull << (a & 63);
+    if (m) return (int)(w * 64 + __ffsll((unsigned long long)m) - 1);
+  }
+  return -1;
+}
+__device__ static inline bool kvb_bit(const uint64_t *M, uint32_t p) { return (M[p >> 6] >> (p & 63)) & 1ull; }
+
+template <int WL>
+__global__ void __launch_bounds__(KVB_T)
+k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+                 const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int force_rounds,
+                 uint64_t *trace) {
+  using F = Fmt<WL>;
+  __shared__ uint32_t Rbm[DINT_MICRO / 32];   // one bit per request of the pass: present in this bin
+  __shared__ uint16_t Rwpre[DINT_MICRO / 32]; // marked bits before each word, within its thread's span
+  __shared__ uint32_t Rbase[KVB_T];           // marked bits before each thread's span of words
+  __shared__ uint32_t Srec[KVB_T];            // window, request order: idx | hash entry << 16
+  __shared__ uint16_t Sop[KVB_T];             // kv_pay descriptor: type | table | quadrant | key-hash bits
+  __shared__ uint64_t Skey[KVB_T];
+  __shared__ uint32_t Hk[DINT_HSIZE];
+  __shared__ uint32_t Ssort[KVB_T];
+  __shared__ uint16_t Sp[KVB_T];              // sorted position -> window position
+  __shared__ uint32_t Slast[KVB_W];           // hash entry of each wave's last lane
+  __shared__ uint64_t Mhead[KVB_W], Mbh[KVB_W], Mbad[KVB_W], Mlop[KVB_W], Mlkseg[KVB_W], Mwr[KVB_W], Mlk[KVB_W], Macq[KVB_W];
+  __shared__ kvb_lead Lead[KVB_T];
+  __shared__ kvb_carry Carry[KVB_T];
+  __shared__ uint32_t Sred[KVB_W];
+  __shared__ kv_dev Skv;
+  const uint32_t bin = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t c = bin_cnt[bin];
+  if (c <= 64) return;  // block-uniform: small bins belong to k_kv_resolve
+  uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;  // [8] start, [9] end (10 ns), [12] rounds, [13] windows, [14] c
+  if (tr && t == 0) { tr[8] = __builtin_amdgcn_s_memrealtime(); tr[14] = c; tr[12] = 0; tr[13] = 0; }
+  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
+  for (uint32_t k = t; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
+  const kv_dev *kv = &Skv;
+
+  // ---- request-order rank of every record of the bin (as dint_rank_lds, built by 512 threads)
+  const uint32_t nwords = (n + 31) >> 5, wpt = (nwords + KVB_T - 1) / KVB_T;  // words per thread
+  for (uint32_t w = t; w < nwords; w += KVB_T) Rbm[w] = 0;
+  __syncthreads();
+  if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
+  for (uint32_t k = t; k < c; k += KVB_T) {
+    const uint32_t idx = rec_idx(recs[k]);
+    atomicOr(&Rbm[idx >> 5], 1u << (idx & 31));
+  }
+  __syncthreads();
+  {
+    uint32_t run = 0;
+    for (uint32_t j = 0; j < wpt; j++) {
+      const uint32_t w = t * wpt + j;
+      if (w < nwords) { Rwpre[w] = (uint16_t)run; run += __popc(Rbm[w]); }
+    }
+    uint32_t tot, base = wave_excl_scan_u32(run, &tot);
+    if (lane == 0) Sred[wave] = tot;
     __syncthreads();
-    for (uint32_t k = lane; k < c; k += 64) {
+    for (uint32_t w = 0; w < wave; w++) base += Sred[w];
+    Rbase[t] = base;
+  }
+  __syncthreads();
+  auto rank_of_idx = [&](uint32_t idx) -> uint32_t {
+    const uint32_t w = idx >> 5;
+    return Rbase[w / wpt] + Rwpre[w] + __popc(Rbm[w] & ((1u << (idx & 31)) - 1u));
+  };
+
+  for (uint32_t lo = 0; lo < c; lo += KVB_T) {
+    const uint32_t wn = min(KVB_T, c - lo);
+    for (uint32_t h = t; h < DINT_HSIZE; h += KVB_T) Hk[h] = DINT_EMPTY;
+    __syncthreads();
+    // ---- gather the window in request order; group by bucket; fetch the keys
+    for (uint32_t k = t; k < c; k += KVB_T) {
       const uint64_t r = recs[k];
-      const uint32_t rk = rank_of(R, rec_idx(r), n) - lo;
+      const uint32_t rk = rank_of_idx(rec_idx(r)) - lo;
       if (rk < wn) {
         bool nw;
         const uint32_t e = lds_hash_insert(Hk, rec_gk(r), &nw);
         Srec[rk] = rec_idx(r) | (e << 16);
-        const uint32_t aux = rec_aux(r);
-        Sop[rk] = (uint16_t)(rec_op(r) | ((aux & 15u) << 8) | ((aux >> 4) << 12));
+        Sop[rk] = (uint16_t)(rec_op(r) | (rec_aux(r) << 8));  // kv_pay descriptor
+        Skey[rk] = ld_u64(rep + (size_t)rec_idx(r) * F::MSG + F::KEY);
       }
     }
     __syncthreads();
-
-    for (uint32_t ch = 0; ch < wn; ch += 64) {
-      // 64 consecutive requests of the window; sorted by (hash entry, idx) so that each bucket's requests are
-      // adjacent and in request order, as kv_chunk expects
-      const uint32_t j = ch + lane;
-      uint64_t w = ~0ull;
-      if (j < wn) {
-        const uint32_t sr = Srec[j];
-        w = ((uint64_t)(sr >> 16) << 32) | ((uint64_t)(sr & 0xFFFF) << 16) | Sop[j];
+    // ---- sort the window by (hash entry, key-hash bits, window position): 512-wide bitonic network
+    uint32_t v = t < wn ? (((Srec[t] >> 16) & (DINT_HSIZE - 1)) << 15) | (pay_kh(Sop[t]) << 9) | t : 0xFFFFFFFFu;
+    for (uint32_t k = 2; k <= KVB_T; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        uint32_t o;
+        if (j < 64) {
+          o = __shfl_xor(v, (int)j, 64);
+        } else {
+          Ssort[t] = v;
+          __syncthreads();
+          o = Ssort[t ^ j];
+          __syncthreads();
+        }
+        const bool up = (t & k) == 0, low = (t & j) == 0;
+        v = (low == up) ? min(v, o) : max(v, o);
       }
-      w = wave_sort_u64(w);
-      const bool valid = w != ~0ull;
-      const uint32_t e = (uint32_t)(w >> 32) & (DINT_HSIZE - 1), idx = (uint32_t)(w >> 16) & 0xFFFF, so = (uint32_t)w & 0xFFFF;
-      kv_chunk<WL>(rep, valid, idx, valid ? Hk[e] : 0xFFFFFFFFu, so & 0xFF, (so >> 8) & 15u, so >> 12, kv, stats,
-                   kv_force_rounds, false);
+    }
+    const bool valid = v != 0xFFFFFFFFu;
+    const uint32_t p = v & 511u, ek = valid ? (v >> 9) : 0xFFFFFFu;  // ek = hash entry << 6 | key-hash bits
+    const uint32_t e = ek >> 6;
+    Sp[t] = (uint16_t)p;
+    const uint32_t sr = valid ? Srec[p] : 0, so = valid ? Sop[p] : 0;
+    const uint32_t idx = sr & 0xFFFF, type = pay_type(so), table = pay_table(so), q = pay_q(so);
+    const uint64_t key = valid ? Skey[p] : 0;
+    const uint32_t gk = valid ? Hk[e] : 0;
+    const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
+    uint8_t *msg = rep + (size_t)idx * F::MSG;
+    // ---- bucket runs and key segments of the sorted window (they may span waves)
+    if (lane == 63) Slast[wave] = ek;
+    __syncthreads();
+    const uint32_t ek_shfl = __shfl_up(ek, 1, 64);  // executed by every lane: a shuffle reads only active lanes
+    const uint32_t ek_up = lane ? ek_shfl : (wave ? Slast[wave - 1] : 0xFFFFFFFFu);
+    const bool bhead = valid && (ek_up >> 6) != e;
+    const bool head = valid && ek_up != ek;
+    {
+      const uint64_t hm = __ballot(head), bm = __ballot(bhead);
+      if (lane == 0) { Mhead[wave] = hm; Mbh[wave] = bm; }
     }
     __syncthreads();
+    uint32_t seg_a = 0, seg_b = wn, bk_a = 0, bk_b = wn;  // my key segment / bucket run = sorted positions [a, b)
+    if (valid) {
+      seg_a = (uint32_t)kvb_range_last(Mhead, 0, t + 1);
+      bk_a = (uint32_t)kvb_range_last(Mbh, 0, t + 1);
+      const int nx = kvb_range_first(Mhead, t + 1), bx = kvb_range_first(Mbh, t + 1);
+      if (nx >= 0) seg_b = (uint32_t)nx;
+      if (bx >= 0) bk_b = (uint32_t)bx;
+    }
+    // heads load their bucket's inline header (+ smallbank counters) before the keys are compared
+    kv_tab tb;
+    uint8_t *ie = nullptr;
+    kv_hdr H;
+    uint32_t la0 = 0, lb0 = 0;
+    if (valid) {
+      tb = kv->tab[table];
+      ie = kv_entry_ptr(tb, bucket, KV_INLINE);
+    }
+    if (head) {
+      kv_hdr_copy(H, *(const kv_hdr *)ie);
+      if (WL == DINT_WL_SMALLBANK) {
+        const uint2 cc = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);
+        la0 = cc.x; lb0 = cc.y;
+      }
+      if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
+    }
+    const uint64_t hkey = valid ? Skey[Sp[seg_a]] : 0;  // Sp[] of other waves: written before the barriers above
+    {
+      const uint64_t bm = __ballot(valid && !(key == hkey && kv_simple_op<WL>(type)));
+      const uint64_t lm = __ballot(valid && kv_lock_op<WL>(type));
+      if (lane == 0) { Mbad[wave] = bm; Mlop[wave] = lm; }
+    }
+    __syncthreads();
+    {  // key segments that carry lock ops: a bucket run with two of them is not simple
+      const uint64_t sm = __ballot(head && kvb_range_popc(Mlop, seg_a, seg_b) != 0);
+      if (lane == 0) Mlkseg[wave] = sm;
+    }
+    __syncthreads();
+    const bool simple = valid && !force_rounds && kvb_range_popc(Mbad, bk_a, bk_b) == 0 &&
+                        kvb_range_popc(Mlkseg, bk_a, bk_b) <= 1;
+    const bool leader = head && simple;
+    if (leader) {
+      const kv_where wh = kv_locate(tb, bucket, H, key);
+      Lead[t].found_link = (wh.found << 31) | wh.link;
+      Lead[t].slot = wh.slot; Lead[t].ver0 = wh.ver; Lead[t].la0 = la0; Lead[t].lb0 = lb0;
+      Carry[t].la = la0; Carry[t].lb = lb0; Carry[t].ver = wh.ver; Carry[t].src = -1; Carry[t].miss = 0;
+    }
+    {
+      const bool writer = simple && (WL == DINT_WL_STORE ? type == 1 : WL == DINT_WL_TATP ? (type == 12 || type == 13)
+                                                                                         : (type == 4 || type == 5));
+      const uint64_t m1 = __ballot(writer);
+      const uint64_t m2 = __ballot(simple && WL == DINT_WL_TATP && (type == 1 || type == 2 || type == 12));
+      const uint64_t m3 = __ballot(simple && WL == DINT_WL_TATP && type == 1);
+      if (lane == 0) { Mwr[wave] = m1; Mlk[wave] = m2; Macq[wave] = m3; }
+    }
+    __syncthreads();
+    // ---- outcomes of the simple segments
+    uint32_t found = 0, link = 0, slot = 0, ver0 = 0;
+    if (simple) {
+      const kvb_lead L = Lead[seg_a];
+      found = L.found_link >> 31; link = L.found_link & 0x7FFFFFFFu; slot = L.slot; ver0 = L.ver0; la0 = L.la0; lb0 = L.lb0;
+    }
+    uint32_t my_code = 0, my_ver = 0, my_get = 0;
+    int my_src = -1;  // SORTED position of the request whose message holds the value this one reads
+    uint32_t fin_ver = ver0, fin_la = la0, fin_lb = lb0, nmiss = 0;
+    int fin_src = -1;
+    if (WL != DINT_WL_SMALLBANK) {
+      if (simple) {
+        my_ver = ver0 + (found ? kvb_range_popc(Mwr, seg_a, t) : 0);
+        my_src = found ? kvb_range_last(Mwr, seg_a, t) : -1;
+        if (WL == DINT_WL_STORE) {
+          my_code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
+          my_get = (type == 0 && found) ? 1 : 0;
+        } else {
+          const int lk = kvb_range_last(Mlk, seg_a, t);
+          const uint32_t lock_seen = lk >= 0 ? (uint32_t)kvb_bit(Macq, (uint32_t)lk) : la0;
+          switch (type) {
+            case 0: my_code = found ? 4 : 6; my_get = found; break;
+            case 1: my_code = lock_seen ? 8 : 7; break;
+            case 2: my_code = 9; break;
+            case 12: my_code = 15; break;
+            default: my_code = 16; break;  // 13 kCommitBck
+          }
+        }
+        if (leader) {
+          const uint32_t nw = kvb_range_popc(Mwr, seg_a, seg_b);
+          fin_ver = ver0 + (found ? nw : 0);
+          fin_src = found ? kvb_range_last(Mwr, seg_a, seg_b) : -1;
+          nmiss = found ? 0 : nw;
+          if (WL == DINT_WL_TATP) {
+            const int lk = kvb_range_last(Mlk, seg_a, seg_b);
+            if (lk >= 0) fin_la = (uint32_t)kvb_bit(Macq, (uint32_t)lk);
+          }
+        }
+      }
+    } else {
+      // smallbank: the counters have no closed form.  Walk every simple segment in sorted order, wave after wave,
+      // with the running state {num_ex, num_sh, version, last writer} carried through Carry[segment head].
+      for (uint32_t wv = 0; wv < KVB_W; wv++) {
+        if (wave == wv) {
+          uint64_t todo = __ballot(simple);
+          while (todo) {  // one iteration per segment present in this wave's 64 lanes
+            const int l0 = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(seg_a, l0);
+            const uint64_t mem = __ballot(simple && seg_a == a);
+            todo &= ~mem;
+            kvb_carry st = Carry[a];
+            const uint32_t fnd = Lead[a].found_link >> 31;
+            for (uint64_t m = mem; m; m &= m - 1) {
+              const int l = __ffsll((unsigned long long)m) - 1;
+              const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
+              uint32_t code, get = 0;
+              bool wr = false;
+              const uint32_t ver_seen = st.ver;
+              const int src_seen = st.src;
+              switch (op) {  // la = num_ex, lb = num_sh   smallbank/udp/server_shard.cc:121-173
+                case 0: if (st.la == 0) { st.lb++; get = fnd; st.miss += !fnd; code = 7; } else code = 8; break;
+                case 1: if (st.la == 0 && st.lb == 0) { st.la++; get = fnd; st.miss += !fnd; code = 9; } else code = 10; break;
+                case 2: st.lb--; code = 11; break;
+                case 3: st.la--; code = 12; break;
+                case 4: wr = fnd; st.miss += !fnd; code = 13; break;
+                default: wr = fnd; st.miss += !fnd; code = 14; break;  // 5 kCommitBck
+              }
+              if (wr) { st.ver++; st.src = (int)(wv * 64 + l); }
+              if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
+            }
+            if ((int)lane == l0) Carry[a] = st;
+          }
+        }
+        __syncthreads();
+      }
+      if (leader) {
+        const kvb_carry st = Carry[t];
+        fin_la = st.la; fin_lb = st.lb; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
+      }
+    }
+    // ---- replies of the simple segments
+    uint8_t *row = nullptr;
+    if (simple) {
+      row = kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS;
+      if (my_get) {
+        const uint8_t *from = my_src >= 0 ? rep + (size_t)(Srec[Sp[my_src]] & 0xFFFF) * F::MSG + F::VAL : row;
+        kv_copy_words(msg + F::VAL, from, F::VS);
+        st_u32(msg + F::VER, my_ver);
+      }
+      msg[F::TYPE] = (uint8_t)my_code;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();  // every table read of the window precedes the write-backs
+    if (leader) {
+      if (fin_src >= 0) {
+        kv_copy_words(row, rep + (size_t)(Srec[Sp[fin_src]] & 0xFFFF) * F::MSG + F::VAL, F::VS);
+        kv_entry_hdr(tb, bucket, link)->ver[slot] = fin_ver;
+      }
+      if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
+      if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = make_uint2(fin_la, fin_lb);
+      if (nmiss) atomicAdd(&stats->missing_keys, (unsigned long long)nmiss);
+    }
+    // ---- every other bucket run: request by request.  Position inside the run = number of its requests that
+    // come earlier in request order (the run is sorted by key first); the k-th request executes in round k.
+    const bool rounds = valid && !simple;
+    uint32_t pos = 0;
+    if (rounds)
+      for (uint32_t m = bk_a; m < bk_b; m++) pos += Sp[m] < p;
+    uint32_t mylen = rounds && bhead ? bk_b - bk_a : 0, tot;
+    {  // longest non-simple run (block max)
+      uint32_t m = mylen;
+      for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, 64));
+      if (lane == 0) Sred[wave] = m;
+      __syncthreads();
+      tot = 0;
+      for (uint32_t w = 0; w < KVB_W; w++) tot = max(tot, Sred[w]);
+    }
+    if (tr && t == 0) { tr[12] += tot; tr[13] += 1; }
+    for (uint32_t r = 0; r < tot; r++) {
+      if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __syncthreads();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();  // the next window sees this window's stores; LDS arrays are free again
   }
-  kv_stamp_real(tr, 11);
+  if (tr && t == 0) tr[9] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
@@ -637,6 +951,11 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   hipLaunchKernelGGL((k_kv_scatter<WL>), dim3(nb), dim3(256), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n,
                      kv.d_dev, log, (const uint32_t *)s.blk_cnt, P - 1, s.bin_cnt, s.bins, s.stats, load_mode);
   if (ev) hipEventRecord(ev[1], st);
+  // The two resolve kernels own disjoint bins (<= 64 records / more).  They run back to back on the pass's stream:
+  // forking the big-bin kernel to a side stream and joining it (measured, r01) costs more in cross-stream event
+  // latency (~10 us per pass) than the overlap saves.
+  hipLaunchKernelGGL((k_kv_resolve_big<WL>), dim3(P), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
+                     (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
                      (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace);
   if (ev) hipEventRecord(ev[2], st);

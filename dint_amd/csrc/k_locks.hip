@@ -123,6 +123,27 @@ struct FasstOps {
       atomicOr(&Hfl[se], 0x80000000u);
     }
   }
+  // the same closed form over a sorted chunk: `seg` = lane mask of this lane's slot (adjacent lanes, request
+  // order); every slot of the chunk is resolved at once.  st0 = the slot's word (same on all lanes of a segment)
+  __device__ static void resolve_sorted(bool valid, uint64_t seg, uint32_t op, uint2 st0, uint32_t &code, uint32_t &rv,
+                                        uint2 &fin, bool &dirty) {
+    const uint64_t lt = lanemask_lt();
+    const uint64_t m_set = __ballot(valid && op != 0) & seg;
+    const uint64_t m_acq = __ballot(valid && op == 1);
+    const uint64_t m_com = __ballot(valid && op == 3) & seg;
+    const uint64_t prev = m_set & lt;
+    const uint32_t lock_before = prev ? (uint32_t)((m_acq >> (63 - __clzll(prev))) & 1ULL) : st0.x;
+    const uint32_t ver_before = st0.y + (uint32_t)__popcll(m_com & lt);
+    switch (op) {
+      case 0: code = 4; rv = ver_before; break;
+      case 1: code = lock_before ? 6 : 5; break;
+      case 2: code = 7; break;
+      default: code = 8; break;
+    }
+    fin.x = m_set ? (uint32_t)((m_acq >> (63 - __clzll(m_set))) & 1ULL) : st0.x;
+    fin.y = st0.y + (uint32_t)__popcll(m_com);
+    dirty = fin.x != st0.x || fin.y != st0.y;
+  }
   __device__ static void write_reply(uint8_t *rep, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
     fasst_msg *m = (fasst_msg *)rep + idx;
     m->type = (uint8_t)code;
@@ -164,6 +185,38 @@ struct TplOps {
       atomicOr(&Hfl[se], 0x80000000u);
     }
   }
+  // sorted chunk: single requests apply their op directly; longer segments are walked once each with
+  // wave-uniform registers (the counters have no closed form)
+  __device__ static void resolve_sorted(bool valid, uint64_t seg, uint32_t op, uint2 st0, uint32_t &code, uint32_t &rv,
+                                        uint2 &fin, bool &dirty) {
+    const uint32_t lane = lane_id();
+    fin = st0;
+    dirty = false;
+    const bool single = valid && seg == (1ull << lane);
+    if (single) code = apply(op, fin, rv, dirty);
+    const bool head = valid && (seg & lanemask_lt()) == 0;
+    uint64_t multi = __ballot(head && !single);
+    while (multi) {
+      const int L = __ffsll((unsigned long long)multi) - 1;
+      multi &= multi - 1;
+      const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((uint32_t)(seg >> 32), L);
+      const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((uint32_t)seg, L);
+      uint2 st;
+      st.x = (uint32_t)__builtin_amdgcn_readlane(st0.x, L);
+      st.y = (uint32_t)__builtin_amdgcn_readlane(st0.y, L);
+      bool wr = false;
+      for (uint64_t m = ((uint64_t)shi << 32) | slo; m; m &= m - 1) {
+        const int l = __ffsll((unsigned long long)m) - 1;
+        const uint32_t lop = __builtin_amdgcn_readlane(op, l);
+        uint32_t lrv = 0;
+        bool lwr = false;
+        const uint32_t lcode = apply(lop, st, lrv, lwr);
+        wr |= lwr;
+        if ((int)lane == l) { code = lcode; rv = lrv; }
+      }
+      if ((int)lane == L) { fin = st; dirty = wr; }
+    }
+  }
   __device__ static void write_reply(uint8_t *rep, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
     (void)op; (void)rv;
     ((tpl_msg *)rep + idx)->action = (uint8_t)code;
@@ -180,9 +233,41 @@ k_lock_resolve(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__
   __shared__ uint2 Hst[DINT_HSIZE];     // its table word
   __shared__ uint32_t Hfl[DINT_HSIZE];  // low 16 bits: lanes of the current chunk on it; bit 31: dirty
   const uint32_t bin = blockIdx.x, lane = threadIdx.x;
+  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
+  const uint64_t r0 = recs[lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
   if (c == 0) return;
-  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
+  if (c <= 64) {
+    // The common case (~32 records per bin): sort the records by (slot, idx) in registers.  Slots commute, so any
+    // order that keeps each slot's requests in idx order is serial-equivalent; after the sort they sit in adjacent
+    // lanes.  Every slot's word is fetched once by its first lane, all slots are resolved at once, and each
+    // changed word is written back once.  No LDS.
+    if (lane == 0) bin_cnt[bin] = 0;
+    uint64_t w = ~0ull;
+    if (lane < c) w = ((uint64_t)rec_gk(r0) << 32) | ((uint64_t)rec_idx(r0) << 16) | rec_op(r0);
+    w = wave_sort_u64(w);
+    const bool valid = lane < c;
+    const uint32_t slot = (uint32_t)(w >> 32), idx = (uint32_t)(w >> 16) & 0xFFFF, op = (uint32_t)w & 0xFF;
+    const uint32_t up = __shfl_up(slot, 1, 64);
+    const bool head = valid && (lane == 0 || up != slot);
+    const uint64_t hm = __ballot(head), vm = __ballot(valid);
+    const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
+    const int hl = valid ? 63 - __clzll(hm & le) : (int)lane;
+    const uint64_t above = hm & ~le;
+    const uint64_t next = above ? (above & (~above + 1ull)) : vm + 1ull;
+    const uint64_t seg = valid ? ((next - 1ull) & ~((1ull << hl) - 1ull)) : 0;
+    uint2 st0 = make_uint2(0, 0);
+    if (head) st0 = table[slot];
+    st0.x = __shfl(st0.x, hl, 64);
+    st0.y = __shfl(st0.y, hl, 64);
+    uint32_t code = 0, rv = 0;
+    uint2 fin = st0;
+    bool dirty = false;
+    Ops::resolve_sorted(valid, seg, op, st0, code, rv, fin, dirty);
+    if (valid) Ops::write_reply(rep, idx, op, code, rv);
+    if (head && dirty) table[slot] = fin;
+    return;
+  }
   rank_build(R, recs, c, n);
 
   for (uint32_t lo = 0; lo < c; lo += DINT_WCAP) {

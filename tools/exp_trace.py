@@ -22,12 +22,23 @@ grp.sync(); grp.restore()
 rp = Replay(trace, grp.msg)
 torch.cuda.synchronize()
 eng = grp.engines[0]
+import time
+per = []
 for e in range(E):
+    grp.sync(); t0 = time.perf_counter()
     eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
-grp.sync()
+    grp.sync(); wall = (time.perf_counter() - t0) * 1e6
+    tt = eng.kv_trace().astype(np.int64)
+    bg = tt[:, 14] > 64
+    if bg.any():
+        d = (tt[bg, 9] - tt[bg, 8]) / 100
+        i = int(np.argmax(d))
+        per.append((e, round(wall), int(bg.sum()), int(tt[bg, 14].max()), round(float(d.max()), 1), int(tt[bg][i, 14]), int(tt[bg][i, 13]), int(tt[bg][i, 12])))
+print("per pass: (epoch, wall_us, n_big, max_c, slowest_big_us, its_c, its_windows, its_rounds)")
+for r in per: print("  ", r)
 t = eng.kv_trace().astype(np.int64)
 c = t[:, 15]
-live = c > 0
+live = (c > 0) & (t[:, 14] == 0)
 t0 = t[live, 0].min()
 names = ["entry->c,Skv", "recs", "sort", "msg key+segments", "heads: hdr+locate", "outcomes+replies", "fence+write-back", "rounds+fence", "exit"]
 small = live & (c <= 64)
@@ -55,7 +66,10 @@ start = t[live, 0] - t0
 end_small = ts[:, 9] - t0
 print(f"wave start (ticks after first): p50 {np.median(start):.0f} p99 {np.percentile(start, 99):.0f} max {start.max()}")
 print(f"small-wave end: p50 {np.median(end_small):.0f} p99 {np.percentile(end_small, 99):.0f} max {end_small.max()}")
-big = live & (c > 64)
+big = t[:, 14] > 64
 if big.any():
+    tb = t[big]
+    o = np.argsort(tb[:, 9] - tb[:, 8])
+    print("big bins (c, windows, rounds, dur_us):", [(int(r[14]), int(r[13]), int(r[12]), round((r[9] - r[8]) / 100, 1)) for r in tb[o]])
     # big bins only stamp 0,1 and the per-chunk stamps get overwritten; report count and start
     print("big bins c:", sorted(c[big].tolist())[-10:])
