@@ -118,7 +118,7 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0) {
   static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
-  static const char *const kv_names[] = {"k_kv_scatter", "k_kv_resolve"};
+  static const char *const kv_names[] = {"k_kv_prepass", "k_kv_scatter", "k_kv_resolve_big", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
@@ -134,7 +134,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 2, kv_names));
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names));
       break;
     default:
       return fail(DINT_EINVAL, "bad workload");

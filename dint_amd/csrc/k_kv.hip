@@ -72,13 +72,18 @@ __device__ static inline uint32_t kv_class(uint32_t type, int load_mode) {
 }
 
 // 16-bit request descriptor carried from the scatter kernel to the resolve kernels
-__device__ static inline uint32_t kv_pay(uint32_t type, uint32_t table, uint32_t q, uint32_t kh) {
-  return (type == DINT_KV_LOAD_OP ? 31u : type) | (table << 5) | (q << 8) | (kh << 10);
+__device__ static inline uint32_t kv_pay(uint32_t type, uint32_t q, uint32_t kh) {
+  return (type == DINT_KV_LOAD_OP ? 31u : type) | (q << 5) | (kh << 7);
 }
 __device__ static inline uint32_t pay_type(uint32_t p) { const uint32_t t = p & 31u; return t == 31u ? DINT_KV_LOAD_OP : t; }
-__device__ static inline uint32_t pay_table(uint32_t p) { return (p >> 5) & 7u; }
-__device__ static inline uint32_t pay_q(uint32_t p) { return (p >> 8) & 3u; }
-__device__ static inline uint32_t pay_kh(uint32_t p) { return (p >> 10) & 63u; }
+__device__ static inline uint32_t pay_q(uint32_t p) { return (p >> 5) & 3u; }
+__device__ static inline uint32_t pay_kh(uint32_t p) { return (p >> 7) & 511u; }
+// table of a group key: group keys are allocated table by table (kv_dev::gk_base)
+__device__ static inline uint32_t kv_table_of(const kv_dev *kv, uint32_t gk) {
+  uint32_t t = 0;
+  for (uint32_t k = 1; k < kv->n_tables; k++) t += gk >= kv->gk_base[k];
+  return t;
+}
 
 __device__ static inline uint64_t ld_u64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ static inline uint32_t ld_u32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -219,8 +224,9 @@ k_kv_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv
     const uint32_t gk = kv->gk_base[table] + local;
     const uint32_t bin = gk & pmask;
     const uint32_t pos = atomicAdd(&bin_cnt[bin], 1u);
-    // record payload (16 bits): type (5 bits, LOAD -> 31) | table << 5 | lock quadrant << 8 | 6 key-hash bits << 10
-    const uint32_t pay = kv_pay(type, table, q, (uint32_t)(h >> 40) & 63u);
+    // record payload (16 bits): type (5 bits, LOAD -> 31) | lock quadrant << 5 | 9 key-hash bits << 7
+    // (the table is implied by the group key)
+    const uint32_t pay = kv_pay(type, q, (uint32_t)(h >> 40) & 511u);
     bins[(size_t)bin * DINT_MICRO + pos] = dint_rec(gk, i, pay & 0xFF, pay >> 8);
   }
 }
@@ -344,10 +350,49 @@ __device__ static inline bool kv_simple_op(uint32_t type) {
   return type <= 5;                                                            // every smallbank table op
 }
 template <int WL>
+__device__ static inline bool kv_struct_op(uint32_t type) {  // inserts / deletes a row (changes the chain)
+  if (WL == DINT_WL_STORE) return type == 2;
+  if (WL == DINT_WL_TATP) return type == 18 || type == 19 || type == 22 || type == 23;
+  return false;
+}
+template <int WL>
 __device__ static inline bool kv_lock_op(uint32_t type) {  // touches the bucket's lock word
   if (WL == DINT_WL_STORE) return false;
-  if (WL == DINT_WL_TATP) return type == 1 || type == 2 || type == 12;
+  if (WL == DINT_WL_TATP) return type == 1 || type == 2 || type == 12 || type == 18 || type == 22;
   return type <= 3;
+}
+// One step of a key's row machine {exists, version, last writer} (store / tatp), in request order.  Used for key
+// segments that contain an INSERT or DELETE; plain segments use the ballot closed form.  Returns the reply code of
+// a row op (0 for lock-only requests, whose code comes from the lock machine).
+struct kv_rowst { uint32_t exists, ver, toggles, miss, bail; int src; };
+template <int WL>
+__device__ static inline uint32_t kv_row_step(uint32_t op, int l, kv_rowst &st, uint32_t &get) {
+  enum { GET, SET, INS, DEL, NONE } a = NONE;
+  uint32_t code = 0;
+  if (WL == DINT_WL_STORE) {
+    if (op == 0) { a = GET; code = st.exists ? 3 : 7; }
+    else if (op == 1) { a = SET; code = st.exists ? 5 : 7; }
+    else { a = INS; code = 8; }
+  } else {
+    switch (op) {
+      case 0: a = GET; code = st.exists ? 4 : 6; break;
+      case 12: a = SET; code = 15; break;
+      case 13: a = SET; code = 16; break;
+      case 18: a = INS; code = 20; break;
+      case 19: a = INS; code = 21; break;
+      case 22: a = DEL; code = 25; break;
+      case 23: a = DEL; code = 26; break;
+      default: break;  // 1 kAcquireLock, 2 kAbort: lock word only
+    }
+  }
+  switch (a) {
+    case GET: get = st.exists; break;
+    case SET: if (st.exists) { st.ver++; st.src = l; } else if (WL != DINT_WL_STORE) st.miss++; break;
+    case INS: if (st.exists) st.bail = 1; else { st.exists = 1; st.ver = 0; st.src = l; st.toggles++; } break;
+    case DEL: if (st.exists) { st.exists = 0; st.toggles++; } else st.miss++; break;
+    default: break;
+  }
+  return code;
 }
 
 __device__ static inline uint64_t shfl_u64(uint64_t v, int src) {
@@ -408,12 +453,19 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
     }
   }
   const uint64_t hkey = shfl_u64(key, hl);
-  const uint64_t m_bad = __ballot(valid && !(key == hkey && kv_simple_op<WL>(type)));
+  const uint64_t m_bad = __ballot(valid && !(key == hkey && (kv_simple_op<WL>(type) || kv_struct_op<WL>(type))));
   const uint64_t m_lockop = __ballot(valid && kv_lock_op<WL>(type));
-  const uint64_t m_lkseg = __ballot(head && (m_lockop & seg) != 0);  // key segments that carry lock ops
-  const bool simple = valid && (m_bad & run) == 0 && __popcll(m_lkseg & run) <= 1 && !force_rounds;
+  const uint64_t m_struct = __ballot(valid && kv_struct_op<WL>(type));
+  // key segments that carry lock ops, per lock quadrant: two of them on one lock word make the run non-simple
+  const bool lkseg = head && (m_lockop & seg) != 0;
+  bool lock_clash = false;
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) lock_clash |= __popcll(__ballot(lkseg && q == k) & run) > 1;
+  const uint64_t m_stseg = __ballot(head && (m_struct & seg) != 0);  // ... that insert / delete their row
+  bool simple = valid && (m_bad & run) == 0 && !lock_clash && __popcll(m_stseg & run) <= 1 && !force_rounds;
+  const bool structural = (m_struct & seg) != 0;  // my key segment inserts / deletes: row machine by walk
   kv_stamp(tr, 4);
-  const bool leader = head && simple;
+  bool leader = head && simple;
   if (leader) {
     if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
     const kv_where w = kv_locate(t, bucket, H, key);
@@ -442,7 +494,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         my_code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
         my_get = (type == 0 && found) ? 1 : 0;
       } else {
-        const uint64_t m_lk = __ballot(simple && (type == 1 || type == 2 || type == 12)) & seg;
+        const uint64_t m_lk = __ballot(simple && kv_lock_op<WL>(type)) & seg;
         const uint64_t m_acq = __ballot(simple && type == 1);
         const uint64_t lk_below = m_lk & lt;
         const uint32_t lock_seen = lk_below ? (uint32_t)((m_acq >> (63 - __clzll(lk_below))) & 1ull) : la0;
@@ -453,9 +505,42 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
           case 1: my_code = lock_seen ? 8 : 7; break;
           case 2: my_code = 9; break;
           case 12: my_code = 15; break;
-          default: my_code = 16; break;  // 13 kCommitBck
+          default: my_code = 16; break;  // 13 kCommitBck (a structural segment overwrites the row ops' codes below)
         }
       }
+      // key segments with an INSERT / DELETE: the row machine {exists, version, last writer} is walked once per
+      // segment with wave-uniform registers.  Two toggles of `exists` (delete then re-insert: the row may move to
+      // another slot) or an INSERT of an existing key (a duplicate row) send the bucket run to the rounds.
+      uint32_t fin_exists = found, my_bail = 0;
+      uint64_t stm = __ballot(leader && structural);
+      while (stm) {
+        const int L = __ffsll((unsigned long long)stm) - 1;
+        stm &= stm - 1;
+        const uint64_t sm = readlane_u64(seg, L);
+        kv_rowst st;
+        st.exists = (uint32_t)__builtin_amdgcn_readlane(found, L);
+        st.ver = (uint32_t)__builtin_amdgcn_readlane(ver0, L);
+        st.toggles = 0; st.miss = 0; st.bail = 0; st.src = -1;
+        for (uint64_t m = sm; m; m &= m - 1) {
+          const int l = __ffsll((unsigned long long)m) - 1;
+          const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
+          uint32_t get = 0;
+          const uint32_t ver_seen = st.ver;
+          const int src_seen = st.src;
+          const uint32_t code = kv_row_step<WL>(op, l, st, get);
+          if (lane == l) {
+            if (code) my_code = code;  // lock-only requests keep the lock machine's code
+            my_ver = ver_seen; my_src = src_seen; my_get = get;
+          }
+        }
+        if (lane == L) {
+          fin_exists = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
+          my_bail = st.bail | (st.toggles > 1);
+        }
+      }
+      const uint64_t m_bail = __ballot(head && my_bail);
+      if (m_bail & run) { simple = false; leader = false; }
+      found = simple && structural ? (found | (fin_exists << 1)) : found;  // bit 1: exists after the segment (head lane)
     } else {
       // smallbank.  cnt = {la: num_ex, lb: num_sh}
       auto sb_step = [](uint32_t op, uint32_t fnd, uint32_t &la, uint32_t &lb, uint32_t &get, uint32_t &miss,
@@ -506,7 +591,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   const uint32_t fin_idx = __shfl(idx, fin_src >= 0 ? fin_src : lane, 64);
   uint8_t *row = nullptr;
   if (simple) {
-    row = kv_entry_ptr(t, bucket, link) + KV_VAL_OFF + slot * F::VS;
+    row = kv_entry_ptr(t, bucket, link) + KV_VAL_OFF + slot * F::VS;  // meaningful when the row was found
     if (my_get) {
       const uint8_t *from = my_src >= 0 ? rep + (size_t)src_idx * F::MSG + F::VAL : row;
       kv_copy_words(msg + F::VAL, from, F::VS);
@@ -519,9 +604,16 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   // ---- 4. final state of each simple segment, written once by its head.  The lock word belongs to the one
   // segment of the bucket that carries lock ops (fin_la / fin_lb differ from la0 / lb0 only there).
   if (leader) {
-    if (fin_src >= 0) {
-      kv_copy_words(row, rep + (size_t)fin_idx * F::MSG + F::VAL, F::VS);
-      kv_entry_hdr(t, bucket, link)->ver[slot] = fin_ver;
+    const uint32_t found0 = found & 1u, exists1 = structural ? (found >> 1) & 1u : found0;
+    if (found0 && exists1) {          // the row stays where it is: value / version of the last writer
+      if (fin_src >= 0) {
+        kv_copy_words(row, rep + (size_t)fin_idx * F::MSG + F::VAL, F::VS);
+        kv_entry_hdr(t, bucket, link)->ver[slot] = fin_ver;
+      }
+    } else if (found0 != exists1) {   // one INSERT or one DELETE took effect: apply it to the chain once
+      const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key,
+                                            rep + (size_t)fin_idx * F::MSG + F::VAL, fin_ver, blockIdx.x);
+      if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
     }
     if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
     if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = make_uint2(fin_la, fin_lb);
@@ -583,15 +675,16 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t
   uint64_t w = ~0ull;  // empty lanes sort last
   if (lane < c) {
     const uint32_t pay = rec_op(r0) | (rec_aux(r0) << 8);
-    w = ((uint64_t)rec_gk(r0) << 32) | ((uint64_t)pay_kh(pay) << 26) | ((uint64_t)rec_idx(r0) << 10) | (pay & 0x3FFu);
+    w = ((uint64_t)rec_gk(r0) << 32) | ((uint64_t)pay_kh(pay) << 23) | ((uint64_t)rec_idx(r0) << 7) | (pay & 0x7Fu);
   }
   kv_stamp(tr, 2);
   w = wave_sort_u64(w);
   kv_stamp(tr, 3);
   const bool valid = lane < c;
-  const uint32_t gk = (uint32_t)(w >> 32), kh = (uint32_t)(w >> 26) & 63u, idx = (uint32_t)(w >> 10) & 0xFFFF;
-  const uint32_t pay = (uint32_t)w & 0x3FFu;
-  kv_chunk<WL>(rep, valid, idx, gk, kh, pay_type(pay), pay_table(pay), pay_q(pay), kv, stats, kv_force_rounds, true, tr);
+  const uint32_t gk = (uint32_t)(w >> 32), kh = (uint32_t)(w >> 23) & 511u, idx = (uint32_t)(w >> 7) & 0xFFFF;
+  const uint32_t pay = (uint32_t)w & 0x7Fu;
+  kv_chunk<WL>(rep, valid, idx, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), kv, stats,
+               kv_force_rounds, true, tr);
   kv_stamp(tr, 9);
   kv_stamp_real(tr, 11);
 }
@@ -656,9 +749,11 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
   __shared__ uint32_t Ssort[KVB_T];
   __shared__ uint16_t Sp[KVB_T];              // sorted position -> window position
   __shared__ uint32_t Slast[KVB_W];           // hash entry of each wave's last lane
-  __shared__ uint64_t Mhead[KVB_W], Mbh[KVB_W], Mbad[KVB_W], Mlop[KVB_W], Mlkseg[KVB_W], Mwr[KVB_W], Mlk[KVB_W], Macq[KVB_W];
+  __shared__ uint64_t Mhead[KVB_W], Mbh[KVB_W], Mbad[KVB_W], Mlop[KVB_W], Mlkseg[4][KVB_W], Mst[KVB_W], Mstseg[KVB_W], Mbail[KVB_W], Mwr[KVB_W], Mlk[KVB_W], Macq[KVB_W];
   __shared__ kvb_lead Lead[KVB_T];
   __shared__ kvb_carry Carry[KVB_T];
+  __shared__ kv_rowst Crow[KVB_T];            // row machine of key segments with an INSERT / DELETE (store / tatp)
+  __shared__ uint32_t Sany;
   __shared__ uint32_t Sred[KVB_W];
   __shared__ kv_dev Skv;
   const uint32_t bin = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -716,7 +811,7 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     }
     __syncthreads();
     // ---- sort the window by (hash entry, key-hash bits, window position): 512-wide bitonic network
-    uint32_t v = t < wn ? (((Srec[t] >> 16) & (DINT_HSIZE - 1)) << 15) | (pay_kh(Sop[t]) << 9) | t : 0xFFFFFFFFu;
+    uint32_t v = t < wn ? (((Srec[t] >> 16) & (DINT_HSIZE - 1)) << 18) | (pay_kh(Sop[t]) << 9) | t : 0xFFFFFFFFu;
     for (uint32_t k = 2; k <= KVB_T; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
         uint32_t o;
@@ -733,13 +828,13 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
       }
     }
     const bool valid = v != 0xFFFFFFFFu;
-    const uint32_t p = v & 511u, ek = valid ? (v >> 9) : 0xFFFFFFu;  // ek = hash entry << 6 | key-hash bits
-    const uint32_t e = ek >> 6;
+    const uint32_t p = v & 511u, ek = valid ? (v >> 9) : 0xFFFFFFu;  // ek = hash entry << 9 | key-hash bits
+    const uint32_t e = ek >> 9;
     Sp[t] = (uint16_t)p;
     const uint32_t sr = valid ? Srec[p] : 0, so = valid ? Sop[p] : 0;
-    const uint32_t idx = sr & 0xFFFF, type = pay_type(so), table = pay_table(so), q = pay_q(so);
-    const uint64_t key = valid ? Skey[p] : 0;
     const uint32_t gk = valid ? Hk[e] : 0;
+    const uint32_t idx = sr & 0xFFFF, type = pay_type(so), table = valid ? kv_table_of(kv, gk) : 0, q = pay_q(so);
+    const uint64_t key = valid ? Skey[p] : 0;
     const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
     uint8_t *msg = rep + (size_t)idx * F::MSG;
     // ---- bucket runs and key segments of the sorted window (they may span waves)
@@ -747,7 +842,7 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     __syncthreads();
     const uint32_t ek_shfl = __shfl_up(ek, 1, 64);  // executed by every lane: a shuffle reads only active lanes
     const uint32_t ek_up = lane ? ek_shfl : (wave ? Slast[wave - 1] : 0xFFFFFFFFu);
-    const bool bhead = valid && (ek_up >> 6) != e;
+    const bool bhead = valid && (ek_up >> 9) != e;
     const bool head = valid && ek_up != ek;
     {
       const uint64_t hm = __ballot(head), bm = __ballot(bhead);
@@ -781,30 +876,46 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     }
     const uint64_t hkey = valid ? Skey[Sp[seg_a]] : 0;  // Sp[] of other waves: written before the barriers above
     {
-      const uint64_t bm = __ballot(valid && !(key == hkey && kv_simple_op<WL>(type)));
+      const uint64_t bm = __ballot(valid && !(key == hkey && (kv_simple_op<WL>(type) || kv_struct_op<WL>(type))));
       const uint64_t lm = __ballot(valid && kv_lock_op<WL>(type));
-      if (lane == 0) { Mbad[wave] = bm; Mlop[wave] = lm; }
+      const uint64_t sm = __ballot(valid && kv_struct_op<WL>(type));
+      if (lane == 0) { Mbad[wave] = bm; Mlop[wave] = lm; Mst[wave] = sm; }
+      if (t == 0) Sany = 0;
     }
     __syncthreads();
-    {  // key segments that carry lock ops: a bucket run with two of them is not simple
-      const uint64_t sm = __ballot(head && kvb_range_popc(Mlop, seg_a, seg_b) != 0);
-      if (lane == 0) Mlkseg[wave] = sm;
+    const bool structural = valid && kvb_range_popc(Mst, seg_a, seg_b) != 0;  // my key segment inserts / deletes
+    {  // key segments that carry lock ops, per lock quadrant: two on one lock word make the bucket run non-simple
+      const bool lkseg = head && kvb_range_popc(Mlop, seg_a, seg_b) != 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint64_t sm = __ballot(lkseg && q == k);
+        if (lane == 0) Mlkseg[k][wave] = sm;
+      }
+      const uint64_t ss = __ballot(head && structural);
+      if (lane == 0) Mstseg[wave] = ss;
     }
     __syncthreads();
-    const bool simple = valid && !force_rounds && kvb_range_popc(Mbad, bk_a, bk_b) == 0 &&
-                        kvb_range_popc(Mlkseg, bk_a, bk_b) <= 1;
-    const bool leader = head && simple;
+    bool lock_clash = false;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) lock_clash |= valid && kvb_range_popc(Mlkseg[k], bk_a, bk_b) > 1;
+    bool simple = valid && !force_rounds && kvb_range_popc(Mbad, bk_a, bk_b) == 0 && !lock_clash &&
+                  kvb_range_popc(Mstseg, bk_a, bk_b) <= 1;
+    bool leader = head && simple;
     if (leader) {
       const kv_where wh = kv_locate(tb, bucket, H, key);
       Lead[t].found_link = (wh.found << 31) | wh.link;
       Lead[t].slot = wh.slot; Lead[t].ver0 = wh.ver; Lead[t].la0 = la0; Lead[t].lb0 = lb0;
       Carry[t].la = la0; Carry[t].lb = lb0; Carry[t].ver = wh.ver; Carry[t].src = -1; Carry[t].miss = 0;
+      if (WL != DINT_WL_SMALLBANK && structural) {
+        Crow[t].exists = wh.found; Crow[t].ver = wh.ver; Crow[t].toggles = 0; Crow[t].miss = 0; Crow[t].bail = 0; Crow[t].src = -1;
+        Sany = 1;
+      }
     }
     {
       const bool writer = simple && (WL == DINT_WL_STORE ? type == 1 : WL == DINT_WL_TATP ? (type == 12 || type == 13)
                                                                                          : (type == 4 || type == 5));
       const uint64_t m1 = __ballot(writer);
-      const uint64_t m2 = __ballot(simple && WL == DINT_WL_TATP && (type == 1 || type == 2 || type == 12));
+      const uint64_t m2 = __ballot(simple && WL == DINT_WL_TATP && kv_lock_op<WL>(type));
       const uint64_t m3 = __ballot(simple && WL == DINT_WL_TATP && type == 1);
       if (lane == 0) { Mwr[wave] = m1; Mlk[wave] = m2; Macq[wave] = m3; }
     }
@@ -848,6 +959,49 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
           }
         }
       }
+      // key segments with an INSERT / DELETE: the row machine is walked in sorted order, wave after wave, with the
+      // state carried through Crow[segment head] (as kv_chunk; rare, so the whole step is skipped when no such
+      // segment exists in the window)
+      uint32_t fin_exists = found;
+      if (Sany) {
+        for (uint32_t wv = 0; wv < KVB_W; wv++) {
+          if (wave == wv) {
+            uint64_t todo = __ballot(simple && structural);
+            while (todo) {
+              const int l0 = __ffsll((unsigned long long)todo) - 1;
+              const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(seg_a, l0);
+              const uint64_t mem = __ballot(simple && structural && seg_a == a);
+              todo &= ~mem;
+              kv_rowst st = Crow[a];
+              for (uint64_t m = mem; m; m &= m - 1) {
+                const int l = __ffsll((unsigned long long)m) - 1;
+                const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
+                uint32_t get = 0;
+                const uint32_t ver_seen = st.ver;
+                const int src_seen = st.src;
+                const uint32_t code = kv_row_step<WL>(op, (int)(wv * 64 + l), st, get);
+                if ((int)lane == l) {
+                  if (code) my_code = code;
+                  my_ver = ver_seen; my_src = src_seen; my_get = get;
+                }
+              }
+              if ((int)lane == l0) Crow[a] = st;
+            }
+          }
+          __syncthreads();
+        }
+        uint32_t my_bail = 0;
+        if (leader && structural) {
+          const kv_rowst st = Crow[t];
+          fin_exists = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
+          my_bail = st.bail | (st.toggles > 1);
+        }
+        const uint64_t bm = __ballot(head && my_bail);
+        if (lane == 0) Mbail[wave] = bm;
+        __syncthreads();
+        if (valid && kvb_range_popc(Mbail, bk_a, bk_b) != 0) { simple = false; leader = false; }
+      }
+      if (leader && structural) found |= fin_exists << 1;  // bit 1: the row exists after the segment
     } else {
       // smallbank: the counters have no closed form.  Walk every simple segment in sorted order, wave after wave,
       // with the running state {num_ex, num_sh, version, last writer} carried through Carry[segment head].
@@ -903,9 +1057,17 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();  // every table read of the window precedes the write-backs
     if (leader) {
-      if (fin_src >= 0) {
-        kv_copy_words(row, rep + (size_t)(Srec[Sp[fin_src]] & 0xFFFF) * F::MSG + F::VAL, F::VS);
-        kv_entry_hdr(tb, bucket, link)->ver[slot] = fin_ver;
+      const uint32_t found0 = found & 1u, exists1 = (WL != DINT_WL_SMALLBANK && structural) ? (found >> 1) & 1u : found0;
+      const uint8_t *fin_val = fin_src >= 0 ? rep + (size_t)(Srec[Sp[fin_src]] & 0xFFFF) * F::MSG + F::VAL : nullptr;
+      if (found0 && exists1) {          // the row stays where it is: value / version of the last writer
+        if (fin_src >= 0) {
+          kv_copy_words(row, fin_val, F::VS);
+          kv_entry_hdr(tb, bucket, link)->ver[slot] = fin_ver;
+        }
+      } else if (found0 != exists1) {   // one INSERT or one DELETE took effect: apply it to the chain once
+        const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key, (uint8_t *)fin_val,
+                                              fin_ver, blockIdx.x);
+        if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
       }
       if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
       if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = make_uint2(fin_la, fin_lb);
@@ -948,17 +1110,19 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   if (WL != DINT_WL_STORE)
     hipLaunchKernelGGL((k_kv_prepass<WL>), dim3(nb), dim3(256), 0, st, (const uint8_t *)d_req, n, kv.d_dev, s.blk_cnt,
                        log.tail);
+  if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_kv_scatter<WL>), dim3(nb), dim3(256), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n,
                      kv.d_dev, log, (const uint32_t *)s.blk_cnt, P - 1, s.bin_cnt, s.bins, s.stats, load_mode);
-  if (ev) hipEventRecord(ev[1], st);
+  if (ev) hipEventRecord(ev[2], st);
   // The two resolve kernels own disjoint bins (<= 64 records / more).  They run back to back on the pass's stream:
   // forking the big-bin kernel to a side stream and joining it (measured, r01) costs more in cross-stream event
   // latency (~10 us per pass) than the overlap saves.
   hipLaunchKernelGGL((k_kv_resolve_big<WL>), dim3(P), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
                      (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace);
+  if (ev) hipEventRecord(ev[3], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
                      (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace);
-  if (ev) hipEventRecord(ev[2], st);
+  if (ev) hipEventRecord(ev[4], st);
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
