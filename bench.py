@@ -95,6 +95,23 @@ def sum_over_ranks(x, world):
     return x
 
 
+def pmc_traffic(kernels):
+    """HBM bytes per launch of `kernels` from the committed rocprofv3 --pmc summary of this same command
+    (profiles/r01_tatp_rocprofv3_summary.txt: FETCH_SIZE + WRITE_SIZE, KiB per dispatch, separate passes as
+    MI355X_MICROARCH.md prescribes).  Raw counter values: the guide's x2 FETCH_SIZE correction applies to wide
+    coalesced streams, the resolve kernels issue 8..64-byte random accesses, for which it is uncalibrated."""
+    path = os.path.join(ROOT, "profiles", "r01_tatp_rocprofv3_summary.txt")
+    try:
+        tot = 0.0
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE") and f[0].split("<")[0] in kernels:
+                tot += float(f[3]) * 1024.0
+        return int(tot) if tot else None
+    except OSError:
+        return None
+
+
 def rand64(extra, value_ops_per_s, dev):
     """Measured random-64B HBM roofline: gathers over an 8 GiB table."""
     from dint_amd.engine import bench_rand64
@@ -323,8 +340,8 @@ def bench_tatp(args, world, rank, dev):
         alg = tot_b / max(1, launches)
         achieved = alg / (dom_us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(alg),
-                "kernel_avg_us": round(dom_us, 3)}
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom.split("+")),
+                "alg_bytes_per_launch": int(alg), "kernel_avg_us": round(dom_us, 3)}
     if rank != 0:
         return None
     if not args.no_rand64 and world == 1:
