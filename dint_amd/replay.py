@@ -30,6 +30,7 @@ class ShardGroup:
                                log_entries=log_entries) for _ in range(N_SHARDS)]
         self.msg = self.engines[0].msg_size
         self.sharded = [ShardedEngine(e, world, rank) for e in self.engines] if world > 1 else None
+        self.last_splits = None  # multi GPU: all-to-all split sizes of the latest submit(), per shard
         for e in self.engines:  # every server holds every row (tatp/udp/server_shard.cc:71-85)
             e.populate(n_rows if populate is None else populate)
 
@@ -37,26 +38,27 @@ class ShardGroup:
     def submit(self, reqs: List[np.ndarray]) -> List[np.ndarray]:
         if self.sharded is None:
             return [self.engines[s].submit(reqs[s]) if len(reqs[s]) else reqs[s] for s in range(N_SHARDS)]
-        out = []
+        out, self.last_splits = [], []
         for s in range(N_SHARDS):  # every rank must enter the collectives, also with an empty batch
             n = len(reqs[s])
             d = torch.from_numpy(np.frombuffer(reqs[s].tobytes(), np.uint8).copy()).cuda()
             r = torch.empty_like(d)
-            self.sharded[s].submit_device(d, n, r)
+            self.last_splits.append(self.sharded[s].submit_device(d, n, r))
             out.append(np.frombuffer(r.cpu().numpy().tobytes(), reqs[s].dtype))
         return out
 
     # ---- device path (replay) --------------------------------------------------------------------------
-    def submit_device(self, d_reqs, counts, d_reps) -> None:
+    def submit_device(self, d_reqs, counts, d_reps, splits=None) -> None:
         """d_reqs / d_reps: per shard uint8 tensors; asynchronous.  Single GPU: each engine runs on its own
-        stream (the three shard servers are independent).  Multi GPU: routed on torch's current stream."""
+        stream (the three shard servers are independent).  Multi GPU: routed on torch's current stream; `splits`
+        (per shard, recorded by submit()) keeps the exchange free of host syncs."""
         if self.sharded is None:
             for s in range(N_SHARDS):
                 if counts[s]:
                     self.engines[s].submit_device(d_reqs[s], counts[s], d_reps[s], 0)
         else:
             for s in range(N_SHARDS):
-                self.sharded[s].submit_device(d_reqs[s], counts[s], d_reps[s])
+                self.sharded[s].submit_device(d_reqs[s], counts[s], d_reps[s], None if splits is None else splits[s])
 
     def sync(self):
         for e in self.engines:
@@ -81,7 +83,7 @@ def record(driver: Driver, group, n_epochs: int):
         req = driver.next()
         rep = group.submit(req)
         driver.consume(rep)
-        trace.append((req, rep))
+        trace.append((req, rep, getattr(group, "last_splits", None)))
         now = driver.stats()["txns"]  # transactions whose last reply arrived in this epoch
         done.append(now - last)
         last = now
@@ -93,9 +95,10 @@ class Replay:
 
     def __init__(self, trace, msg_size: int):
         self.msg = msg_size
-        self.counts = [[len(req[s]) for s in range(N_SHARDS)] for req, _ in trace]
+        self.counts = [[len(t[0][s]) for s in range(N_SHARDS)] for t in trace]
+        self.splits = [t[2] if len(t) > 2 else None for t in trace]
         self.d_req, self.d_rep, self.want = [], [], []
-        for req, rep in trace:
+        for req, rep in ((t[0], t[1]) for t in trace):
             self.d_req.append([torch.from_numpy(np.frombuffer(req[s].tobytes(), np.uint8).copy()).cuda()
                                for s in range(N_SHARDS)])
             self.d_rep.append([torch.empty(len(req[s]) * msg_size, dtype=torch.uint8, device="cuda")
@@ -107,7 +110,7 @@ class Replay:
 
     def run(self, group: ShardGroup, lo: int, hi: int) -> None:
         for e in range(lo, hi):
-            group.submit_device(self.d_req[e], self.counts[e], self.d_rep[e])
+            group.submit_device(self.d_req[e], self.counts[e], self.d_rep[e], self.splits[e])
 
     def check(self, lo: int, hi: int) -> None:
         """The replayed replies must equal the recorded ones byte for byte."""

@@ -49,18 +49,26 @@ class ShardedEngine:
         st = torch.cuda.current_stream().cuda_stream
         self.engine.submit_device(recv2d, n, recv2d, st)
 
-    def submit_device(self, d_req: torch.Tensor, n: int, d_rep: torch.Tensor) -> None:
-        """d_req / d_rep: uint8 tensors of n * msg_size bytes on this rank's device."""
+    def submit_device(self, d_req: torch.Tensor, n: int, d_rep: torch.Tensor, splits=None):
+        """d_req / d_rep: uint8 tensors of n * msg_size bytes on this rank's device.
+
+        The collective API wants the split sizes as host integers.  Without `splits` they are exchanged and read
+        back (two host syncs per call); a caller that already knows them -- a replayed recorded trace, or an
+        ingest path with fixed-capacity slots -- passes `splits = (send_splits, recv_splits)` and the whole step
+        stays asynchronous on the stream.  Returns the splits used."""
         W, msg = self.world, self.msg
         req2d = d_req.view(n, msg)
         home = self._home(req2d, n).to(torch.int64)
         home = torch.where(home >= W, torch.full_like(home, self.rank), home)  # no home: counted as bad locally
         order = torch.argsort(home, stable=True)
-        counts = torch.bincount(home, minlength=W)
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts, group=self.group)
-        send_splits = counts.tolist()          # host sync: split sizes must be host integers
-        recv_splits = recv_counts.tolist()
+        if splits is None:
+            counts = torch.bincount(home, minlength=W)
+            recv_counts = torch.empty_like(counts)
+            dist.all_to_all_single(recv_counts, counts, group=self.group)
+            send_splits = counts.tolist()          # host sync: split sizes must be host integers
+            recv_splits = recv_counts.tolist()
+        else:
+            send_splits, recv_splits = splits
         send = req2d.index_select(0, order).contiguous()
         n_recv = int(sum(recv_splits))
         recv = torch.empty((n_recv, msg), dtype=torch.uint8, device=d_req.device)
@@ -70,3 +78,4 @@ class ShardedEngine:
         back = torch.empty_like(send)
         dist.all_to_all_single(back, recv, send_splits, recv_splits, group=self.group)
         d_rep.view(n, msg).index_copy_(0, order, back)
+        return send_splits, recv_splits

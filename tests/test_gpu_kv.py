@@ -345,3 +345,25 @@ def test_hot_key_paths_agree_with_oracle(flags):
     o = orc.SmallbankOracle(10_000, log_entries=100_000, populate_n=2)
     assert eng.submit(req).tobytes() == o.replay(req).tobytes()
     _sb_state(eng, o)
+
+
+def test_store_baseline_config_16m_keys_95_5():
+    """BASELINE.json configs[2]: store KV, 16M keys (1.4M subscribers x 12 rows = 16.8M), 95/5 read/write.
+    Full population equals the oracle's row for row; 4 x 64k requests with tatp_nurand-like skew, bit-exact."""
+    n_sub = 1_400_000
+    eng = _engine(W.STORE, n_rows=n_sub)
+    eng.populate(n_sub)
+    o = orc.StoreOracle(n_sub * 18 // 4, n_sub)
+    rng = np.random.default_rng(2)
+    n = 4 * 65536
+    req = np.zeros(n, wire.STORE_MSG)
+    s_id = (rng.integers(0, n_sub, n) | (rng.integers(0, 1 << 20, n) & 0xFFFFF)) % n_sub  # NURand(A = 2^20 - 1)
+    req["key"] = tracegen.store_key(s_id, rng.integers(1, 5, n), rng.integers(0, 3, n) * 8)
+    req["type"] = np.where(rng.random(n) < 0.05, wire.Store.SET, wire.Store.READ)
+    req["val"] = rng.integers(0, 256, (n, 40), dtype=np.uint8)
+    got, want = eng.submit(req), o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    assert (got["type"] == wire.Store.GRANT_READ).sum() > 0.9 * n
+    a, b = eng.dump_rows(0), o.dump()
+    assert len(a[0]) == 12 * n_sub and _same_rows(a, b)
+    assert eng.stats()["pool_exhausted"] == 0

@@ -50,13 +50,25 @@ def _worker(rank, world, port, nslots, q):
         recv2d.copy_(torch.from_numpy(np.frombuffer(out.tobytes(), np.uint8).reshape(-1, msg).copy()))
 
     sh = ShardedEngine(None, world, rank, msg_size=msg, home_fn=home_fn, local_fn=local_fn)
+    # a second, independent server double replays the same steps with the split sizes the first run discovered
+    # (the host-sync-free form bench.py uses for a recorded trace)
+    full2 = orc.FasstOracle(nslots)
+
+    def local_fn2(recv2d):
+        m = np.frombuffer(recv2d.numpy().tobytes(), wire.FASST_MSG)
+        recv2d.copy_(torch.from_numpy(np.frombuffer(full2.replay(m).tobytes(), np.uint8).reshape(-1, msg).copy()))
+
+    sh2 = ShardedEngine(None, world, rank, msg_size=msg, home_fn=home_fn, local_fn=local_fn2)
     outs = []
     for step in range(3):
         req = tracegen.fasst_random(n, seed=100 * step + rank, n_hot=16, p_hot=0.8)
         d_req = torch.from_numpy(np.frombuffer(req.tobytes(), np.uint8).copy())
         d_rep = torch.empty_like(d_req)
-        sh.submit_device(d_req, n, d_rep)
+        splits = sh.submit_device(d_req, n, d_rep)
         outs.append(d_rep.numpy().tobytes())
+        d_rep2 = torch.empty_like(d_req)
+        assert sh2.submit_device(d_req, n, d_rep2, splits=splits) == splits
+        assert d_rep2.numpy().tobytes() == outs[-1]
     q.put((rank, outs))
     dist.barrier()
     dist.destroy_process_group()

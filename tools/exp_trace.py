@@ -57,20 +57,10 @@ order = np.argsort(re)[-8:]
 print("last waves to finish: (c, start, end)", [(int(c[live][i]), int(rs[i] - r0), int(re[i] - r0)) for i in order])
 tl = t[live]
 for i in order[-5:]:
-    print("   slow wave c=%d phases(cycles):" % tl[i, 15], np.diff(tl[i, :10]).tolist(), "dur_10ns", int(re[i] - rs[i]),
-          "| do_request: type", int(tl[i, 14]), "t7->loads", int(tl[i, 12] - tl[i, 7]), "apply", int(tl[i, 13] - tl[i, 12]), "->t8", int(tl[i, 8] - tl[i, 13]))
-why = tl[:, 12]
-hasr = ((why >> 24) & 255) > 0
-print("small waves with rounds:", int(hasr.sum()), "of", len(why), "| with bad op/key lanes:", int((hasr & ((why & 255) > 0)).sum()),
-      "| >=2 lock segs in wave:", int((hasr & (((why >> 8) & 255) >= 2)).sum()), "| struct segs>0:", int((hasr & (((why >> 16) & 255) > 0)).sum()),
-      "| lanes in rounds p50/max:", int(np.median((why[hasr] >> 32) & 255)) if hasr.any() else 0, int(((why[hasr] >> 32) & 255).max()) if hasr.any() else 0)
+    print("   slow wave c=%d phases(cycles):" % tl[i, 15], np.diff(tl[i, :10]).tolist(), "dur_10ns", int(re[i] - rs[i]))
 dur = re - rs
 sm = tl[:, 15] <= 64
 print("small-wave duration (10ns): p50 %d p90 %d p99 %d max %d" % tuple(np.percentile(dur[sm], [50, 90, 99, 100])))
-start = t[live, 0] - t0
-end_small = ts[:, 9] - t0
-print(f"wave start (ticks after first): p50 {np.median(start):.0f} p99 {np.percentile(start, 99):.0f} max {start.max()}")
-print(f"small-wave end: p50 {np.median(end_small):.0f} p99 {np.percentile(end_small, 99):.0f} max {end_small.max()}")
 big = t[:, 14] > 64
 if big.any():
     tb = t[big]
