@@ -254,7 +254,7 @@ __device__ static inline void kv_stamp_real(uint64_t *tr, uint32_t k) {
 //   act phase    : kv_apply (value copy, row / header stores) and the lock-word store.
 template <int WL>
 __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_t table, uint32_t q, uint64_t bucket,
-                                            const kv_dev *kv, dint_dev_stats *__restrict__ stats, uint64_t *tr = nullptr) {
+                                            const kv_dev *kv, dint_dev_stats *__restrict__ stats) {
   using F = Fmt<WL>;
   const kv_tab t = kv->tab[table];
   uint8_t *ie = kv_entry_ptr(t, bucket, KV_INLINE);
@@ -265,7 +265,6 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
   if (WL == DINT_WL_SMALLBANK) cnt = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);  // {num_ex, num_sh}
   const uint64_t key = ld_u64(msg + F::KEY);
   uint8_t *val = msg + F::VAL;
-  if (tr) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[12] = __builtin_amdgcn_s_memtime(); tr[14] = type; }
 
   // ---- decide phase
   uint32_t act = KV_ACT_NONE, code = 0, ins_ver = 0;
@@ -308,7 +307,6 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
 
   // ---- act phase
   const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, act, key, val, ins_ver, blockIdx.x);
-  if (tr) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); tr[13] = __builtin_amdgcn_s_memtime(); }
   if (WL == DINT_WL_TATP && lock_store >= 0) ie[KV_LOCKB_OFF + q] = (uint8_t)lock_store;
   if (WL == DINT_WL_SMALLBANK && cnt_store) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = cnt;
   if (act == KV_ACT_GET && r.ok) st_u32(msg + F::VER, r.ver);
