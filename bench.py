@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = 65536
+KV_PASS = 1 << 20  # requests per kernel pass of the store / tatp / smallbank engines (dint_config.max_pass = 0)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -322,10 +323,10 @@ def bench_tatp(args, world, rank, dev):
         extra["kernels_us"] = {k: round(v, 3) for k, v in avg.items()}
         # The table requests of a pass are resolved by two kernels that own disjoint bins (> 64 records / the rest)
         # and run back to back: they are one unit for the roofline -- algorithmic bytes of the table requests
-        # over the sum of the two durations.  Log requests are finished by the scatter kernel.
+        # over the sum of the two durations.  Log requests are finished by k_kv_place.
         resolve_us = avg.get("k_kv_resolve_big", 0.0) + avg.get("k_kv_resolve", 0.0)
-        scatter_us = avg.get("k_kv_prepass", 0.0) + avg.get("k_kv_scatter", 0.0)
-        dom = "k_kv_resolve_big+k_kv_resolve" if resolve_us >= scatter_us else "k_kv_prepass+k_kv_scatter"
+        scatter_us = avg.get("k_kv_count", 0.0) + avg.get("k_kv_scan", 0.0) + avg.get("k_kv_place", 0.0)
+        dom = "k_kv_resolve_big+k_kv_resolve" if resolve_us >= scatter_us else "k_kv_count+k_kv_scan+k_kv_place"
         dom_us = max(resolve_us, scatter_us)
         tot_b, launches = 0.0, 0
         for e in range(n_t):
@@ -333,7 +334,7 @@ def bench_tatp(args, world, rank, dev):
                 ty = trace[e][0][s]["type"]
                 if len(ty) == 0:
                     continue
-                launches += -(-len(ty) // BATCH)
+                launches += -(-len(ty) // KV_PASS)
                 for code, b in TATP_ALG.items():
                     if resolve_us < scatter_us or code not in TATP_LOG_TYPES:
                         tot_b += b * int((ty == code).sum())

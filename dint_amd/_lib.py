@@ -27,7 +27,8 @@ class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("workload", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
         ("n_slots", C.c_uint64), ("n_rows", C.c_uint64), ("log_entries", C.c_uint32),
-        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("reserved", C.c_uint32 * 5),
+        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("max_pass", C.c_uint32),
+        ("reserved", C.c_uint32 * 4),
     ]
 
 

@@ -11,6 +11,9 @@
 
 #define DINT_MICRO 65536u          // max requests per kernel pass (idx fits 16 bits)
 #define DINT_PMAX 2048u            // max bins per pass
+#define DINT_KV_PASS 1048576u      // store / tatp / smallbank: max requests per kernel pass (idx fits 20 bits)
+#define DINT_KV_PMAX 32768u        // ... and max bins per pass
+#define DINT_KV_BINCAP 64u         // records a bin holds in place; the rest goes to the pass's overflow area
 #define DINT_WCAP 512u             // records resolved per window inside one bin
 #define DINT_HSIZE 1024u           // LDS hash slots per window (2 x WCAP)
 #define DINT_EMPTY 0xFFFFFFFFu

@@ -15,10 +15,17 @@ struct dint_dev_stats {
 
 // scratch shared by every workload: bins of batch records
 struct dint_scratch {
-  uint32_t *bin_cnt;   // [DINT_PMAX]   zero between passes (the resolve kernel re-zeroes its own)
-  uint64_t *bins;      // [DINT_PMAX][DINT_MICRO]
+  uint32_t *bin_cnt;   // [DINT_PMAX | DINT_KV_PMAX]   zero between passes (the resolve kernels re-zero their own)
+  uint64_t *bins;      // locks: [DINT_PMAX][DINT_MICRO];  kv: [DINT_KV_PMAX][DINT_KV_BINCAP]
   dint_dev_stats *stats;
-  uint32_t *blk_cnt;   // [256] per-block counts of the log scan
+  uint32_t *blk_cnt;   // per-block counts of the log scan: [256], kv [1024]
+  // ---- store / tatp / smallbank only (k_kv.hip) ----
+  uint32_t *blk_off;   // [1024] exclusive scan of blk_cnt
+  uint32_t *big;       // [2 + DINT_KV_PMAX]: big[0] = number of bins with more than DINT_KV_BINCAP records in this
+                       // pass, big[1] = number of overflow records, then the ids of those bins
+  uint32_t *bin_off;   // [DINT_KV_PMAX] start of a big bin's records DINT_KV_BINCAP.. in `ovf`
+  uint4 *ovl;          // [pass_max] overflow records as counted: {record lo, record hi, bin, position in bin}
+  uint64_t *ovf;       // [pass_max] overflow records grouped by bin
 };
 
 struct dint_shard {
@@ -30,6 +37,11 @@ static inline uint32_t dint_pick_bins(uint32_t n) {
   // bin); power of two, <= DINT_PMAX
   uint32_t p = 1;
   while (p < DINT_PMAX && p * 32u < n) p <<= 1;
+  return p;
+}
+static inline uint32_t dint_pick_bins_kv(uint32_t n) {
+  uint32_t p = 1;
+  while (p < DINT_KV_PMAX && p * 32u < n) p <<= 1;
   return p;
 }
 

@@ -44,7 +44,7 @@ struct KernelTimer {
   static const int kMaxLaunch = 4096;
   bool on = false;
   int n_kernels = 0;             // kernels per pass (events per pass = n_kernels + 1)
-  const char *names[4] = {0, 0, 0, 0};
+  const char *names[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<hipEvent_t> ev;    // (n_kernels + 1) per recorded pass
   int passes = 0;
 };
@@ -118,7 +118,7 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0) {
   static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
-  static const char *const kv_names[] = {"k_kv_prepass", "k_kv_scatter", "k_kv_resolve_big", "k_kv_resolve"};
+  static const char *const kv_names[] = {"k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve_big", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
@@ -134,7 +134,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names));
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 5, kv_names));
       break;
     default:
       return fail(DINT_EINVAL, "bad workload");
@@ -212,19 +212,40 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     delete e;
     return fail(DINT_EHIP, "hipStreamCreate");
   }
-  TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_PMAX * sizeof(uint32_t)));
-  TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_PMAX * DINT_MICRO * sizeof(uint64_t), false));
+  const uint32_t wl = cfg->workload;
+  const bool is_kv = wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK;
+  // requests per kernel pass: the request index must fit the batch record (16 bits, kv passes 20 bits)
+  e->pass_max = is_kv ? DINT_KV_PASS : DINT_MICRO;
+  if (cfg->max_pass) e->pass_max = std::min<uint32_t>(e->pass_max, std::max<uint32_t>(cfg->max_pass, 64u));
+  if (wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
+    // a pass never laps the log ring, so a DELETE_LOG record keeps the val bytes of the record it overwrites
+    // exactly as in the serial reference
+    const uint32_t cap = cfg->log_entries ? cfg->log_entries : 1000000u;
+    e->pass_max = std::min<uint32_t>(e->pass_max, cap);
+  }
   TRY(dev_alloc((void **)&e->scratch.stats, sizeof(dint_dev_stats)));
-  TRY(dev_alloc((void **)&e->scratch.blk_cnt, 256 * sizeof(uint32_t)));
   add_region(e, e->scratch.stats, sizeof(dint_dev_stats));
-  TRY(dev_alloc((void **)&e->d_stage_req, (size_t)DINT_MICRO * e->msg_size + 64, false));
-  TRY(dev_alloc((void **)&e->d_stage_rep, (size_t)DINT_MICRO * e->msg_size + 64, false));
-  if (hipHostMalloc((void **)&e->h_pinned, (size_t)DINT_MICRO * e->msg_size + 64, hipHostMallocDefault) != hipSuccess) {
+  if (is_kv) {
+    TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_KV_PMAX * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
+    TRY(dev_alloc((void **)&e->scratch.blk_cnt, 1024 * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.blk_off, 1024 * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.big, (2 + DINT_KV_PMAX) * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4), false));
+    TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
+  } else {
+    TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_PMAX * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_PMAX * DINT_MICRO * sizeof(uint64_t), false));
+    TRY(dev_alloc((void **)&e->scratch.blk_cnt, 256 * sizeof(uint32_t)));
+  }
+  TRY(dev_alloc((void **)&e->d_stage_req, (size_t)e->pass_max * e->msg_size + 64, false));
+  TRY(dev_alloc((void **)&e->d_stage_rep, (size_t)e->pass_max * e->msg_size + 64, false));
+  if (hipHostMalloc((void **)&e->h_pinned, (size_t)e->pass_max * e->msg_size + 64, hipHostMallocDefault) != hipSuccess) {
     dint_engine_destroy(e);
     return fail(DINT_ENOMEM, "hipHostMalloc");
   }
 
-  const uint32_t wl = cfg->workload;
   if (wl == DINT_WL_FASST || wl == DINT_WL_2PL) {
     e->n_slots = cfg->n_slots ? cfg->n_slots : 36000000ull;  // lock_fasst/udp/utils.h:12
     if (e->n_slots > 0xFFFFFFF0ull) { dint_engine_destroy(e); return fail(DINT_EINVAL, "n_slots too large"); }
@@ -239,11 +260,8 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     TRY(dev_alloc((void **)&e->log.tail, 2 * sizeof(uint32_t)));
     add_region(e, e->log.ring, (size_t)e->log.cap * 64);
     add_region(e, e->log.tail, 2 * sizeof(uint32_t));
-    // tatp / smallbank: a pass never laps the ring, so a DELETE_LOG record keeps the val bytes of the
-    // record it overwrites exactly as in the serial reference
-    if (wl != DINT_WL_LOG) e->pass_max = std::min<uint32_t>(DINT_MICRO, e->log.cap);
   }
-  if (wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
+  if (is_kv) {
     rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard);
     if (rc) { dint_engine_destroy(e); return fail(rc, "kv table allocation failed (%s)", g_err.c_str()); }
     e->kv.force_rounds = (cfg->flags & DINT_FLAG_KV_ROUNDS) ? 1 : 0;
@@ -265,6 +283,11 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bins);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
+  hipFree(e->scratch.blk_off);
+  hipFree(e->scratch.big);
+  hipFree(e->scratch.bin_off);
+  hipFree(e->scratch.ovl);
+  hipFree(e->scratch.ovf);
   hipFree(e->d_stage_req);
   hipFree(e->d_stage_rep);
   if (e->h_pinned) hipHostFree(e->h_pinned);
@@ -477,9 +500,9 @@ int dint_kv_trace_read(dint_engine_t *e, uint64_t *out, uint64_t cap) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  const uint64_t words = std::min<uint64_t>(cap, (uint64_t)DINT_PMAX * 16);
+  const uint64_t words = std::min<uint64_t>(cap, (uint64_t)DINT_KV_PMAX * 16);
   HIP_TRY(hipMemcpy(out, e->kv.d_trace, words * 8, hipMemcpyDeviceToHost));
-  return (int)DINT_PMAX;
+  return (int)DINT_KV_PMAX;
 }
 
 int dint_timing_enable(dint_engine_t *e, int on) {

@@ -100,134 +100,250 @@ struct kv_dev_mem {
   }
 };
 
-// ---- k_kv_prepass ------------------------------------------------------------------------------------
-template <int WL>
-__global__ void __launch_bounds__(256)
-k_kv_prepass(const uint8_t *__restrict__ req, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *__restrict__ blk_cnt,
-             uint32_t *tail) {
-  using F = Fmt<WL>;
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) tail[0] = tail[1];
-  bool is_log = false;
-  if (i < n) {
-    const uint8_t *m = req + (size_t)i * F::MSG;
-    is_log = kv_class<WL>(m[F::TYPE], 0) == 2 && m[F::TABLE] < kv->n_tables;
-  }
-  const uint32_t cnt = __syncthreads_count(is_log);
-  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = cnt;
+// ---- batch record of the kv passes: one 64-bit word per table request ------------------------------------
+//   bits 0..15            payload: type (5 bits, LOAD -> 31) | lock quadrant << 5 | 9 key-hash bits << 7
+//   bits 16..31+pbits     request index inside the pass   (n <= 2^(16+pbits); P = 2^pbits bins, ~32 records each)
+//   bits 32+pbits..63     group key >> pbits             (the low pbits bits are the bin id)
+__device__ static inline uint64_t kv_rec(uint32_t gk, uint32_t idx, uint32_t pay, uint32_t pbits) {
+  return ((uint64_t)(gk >> pbits) << (32 + pbits)) | ((uint64_t)idx << 16) | (pay & 0xFFFFu);
+}
+__device__ static inline uint32_t kv_rec_pay(uint64_t r) { return (uint32_t)r & 0xFFFFu; }
+__device__ static inline uint32_t kv_rec_idx(uint64_t r, uint32_t pbits) { return (uint32_t)(r >> 16) & ((1u << (16 + pbits)) - 1u); }
+__device__ static inline uint32_t kv_rec_gk(uint64_t r, uint32_t pbits, uint32_t bin) {
+  return ((uint32_t)(r >> (32 + pbits)) << pbits) | bin;
 }
 
-// ---- k_kv_scatter ------------------------------------------------------------------------------------
+#define KV_TB 1024u           // threads per workgroup of k_kv_count / k_kv_place (= requests per workgroup)
+#define KV_NONE 0xFFFFFFFFu
+
+// what one request is, from its wire bytes: shared by k_kv_count and k_kv_place
+struct kv_reqinfo {
+  uint32_t type, table, cls;  // cls 0 = bad, 1 = table request, 2 = log request
+  uint64_t key;
+};
 template <int WL>
-__global__ void __launch_bounds__(256)
-k_kv_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
-             const uint32_t *__restrict__ blk_cnt, uint32_t pmask, uint32_t *__restrict__ bin_cnt,
-             uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int load_mode) {
+__device__ static inline kv_reqinfo kv_read_request(const uint8_t *m, bool live, const kv_dev *kv, int load_mode) {
   using F = Fmt<WL>;
-  __shared__ uint32_t red[4];
-  __shared__ uint32_t wcnt[4];
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  kv_reqinfo r = {0, 0, 0, 0};
+  if (live) {
+    r.type = m[F::TYPE];
+    r.table = F::HAS_TABLE ? m[F::TABLE] : 0;
+    r.cls = kv_class<WL>(r.type, load_mode);
+    if (r.table >= kv->n_tables) r.cls = 0;  // the reference indexes tables[] out of bounds
+    if (r.cls) r.key = ld_u64(m + F::KEY);
+  }
+  return r;
+}
 
-  if (blockIdx.x == 0 && threadIdx.x < KV_NLISTS)  // entries freed by earlier passes become reusable
-    for (uint32_t t = 0; t < kv->n_tables; t++) kv_pool_rotate<kv_dev_mem>(kv->tab[t], threadIdx.x);
+__device__ static inline uint32_t block_hash_insert(uint32_t *keys, uint32_t k) {  // 2 * KV_TB slots, keys != KV_NONE
+  uint32_t h = (k * 0x9E3779B1u) >> (32 - 11);
+  for (;;) {
+    const uint32_t old = atomicCAS(&keys[h], KV_NONE, k);
+    if (old == KV_NONE || old == k) return h;
+    h = (h + 1) & (2 * KV_TB - 1);
+  }
+}
+static_assert(KV_TB == 1024, "block_hash_insert assumes 2048 slots");
 
-  // copy this block's messages to the reply array (replies are the request mutated in place).  All loads of a
-  // thread are issued before its first store: one memory round trip for the 256 * MSG <= 16 KiB of the block.
+// ---- k_kv_count --------------------------------------------------------------------------------------
+// One thread per request: copy the message to the reply array, classify, hash, reserve a position in the bin
+// of the request's bucket group.  The reservations of one workgroup on one bin are merged in an LDS hash first,
+// so a hot key costs one device atomic per workgroup, not one per request.  Records at positions below
+// DINT_KV_BINCAP are stored in place; the others are listed for k_kv_place.
+template <int WL>
+__global__ void __launch_bounds__(KV_TB)
+k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *tail,
+           uint32_t pbits, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
+           uint4 *__restrict__ ovl, uint32_t *__restrict__ blk_cnt, dint_dev_stats *__restrict__ stats, int load_mode) {
+  using F = Fmt<WL>;
+  __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
+  __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
+  const uint32_t t = threadIdx.x, lane = t & 63;
+  const uint32_t i = blockIdx.x * KV_TB + t;
+  if (blockIdx.x == 0 && t == 0 && tail) tail[0] = tail[1];
+  Hb[t] = KV_NONE; Hb[t + KV_TB] = KV_NONE;
+  Hc[t] = 0; Hc[t + KV_TB] = 0;
+
+  // copy this workgroup's messages to the reply array (replies are the request mutated in place).  All loads of a
+  // thread are issued before its first store: one memory round trip for the KV_TB * MSG <= 55 KiB of the workgroup.
   if (rep != req) {
-    const size_t lo = (size_t)blockIdx.x * 256u * F::MSG;
-    const size_t hi = min((size_t)n * F::MSG, lo + (size_t)256u * F::MSG);
+    const size_t lo = (size_t)blockIdx.x * KV_TB * F::MSG;
+    const size_t hi = min((size_t)n * F::MSG, lo + (size_t)KV_TB * F::MSG);
     if ((((uintptr_t)req | (uintptr_t)rep) & 15) == 0) {
-      const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 880 vectors
+      const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 3520 vectors
       const uint4 *s = (const uint4 *)(req + lo);
       uint4 *d = (uint4 *)(rep + lo);
-      // unconditional loads at clamped indices (branch-free, so the four loads stay in flight together; nv >= 1)
-      const uint32_t a0 = min(threadIdx.x, nv - 1), a1 = min(threadIdx.x + 256u, nv - 1);
-      const uint32_t a2 = min(threadIdx.x + 512u, nv - 1), a3 = min(threadIdx.x + 768u, nv - 1);
-      const uint4 v0 = s[a0], v1 = s[a1], v2 = s[a2], v3 = s[a3];
-      // ... and unconditional stores: a clamped lane rewrites vector nv-1 with the same bytes
-      d[a0] = v0; d[a1] = v1; d[a2] = v2; d[a3] = v3;
-      for (size_t k = lo + (size_t)nv * 16 + threadIdx.x; k < hi; k += 256) rep[k] = req[k];
+      if (nv) {
+        // unconditional loads at clamped indices (branch-free, so the four loads stay in flight together)
+        const uint32_t a0 = min(t, nv - 1), a1 = min(t + KV_TB, nv - 1);
+        const uint32_t a2 = min(t + 2 * KV_TB, nv - 1), a3 = min(t + 3 * KV_TB, nv - 1);
+        const uint4 v0 = s[a0], v1 = s[a1], v2 = s[a2], v3 = s[a3];
+        // ... and unconditional stores: a clamped lane rewrites vector nv-1 with the same bytes
+        d[a0] = v0; d[a1] = v1; d[a2] = v2; d[a3] = v3;
+      }
+      for (size_t k = lo + (size_t)nv * 16 + t; k < hi; k += KV_TB) rep[k] = req[k];
     } else {
-      for (size_t k = lo + threadIdx.x; k < hi; k += 256) rep[k] = req[k];
+      for (size_t k = lo + t; k < hi; k += KV_TB) rep[k] = req[k];
     }
   }
 
-  uint32_t type = 0, table = 0, cls = 0;
-  uint64_t key = 0;
-  const uint8_t *m = req + (size_t)i * F::MSG;
-  if (i < n) {
-    type = m[F::TYPE];
-    table = F::HAS_TABLE ? m[F::TABLE] : 0;
-    cls = kv_class<WL>(type, load_mode);
-    if (table >= kv->n_tables) cls = 0;  // the reference indexes tables[] out of bounds
-    if (cls) key = ld_u64(m + F::KEY);
-    else atomicAdd(&stats->bad_requests, 1ULL);
-  }
+  const kv_reqinfo r = kv_read_request<WL>(req + (size_t)i * F::MSG, i < n, kv, load_mode);
+  if (i < n && !r.cls) atomicAdd(&stats->bad_requests, 1ULL);
 
-  // ---- log requests: ring position = tail + exclusive count of log requests below i ----
-  if (WL != DINT_WL_STORE) {
-    uint32_t part = (threadIdx.x < blockIdx.x) ? blk_cnt[threadIdx.x] : 0, tot;
-    wave_excl_scan_u32(part, &tot);
-    if (lane == 0) red[wv] = tot;
-    const uint64_t lm = __ballot(cls == 2);
-    if (lane == 0) wcnt[wv] = (uint32_t)__popcll(lm);
-    __syncthreads();
-    uint32_t base = red[0] + red[1] + red[2] + red[3];
-    for (uint32_t w = 0; w < wv; w++) base += wcnt[w];
-    const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
-    if (cls == 2) {
-      const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
-      uint8_t *e = log.ring + (size_t)pos * 64;
-      const uint32_t ver = ld_u32(m + F::VER);
-      uint8_t *r = rep + (size_t)i * F::MSG;
-      if (WL == DINT_WL_TATP && type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
-        *(uint64_t *)e = key;
-        *(uint2 *)(e + 48) = make_uint2(ver, 1u | (table << 8));
-        r[F::TYPE] = 27;
-      } else {  // kCommitLog  (tatp server_shard.cc:182-194, smallbank server_shard.cc:175-186)
-        uint32_t w[16];
-        __builtin_memcpy(&w[0], &key, 8);
-#pragma unroll
-        for (uint32_t k = 0; k < F::VS / 4; k++) w[2 + k] = ld_u32(m + F::VAL + 4 * k);
-        uint4 *e4 = (uint4 *)e;
-        e4[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        if (F::VS == 40) {
-          e4[1] = make_uint4(w[4], w[5], w[6], w[7]);
-          e4[2] = make_uint4(w[8], w[9], w[10], w[11]);
-        }
-        *(uint2 *)(e + 48) = make_uint2(ver, table << 8);
-        r[F::TYPE] = (WL == DINT_WL_TATP) ? 17 : 15;
-      }
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
-      const uint32_t total = pos_in_batch + (cls == 2 ? 1u : 0u);
-      log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
-    }
-  }
-
-  // ---- table requests: record -> bin ----
-  if (cls == 1) {
-    const uint64_t h = dint_hash_key(key);
-    const uint64_t g = dint_fastmod(h, kv->mod[table]);
+  uint32_t bin = KV_NONE, gk = 0, pay = 0;
+  if (r.cls == 1) {
+    const uint64_t h = dint_hash_key(r.key);
+    const uint64_t g = dint_fastmod(h, kv->mod[r.table]);
     uint32_t local = (uint32_t)g;
+    bool mine = true;
     if (kv->shard_count > 1) {
-      if ((uint32_t)(g % kv->shard_count) != kv->shard_index) {
-        if (!load_mode) atomicAdd(&stats->foreign_requests, 1ULL);
-        return;
-      }
+      mine = (uint32_t)(g % kv->shard_count) == kv->shard_index;
+      if (!mine && !load_mode) atomicAdd(&stats->foreign_requests, 1ULL);
       local = (uint32_t)(g / kv->shard_count);
     }
-    // lock quadrant: lock_hash / hash_size, lock_hash = h % (4 * hash_size)
-    const uint64_t hs = kv->mod[table].d, dq = dint_fastmod(h, kv->lockmod[table]) - g;  // 0, hs, 2hs or 3hs
-    const uint32_t q = dq >= 2 * hs ? (dq >= 3 * hs ? 3u : 2u) : (dq >= hs ? 1u : 0u);
-    const uint32_t gk = kv->gk_base[table] + local;
-    const uint32_t bin = gk & pmask;
-    const uint32_t pos = atomicAdd(&bin_cnt[bin], 1u);
-    // record payload (16 bits): type (5 bits, LOAD -> 31) | lock quadrant << 5 | 9 key-hash bits << 7
-    // (the table is implied by the group key)
-    const uint32_t pay = kv_pay(type, q, (uint32_t)(h >> 40) & 511u);
-    bins[(size_t)bin * DINT_MICRO + pos] = dint_rec(gk, i, pay & 0xFF, pay >> 8);
+    if (mine) {
+      // lock quadrant: lock_hash / hash_size, lock_hash = h % (4 * hash_size)
+      const uint64_t hs = kv->mod[r.table].d, dq = dint_fastmod(h, kv->lockmod[r.table]) - g;  // 0, hs, 2hs or 3hs
+      const uint32_t q = dq >= 2 * hs ? (dq >= 3 * hs ? 3u : 2u) : (dq >= hs ? 1u : 0u);
+      gk = kv->gk_base[r.table] + local;
+      bin = gk & ((1u << pbits) - 1u);
+      pay = kv_pay(r.type, q, (uint32_t)(h >> 40) & 511u);  // the table is implied by the group key
+    }
+  }
+  __syncthreads();
+  uint32_t e = 0, mypos = 0;
+  if (bin != KV_NONE) {
+    e = block_hash_insert(Hb, bin);
+    mypos = atomicAdd(&Hc[e], 1u);
+  }
+  const uint32_t nlog = __syncthreads_count(r.cls == 2);
+  if (t == 0 && blk_cnt) blk_cnt[blockIdx.x] = nlog;
+#pragma unroll
+  for (uint32_t k = 0; k < 2; k++) {
+    const uint32_t sl = t + k * KV_TB;
+    if (Hb[sl] != KV_NONE) Hc[sl] = atomicAdd(&bin_cnt[Hb[sl]], Hc[sl]);
+  }
+  __syncthreads();
+  if (bin != KV_NONE) mypos += Hc[e];
+  const uint64_t rec = kv_rec(gk, i, pay, pbits);
+  const bool over = bin != KV_NONE && mypos >= DINT_KV_BINCAP;
+  if (bin != KV_NONE && !over) bins[(size_t)bin * DINT_KV_BINCAP + mypos] = rec;
+  const uint64_t om = __ballot(over);
+  if (om) {  // one reservation in the overflow list per wave
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((unsigned long long)om) - 1)) base = atomicAdd(&big[1], (uint32_t)__popcll(om));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((unsigned long long)om) - 1);
+    if (over) ovl[base + (uint32_t)__popcll(om & lanemask_lt())] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
+  }
+}
+
+// ---- k_kv_scan: one workgroup ---------------------------------------------------------------------------
+// Bins with more than DINT_KV_BINCAP records: list them and give each a range of the overflow area; exclusive scan
+// of the per-workgroup log counts and the new ring tail; rotate the pools' free lists.
+__device__ static inline uint32_t block_excl_scan_1024(uint32_t v, uint32_t *Sw, uint32_t *total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t tot, x = wave_excl_scan_u32(v, &tot);
+  __syncthreads();  // Sw may still be read by a previous scan
+  if (lane == 0) Sw[wave] = tot;
+  __syncthreads();
+  uint32_t all = 0;
+  for (uint32_t w = 0; w < 16; w++) {
+    const uint32_t s = Sw[w];
+    if (w < wave) x += s;
+    all += s;
+  }
+  *total = all;
+  return x;
+}
+
+__global__ void __launch_bounds__(1024)
+k_kv_scan(uint32_t P, uint32_t nb, const kv_dev *__restrict__ kv, const uint32_t *__restrict__ bin_cnt,
+          uint32_t *__restrict__ bin_off, uint32_t *__restrict__ big, const uint32_t *__restrict__ blk_cnt,
+          uint32_t *__restrict__ blk_off, uint32_t *tail, uint32_t log_cap) {
+  __shared__ uint32_t Sw[16];
+  const uint32_t t = threadIdx.x;
+  if (t < KV_NLISTS)  // entries freed by earlier passes become reusable
+    for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t);
+  // thread t owns bins t, t + 1024, ... (coalesced, all loads in flight at once)
+  uint32_t c[DINT_KV_PMAX / 1024];
+  uint32_t extra = 0, nbig = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < DINT_KV_PMAX / 1024; j++) {
+    const uint32_t b = t + 1024u * j;
+    c[j] = b < P ? bin_cnt[b] : 0;
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < DINT_KV_PMAX / 1024; j++)
+    if (c[j] > DINT_KV_BINCAP) { extra += c[j] - DINT_KV_BINCAP; nbig++; }
+  uint32_t tot_extra, tot_big;
+  uint32_t off = block_excl_scan_1024(extra, Sw, &tot_extra);
+  uint32_t at = block_excl_scan_1024(nbig, Sw, &tot_big);
+#pragma unroll
+  for (uint32_t j = 0; j < DINT_KV_PMAX / 1024; j++)
+    if (c[j] > DINT_KV_BINCAP) {
+      const uint32_t b = t + 1024u * j;
+      bin_off[b] = off;
+      off += c[j] - DINT_KV_BINCAP;
+      big[2 + at++] = b;
+    }
+  if (t == 0) big[0] = tot_big;
+  if (blk_cnt) {  // log ring: position of request i = tail + (log requests below i)
+    uint32_t total;
+    const uint32_t mine = t < nb ? blk_cnt[t] : 0;
+    const uint32_t x = block_excl_scan_1024(mine, Sw, &total);
+    if (t < nb) blk_off[t] = x;
+    if (t == 0) tail[1] = (uint32_t)(((uint64_t)tail[0] + total) % log_cap);
+  }
+}
+
+// ---- k_kv_place ----------------------------------------------------------------------------------------
+// Log requests: the canonical 64-byte record at ring position tail + (#log requests below i) [deterministic: an
+// exclusive scan, not an atomic].  Overflow records: into their bin's range of the overflow area.
+template <int WL>
+__global__ void __launch_bounds__(KV_TB)
+k_kv_place(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
+           const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+           const uint4 *__restrict__ ovl, uint64_t *__restrict__ ovf, int load_mode) {
+  using F = Fmt<WL>;
+  __shared__ uint32_t wcnt[KV_TB / 64];
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t i = blockIdx.x * KV_TB + t;
+  if (i < big[1]) {
+    const uint4 o = ovl[i];
+    ovf[bin_off[o.z] + o.w - DINT_KV_BINCAP] = ((uint64_t)o.y << 32) | o.x;
+  }
+  if (WL == DINT_WL_STORE) return;
+  const uint8_t *m = req + (size_t)i * F::MSG;
+  const kv_reqinfo r = kv_read_request<WL>(m, i < n, kv, load_mode);
+  const uint64_t lm = __ballot(r.cls == 2);
+  if (lane == 0) wcnt[wv] = (uint32_t)__popcll(lm);
+  __syncthreads();
+  uint32_t base = blk_off[blockIdx.x];
+  for (uint32_t w = 0; w < wv; w++) base += wcnt[w];
+  if (r.cls == 2) {
+    const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
+    const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
+    uint8_t *e = log.ring + (size_t)pos * 64;
+    const uint32_t ver = ld_u32(m + F::VER);
+    uint8_t *rp = rep + (size_t)i * F::MSG;
+    if (WL == DINT_WL_TATP && r.type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
+      *(uint64_t *)e = r.key;
+      *(uint2 *)(e + 48) = make_uint2(ver, 1u | (r.table << 8));
+      rp[F::TYPE] = 27;
+    } else {  // kCommitLog  (tatp server_shard.cc:182-194, smallbank server_shard.cc:175-186)
+      uint32_t w[16];
+      __builtin_memcpy(&w[0], &r.key, 8);
+#pragma unroll
+      for (uint32_t k = 0; k < F::VS / 4; k++) w[2 + k] = ld_u32(m + F::VAL + 4 * k);
+      uint4 *e4 = (uint4 *)e;
+      e4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      if (F::VS == 40) {
+        e4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        e4[2] = make_uint4(w[8], w[9], w[10], w[11]);
+      }
+      *(uint2 *)(e + 48) = make_uint2(ver, r.table << 8);
+      rp[F::TYPE] = (WL == DINT_WL_TATP) ? 17 : 15;
+    }
   }
 }
 
@@ -649,39 +765,42 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 // ---- k_kv_resolve: bins of <= 64 records, one wave each ---------------------------------------------------
 template <int WL>
 __global__ void __launch_bounds__(64)
-k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int kv_force_rounds,
-             uint64_t *trace) {
+k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, uint32_t *__restrict__ big, dint_dev_stats *__restrict__ stats,
+             int kv_force_rounds, uint64_t *trace) {
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   const uint32_t bin = blockIdx.x, lane = threadIdx.x;
+  if (bin == 0 && lane == 0) big[1] = 0;  // k_kv_place (an earlier launch) is done with the overflow list
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
   kv_stamp_real(tr, 10);
   kv_stamp(tr, 0);
-  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
-  const uint64_t r0 = recs[lane];  // speculative (the bin region always exists): overlaps the counter load
+  const uint64_t r0 = bins[(size_t)bin * DINT_KV_BINCAP + lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
   if (tr && lane == 0 && c) { tr[15] = c; tr[14] = 0; }
-  if (c == 0 || c > 64) return;    // larger bins belong to k_kv_resolve_big
+  if (c == 0 || c > DINT_KV_BINCAP) return;  // larger bins belong to k_kv_resolve_big
   if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
   for (uint32_t k = lane; k < sizeof(kv_dev) / 4; k += 64) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
   const kv_dev *kv = &Skv;
   kv_stamp(tr, 1);
-  // Sort the records by (bucket group, idx) in registers: groups commute, so any order that keeps each group's
-  // requests in idx order is serial-equivalent, and after the sort the requests of a group sit in adjacent
-  // lanes -- no LDS, no rank bitmap, no hash.
+  // Sort the records by (bucket group, key hash, idx) in registers: groups commute, so any order that keeps each
+  // group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in adjacent
+  // lanes -- no LDS, no rank bitmap, no hash.  Key: group >> pbits | 9 key-hash bits | idx (16 + pbits bits) | 7
+  // payload bits = 64 bits for every pbits.
   uint64_t w = ~0ull;  // empty lanes sort last
   if (lane < c) {
-    const uint32_t pay = rec_op(r0) | (rec_aux(r0) << 8);
-    w = ((uint64_t)rec_gk(r0) << 32) | ((uint64_t)pay_kh(pay) << 23) | ((uint64_t)rec_idx(r0) << 7) | (pay & 0x7Fu);
+    const uint32_t pay = kv_rec_pay(r0);
+    w = ((r0 >> (32 + pbits)) << (32 + pbits)) | ((uint64_t)pay_kh(pay) << (23 + pbits)) |
+        ((uint64_t)kv_rec_idx(r0, pbits) << 7) | (pay & 0x7Fu);
   }
   kv_stamp(tr, 2);
   w = wave_sort_u64(w);
   kv_stamp(tr, 3);
   const bool valid = lane < c;
-  const uint32_t gk = (uint32_t)(w >> 32), kh = (uint32_t)(w >> 23) & 511u, idx = (uint32_t)(w >> 7) & 0xFFFF;
+  const uint32_t gk = ((uint32_t)(w >> (32 + pbits)) << pbits) | bin, kh = (uint32_t)(w >> (23 + pbits)) & 511u;
+  const uint32_t idx = (uint32_t)(w >> 7) & ((1u << (16 + pbits)) - 1u);
   const uint32_t pay = (uint32_t)w & 0x7Fu;
-  kv_chunk<WL>(rep, valid, idx, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), kv, stats,
+  kv_chunk<WL>(rep, valid, valid ? idx : 0, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), kv, stats,
                kv_force_rounds, true, tr);
   kv_stamp(tr, 9);
   kv_stamp_real(tr, 11);
@@ -698,6 +817,8 @@ k_kv_resolve(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t
 //   the running state carried through LDS.  Segments with several keys / inserts / deletes run in rounds.
 #define KVB_T 512u
 #define KVB_W (KVB_T / 64u)
+#define KVB_GRID 128u  // workgroups of k_kv_resolve_big; each walks its share of the big-bin list
+#define KVB_NBK 8192u  // idx buckets that define the windows of a bin with more than KVB_T records
 struct kvb_lead { uint32_t found_link, slot, ver0, la0, lb0; };   // found_link: found << 31 | link
 struct kvb_carry { uint32_t la, lb, ver; int src; uint32_t miss; };
 
@@ -733,88 +854,111 @@ __device__ static inline bool kvb_bit(const uint64_t *M, uint32_t p) { return (M
 
 template <int WL>
 __global__ void __launch_bounds__(KVB_T)
-k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-                 const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int force_rounds,
-                 uint64_t *trace) {
+k_kv_resolve_big(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g,
+                 uint32_t *__restrict__ bin_cnt, const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big,
+                 const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
+                 dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace) {
   using F = Fmt<WL>;
-  __shared__ uint32_t Rbm[DINT_MICRO / 32];   // one bit per request of the pass: present in this bin
-  __shared__ uint16_t Rwpre[DINT_MICRO / 32]; // marked bits before each word, within its thread's span
-  __shared__ uint32_t Rbase[KVB_T];           // marked bits before each thread's span of words
-  __shared__ uint32_t Srec[KVB_T];            // window, request order: idx | hash entry << 16
-  __shared__ uint16_t Sop[KVB_T];             // kv_pay descriptor: type | table | quadrant | key-hash bits
+  __shared__ uint32_t Bcnt[KVB_NBK / 4];      // records per idx bucket, one byte each (a bucket spans <= 128 requests)
+  __shared__ uint16_t Bwin[KVB_NBK];          // window each idx bucket belongs to
+  __shared__ uint32_t Srec[KVB_T];            // window, as gathered: idx | hash entry << 20
+  __shared__ uint16_t Sop[KVB_T];             // kv_pay descriptor: type | quadrant | key-hash bits
   __shared__ uint64_t Skey[KVB_T];
   __shared__ uint32_t Hk[DINT_HSIZE];
-  __shared__ uint32_t Ssort[KVB_T];
-  __shared__ uint16_t Sp[KVB_T];              // sorted position -> window position
+  __shared__ uint64_t Ssort[KVB_T];
+  __shared__ uint16_t Sp[KVB_T];              // sorted position -> gather position
   __shared__ uint32_t Slast[KVB_W];           // hash entry of each wave's last lane
   __shared__ uint64_t Mhead[KVB_W], Mbh[KVB_W], Mbad[KVB_W], Mlop[KVB_W], Mlkseg[4][KVB_W], Mst[KVB_W], Mstseg[KVB_W], Mbail[KVB_W], Mwr[KVB_W], Mlk[KVB_W], Macq[KVB_W];
   __shared__ kvb_lead Lead[KVB_T];
   __shared__ kvb_carry Carry[KVB_T];
   __shared__ kv_rowst Crow[KVB_T];            // row machine of key segments with an INSERT / DELETE (store / tatp)
-  __shared__ uint32_t Sany;
+  __shared__ uint32_t Sany, Swn;
   __shared__ uint32_t Sred[KVB_W];
   __shared__ kv_dev Skv;
-  const uint32_t bin = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // k_kv_scan listed the bins with more than DINT_KV_BINCAP records; workgroup b takes entries b, b + grid, ...
+  const uint32_t nbig = big[0];
+  // idx buckets for the windows of a bin with more than KVB_T records: 2^bs requests per bucket, <= KVB_NBK buckets
+  const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 13 ? nbits - 13 : 0u;
+  const uint32_t wcap = KVB_T - (1u << bs);  // a window = the buckets whose exclusive record count / wcap is equal
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+  const uint32_t bin = big[2 + bi];
+  __syncthreads();  // the previous bin's LDS is free
   const uint32_t c = bin_cnt[bin];
-  if (c <= 64) return;  // block-uniform: small bins belong to k_kv_resolve
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;  // [8] start, [9] end (10 ns), [12] rounds, [13] windows, [14] c
   if (tr && t == 0) { tr[8] = __builtin_amdgcn_s_memrealtime(); tr[14] = c; tr[12] = 0; tr[13] = 0; }
-  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
+  const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
+  const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;  // records DINT_KV_BINCAP.. of the bin
+  auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
   for (uint32_t k = t; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   const kv_dev *kv = &Skv;
 
-  // ---- request-order rank of every record of the bin (as dint_rank_lds, built by 512 threads)
-  const uint32_t nwords = (n + 31) >> 5, wpt = (nwords + KVB_T - 1) / KVB_T;  // words per thread
-  for (uint32_t w = t; w < nwords; w += KVB_T) Rbm[w] = 0;
-  __syncthreads();
-  if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
-  for (uint32_t k = t; k < c; k += KVB_T) {
-    const uint32_t idx = rec_idx(recs[k]);
-    atomicOr(&Rbm[idx >> 5], 1u << (idx & 31));
-  }
-  __syncthreads();
-  {
-    uint32_t run = 0;
-    for (uint32_t j = 0; j < wpt; j++) {
-      const uint32_t w = t * wpt + j;
-      if (w < nwords) { Rwpre[w] = (uint16_t)run; run += __popc(Rbm[w]); }
+  // ---- windows: runs of consecutive idx buckets holding < KVB_T records, so that every request of a window comes
+  // before every request of the next one in request order
+  uint32_t nwin = 1;
+  if (c > KVB_T) {
+    for (uint32_t w = t; w < KVB_NBK / 4; w += KVB_T) Bcnt[w] = 0;
+    __syncthreads();
+    for (uint32_t k = t; k < c; k += KVB_T) {
+      const uint32_t b = kv_rec_idx(rec_at(k), pbits) >> bs;
+      atomicAdd(&Bcnt[b >> 2], 1u << (8 * (b & 3)));
+    }
+    __syncthreads();
+    uint32_t cw[4], run = 0;  // thread t owns buckets 16t .. 16t+15
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+      cw[j] = Bcnt[4 * t + j];
+      run += (cw[j] & 0xFF) + ((cw[j] >> 8) & 0xFF) + ((cw[j] >> 16) & 0xFF) + (cw[j] >> 24);
     }
     uint32_t tot, base = wave_excl_scan_u32(run, &tot);
     if (lane == 0) Sred[wave] = tot;
     __syncthreads();
     for (uint32_t w = 0; w < wave; w++) base += Sred[w];
-    Rbase[t] = base;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+      Bwin[16 * t + j] = (uint16_t)(base / wcap);
+      base += (cw[j >> 2] >> (8 * (j & 3))) & 0xFF;
+    }
+    nwin = (c - 1) / wcap + 1;  // upper bound: the last one may be empty
+    __syncthreads();
   }
   __syncthreads();
-  auto rank_of_idx = [&](uint32_t idx) -> uint32_t {
-    const uint32_t w = idx >> 5;
-    return Rbase[w / wpt] + Rwpre[w] + __popc(Rbm[w] & ((1u << (idx & 31)) - 1u));
-  };
+  if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
 
-  for (uint32_t lo = 0; lo < c; lo += KVB_T) {
-    const uint32_t wn = min(KVB_T, c - lo);
+  for (uint32_t win = 0; win < nwin; win++) {
     for (uint32_t h = t; h < DINT_HSIZE; h += KVB_T) Hk[h] = DINT_EMPTY;
+    if (t == 0) Swn = 0;
     __syncthreads();
-    // ---- gather the window in request order; group by bucket; fetch the keys
+    // ---- gather the window (any order); group by bucket; fetch the keys
     for (uint32_t k = t; k < c; k += KVB_T) {
-      const uint64_t r = recs[k];
-      const uint32_t rk = rank_of_idx(rec_idx(r)) - lo;
-      if (rk < wn) {
+      const uint64_t r = rec_at(k);
+      const uint32_t idx = kv_rec_idx(r, pbits);
+      if (c <= KVB_T || Bwin[idx >> bs] == win) {
         bool nw;
-        const uint32_t e = lds_hash_insert(Hk, rec_gk(r), &nw);
-        Srec[rk] = rec_idx(r) | (e << 16);
-        Sop[rk] = (uint16_t)(rec_op(r) | (rec_aux(r) << 8));  // kv_pay descriptor
-        Skey[rk] = ld_u64(rep + (size_t)rec_idx(r) * F::MSG + F::KEY);
+        const uint32_t at = atomicAdd(&Swn, 1u);
+        const uint32_t e = lds_hash_insert(Hk, kv_rec_gk(r, pbits, bin), &nw);
+        Srec[at] = idx | (e << 20);
+        Sop[at] = (uint16_t)kv_rec_pay(r);
+        Skey[at] = ld_u64(rep + (size_t)idx * F::MSG + F::KEY);
       }
     }
     __syncthreads();
-    // ---- sort the window by (hash entry, key-hash bits, window position): 512-wide bitonic network
-    uint32_t v = t < wn ? (((Srec[t] >> 16) & (DINT_HSIZE - 1)) << 18) | (pay_kh(Sop[t]) << 9) | t : 0xFFFFFFFFu;
+    const uint32_t wn = Swn;
+    __syncthreads();  // Swn is reset at the top of the next window
+    if (wn == 0) continue;  // workgroup-uniform
+    // ---- sort the window by (hash entry, key-hash bits, idx): 512-wide bitonic network; the low 9 bits carry the
+    // gather position
+    uint64_t v = ~0ull;
+    if (t < wn) {
+      const uint32_t sr = Srec[t];
+      v = ((uint64_t)(sr >> 20) << 38) | ((uint64_t)pay_kh(Sop[t]) << 29) | ((uint64_t)(sr & 0xFFFFFu) << 9) | t;
+    }
     for (uint32_t k = 2; k <= KVB_T; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        uint32_t o;
+        uint64_t o;
         if (j < 64) {
-          o = __shfl_xor(v, (int)j, 64);
+          const uint32_t lo = __shfl_xor((uint32_t)v, (int)j, 64), hi = __shfl_xor((uint32_t)(v >> 32), (int)j, 64);
+          o = ((uint64_t)hi << 32) | lo;
         } else {
           Ssort[t] = v;
           __syncthreads();
@@ -822,16 +966,16 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
           __syncthreads();
         }
         const bool up = (t & k) == 0, low = (t & j) == 0;
-        v = (low == up) ? min(v, o) : max(v, o);
+        v = (low == up) ? (v < o ? v : o) : (v < o ? o : v);
       }
     }
-    const bool valid = v != 0xFFFFFFFFu;
-    const uint32_t p = v & 511u, ek = valid ? (v >> 9) : 0xFFFFFFu;  // ek = hash entry << 9 | key-hash bits
+    const bool valid = v != ~0ull;
+    const uint32_t p = (uint32_t)v & 511u, ek = valid ? (uint32_t)(v >> 29) : 0xFFFFFFu;  // ek = hash entry << 9 | key-hash bits
     const uint32_t e = ek >> 9;
     Sp[t] = (uint16_t)p;
-    const uint32_t sr = valid ? Srec[p] : 0, so = valid ? Sop[p] : 0;
+    const uint32_t so = valid ? Sop[p] : 0;
     const uint32_t gk = valid ? Hk[e] : 0;
-    const uint32_t idx = sr & 0xFFFF, type = pay_type(so), table = valid ? kv_table_of(kv, gk) : 0, q = pay_q(so);
+    const uint32_t idx = valid ? (uint32_t)(v >> 9) & 0xFFFFFu : 0, type = pay_type(so), table = valid ? kv_table_of(kv, gk) : 0, q = pay_q(so);
     const uint64_t key = valid ? Skey[p] : 0;
     const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
     uint8_t *msg = rep + (size_t)idx * F::MSG;
@@ -1046,7 +1190,7 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     if (simple) {
       row = kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS;
       if (my_get) {
-        const uint8_t *from = my_src >= 0 ? rep + (size_t)(Srec[Sp[my_src]] & 0xFFFF) * F::MSG + F::VAL : row;
+        const uint8_t *from = my_src >= 0 ? rep + (size_t)(Srec[Sp[my_src]] & 0xFFFFFu) * F::MSG + F::VAL : row;
         kv_copy_words(msg + F::VAL, from, F::VS);
         st_u32(msg + F::VER, my_ver);
       }
@@ -1056,7 +1200,7 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     __syncthreads();  // every table read of the window precedes the write-backs
     if (leader) {
       const uint32_t found0 = found & 1u, exists1 = (WL != DINT_WL_SMALLBANK && structural) ? (found >> 1) & 1u : found0;
-      const uint8_t *fin_val = fin_src >= 0 ? rep + (size_t)(Srec[Sp[fin_src]] & 0xFFFF) * F::MSG + F::VAL : nullptr;
+      const uint8_t *fin_val = fin_src >= 0 ? rep + (size_t)(Srec[Sp[fin_src]] & 0xFFFFFu) * F::MSG + F::VAL : nullptr;
       if (found0 && exists1) {          // the row stays where it is: value / version of the last writer
         if (fin_src >= 0) {
           kv_copy_words(row, fin_val, F::VS);
@@ -1076,7 +1220,7 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     const bool rounds = valid && !simple;
     uint32_t pos = 0;
     if (rounds)
-      for (uint32_t m = bk_a; m < bk_b; m++) pos += Sp[m] < p;
+      for (uint32_t m = bk_a; m < bk_b; m++) pos += (Srec[Sp[m]] & 0xFFFFFu) < idx;
     uint32_t mylen = rounds && bhead ? bk_b - bk_a : 0, tot;
     {  // longest non-simple run (block max)
       uint32_t m = mylen;
@@ -1096,31 +1240,40 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv_g, uint
     __syncthreads();  // the next window sees this window's stores; LDS arrays are free again
   }
   if (tr && t == 0) tr[9] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
 template <int WL>
 static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
                       int load_mode, hipStream_t st, hipEvent_t *ev) {
-  const uint32_t P = dint_pick_bins(n);
-  const uint32_t nb = (n + 255) / 256;
+  const uint32_t P = dint_pick_bins_kv(n);
+  uint32_t pbits = 0;
+  while ((1u << pbits) < P) pbits++;
+  const uint32_t nb = (n + KV_TB - 1) / KV_TB;  // <= 1024 for n <= DINT_KV_PASS
+  const bool has_log = WL != DINT_WL_STORE;
   if (ev) hipEventRecord(ev[0], st);
-  if (WL != DINT_WL_STORE)
-    hipLaunchKernelGGL((k_kv_prepass<WL>), dim3(nb), dim3(256), 0, st, (const uint8_t *)d_req, n, kv.d_dev, s.blk_cnt,
-                       log.tail);
+  hipLaunchKernelGGL((k_kv_count<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
+                     has_log ? log.tail : nullptr, pbits, s.bin_cnt, s.bins, s.big, s.ovl, has_log ? s.blk_cnt : nullptr,
+                     s.stats, load_mode);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL((k_kv_scatter<WL>), dim3(nb), dim3(256), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n,
-                     kv.d_dev, log, (const uint32_t *)s.blk_cnt, P - 1, s.bin_cnt, s.bins, s.stats, load_mode);
+  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(1024), 0, st, P, nb, kv.d_dev, (const uint32_t *)s.bin_cnt, s.bin_off, s.big,
+                     has_log ? (const uint32_t *)s.blk_cnt : nullptr, s.blk_off, log.tail, log.cap);
   if (ev) hipEventRecord(ev[2], st);
-  // The two resolve kernels own disjoint bins (<= 64 records / more).  They run back to back on the pass's stream:
-  // forking the big-bin kernel to a side stream and joining it (measured, r01) costs more in cross-stream event
-  // latency (~10 us per pass) than the overlap saves.
-  hipLaunchKernelGGL((k_kv_resolve_big<WL>), dim3(P), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
-                     (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace);
+  hipLaunchKernelGGL((k_kv_place<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
+                     log, (const uint32_t *)s.blk_off, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+                     (const uint4 *)s.ovl, s.ovf, load_mode);
   if (ev) hipEventRecord(ev[3], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, kv.d_dev, s.bin_cnt,
-                     (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace);
+  // The two resolve kernels own disjoint bins (<= DINT_KV_BINCAP records / more).  They run back to back on the
+  // pass's stream: forking the big-bin kernel to a side stream and joining it (measured, r01) costs more in
+  // cross-stream event latency (~10 us per pass) than the overlap saves.
+  hipLaunchKernelGGL((k_kv_resolve_big<WL>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits, kv.d_dev,
+                     s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+                     (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace);
   if (ev) hipEventRecord(ev[4], st);
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, pbits, kv.d_dev, s.bin_cnt,
+                     (const uint64_t *)s.bins, s.big, s.stats, kv.force_rounds, kv.d_trace);
+  if (ev) hipEventRecord(ev[5], st);
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
@@ -1207,8 +1360,8 @@ int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard s
     gk += tb.n_local;
   }
   if (getenv("DINT_KV_TRACE")) {
-    if (hipMalloc((void **)&kv->d_trace, (size_t)DINT_PMAX * 16 * 8) != hipSuccess) return DINT_ENOMEM;
-    hipMemset(kv->d_trace, 0, (size_t)DINT_PMAX * 16 * 8);
+    if (hipMalloc((void **)&kv->d_trace, (size_t)DINT_KV_PMAX * 16 * 8) != hipSuccess) return DINT_ENOMEM;
+    hipMemset(kv->d_trace, 0, (size_t)DINT_KV_PMAX * 16 * 8);
   }
   if (hipMalloc((void **)&kv->d_dev, sizeof(kv_dev)) != hipSuccess) return DINT_ENOMEM;
   if (hipMemcpy(kv->d_dev, &kv->h, sizeof(kv_dev), hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;

@@ -25,13 +25,14 @@ def _ptr(x):
 
 class Engine:
     def __init__(self, workload: Workload, *, n_slots: int = 0, n_rows: int = 0, log_entries: int = 0,
-                 device: int = -1, shard_index: int = 0, shard_count: int = 1, flags: int = 0):
+                 device: int = -1, shard_index: int = 0, shard_count: int = 1, flags: int = 0, max_pass: int = 0):
         self._L = _lib.load()
         self.workload = Workload(workload)
         self.msg_dtype = MSG_DTYPE[self.workload]
         self.msg_size = self.msg_dtype.itemsize
         cfg = _lib.Config(abi_version=_lib.ABI_VERSION, workload=int(workload), device=device, flags=flags, n_slots=n_slots,
-                          n_rows=n_rows, log_entries=log_entries, shard_index=shard_index, shard_count=shard_count)
+                          n_rows=n_rows, log_entries=log_entries, shard_index=shard_index, shard_count=shard_count,
+                          max_pass=max_pass)
         h = C.c_void_p()
         _lib.check(self._L.dint_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -90,7 +90,10 @@ typedef struct dint_config {
    * shard_count 0 or 1 = unsharded. */
   uint32_t shard_index;
   uint32_t shard_count;
-  uint32_t reserved[5];
+  /* requests per kernel pass; longer submissions run as several passes.  0 = the engine's maximum
+   * (FASST / 2PL / LOG 65,536; STORE / TATP / SMALLBANK 1,048,576, and never more than log_entries). */
+  uint32_t max_pass;
+  uint32_t reserved[4];
 } dint_config;
 
 typedef struct dint_stats {

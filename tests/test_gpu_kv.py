@@ -367,3 +367,61 @@ def test_store_baseline_config_16m_keys_95_5():
     a, b = eng.dump_rows(0), o.dump()
     assert len(a[0]) == 12 * n_sub and _same_rows(a, b)
     assert eng.stats()["pool_exhausted"] == 0
+
+
+# ---------------------------------------------------------------- pass size
+@pytest.mark.parametrize("max_pass", [0, 65536, 5000, 777])
+def test_pass_size_does_not_change_the_answer(max_pass):
+    """One submission = ceil(n / max_pass) kernel passes; the reply stream, rows, locks and log are those of the
+    serial reference whatever the split (0 = the engine's largest pass, 2^20 requests)."""
+    o = orc.TatpOracle(50_000, populate_n=700)
+    req = tracegen.tatp_random(180_000, [o.dump(t)[0] for t in range(5)], seed=51, n_sub_touch=700)
+    eng = _engine(W.TATP, n_rows=50_000, max_pass=max_pass)
+    eng.populate(700)
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+    _tatp_locks(eng, o)
+    ring, tail = eng.read_log(1_000_000)
+    assert tail == o.tail and (np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64)[:tail] == o.ring[:tail]).all()
+    assert eng.stats()["batches"] == -(-180_000 // (max_pass or (1 << 20)))
+
+    req = tracegen.sb_random(150_000, seed=52, n_acct_touch=300)
+    eng = _engine(W.SMALLBANK, n_rows=100_000, max_pass=max_pass)
+    eng.populate(300)
+    o = orc.SmallbankOracle(100_000, populate_n=300)
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    _sb_state(eng, o)
+
+
+@pytest.mark.parametrize("wl,n,touch", [("store", 1_000_000, 20_000), ("store", 400_000, 1), ("tatp", 1_000_000, 30_000),
+                                        ("tatp", 300_000, 2), ("smallbank", 1_000_000, 40_000), ("smallbank", 250_000, 1)])
+def test_one_pass_of_up_to_a_million_requests(wl, n, touch):
+    """The largest passes (20-bit request index, 32768 bins), spread wide and piled on one or two hot keys (bins of
+    10^5 records: hundreds of 512-request windows cut along request-index buckets)."""
+    if wl == "store":
+        req = tracegen.store_random(n, seed=n + touch, n_sub_touch=touch, p_set=0.4, p_insert=0.02)
+        eng = _engine(W.STORE, n_rows=100_000)
+        eng.populate(min(2 * touch, 100_000))
+        o = orc.StoreOracle(100_000 * 18 // 4, min(2 * touch, 100_000))
+        assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+        assert _same_rows(eng.dump_rows(0), o.dump())
+    elif wl == "tatp":
+        o = orc.TatpOracle(100_000, populate_n=touch)
+        req = tracegen.tatp_random(n, [o.dump(t)[0] for t in range(5)], seed=n + touch, n_sub_touch=touch)
+        eng = _engine(W.TATP, n_rows=100_000)
+        eng.populate(touch)
+        assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+        for t in range(5):
+            assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+        _tatp_locks(eng, o)
+        ring, tail = eng.read_log(1_000_000)
+        assert tail == o.tail and (np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64) == o.ring).all()
+    else:
+        req = tracegen.sb_random(n, seed=n + touch, n_acct_touch=touch)
+        eng = _engine(W.SMALLBANK, n_rows=1_000_000)
+        eng.populate(touch)
+        o = orc.SmallbankOracle(1_000_000, populate_n=touch)
+        assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+        _sb_state(eng, o)
+    assert eng.stats()["batches"] == 1 and eng.stats()["pool_exhausted"] == 0
