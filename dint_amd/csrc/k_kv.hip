@@ -158,9 +158,12 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
   using F = Fmt<WL>;
   __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
   __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
+  __shared__ uint32_t Sov[2];         // overflow records of the workgroup; their place in the pass's list
   const uint32_t t = threadIdx.x, lane = t & 63;
   const uint32_t i = blockIdx.x * KV_TB + t;
   if (blockIdx.x == 0 && t == 0 && tail) tail[0] = tail[1];
+  if (blockIdx.x == 0 && t < KV_NLISTS)  // entries freed by earlier passes become reusable
+    for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t);
   Hb[t] = KV_NONE; Hb[t + KV_TB] = KV_NONE;
   Hc[t] = 0; Hc[t + KV_TB] = 0;
 
@@ -218,81 +221,51 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
   }
   const uint32_t nlog = __syncthreads_count(r.cls == 2);
   if (t == 0 && blk_cnt) blk_cnt[blockIdx.x] = nlog;
+  if (t == 0) Sov[0] = 0;
 #pragma unroll
   for (uint32_t k = 0; k < 2; k++) {
     const uint32_t sl = t + k * KV_TB;
-    if (Hb[sl] != KV_NONE) Hc[sl] = atomicAdd(&bin_cnt[Hb[sl]], Hc[sl]);
+    if (Hb[sl] != KV_NONE) {
+      const uint32_t cnt = Hc[sl], base = atomicAdd(&bin_cnt[Hb[sl]], cnt);
+      Hc[sl] = base;
+      // the workgroup whose records cross position DINT_KV_BINCAP lists the bin for k_kv_resolve_big
+      if (base <= DINT_KV_BINCAP && base + cnt > DINT_KV_BINCAP) big[2 + atomicAdd(&big[0], 1u)] = Hb[sl];
+    }
   }
   __syncthreads();
   if (bin != KV_NONE) mypos += Hc[e];
   const uint64_t rec = kv_rec(gk, i, pay, pbits);
   const bool over = bin != KV_NONE && mypos >= DINT_KV_BINCAP;
   if (bin != KV_NONE && !over) bins[(size_t)bin * DINT_KV_BINCAP + mypos] = rec;
-  const uint64_t om = __ballot(over);
-  if (om) {  // one reservation in the overflow list per wave
-    uint32_t base = 0;
-    if (lane == (uint32_t)(__ffsll((unsigned long long)om) - 1)) base = atomicAdd(&big[1], (uint32_t)__popcll(om));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((unsigned long long)om) - 1);
-    if (over) ovl[base + (uint32_t)__popcll(om & lanemask_lt())] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
+  // overflow records: one reservation in the pass's list per workgroup
+  uint32_t orank = 0;
+  if (over) orank = atomicAdd(&Sov[0], 1u);
+  __syncthreads();
+  if (Sov[0]) {  // workgroup-uniform
+    if (t == 0) Sov[1] = atomicAdd(&big[1], Sov[0]);
+    __syncthreads();
+    if (over) ovl[Sov[1] + orank] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
   }
 }
 
 // ---- k_kv_scan: one workgroup ---------------------------------------------------------------------------
-// Bins with more than DINT_KV_BINCAP records: list them and give each a range of the overflow area; exclusive scan
-// of the per-workgroup log counts and the new ring tail; rotate the pools' free lists.
-__device__ static inline uint32_t block_excl_scan_1024(uint32_t v, uint32_t *Sw, uint32_t *total) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t tot, x = wave_excl_scan_u32(v, &tot);
-  __syncthreads();  // Sw may still be read by a previous scan
-  if (lane == 0) Sw[wave] = tot;
-  __syncthreads();
-  uint32_t all = 0;
-  for (uint32_t w = 0; w < 16; w++) {
-    const uint32_t s = Sw[w];
-    if (w < wave) x += s;
-    all += s;
-  }
-  *total = all;
-  return x;
-}
-
-__global__ void __launch_bounds__(1024)
-k_kv_scan(uint32_t P, uint32_t nb, const kv_dev *__restrict__ kv, const uint32_t *__restrict__ bin_cnt,
-          uint32_t *__restrict__ bin_off, uint32_t *__restrict__ big, const uint32_t *__restrict__ blk_cnt,
-          uint32_t *__restrict__ blk_off, uint32_t *tail, uint32_t log_cap) {
-  __shared__ uint32_t Sw[16];
-  const uint32_t t = threadIdx.x;
-  if (t < KV_NLISTS)  // entries freed by earlier passes become reusable
-    for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t);
-  // thread t owns bins t, t + 1024, ... (coalesced, all loads in flight at once)
-  uint32_t c[DINT_KV_PMAX / 1024];
-  uint32_t extra = 0, nbig = 0;
-#pragma unroll
-  for (uint32_t j = 0; j < DINT_KV_PMAX / 1024; j++) {
-    const uint32_t b = t + 1024u * j;
-    c[j] = b < P ? bin_cnt[b] : 0;
-  }
-#pragma unroll
-  for (uint32_t j = 0; j < DINT_KV_PMAX / 1024; j++)
-    if (c[j] > DINT_KV_BINCAP) { extra += c[j] - DINT_KV_BINCAP; nbig++; }
-  uint32_t tot_extra, tot_big;
-  uint32_t off = block_excl_scan_1024(extra, Sw, &tot_extra);
-  uint32_t at = block_excl_scan_1024(nbig, Sw, &tot_big);
-#pragma unroll
-  for (uint32_t j = 0; j < DINT_KV_PMAX / 1024; j++)
-    if (c[j] > DINT_KV_BINCAP) {
-      const uint32_t b = t + 1024u * j;
-      bin_off[b] = off;
-      off += c[j] - DINT_KV_BINCAP;
-      big[2 + at++] = b;
-    }
-  if (t == 0) big[0] = tot_big;
-  if (blk_cnt) {  // log ring: position of request i = tail + (log requests below i)
-    uint32_t total;
-    const uint32_t mine = t < nb ? blk_cnt[t] : 0;
-    const uint32_t x = block_excl_scan_1024(mine, Sw, &total);
-    if (t < nb) blk_off[t] = x;
-    if (t == 0) tail[1] = (uint32_t)(((uint64_t)tail[0] + total) % log_cap);
+// Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area.
+__global__ void __launch_bounds__(256)
+k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big) {
+  __shared__ uint32_t Sw[4];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t nbig = big[0];
+  uint32_t run = 0;
+  for (uint32_t lo = 0; lo < nbig; lo += 256) {  // workgroup-uniform trip count; one trip unless the pass is very skewed
+    const uint32_t bin = lo + t < nbig ? big[2 + lo + t] : KV_NONE;
+    const uint32_t extra = bin != KV_NONE ? bin_cnt[bin] - DINT_KV_BINCAP : 0;
+    uint32_t tot, x = wave_excl_scan_u32(extra, &tot);
+    __syncthreads();
+    if (lane == 0) Sw[wave] = tot;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; w++) x += Sw[w];
+    if (bin != KV_NONE) bin_off[bin] = run + x;
+    run += Sw[0] + Sw[1] + Sw[2] + Sw[3];
   }
 }
 
@@ -302,10 +275,10 @@ k_kv_scan(uint32_t P, uint32_t nb, const kv_dev *__restrict__ kv, const uint32_t
 template <int WL>
 __global__ void __launch_bounds__(KV_TB)
 k_kv_place(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
-           const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+           const uint32_t *__restrict__ blk_cnt, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
            const uint4 *__restrict__ ovl, uint64_t *__restrict__ ovf, int load_mode) {
   using F = Fmt<WL>;
-  __shared__ uint32_t wcnt[KV_TB / 64];
+  __shared__ uint32_t wcnt[KV_TB / 64], wpre[KV_TB / 64];
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t i = blockIdx.x * KV_TB + t;
   if (i < big[1]) {
@@ -315,11 +288,23 @@ k_kv_place(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
   if (WL == DINT_WL_STORE) return;
   const uint8_t *m = req + (size_t)i * F::MSG;
   const kv_reqinfo r = kv_read_request<WL>(m, i < n, kv, load_mode);
+  // ring position = tail + (log requests below i): the workgroups before this one (<= 1023 counts, one per
+  // thread) + the waves before this one + the lanes before this one
+  {
+    uint32_t part = t < blockIdx.x ? blk_cnt[t] : 0, tot;
+    wave_excl_scan_u32(part, &tot);
+    if (lane == 0) wpre[wv] = tot;
+  }
   const uint64_t lm = __ballot(r.cls == 2);
   if (lane == 0) wcnt[wv] = (uint32_t)__popcll(lm);
   __syncthreads();
-  uint32_t base = blk_off[blockIdx.x];
-  for (uint32_t w = 0; w < wv; w++) base += wcnt[w];
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < KV_TB / 64; w++) base += wpre[w] + (w < wv ? wcnt[w] : 0);
+  if (blockIdx.x == gridDim.x - 1 && t == 0) {  // the pass's new tail
+    uint32_t total = base;
+    for (uint32_t w = 0; w < KV_TB / 64; w++) total += wcnt[w];
+    log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
+  }
   if (r.cls == 2) {
     const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
     const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
@@ -770,7 +755,7 @@ k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict_
              int kv_force_rounds, uint64_t *trace) {
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   const uint32_t bin = blockIdx.x, lane = threadIdx.x;
-  if (bin == 0 && lane == 0) big[1] = 0;  // k_kv_place (an earlier launch) is done with the overflow list
+  if (bin == 0 && lane == 0) { big[0] = 0; big[1] = 0; }  // the earlier launches are done with the big-bin and overflow lists
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
   kv_stamp_real(tr, 10);
   kv_stamp(tr, 0);
@@ -1257,11 +1242,10 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
                      has_log ? log.tail : nullptr, pbits, s.bin_cnt, s.bins, s.big, s.ovl, has_log ? s.blk_cnt : nullptr,
                      s.stats, load_mode);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(1024), 0, st, P, nb, kv.d_dev, (const uint32_t *)s.bin_cnt, s.bin_off, s.big,
-                     has_log ? (const uint32_t *)s.blk_cnt : nullptr, s.blk_off, log.tail, log.cap);
+  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big);
   if (ev) hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_kv_place<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
-                     log, (const uint32_t *)s.blk_off, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+                     log, (const uint32_t *)s.blk_cnt, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
                      (const uint4 *)s.ovl, s.ovf, load_mode);
   if (ev) hipEventRecord(ev[3], st);
   // The two resolve kernels own disjoint bins (<= DINT_KV_BINCAP records / more).  They run back to back on the

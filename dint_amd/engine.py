@@ -121,8 +121,8 @@ class Engine:
         return out
 
     def timing_read(self) -> dict:
-        names = (C.c_char_p * 4)(); us = (C.c_double * 4)(); cnt = (C.c_uint64 * 4)()
-        k = _lib.check(self._L.dint_timing_read(self._h, names, us, cnt, 4))
+        names = (C.c_char_p * 8)(); us = (C.c_double * 8)(); cnt = (C.c_uint64 * 8)()
+        k = _lib.check(self._L.dint_timing_read(self._h, names, us, cnt, 8))
         return {names[i].decode(): {"avg_us": us[i], "launches": cnt[i]} for i in range(k)}
 
 
