@@ -23,6 +23,7 @@ struct dint_scratch {
   uint32_t *blk_off;   // [1024] exclusive scan of blk_cnt
   uint32_t *big;       // [2 + DINT_KV_PMAX]: big[0] = number of bins with more than DINT_KV_BINCAP records in this
                        // pass, big[1] = number of overflow records, then the ids of those bins
+  uint32_t *big_next;  // the list of the next pass (two lists, used alternately)
   uint32_t *bin_off;   // [DINT_KV_PMAX] start of a big bin's records DINT_KV_BINCAP.. in `ovf`
   uint4 *ovl;          // [pass_max] overflow records as counted: {record lo, record hi, bin, position in bin}
   uint64_t *ovf;       // [pass_max] overflow records grouped by bin

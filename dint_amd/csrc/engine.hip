@@ -118,7 +118,7 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0) {
   static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
-  static const char *const kv_names[] = {"k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve_big", "k_kv_resolve"};
+  static const char *const kv_names[] = {"k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
@@ -134,7 +134,8 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 5, kv_names));
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names));
+      std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists alternate between passes
       break;
     default:
       return fail(DINT_EINVAL, "bad workload");
@@ -166,6 +167,7 @@ int load_rows_locked(dint_engine *e, uint32_t table, const uint64_t *keys, const
     }
     HIP_TRY(hipMemcpyAsync(e->d_stage_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
     dint_launch_kv(e->d_stage_req, e->d_stage_req, m, e->kv, e->log, e->scratch, 1, e->stream, nullptr);
+    std::swap(e->scratch.big, e->scratch.big_next);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -230,7 +232,8 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
     TRY(dev_alloc((void **)&e->scratch.blk_cnt, 1024 * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.blk_off, 1024 * sizeof(uint32_t)));
-    TRY(dev_alloc((void **)&e->scratch.big, (2 + DINT_KV_PMAX) * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.big, 2 * (2 + DINT_KV_PMAX) * sizeof(uint32_t)));
+    e->scratch.big_next = e->scratch.big + (2 + DINT_KV_PMAX);
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
@@ -284,7 +287,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
   hipFree(e->scratch.blk_off);
-  hipFree(e->scratch.big);
+  hipFree(std::min(e->scratch.big, e->scratch.big_next));
   hipFree(e->scratch.bin_off);
   hipFree(e->scratch.ovl);
   hipFree(e->scratch.ovf);

@@ -249,11 +249,14 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
 }
 
 // ---- k_kv_scan: one workgroup ---------------------------------------------------------------------------
-// Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area.
+// Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area; clear the counters of the
+// list the next pass will use (the lists alternate, so nothing has to be reset behind the resolve kernel).
 __global__ void __launch_bounds__(256)
-k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big) {
+k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
+          uint32_t *__restrict__ big_next) {
   __shared__ uint32_t Sw[4];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 2) big_next[t] = 0;  // the next pass counts into the other list (this one is read until the pass ends)
   const uint32_t nbig = big[0];
   uint32_t run = 0;
   for (uint32_t lo = 0; lo < nbig; lo += 256) {  // workgroup-uniform trip count; one trip unless the pass is very skewed
@@ -749,24 +752,18 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 
 // ---- k_kv_resolve: bins of <= 64 records, one wave each ---------------------------------------------------
 template <int WL>
-__global__ void __launch_bounds__(64)
-k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, uint32_t *__restrict__ big, dint_dev_stats *__restrict__ stats,
-             int kv_force_rounds, uint64_t *trace) {
-  __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
-  const uint32_t bin = blockIdx.x, lane = threadIdx.x;
-  if (bin == 0 && lane == 0) { big[0] = 0; big[1] = 0; }  // the earlier launches are done with the big-bin and overflow lists
+__device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const kv_dev *kv, uint32_t bin,
+                                           uint32_t *__restrict__ bin_cnt, const uint64_t *__restrict__ bins,
+                                           dint_dev_stats *__restrict__ stats, int kv_force_rounds, uint64_t *trace) {
+  const uint32_t lane = threadIdx.x & 63;
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
   kv_stamp_real(tr, 10);
   kv_stamp(tr, 0);
   const uint64_t r0 = bins[(size_t)bin * DINT_KV_BINCAP + lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
   if (tr && lane == 0 && c) { tr[15] = c; tr[14] = 0; }
-  if (c == 0 || c > DINT_KV_BINCAP) return;  // larger bins belong to k_kv_resolve_big
+  if (c == 0 || c > DINT_KV_BINCAP) return;  // larger bins are on the big-bin list
   if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
-  for (uint32_t k = lane; k < sizeof(kv_dev) / 4; k += 64) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
-  __syncthreads();
-  const kv_dev *kv = &Skv;
   kv_stamp(tr, 1);
   // Sort the records by (bucket group, key hash, idx) in registers: groups commute, so any order that keeps each
   // group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in adjacent
@@ -838,11 +835,11 @@ __device__ static inline int kvb_range_first(const uint64_t *M, uint32_t a) {  /
 __device__ static inline bool kvb_bit(const uint64_t *M, uint32_t p) { return (M[p >> 6] >> (p & 63)) & 1ull; }
 
 template <int WL>
-__global__ void __launch_bounds__(KVB_T)
-k_kv_resolve_big(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g,
-                 uint32_t *__restrict__ bin_cnt, const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big,
-                 const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
-                 dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace) {
+__device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *kv, uint32_t first,
+                                          uint32_t stride, uint32_t *__restrict__ bin_cnt,
+                                          const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big,
+                                          const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
+                                          dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace) {
   using F = Fmt<WL>;
   __shared__ uint32_t Bcnt[KVB_NBK / 4];      // records per idx bucket, one byte each (a bucket spans <= 128 requests)
   __shared__ uint16_t Bwin[KVB_NBK];          // window each idx bucket belongs to
@@ -859,14 +856,13 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restr
   __shared__ kv_rowst Crow[KVB_T];            // row machine of key segments with an INSERT / DELETE (store / tatp)
   __shared__ uint32_t Sany, Swn;
   __shared__ uint32_t Sred[KVB_W];
-  __shared__ kv_dev Skv;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // k_kv_scan listed the bins with more than DINT_KV_BINCAP records; workgroup b takes entries b, b + grid, ...
   const uint32_t nbig = big[0];
   // idx buckets for the windows of a bin with more than KVB_T records: 2^bs requests per bucket, <= KVB_NBK buckets
   const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 13 ? nbits - 13 : 0u;
   const uint32_t wcap = KVB_T - (1u << bs);  // a window = the buckets whose exclusive record count / wcap is equal
-  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+  for (uint32_t bi = first; bi < nbig; bi += stride) {
   const uint32_t bin = big[2 + bi];
   __syncthreads();  // the previous bin's LDS is free
   const uint32_t c = bin_cnt[bin];
@@ -875,8 +871,6 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restr
   const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
   const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;  // records DINT_KV_BINCAP.. of the bin
   auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
-  for (uint32_t k = t; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
-  const kv_dev *kv = &Skv;
 
   // ---- windows: runs of consecutive idx buckets holding < KVB_T records, so that every request of a window comes
   // before every request of the next one in request order
@@ -1228,6 +1222,26 @@ k_kv_resolve_big(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restr
   }
 }
 
+// ---- k_kv_resolve: every bin of the pass, one launch ------------------------------------------------------
+// Workgroups 0 .. KVB_GRID-1 walk the big-bin list (kv_big_bins); each wave of the others resolves one bin of
+// <= DINT_KV_BINCAP records (kv_small_bin).  The two kinds own disjoint bins, hence disjoint buckets, so they run
+// side by side: the hot keys' windows overlap the bulk of the pass instead of preceding it.
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 4)
+k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace) {
+  __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
+  for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
+  __syncthreads();
+  if (blockIdx.x < KVB_GRID) {
+    kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_rounds, trace);
+  } else {
+    const uint32_t bin = (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
+    if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_rounds, trace);
+  }
+}
+
 // ---- launch -------------------------------------------------------------------------------------------
 template <int WL>
 static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
@@ -1242,22 +1256,17 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
                      has_log ? log.tail : nullptr, pbits, s.bin_cnt, s.bins, s.big, s.ovl, has_log ? s.blk_cnt : nullptr,
                      s.stats, load_mode);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big);
+  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
+                     s.big_next);
   if (ev) hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_kv_place<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
                      log, (const uint32_t *)s.blk_cnt, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
                      (const uint4 *)s.ovl, s.ovf, load_mode);
   if (ev) hipEventRecord(ev[3], st);
-  // The two resolve kernels own disjoint bins (<= DINT_KV_BINCAP records / more).  They run back to back on the
-  // pass's stream: forking the big-bin kernel to a side stream and joining it (measured, r01) costs more in
-  // cross-stream event latency (~10 us per pass) than the overlap saves.
-  hipLaunchKernelGGL((k_kv_resolve_big<WL>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits, kv.d_dev,
-                     s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
-                     (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace);
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
+                     pbits, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
+                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace);
   if (ev) hipEventRecord(ev[4], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, pbits, kv.d_dev, s.bin_cnt,
-                     (const uint64_t *)s.bins, s.big, s.stats, kv.force_rounds, kv.d_trace);
-  if (ev) hipEventRecord(ev[5], st);
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
