@@ -560,9 +560,17 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   const uint64_t m_struct = __ballot(valid && kv_struct_op<WL>(type));
   // key segments that carry lock ops, per lock quadrant: two of them on one lock word make the run non-simple
   const bool lkseg = head && (m_lockop & seg) != 0;
-  bool lock_clash = false;
+  bool lock_clash = false;  // several key segments of my bucket run use one lock word ...
+  bool my_clash = false;    // ... the one of my quadrant
 #pragma unroll
-  for (uint32_t k = 0; k < 4; k++) lock_clash |= __popcll(__ballot(lkseg && q == k) & run) > 1;
+  for (uint32_t k = 0; k < 4; k++) {
+    const bool cl = __popcll(__ballot(lkseg && q == k) & run) > 1;
+    lock_clash |= cl;
+    my_clash |= cl && q == k;
+  }
+  // tatp's lock byte is a last-writer-wins register (ACQUIRE leaves 1, every other lock op 0; only ACQUIRE's reply
+  // depends on it), so sharing it does not serialise the run: see the lock machine below.  smallbank's counters do.
+  if (WL == DINT_WL_TATP) lock_clash = false;
   const uint64_t m_stseg = __ballot(head && (m_struct & seg) != 0);  // ... that insert / delete their row
   bool simple = valid && (m_bad & run) == 0 && !lock_clash && __popcll(m_stseg & run) <= 1 && !force_rounds;
   const bool structural = (m_struct & seg) != 0;  // my key segment inserts / deletes: row machine by walk
@@ -599,8 +607,29 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         const uint64_t m_lk = __ballot(simple && kv_lock_op<WL>(type)) & seg;
         const uint64_t m_acq = __ballot(simple && type == 1);
         const uint64_t lk_below = m_lk & lt;
-        const uint32_t lock_seen = lk_below ? (uint32_t)((m_acq >> (63 - __clzll(lk_below))) & 1ull) : la0;
+        uint32_t lock_seen = lk_below ? (uint32_t)((m_acq >> (63 - __clzll(lk_below))) & 1ull) : la0;
         if (m_lk) fin_la = (uint32_t)((m_acq >> (63 - __clzll(m_lk))) & 1ull);
+        // a lock byte shared by several keys of the run: the latest lock op on it that precedes me in request
+        // order, looked up among the run's lock ops (one wave-uniform step per such op; rare)
+        const uint64_t cm = __ballot(simple && my_clash && kv_lock_op<WL>(type));
+        if (cm) {
+          int seen = -1, fin = -1;
+          uint32_t seen_at = 0, fin_at = 0;
+          for (uint64_t mm = cm; mm; mm &= mm - 1) {
+            const int l = __ffsll((unsigned long long)mm) - 1;
+            const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane(idx, l), og = (uint32_t)__builtin_amdgcn_readlane(gk, l);
+            const uint32_t oq = (uint32_t)__builtin_amdgcn_readlane(q, l);
+            const int acq = (uint32_t)__builtin_amdgcn_readlane(type, l) == 1;
+            if (og == gk && oq == q) {
+              if (oi < idx && (seen < 0 || oi > seen_at)) { seen_at = oi; seen = acq; }
+              if (fin < 0 || oi > fin_at) { fin_at = oi; fin = acq; }
+            }
+          }
+          if (simple && my_clash) {
+            lock_seen = seen >= 0 ? (uint32_t)seen : la0;
+            if (m_lk && fin >= 0) fin_la = (uint32_t)fin;  // every segment of the group stores the same byte
+          }
+        }
         nmiss = found ? 0 : (uint32_t)__popcll(__ballot(writer) & seg);
         switch (type) {
           case 0: my_code = found ? 4 : 6; my_get = found; break;
@@ -788,23 +817,76 @@ __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const k
   kv_stamp_real(tr, 11);
 }
 
-// ---- k_kv_resolve_big: bins of > 64 records (hot keys), one 512-thread workgroup each ------------------------
-// The same algorithm as kv_chunk, over a window of 512 requests at a time and 8 waves:
-//   restore request order (bitmap rank over idx, built by the whole workgroup), take the next 512 requests, group
-//   them by bucket in an LDS hash, sort the window by (bucket group, request order) with a 512-wide bitonic network
-//   (in-wave steps by shuffle, the 6 wide steps through LDS), and resolve every segment of the sorted window at
-//   once: per-wave ballot masks go to LDS, and "writers below me in my segment" / "last writer below" / "last lock
-//   op below" become popcounts and find-last-bit over the mask words the segment spans.  A hot key's 500 requests
-//   therefore cost the same handful of memory round trips as 5.  smallbank's counters are walked wave by wave with
-//   the running state carried through LDS.  Segments with several keys / inserts / deletes run in rounds.
+// ---- big bins (more than DINT_KV_BINCAP records: hot keys), one 512-thread workgroup each -----------------------
+// The same algorithm as kv_chunk, over up to KVB_NMAX requests at a time:
+//   sort the bin by (bucket group, key hash, request index) in LDS; the requests of one key are then one segment of
+//   the sorted order, however many there are.  Ballot masks over the WHOLE sorted stretch (heads, writers, lock ops,
+//   ...) plus one small table per mask (bits set / last set bit / next set bit per 64-bit word, built by one wave
+//   with a lane per word) answer "writers below me in my segment", "last writer below", "last lock op below" in
+//   O(1) for every request.  The memory work then runs tile by tile (512 requests per tile, one per thread) with no
+//   table dependency between tiles: a segment that crosses a tile boundary (the hot key) is located once, its
+//   {row location, version, lock state} travels in LDS, and its row is written back once, by its last request.  A
+//   hot key's 3000 requests therefore cost one sort and six tiles of independent loads and stores.  smallbank's
+//   counters are walked wave by wave with the running state carried through LDS.  Bucket runs with several keys on
+//   one lock word, a bad key or several inserts / deletes run request by request after the tiles.
+// A bin of more than KVB_NMAX records is cut into stretches along request-index buckets (every request of a
+// stretch precedes every request of the next one) and the stretches run one after the other.
 #define KVB_T 512u
 #define KVB_W (KVB_T / 64u)
-#define KVB_GRID 128u  // workgroups of k_kv_resolve_big; each walks its share of the big-bin list
-#define KVB_NBK 8192u  // idx buckets that define the windows of a bin with more than KVB_T records
+#define KVB_GRID 128u              // workgroups that walk the big-bin list
+#define KVB_NMAX 4096u             // requests resolved together (one stretch of a bin)
+#define KVB_NW (KVB_NMAX / 64u)    // mask words of a stretch = lanes of one wave
+#define KVB_NBK 2048u              // request-index buckets that cut a longer bin into stretches
+static_assert(KVB_NW == 64, "the per-word tables are built with one lane per mask word");
 struct kvb_lead { uint32_t found_link, slot, ver0, la0, lb0; };   // found_link: found << 31 | link
 struct kvb_carry { uint32_t la, lb, ver; int src; uint32_t miss; };
+struct kvb_pop { uint16_t below[KVB_NW + 1]; };                  // bits set in the words before w
+struct kvb_edge { int16_t last[KVB_NW], next[KVB_NW]; };         // highest set bit before word w / lowest after it, -1: none
 
-__device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, uint32_t b) {  // bits set in [a, b)
+__device__ static inline void kvb_build_pop(const uint64_t *M, kvb_pop &P) {  // one whole wave
+  const uint32_t lane = lane_id();
+  uint32_t tot;
+  const uint32_t x = wave_excl_scan_u32((uint32_t)__popcll(M[lane]), &tot);
+  P.below[lane] = (uint16_t)x;
+  if (lane == 63) P.below[KVB_NW] = (uint16_t)tot;
+}
+__device__ static inline void kvb_build_edge(const uint64_t *M, kvb_edge &E) {  // one whole wave
+  const int lane = (int)lane_id();
+  const uint64_t m = M[lane];
+  int hi = m ? lane * 64 + 63 - __clzll((long long)m) : -1;
+  int lo = m ? lane * 64 + __ffsll((unsigned long long)m) - 1 : 0x7FFF;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int a = __shfl_up(hi, d, 64), b = __shfl_down(lo, d, 64);
+    if (lane >= d) hi = max(hi, a);
+    if (lane + d < 64) lo = min(lo, b);
+  }
+  const int a = __shfl_up(hi, 1, 64), b = __shfl_down(lo, 1, 64);
+  E.last[lane] = (int16_t)(lane ? a : -1);
+  E.next[lane] = (int16_t)((lane == 63 || b == 0x7FFF) ? -1 : b);
+}
+__device__ static inline bool kvb_bit(const uint64_t *M, uint32_t p) { return (M[p >> 6] >> (p & 63)) & 1ull; }
+__device__ static inline uint32_t kvb_below(const uint64_t *M, const kvb_pop &P, uint32_t x) {  // bits set in [0, x)
+  const uint32_t w = x >> 6, r = x & 63;
+  return P.below[w] + (r ? (uint32_t)__popcll(M[w] & ((1ull << r) - 1ull)) : 0u);
+}
+__device__ static inline uint32_t kvb_popc(const uint64_t *M, const kvb_pop &P, uint32_t a, uint32_t b) {  // in [a, b)
+  return a < b ? kvb_below(M, P, b) - kvb_below(M, P, a) : 0u;
+}
+__device__ static inline int kvb_last(const uint64_t *M, const kvb_edge &E, uint32_t a, uint32_t b) {  // highest in [a, b) or -1
+  if (a >= b) return -1;
+  const uint32_t w = (b - 1) >> 6, r = b & 63;
+  const uint64_t m = M[w] & (r ? (1ull << r) - 1ull : ~0ull);
+  const int res = m ? (int)(w * 64 + 63 - __clzll((long long)m)) : (int)E.last[w];
+  return res >= (int)a ? res : -1;
+}
+__device__ static inline int kvb_first(const uint64_t *M, const kvb_edge &E, uint32_t a) {  // lowest at or above a, or -1
+  if (a >= KVB_NMAX) return -1;
+  const uint32_t w = a >> 6;
+  const uint64_t m = M[w] & (~0ull << (a & 63));
+  return m ? (int)(w * 64 + __ffsll((unsigned long long)m) - 1) : (int)E.next[w];
+}
+__device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, uint32_t b) {  // bits set in [a, b), no table
   uint32_t cnt = 0;
   for (uint32_t w = a >> 6; w <= ((b - 1) >> 6) && a < b; w++) {
     uint64_t m = M[w];
@@ -814,25 +896,6 @@ __device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, 
   }
   return cnt;
 }
-__device__ static inline int kvb_range_last(const uint64_t *M, uint32_t a, uint32_t b) {  // highest set bit in [a, b) or -1
-  if (a >= b) return -1;
-  for (int w = (int)((b - 1) >> 6); w >= (int)(a >> 6); w--) {
-    uint64_t m = M[w];
-    if ((uint32_t)w == (a >> 6)) m &= ~0ull << (a & 63);
-    if ((uint32_t)w == ((b - 1) >> 6) && (b & 63)) m &= (1ull << (b & 63)) - 1ull;
-    if (m) return w * 64 + 63 - __clzll(m);
-  }
-  return -1;
-}
-__device__ static inline int kvb_range_first(const uint64_t *M, uint32_t a) {  // lowest set bit at or above a, or -1
-  for (uint32_t w = a >> 6; w < KVB_W && a < KVB_T; w++) {
-    uint64_t m = M[w];
-    if (w == (a >> 6)) m &= ~0ull << (a & 63);
-    if (m) return (int)(w * 64 + __ffsll((unsigned long long)m) - 1);
-  }
-  return -1;
-}
-__device__ static inline bool kvb_bit(const uint64_t *M, uint32_t p) { return (M[p >> 6] >> (p & 63)) & 1ull; }
 
 template <int WL>
 __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *kv, uint32_t first,
@@ -841,382 +904,518 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
                                           const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
                                           dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace) {
   using F = Fmt<WL>;
-  __shared__ uint32_t Bcnt[KVB_NBK / 4];      // records per idx bucket, one byte each (a bucket spans <= 128 requests)
-  __shared__ uint16_t Bwin[KVB_NBK];          // window each idx bucket belongs to
-  __shared__ uint32_t Srec[KVB_T];            // window, as gathered: idx | hash entry << 20
-  __shared__ uint16_t Sop[KVB_T];             // kv_pay descriptor: type | quadrant | key-hash bits
-  __shared__ uint64_t Skey[KVB_T];
-  __shared__ uint32_t Hk[DINT_HSIZE];
-  __shared__ uint64_t Ssort[KVB_T];
-  __shared__ uint16_t Sp[KVB_T];              // sorted position -> gather position
-  __shared__ uint32_t Slast[KVB_W];           // hash entry of each wave's last lane
-  __shared__ uint64_t Mhead[KVB_W], Mbh[KVB_W], Mbad[KVB_W], Mlop[KVB_W], Mlkseg[4][KVB_W], Mst[KVB_W], Mstseg[KVB_W], Mbail[KVB_W], Mwr[KVB_W], Mlk[KVB_W], Macq[KVB_W];
-  __shared__ kvb_lead Lead[KVB_T];
+  __shared__ uint64_t Sk[KVB_NMAX];           // the stretch: group >> pbits | key-hash bits | idx | type, quadrant
+  __shared__ uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
+  __shared__ uint16_t Bwin[KVB_NBK];          // stretch each idx bucket belongs to
+  __shared__ uint64_t Mhead[KVB_NW], Mbh[KVB_NW], Mbad[KVB_NW], Mlop[KVB_NW], Mst[KVB_NW], Mlkseg[4][KVB_NW],
+      Mstseg[KVB_NW], Msimple[KVB_NW], Mwr[KVB_NW], Mlk[KVB_NW], Macq[KVB_NW];
+  __shared__ kvb_pop Pbad, Plop, Pst, Plkseg[4], Pstseg, Pwr;
+  __shared__ kvb_edge Ehead, Ebh, Ewr, Elk;
+  __shared__ uint64_t Mbail[KVB_W];           // tile-local
+  __shared__ kvb_lead Lead[KVB_T];            // by key segment number (a stretch with more segments runs request by request)
   __shared__ kvb_carry Carry[KVB_T];
   __shared__ kv_rowst Crow[KVB_T];            // row machine of key segments with an INSERT / DELETE (store / tatp)
+  __shared__ uint16_t HeadPos[KVB_T];         // sorted position of each segment's head
+  __shared__ kvb_pop Phead;
   __shared__ uint32_t Sany, Swn;
   __shared__ uint32_t Sred[KVB_W];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // k_kv_scan listed the bins with more than DINT_KV_BINCAP records; workgroup b takes entries b, b + grid, ...
+  // k_kv_count listed the bins with more than DINT_KV_BINCAP records; this workgroup takes entries first, first + stride, ...
   const uint32_t nbig = big[0];
-  // idx buckets for the windows of a bin with more than KVB_T records: 2^bs requests per bucket, <= KVB_NBK buckets
-  const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 13 ? nbits - 13 : 0u;
-  const uint32_t wcap = KVB_T - (1u << bs);  // a window = the buckets whose exclusive record count / wcap is equal
+  // idx buckets for the stretches of a bin with more than KVB_NMAX records: 2^bs requests per bucket, <= KVB_NBK buckets
+  const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 11 ? nbits - 11 : 0u;
+  const uint32_t wcap = KVB_NMAX - (1u << bs);  // a stretch = the buckets whose exclusive record count / wcap is equal
+  const uint32_t sh_g = 32 + pbits, sh_k = 23 + pbits, idx_mask = (1u << (16 + pbits)) - 1u;
+  auto k_idx = [&](uint64_t w) -> uint32_t { return (uint32_t)(w >> 7) & idx_mask; };
+  auto k_type = [&](uint64_t w) -> uint32_t { return pay_type((uint32_t)w & 0x7Fu); };
+  auto k_q = [&](uint64_t w) -> uint32_t { return pay_q((uint32_t)w & 0x7Fu); };
+  auto is_writer = [&](uint32_t type) -> bool {
+    return WL == DINT_WL_STORE ? type == 1 : WL == DINT_WL_TATP ? (type == 12 || type == 13) : (type == 4 || type == 5);
+  };
+  // tatp's lock byte is a last-writer-wins register: ACQUIRE leaves 1 (granted or not), every other lock op leaves 0,
+  // and only ACQUIRE's reply depends on it.  When several keys of a bucket run use one lock byte, an ACQUIRE looks
+  // through the run's lock ops for the latest one on its byte that precedes it in request order.
+  // Returns 1 / 0 = what that op left, -1 = there is none.
+  auto lock_scan = [&](uint32_t a, uint32_t b, uint32_t qq, uint32_t before_idx) -> int {
+    int kind = -1;
+    uint32_t at = 0;
+    for (uint32_t w = a >> 6; a < b && w <= ((b - 1) >> 6); w++) {
+      uint64_t mm = Mlop[w];
+      if (w == (a >> 6)) mm &= ~0ull << (a & 63);
+      if (w == ((b - 1) >> 6) && (b & 63)) mm &= (1ull << (b & 63)) - 1ull;
+      for (; mm; mm &= mm - 1) {
+        const uint64_t o = Sk[w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1];
+        const uint32_t oi = k_idx(o);
+        if (k_q(o) == qq && oi < before_idx && (kind < 0 || oi > at)) { at = oi; kind = k_type(o) == 1; }
+      }
+    }
+    return kind;
+  };
   for (uint32_t bi = first; bi < nbig; bi += stride) {
   const uint32_t bin = big[2 + bi];
   __syncthreads();  // the previous bin's LDS is free
   const uint32_t c = bin_cnt[bin];
-  uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;  // [8] start, [9] end (10 ns), [12] rounds, [13] windows, [14] c
+  uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;  // [8] start, [9] end (10 ns), [12] rounds, [13] stretches, [14] c
   if (tr && t == 0) { tr[8] = __builtin_amdgcn_s_memrealtime(); tr[14] = c; tr[12] = 0; tr[13] = 0; }
   const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
   const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;  // records DINT_KV_BINCAP.. of the bin
   auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
 
-  // ---- windows: runs of consecutive idx buckets holding < KVB_T records, so that every request of a window comes
-  // before every request of the next one in request order
   uint32_t nwin = 1;
-  if (c > KVB_T) {
-    for (uint32_t w = t; w < KVB_NBK / 4; w += KVB_T) Bcnt[w] = 0;
+  if (c > KVB_NMAX) {
+    for (uint32_t w = t; w < KVB_NBK / 2; w += KVB_T) Bcnt[w] = 0;
     __syncthreads();
     for (uint32_t k = t; k < c; k += KVB_T) {
       const uint32_t b = kv_rec_idx(rec_at(k), pbits) >> bs;
-      atomicAdd(&Bcnt[b >> 2], 1u << (8 * (b & 3)));
+      atomicAdd(&Bcnt[b >> 1], 1u << (16 * (b & 1)));
     }
     __syncthreads();
-    uint32_t cw[4], run = 0;  // thread t owns buckets 16t .. 16t+15
+    uint32_t cw[2], run = 0;  // thread t owns buckets 4t .. 4t+3
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
-      cw[j] = Bcnt[4 * t + j];
-      run += (cw[j] & 0xFF) + ((cw[j] >> 8) & 0xFF) + ((cw[j] >> 16) & 0xFF) + (cw[j] >> 24);
+    for (uint32_t j = 0; j < 2; j++) {
+      cw[j] = Bcnt[2 * t + j];
+      run += (cw[j] & 0xFFFF) + (cw[j] >> 16);
     }
     uint32_t tot, base = wave_excl_scan_u32(run, &tot);
     if (lane == 0) Sred[wave] = tot;
     __syncthreads();
     for (uint32_t w = 0; w < wave; w++) base += Sred[w];
 #pragma unroll
-    for (uint32_t j = 0; j < 16; j++) {
-      Bwin[16 * t + j] = (uint16_t)(base / wcap);
-      base += (cw[j >> 2] >> (8 * (j & 3))) & 0xFF;
+    for (uint32_t j = 0; j < 4; j++) {
+      Bwin[4 * t + j] = (uint16_t)(base / wcap);
+      base += (cw[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
     }
     nwin = (c - 1) / wcap + 1;  // upper bound: the last one may be empty
-    __syncthreads();
   }
   __syncthreads();
   if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
 
   for (uint32_t win = 0; win < nwin; win++) {
-    for (uint32_t h = t; h < DINT_HSIZE; h += KVB_T) Hk[h] = DINT_EMPTY;
     if (t == 0) Swn = 0;
     __syncthreads();
-    // ---- gather the window (any order); group by bucket; fetch the keys
+    // ---- gather the stretch (any order) as sort keys
     for (uint32_t k = t; k < c; k += KVB_T) {
       const uint64_t r = rec_at(k);
       const uint32_t idx = kv_rec_idx(r, pbits);
-      if (c <= KVB_T || Bwin[idx >> bs] == win) {
-        bool nw;
-        const uint32_t at = atomicAdd(&Swn, 1u);
-        const uint32_t e = lds_hash_insert(Hk, kv_rec_gk(r, pbits, bin), &nw);
-        Srec[at] = idx | (e << 20);
-        Sop[at] = (uint16_t)kv_rec_pay(r);
-        Skey[at] = ld_u64(rep + (size_t)idx * F::MSG + F::KEY);
+      if (c <= KVB_NMAX || Bwin[idx >> bs] == win) {
+        const uint32_t pay = kv_rec_pay(r);
+        Sk[atomicAdd(&Swn, 1u)] = ((r >> sh_g) << sh_g) | ((uint64_t)pay_kh(pay) << sh_k) | ((uint64_t)idx << 7) | (pay & 0x7Fu);
       }
     }
     __syncthreads();
-    const uint32_t wn = Swn;
-    __syncthreads();  // Swn is reset at the top of the next window
-    if (wn == 0) continue;  // workgroup-uniform
-    // ---- sort the window by (hash entry, key-hash bits, idx): 512-wide bitonic network; the low 9 bits carry the
-    // gather position
-    uint64_t v = ~0ull;
-    if (t < wn) {
-      const uint32_t sr = Srec[t];
-      v = ((uint64_t)(sr >> 20) << 38) | ((uint64_t)pay_kh(Sop[t]) << 29) | ((uint64_t)(sr & 0xFFFFFu) << 9) | t;
-    }
-    for (uint32_t k = 2; k <= KVB_T; k <<= 1) {
+    const uint32_t m = Swn;
+    __syncthreads();  // Swn is reset at the top of the next stretch
+    if (m == 0) continue;  // workgroup-uniform
+    uint32_t N = KVB_T;
+    while (N < m) N <<= 1;
+    for (uint32_t k = m + t; k < N; k += KVB_T) Sk[k] = ~0ull;  // empty slots sort last
+    __syncthreads();
+    // ---- sort: bitonic network over N keys in LDS (N / 2 compare-exchanges per step)
+    for (uint32_t k = 2; k <= N; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        uint64_t o;
-        if (j < 64) {
-          const uint32_t lo = __shfl_xor((uint32_t)v, (int)j, 64), hi = __shfl_xor((uint32_t)(v >> 32), (int)j, 64);
-          o = ((uint64_t)hi << 32) | lo;
-        } else {
-          Ssort[t] = v;
-          __syncthreads();
-          o = Ssort[t ^ j];
-          __syncthreads();
+        for (uint32_t i = t; i < N / 2; i += KVB_T) {
+          const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1)), b = a | j;
+          const uint64_t x = Sk[a], y = Sk[b];
+          if ((x > y) == ((a & k) == 0)) { Sk[a] = y; Sk[b] = x; }
         }
-        const bool up = (t & k) == 0, low = (t & j) == 0;
-        v = (low == up) ? (v < o ? v : o) : (v < o ? o : v);
+        __syncthreads();
       }
     }
-    const bool valid = v != ~0ull;
-    const uint32_t p = (uint32_t)v & 511u, ek = valid ? (uint32_t)(v >> 29) : 0xFFFFFFu;  // ek = hash entry << 9 | key-hash bits
-    const uint32_t e = ek >> 9;
-    Sp[t] = (uint16_t)p;
-    const uint32_t so = valid ? Sop[p] : 0;
-    const uint32_t gk = valid ? Hk[e] : 0;
-    const uint32_t idx = valid ? (uint32_t)(v >> 9) & 0xFFFFFu : 0, type = pay_type(so), table = valid ? kv_table_of(kv, gk) : 0, q = pay_q(so);
-    const uint64_t key = valid ? Skey[p] : 0;
-    const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
-    uint8_t *msg = rep + (size_t)idx * F::MSG;
-    // ---- bucket runs and key segments of the sorted window (they may span waves)
-    if (lane == 63) Slast[wave] = ek;
-    __syncthreads();
-    const uint32_t ek_shfl = __shfl_up(ek, 1, 64);  // executed by every lane: a shuffle reads only active lanes
-    const uint32_t ek_up = lane ? ek_shfl : (wave ? Slast[wave - 1] : 0xFFFFFFFFu);
-    const bool bhead = valid && (ek_up >> 9) != e;
-    const bool head = valid && ek_up != ek;
-    {
-      const uint64_t hm = __ballot(head), bm = __ballot(bhead);
-      if (lane == 0) { Mhead[wave] = hm; Mbh[wave] = bm; }
+    const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
+
+    // ---- pass A: segment heads (key hash changes), bucket-run heads (group changes), op classes
+    for (uint32_t j = 0; j < ntile; j++) {
+      const uint32_t p = j * KVB_T + t;
+      const uint64_t cur = Sk[p], prev = p ? Sk[p - 1] : ~0ull;
+      const bool valid = p < m;
+      const uint32_t type = k_type(cur);
+      const uint64_t m1 = __ballot(valid && (p == 0 || (cur >> sh_k) != (prev >> sh_k)));
+      const uint64_t m2 = __ballot(valid && (p == 0 || (cur >> sh_g) != (prev >> sh_g)));
+      const uint64_t m3 = __ballot(valid && kv_lock_op<WL>(type));
+      const uint64_t m4 = __ballot(valid && kv_struct_op<WL>(type));
+      if (lane == 0) { Mhead[p >> 6] = m1; Mbh[p >> 6] = m2; Mlop[p >> 6] = m3; Mst[p >> 6] = m4; }
+    }
+    for (uint32_t w = ntile * KVB_W + t; w < KVB_NW; w += KVB_T) {
+      Mhead[w] = 0; Mbh[w] = 0; Mlop[w] = 0; Mst[w] = 0; Mbad[w] = 0; Mstseg[w] = 0; Msimple[w] = 0; Mwr[w] = 0; Mlk[w] = 0; Macq[w] = 0;
+      Mlkseg[0][w] = 0; Mlkseg[1][w] = 0; Mlkseg[2][w] = 0; Mlkseg[3][w] = 0;
     }
     __syncthreads();
-    uint32_t seg_a = 0, seg_b = wn, bk_a = 0, bk_b = wn;  // my key segment / bucket run = sorted positions [a, b)
-    if (valid) {
-      seg_a = (uint32_t)kvb_range_last(Mhead, 0, t + 1);
-      bk_a = (uint32_t)kvb_range_last(Mbh, 0, t + 1);
-      const int nx = kvb_range_first(Mhead, t + 1), bx = kvb_range_first(Mbh, t + 1);
-      if (nx >= 0) seg_b = (uint32_t)nx;
-      if (bx >= 0) bk_b = (uint32_t)bx;
-    }
-    // heads load their bucket's inline header (+ smallbank counters) before the keys are compared
-    kv_tab tb;
-    uint8_t *ie = nullptr;
-    kv_hdr H;
-    uint32_t la0 = 0, lb0 = 0;
-    if (valid) {
-      tb = kv->tab[table];
-      ie = kv_entry_ptr(tb, bucket, KV_INLINE);
-    }
-    if (head) {
-      kv_hdr_copy(H, *(const kv_hdr *)ie);
-      if (WL == DINT_WL_SMALLBANK) {
-        const uint2 cc = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);
-        la0 = cc.x; lb0 = cc.y;
-      }
-      if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
-    }
-    const uint64_t hkey = valid ? Skey[Sp[seg_a]] : 0;  // Sp[] of other waves: written before the barriers above
-    {
+    if (wave == 0) kvb_build_edge(Mhead, Ehead);
+    if (wave == 1) kvb_build_edge(Mbh, Ebh);
+    if (wave == 2) kvb_build_pop(Mlop, Plop);
+    if (wave == 3) kvb_build_pop(Mst, Pst);
+    if (wave == 4) kvb_build_pop(Mhead, Phead);
+    __syncthreads();
+    const uint32_t nseg = Phead.below[KVB_NW];
+    // ---- pass B: a segment must be one key (9 hash bits can collide) and carry only ops the closed form knows
+    for (uint32_t j = 0; j < ntile; j++) {
+      const uint32_t p = j * KVB_T + t;
+      const uint64_t cur = Sk[p];
+      const bool valid = p < m;
+      const uint32_t type = k_type(cur);
+      const uint32_t seg_a = valid ? (uint32_t)kvb_last(Mhead, Ehead, 0, p + 1) : 0;
+      const uint64_t key = valid ? ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY) : 0;
+      const uint64_t hkey = valid ? ld_u64(rep + (size_t)k_idx(Sk[seg_a]) * F::MSG + F::KEY) : 0;
       const uint64_t bm = __ballot(valid && !(key == hkey && (kv_simple_op<WL>(type) || kv_struct_op<WL>(type))));
-      const uint64_t lm = __ballot(valid && kv_lock_op<WL>(type));
-      const uint64_t sm = __ballot(valid && kv_struct_op<WL>(type));
-      if (lane == 0) { Mbad[wave] = bm; Mlop[wave] = lm; Mst[wave] = sm; }
-      if (t == 0) Sany = 0;
+      if (lane == 0) Mbad[p >> 6] = bm;
     }
     __syncthreads();
-    const bool structural = valid && kvb_range_popc(Mst, seg_a, seg_b) != 0;  // my key segment inserts / deletes
-    {  // key segments that carry lock ops, per lock quadrant: two on one lock word make the bucket run non-simple
-      const bool lkseg = head && kvb_range_popc(Mlop, seg_a, seg_b) != 0;
+    if (wave == 0) kvb_build_pop(Mbad, Pbad);
+    __syncthreads();
+    // ---- pass C: key segments that carry lock ops, per lock quadrant (two on one lock word make the bucket run
+    // non-simple); key segments that insert / delete
+    for (uint32_t j = 0; j < ntile; j++) {
+      const uint32_t p = j * KVB_T + t;
+      const bool valid = p < m;
+      const uint32_t q = k_q(Sk[p]);
+      const bool head = valid && kvb_bit(Mhead, p);
+      uint32_t seg_b = m;
+      if (head) { const int nx = kvb_first(Mhead, Ehead, p + 1); if (nx >= 0) seg_b = (uint32_t)nx; }
+      if (head) { const uint32_t sn = kvb_below(Mhead, Phead, p); if (sn < KVB_T) HeadPos[sn] = (uint16_t)p; }
+      const bool lkseg = head && kvb_popc(Mlop, Plop, p, seg_b) != 0;
+      const bool stseg = head && kvb_popc(Mst, Pst, p, seg_b) != 0;
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++) {
         const uint64_t sm = __ballot(lkseg && q == k);
-        if (lane == 0) Mlkseg[k][wave] = sm;
+        if (lane == 0) Mlkseg[k][p >> 6] = sm;
       }
-      const uint64_t ss = __ballot(head && structural);
-      if (lane == 0) Mstseg[wave] = ss;
+      const uint64_t ss = __ballot(stseg);
+      if (lane == 0) Mstseg[p >> 6] = ss;
     }
     __syncthreads();
-    bool lock_clash = false;
+    if (wave < 4) kvb_build_pop(Mlkseg[wave], Plkseg[wave]);
+    if (wave == 4) kvb_build_pop(Mstseg, Pstseg);
+    __syncthreads();
+    // ---- pass D: simple bucket runs; their writers and lock ops
+    for (uint32_t j = 0; j < ntile; j++) {
+      const uint32_t p = j * KVB_T + t;
+      const bool valid = p < m;
+      const uint32_t type = k_type(Sk[p]);
+      bool simple = false;
+      if (valid && !force_rounds && nseg <= KVB_T) {
+        const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, p + 1);
+        const int bx = kvb_first(Mbh, Ebh, p + 1);
+        const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m;
+        bool clash = false;
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) lock_clash |= valid && kvb_range_popc(Mlkseg[k], bk_a, bk_b) > 1;
-    bool simple = valid && !force_rounds && kvb_range_popc(Mbad, bk_a, bk_b) == 0 && !lock_clash &&
-                  kvb_range_popc(Mstseg, bk_a, bk_b) <= 1;
-    bool leader = head && simple;
-    if (leader) {
-      const kv_where wh = kv_locate(tb, bucket, H, key);
-      Lead[t].found_link = (wh.found << 31) | wh.link;
-      Lead[t].slot = wh.slot; Lead[t].ver0 = wh.ver; Lead[t].la0 = la0; Lead[t].lb0 = lb0;
-      Carry[t].la = la0; Carry[t].lb = lb0; Carry[t].ver = wh.ver; Carry[t].src = -1; Carry[t].miss = 0;
-      if (WL != DINT_WL_SMALLBANK && structural) {
-        Crow[t].exists = wh.found; Crow[t].ver = wh.ver; Crow[t].toggles = 0; Crow[t].miss = 0; Crow[t].bail = 0; Crow[t].src = -1;
-        Sany = 1;
+        for (uint32_t k = 0; k < 4; k++) clash |= WL != DINT_WL_TATP && kvb_popc(Mlkseg[k], Plkseg[k], bk_a, bk_b) > 1;
+        const uint32_t nst = kvb_popc(Mstseg, Pstseg, bk_a, bk_b);
+        const bool spans = bk_a / KVB_T != (bk_b - 1) / KVB_T;  // a run with an insert / delete stays inside one tile
+        simple = kvb_popc(Mbad, Pbad, bk_a, bk_b) == 0 && !clash && nst <= 1 && !(nst && spans);
       }
-    }
-    {
-      const bool writer = simple && (WL == DINT_WL_STORE ? type == 1 : WL == DINT_WL_TATP ? (type == 12 || type == 13)
-                                                                                         : (type == 4 || type == 5));
-      const uint64_t m1 = __ballot(writer);
+      const uint64_t m0 = __ballot(simple);
+      const uint64_t m1 = __ballot(simple && is_writer(type));
       const uint64_t m2 = __ballot(simple && WL == DINT_WL_TATP && kv_lock_op<WL>(type));
       const uint64_t m3 = __ballot(simple && WL == DINT_WL_TATP && type == 1);
-      if (lane == 0) { Mwr[wave] = m1; Mlk[wave] = m2; Macq[wave] = m3; }
+      if (lane == 0) { Msimple[p >> 6] = m0; Mwr[p >> 6] = m1; Mlk[p >> 6] = m2; Macq[p >> 6] = m3; }
     }
     __syncthreads();
-    // ---- outcomes of the simple segments
-    uint32_t found = 0, link = 0, slot = 0, ver0 = 0;
-    if (simple) {
-      const kvb_lead L = Lead[seg_a];
-      found = L.found_link >> 31; link = L.found_link & 0x7FFFFFFFu; slot = L.slot; ver0 = L.ver0; la0 = L.la0; lb0 = L.lb0;
-    }
-    uint32_t my_code = 0, my_ver = 0, my_get = 0;
-    int my_src = -1;  // SORTED position of the request whose message holds the value this one reads
-    uint32_t fin_ver = ver0, fin_la = la0, fin_lb = lb0, nmiss = 0;
-    int fin_src = -1;
-    if (WL != DINT_WL_SMALLBANK) {
-      if (simple) {
-        my_ver = ver0 + (found ? kvb_range_popc(Mwr, seg_a, t) : 0);
-        my_src = found ? kvb_range_last(Mwr, seg_a, t) : -1;
-        if (WL == DINT_WL_STORE) {
-          my_code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
-          my_get = (type == 0 && found) ? 1 : 0;
-        } else {
-          const int lk = kvb_range_last(Mlk, seg_a, t);
-          const uint32_t lock_seen = lk >= 0 ? (uint32_t)kvb_bit(Macq, (uint32_t)lk) : la0;
-          switch (type) {
-            case 0: my_code = found ? 4 : 6; my_get = found; break;
-            case 1: my_code = lock_seen ? 8 : 7; break;
-            case 2: my_code = 9; break;
-            case 12: my_code = 15; break;
-            default: my_code = 16; break;  // 13 kCommitBck
-          }
+    if (wave == 0) kvb_build_pop(Mwr, Pwr);
+    if (wave == 1) kvb_build_edge(Mwr, Ewr);
+    if (wave == 2) kvb_build_edge(Mlk, Elk);
+    __syncthreads();
+
+    // ---- leaders: one thread per simple key segment loads the bucket's inline header (+ smallbank counters) and
+    // locates the row; every segment of the stretch at once
+    if (t == 0) Sany = 0;
+    __syncthreads();
+    if (t < nseg && nseg <= KVB_T) {
+      const uint32_t a = HeadPos[t];
+      if (kvb_bit(Msimple, a)) {
+        const uint64_t cur = Sk[a];
+        const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk), q = k_q(cur);
+        const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
+        const kv_tab tb = kv->tab[table];
+        const uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
+        kv_hdr H;
+        kv_hdr_copy(H, *(const kv_hdr *)ie);
+        const uint64_t key = ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY);
+        uint32_t la0 = 0, lb0 = 0;
+        if (WL == DINT_WL_SMALLBANK) {
+          const uint2 cc = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);
+          la0 = cc.x; lb0 = cc.y;
         }
-        if (leader) {
-          const uint32_t nw = kvb_range_popc(Mwr, seg_a, seg_b);
-          fin_ver = ver0 + (found ? nw : 0);
-          fin_src = found ? kvb_range_last(Mwr, seg_a, seg_b) : -1;
-          nmiss = found ? 0 : nw;
-          if (WL == DINT_WL_TATP) {
-            const int lk = kvb_range_last(Mlk, seg_a, seg_b);
-            if (lk >= 0) fin_la = (uint32_t)kvb_bit(Macq, (uint32_t)lk);
+        if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
+        const kv_where wh = kv_locate(tb, bucket, H, key);
+        Lead[t].found_link = (wh.found << 31) | wh.link;
+        Lead[t].slot = wh.slot; Lead[t].ver0 = wh.ver; Lead[t].la0 = la0; Lead[t].lb0 = lb0;
+        if (WL == DINT_WL_SMALLBANK) { Carry[t].la = la0; Carry[t].lb = lb0; Carry[t].ver = wh.ver; Carry[t].src = -1; Carry[t].miss = 0; }
+        if (WL != DINT_WL_SMALLBANK) {
+          const int nx = kvb_first(Mhead, Ehead, a + 1);
+          if (kvb_popc(Mst, Pst, a, nx >= 0 ? (uint32_t)nx : m) != 0) {  // the segment inserts / deletes
+            Crow[t].exists = wh.found; Crow[t].ver = wh.ver; Crow[t].toggles = 0; Crow[t].miss = 0; Crow[t].bail = 0; Crow[t].src = -1;
+            Sany = 1;
           }
         }
       }
-      // key segments with an INSERT / DELETE: the row machine is walked in sorted order, wave after wave, with the
-      // state carried through Crow[segment head] (as kv_chunk; rare, so the whole step is skipped when no such
-      // segment exists in the window)
-      uint32_t fin_exists = found;
-      if (Sany) {
+    }
+    __syncthreads();
+
+    // ---- tiles: outcomes and replies of the simple segments, 512 requests at a time.  Nothing a tile reads from
+    // the table is written before the last tile is done, so the tiles' loads and stores stream back to back.
+    const bool walks = WL == DINT_WL_SMALLBANK || Sany;  // workgroup-uniform
+    for (uint32_t j = 0; j < ntile; j++) {
+      const uint32_t lo = j * KVB_T, hi = min(lo + KVB_T, m), p = lo + t;
+      const bool valid = p < m;
+      const uint64_t cur = Sk[p];
+      const uint32_t gk = valid ? ((uint32_t)(cur >> sh_g) << pbits) | bin : 0, idx = valid ? k_idx(cur) : 0;
+      const uint32_t type = k_type(cur), table = valid ? kv_table_of(kv, gk) : 0;
+      const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
+      uint8_t *msg = rep + (size_t)idx * F::MSG;
+      bool simple = valid && kvb_bit(Msimple, p);
+      uint32_t seg_a = 0, seg_b = m;  // my key segment = sorted positions [a, b)
+      if (valid) {
+        seg_a = (uint32_t)kvb_last(Mhead, Ehead, 0, p + 1);
+        const int nx = kvb_first(Mhead, Ehead, p + 1);
+        if (nx >= 0) seg_b = (uint32_t)nx;
+      }
+      const uint32_t si = simple ? kvb_below(Mhead, Phead, p + 1) - 1 : 0;  // my segment's number = its Lead / Carry slot
+      uint32_t found = 0, link = 0, slot = 0, ver0 = 0, la0 = 0;
+      if (simple) {
+        const kvb_lead L = Lead[si];
+        found = L.found_link >> 31; link = L.found_link & 0x7FFFFFFFu; slot = L.slot; ver0 = L.ver0; la0 = L.la0;
+      }
+      uint32_t my_code = 0, my_ver = 0, my_get = 0;
+      int my_src = -1;  // SORTED position of the request whose message holds the value this one reads
+      if (WL != DINT_WL_SMALLBANK) {
+        if (simple) {
+          my_ver = ver0 + (found ? kvb_popc(Mwr, Pwr, seg_a, p) : 0);
+          my_src = found ? kvb_last(Mwr, Ewr, seg_a, p) : -1;
+          if (WL == DINT_WL_STORE) {
+            my_code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
+            my_get = (type == 0 && found) ? 1 : 0;
+          } else {
+            uint32_t lock_seen = la0;
+            if (type == 1) {
+              const uint32_t q = k_q(cur);
+              const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, p + 1);
+              const int bx = kvb_first(Mbh, Ebh, p + 1);
+              const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m;
+              int lk;
+              if (kvb_popc(Mlkseg[q], Plkseg[q], bk_a, bk_b) > 1) {  // other keys of the bucket use my lock byte
+                lk = lock_scan(bk_a, bk_b, q, idx);
+              } else {
+                lk = kvb_last(Mlk, Elk, seg_a, p);
+                if (lk >= 0) lk = (int)kvb_bit(Macq, (uint32_t)lk);
+              }
+              if (lk >= 0) lock_seen = (uint32_t)lk;
+            }
+            switch (type) {
+              case 0: my_code = found ? 4 : 6; my_get = found; break;
+              case 1: my_code = lock_seen ? 8 : 7; break;
+              case 2: my_code = 9; break;
+              case 12: my_code = 15; break;
+              default: my_code = 16; break;  // 13 kCommitBck
+            }
+          }
+        }
+        // key segments with an INSERT / DELETE (their bucket run lies inside the tile): the row machine is walked
+        // in sorted order, wave after wave, with the state carried through Crow[segment] (as kv_chunk; rare, so
+        // the whole step is skipped when the stretch has no such segment)
+        if (walks) {
+          const bool structural = simple && kvb_popc(Mst, Pst, seg_a, seg_b) != 0;
+          if (t < KVB_W) Mbail[t] = 0;
+          __syncthreads();
+          for (uint32_t wv = 0; wv < KVB_W; wv++) {
+            if (wave == wv) {
+              uint64_t todo = __ballot(structural);
+              while (todo) {
+                const int l0 = __ffsll((unsigned long long)todo) - 1;
+                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(seg_a, l0);
+                const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane(si, l0);
+                const uint64_t mem = __ballot(structural && seg_a == a);
+                todo &= ~mem;
+                kv_rowst st = Crow[sa];
+                for (uint64_t mm = mem; mm; mm &= mm - 1) {
+                  const int l = __ffsll((unsigned long long)mm) - 1;
+                  const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
+                  uint32_t get = 0;
+                  const uint32_t ver_seen = st.ver;
+                  const int src_seen = st.src;
+                  const uint32_t code = kv_row_step<WL>(op, (int)(lo + wv * 64 + l), st, get);
+                  if ((int)lane == l) {
+                    if (code) my_code = code;
+                    my_ver = ver_seen; my_src = src_seen; my_get = get;
+                  }
+                }
+                if ((int)lane == l0) Crow[sa] = st;
+              }
+            }
+            __syncthreads();
+          }
+          // a segment whose walk bailed out (insert of an existing row, several toggles) sends its bucket run to the
+          // request-by-request path
+          const bool bhead = valid && kvb_bit(Mhead, p) && structural;
+          uint32_t my_bail = 0;
+          if (bhead) { const kv_rowst st = Crow[si]; my_bail = st.bail | (st.toggles > 1); }
+          const uint64_t bm = __ballot(my_bail != 0);
+          if (lane == 0) Mbail[wave] = bm;
+          __syncthreads();
+          if (simple && (Mbail[0] | Mbail[1] | Mbail[2] | Mbail[3] | Mbail[4] | Mbail[5] | Mbail[6] | Mbail[7])) {
+            const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, p + 1);
+            const int bx = kvb_first(Mbh, Ebh, p + 1);
+            const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m;
+            if (bk_a >= lo && bk_b <= hi && kvb_range_popc(Mbail, bk_a - lo, bk_b - lo) != 0) simple = false;
+          }
+          const uint64_t sm = __ballot(simple);
+          if (lane == 0) Msimple[p >> 6] = sm;
+        }
+      } else {
+        // smallbank: the counters have no closed form.  Walk every simple segment in sorted order, wave after wave,
+        // with the running state {num_ex, num_sh, version, last writer} carried through Carry[segment].
         for (uint32_t wv = 0; wv < KVB_W; wv++) {
           if (wave == wv) {
-            uint64_t todo = __ballot(simple && structural);
-            while (todo) {
+            uint64_t todo = __ballot(simple);
+            while (todo) {  // one iteration per segment present in this wave's 64 lanes
               const int l0 = __ffsll((unsigned long long)todo) - 1;
               const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(seg_a, l0);
-              const uint64_t mem = __ballot(simple && structural && seg_a == a);
+              const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane(si, l0);
+              const uint64_t mem = __ballot(simple && seg_a == a);
               todo &= ~mem;
-              kv_rowst st = Crow[a];
-              for (uint64_t m = mem; m; m &= m - 1) {
-                const int l = __ffsll((unsigned long long)m) - 1;
+              kvb_carry st = Carry[sa];
+              const uint32_t fnd = Lead[sa].found_link >> 31;
+              for (uint64_t mm = mem; mm; mm &= mm - 1) {
+                const int l = __ffsll((unsigned long long)mm) - 1;
                 const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
-                uint32_t get = 0;
+                uint32_t code, get = 0;
+                bool wr = false;
                 const uint32_t ver_seen = st.ver;
                 const int src_seen = st.src;
-                const uint32_t code = kv_row_step<WL>(op, (int)(wv * 64 + l), st, get);
-                if ((int)lane == l) {
-                  if (code) my_code = code;
-                  my_ver = ver_seen; my_src = src_seen; my_get = get;
+                switch (op) {  // la = num_ex, lb = num_sh   smallbank/udp/server_shard.cc:121-173
+                  case 0: if (st.la == 0) { st.lb++; get = fnd; st.miss += !fnd; code = 7; } else code = 8; break;
+                  case 1: if (st.la == 0 && st.lb == 0) { st.la++; get = fnd; st.miss += !fnd; code = 9; } else code = 10; break;
+                  case 2: st.lb--; code = 11; break;
+                  case 3: st.la--; code = 12; break;
+                  case 4: wr = fnd; st.miss += !fnd; code = 13; break;
+                  default: wr = fnd; st.miss += !fnd; code = 14; break;  // 5 kCommitBck
                 }
+                if (wr) { st.ver++; st.src = (int)(lo + wv * 64 + l); }
+                if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
               }
-              if ((int)lane == l0) Crow[a] = st;
+              if ((int)lane == l0) Carry[sa] = st;
             }
           }
           __syncthreads();
         }
-        uint32_t my_bail = 0;
-        if (leader && structural) {
-          const kv_rowst st = Crow[t];
-          fin_exists = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
-          my_bail = st.bail | (st.toggles > 1);
+      }
+      // ---- replies
+      if (simple) {
+        if (my_get) {
+          const kv_tab tb = kv->tab[table];
+          const uint8_t *row = kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS;
+          const uint8_t *from = my_src >= 0 ? rep + (size_t)k_idx(Sk[my_src]) * F::MSG + F::VAL : row;
+          kv_copy_words(msg + F::VAL, from, F::VS);
+          st_u32(msg + F::VER, my_ver);
         }
-        const uint64_t bm = __ballot(head && my_bail);
-        if (lane == 0) Mbail[wave] = bm;
-        __syncthreads();
-        if (valid && kvb_range_popc(Mbail, bk_a, bk_b) != 0) { simple = false; leader = false; }
+        msg[F::TYPE] = (uint8_t)my_code;
       }
-      if (leader && structural) found |= fin_exists << 1;  // bit 1: the row exists after the segment
-    } else {
-      // smallbank: the counters have no closed form.  Walk every simple segment in sorted order, wave after wave,
-      // with the running state {num_ex, num_sh, version, last writer} carried through Carry[segment head].
-      for (uint32_t wv = 0; wv < KVB_W; wv++) {
-        if (wave == wv) {
-          uint64_t todo = __ballot(simple);
-          while (todo) {  // one iteration per segment present in this wave's 64 lanes
-            const int l0 = __ffsll((unsigned long long)todo) - 1;
-            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(seg_a, l0);
-            const uint64_t mem = __ballot(simple && seg_a == a);
-            todo &= ~mem;
-            kvb_carry st = Carry[a];
-            const uint32_t fnd = Lead[a].found_link >> 31;
-            for (uint64_t m = mem; m; m &= m - 1) {
-              const int l = __ffsll((unsigned long long)m) - 1;
-              const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
-              uint32_t code, get = 0;
-              bool wr = false;
-              const uint32_t ver_seen = st.ver;
-              const int src_seen = st.src;
-              switch (op) {  // la = num_ex, lb = num_sh   smallbank/udp/server_shard.cc:121-173
-                case 0: if (st.la == 0) { st.lb++; get = fnd; st.miss += !fnd; code = 7; } else code = 8; break;
-                case 1: if (st.la == 0 && st.lb == 0) { st.la++; get = fnd; st.miss += !fnd; code = 9; } else code = 10; break;
-                case 2: st.lb--; code = 11; break;
-                case 3: st.la--; code = 12; break;
-                case 4: wr = fnd; st.miss += !fnd; code = 13; break;
-                default: wr = fnd; st.miss += !fnd; code = 14; break;  // 5 kCommitBck
-              }
-              if (wr) { st.ver++; st.src = (int)(wv * 64 + l); }
-              if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
-            }
-            if ((int)lane == l0) Carry[a] = st;
-          }
-        }
-        __syncthreads();
-      }
-      if (leader) {
-        const kvb_carry st = Carry[t];
-        fin_la = st.la; fin_lb = st.lb; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
-      }
-    }
-    // ---- replies of the simple segments
-    uint8_t *row = nullptr;
-    if (simple) {
-      row = kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS;
-      if (my_get) {
-        const uint8_t *from = my_src >= 0 ? rep + (size_t)(Srec[Sp[my_src]] & 0xFFFFFu) * F::MSG + F::VAL : row;
-        kv_copy_words(msg + F::VAL, from, F::VS);
-        st_u32(msg + F::VER, my_ver);
-      }
-      msg[F::TYPE] = (uint8_t)my_code;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();  // every table read of the window precedes the write-backs
-    if (leader) {
-      const uint32_t found0 = found & 1u, exists1 = (WL != DINT_WL_SMALLBANK && structural) ? (found >> 1) & 1u : found0;
-      const uint8_t *fin_val = fin_src >= 0 ? rep + (size_t)(Srec[Sp[fin_src]] & 0xFFFFFu) * F::MSG + F::VAL : nullptr;
-      if (found0 && exists1) {          // the row stays where it is: value / version of the last writer
-        if (fin_src >= 0) {
-          kv_copy_words(row, fin_val, F::VS);
-          kv_entry_hdr(tb, bucket, link)->ver[slot] = fin_ver;
+    __syncthreads();  // every table read of the stretch precedes the write-backs
+
+    // ---- write-back: one thread per simple key segment
+    if (t < nseg && nseg <= KVB_T) {
+      const uint32_t a = HeadPos[t];
+      if (kvb_bit(Msimple, a)) {
+        const uint64_t cur = Sk[a];
+        const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk), q = k_q(cur);
+        const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
+        const kv_tab tb = kv->tab[table];
+        uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
+        const int nx = kvb_first(Mhead, Ehead, a + 1);
+        const uint32_t seg_b = nx >= 0 ? (uint32_t)nx : m;
+        const kvb_lead L = Lead[t];
+        const uint32_t found0 = L.found_link >> 31, link = L.found_link & 0x7FFFFFFFu, slot = L.slot, la0 = L.la0, lb0 = L.lb0;
+        uint32_t exists1 = found0, fin_ver = L.ver0, fin_la = la0, fin_lb = lb0, nmiss = 0;
+        int fin_src = -1;
+        if (WL == DINT_WL_SMALLBANK) {
+          const kvb_carry st = Carry[t];
+          fin_la = st.la; fin_lb = st.lb; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
+        } else if (kvb_popc(Mst, Pst, a, seg_b) != 0) {
+          const kv_rowst st = Crow[t];
+          exists1 = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
+        } else {
+          const uint32_t nw = kvb_popc(Mwr, Pwr, a, seg_b);
+          fin_ver = L.ver0 + (found0 ? nw : 0);
+          fin_src = found0 ? kvb_last(Mwr, Ewr, a, seg_b) : -1;
+          nmiss = found0 ? 0 : nw;
         }
-      } else if (found0 != exists1) {   // one INSERT or one DELETE took effect: apply it to the chain once
-        const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key, (uint8_t *)fin_val,
-                                              fin_ver, blockIdx.x);
-        if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
+        if (WL == DINT_WL_TATP && kvb_popc(Mlop, Plop, a, seg_b) != 0) {  // what the last lock op on my lock byte leaves
+          const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, a + 1);
+          const int bx = kvb_first(Mbh, Ebh, a + 1);
+          const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m;
+          int lk;
+          if (kvb_popc(Mlkseg[q], Plkseg[q], bk_a, bk_b) > 1) {  // shared with other keys of the bucket: every one of
+            lk = lock_scan(bk_a, bk_b, q, 0xFFFFFFFFu);          // their segments stores the same byte
+          } else {
+            lk = kvb_last(Mlk, Elk, a, seg_b);
+            if (lk >= 0) lk = (int)kvb_bit(Macq, (uint32_t)lk);
+          }
+          if (lk >= 0) fin_la = (uint32_t)lk;
+        }
+        const uint8_t *fin_val = fin_src >= 0 ? rep + (size_t)k_idx(Sk[fin_src]) * F::MSG + F::VAL : nullptr;
+        if (found0 && exists1) {          // the row stays where it is: value / version of the last writer
+          if (fin_src >= 0) {
+            kv_copy_words(kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS, fin_val, F::VS);
+            kv_entry_hdr(tb, bucket, link)->ver[slot] = fin_ver;
+          }
+        } else if (found0 != exists1) {   // one INSERT or one DELETE took effect: apply it to the chain once
+          kv_hdr H;
+          kv_hdr_copy(H, *(const kv_hdr *)ie);
+          const uint64_t key = ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY);
+          const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key, (uint8_t *)fin_val,
+                                                fin_ver, blockIdx.x);
+          if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
+        }
+        if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
+        if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = make_uint2(fin_la, fin_lb);
+        if (nmiss) atomicAdd(&stats->missing_keys, (unsigned long long)nmiss);
       }
-      if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
-      if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = make_uint2(fin_la, fin_lb);
-      if (nmiss) atomicAdd(&stats->missing_keys, (unsigned long long)nmiss);
     }
-    // ---- every other bucket run: request by request.  Position inside the run = number of its requests that
-    // come earlier in request order (the run is sorted by key first); the k-th request executes in round k.
-    const bool rounds = valid && !simple;
-    uint32_t pos = 0;
-    if (rounds)
-      for (uint32_t m = bk_a; m < bk_b; m++) pos += (Srec[Sp[m]] & 0xFFFFFu) < idx;
-    uint32_t mylen = rounds && bhead ? bk_b - bk_a : 0, tot;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+
+    // ---- every other bucket run: request by request.  Position inside the run = number of its requests that come
+    // earlier in request order (the run is sorted by key first); the k-th request executes in round k.
+    uint16_t *Rpos = (uint16_t *)Lead;  // by sorted position; Lead is free now
+    uint32_t mylen = 0, tot;
+    for (uint32_t j = 0; j < ntile; j++) {
+      const uint32_t p = j * KVB_T + t;
+      uint32_t pos = 0xFFFFu;
+      if (p < m && !kvb_bit(Msimple, p)) {
+        const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, p + 1);
+        const int bx = kvb_first(Mbh, Ebh, p + 1);
+        const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m, myidx = k_idx(Sk[p]);
+        pos = 0;
+        for (uint32_t k = bk_a; k < bk_b; k++) pos += k_idx(Sk[k]) < myidx;
+        if (p == bk_a) mylen = max(mylen, bk_b - bk_a);
+      }
+      Rpos[p] = (uint16_t)pos;
+    }
     {  // longest non-simple run (block max)
-      uint32_t m = mylen;
-      for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d, 64));
-      if (lane == 0) Sred[wave] = m;
+      uint32_t mx = mylen;
+      for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
+      if (lane == 0) Sred[wave] = mx;
       __syncthreads();
       tot = 0;
       for (uint32_t w = 0; w < KVB_W; w++) tot = max(tot, Sred[w]);
     }
     if (tr && t == 0) { tr[12] += tot; tr[13] += 1; }
     for (uint32_t r = 0; r < tot; r++) {
-      if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats);
+      for (uint32_t j = 0; j < ntile; j++) {
+        const uint32_t p = j * KVB_T + t;
+        if (p < m && Rpos[p] == r) {
+          const uint64_t cur = Sk[p];
+          const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk);
+          kv_do_request<WL>(rep + (size_t)k_idx(cur) * F::MSG, k_type(cur), table, k_q(cur),
+                            (uint64_t)(gk - kv->gk_base[table]), kv, stats);
+        }
+      }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __syncthreads();
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();  // the next window sees this window's stores; LDS arrays are free again
+    __syncthreads();  // the next stretch sees this stretch's stores; LDS arrays are free again
   }
   if (tr && t == 0) tr[9] = __builtin_amdgcn_s_memrealtime();
   }

@@ -425,3 +425,44 @@ def test_one_pass_of_up_to_a_million_requests(wl, n, touch):
         assert eng.submit(req).tobytes() == o.replay(req).tobytes()
         _sb_state(eng, o)
     assert eng.stats()["batches"] == 1 and eng.stats()["pool_exhausted"] == 0
+
+
+@pytest.mark.parametrize("n,hot", [(3000, False), (120_000, True)])
+def test_tatp_keys_sharing_a_lock_byte(n, hot):
+    """Subscribers whose keys fall into one bucket and one lock quadrant share a lock byte (tatp/udp/tatp.h:12-14,
+    lock_hash % hash_size == bucket).  ACQUIRE / ABORT / COMMIT_PRIM streams on such keys interleave on that byte;
+    the engine resolves them without serialising the bucket (the byte is a last-writer-wins register)."""
+    import struct
+
+    n_sub = 3000
+    o = orc.TatpOracle(n_sub, populate_n=n_sub)
+    hs = o.hash_size(0)
+    groups = {}
+    for s in range(n_sub):  # subscriber table: key = s_id
+        h = orc.fasthash64(struct.pack("<Q", s))
+        groups.setdefault((h % hs, (h % (4 * hs)) // hs), []).append(s)
+    shared = [g for g in groups.values() if len(g) >= 2]
+    assert len(shared) >= 20
+    rng = np.random.default_rng(7)
+    T = wire.Tatp
+    keys = np.array([s for g in shared[:6] for s in g[:3]], dtype=np.uint64)
+    if hot:   # nearly everything on the first group: its bin holds ~10^5 records
+        pk = np.r_[np.full(len(shared[0][:3]), 0.9 / len(shared[0][:3])), np.full(len(keys) - len(shared[0][:3]), 0.1 / (len(keys) - len(shared[0][:3])))]
+    else:
+        pk = np.full(len(keys), 1.0 / len(keys))
+    req = np.zeros(n, wire.TATP_MSG)
+    req["key"] = rng.choice(keys, n, p=pk)
+    req["table"] = 0
+    req["type"] = rng.choice([T.READ, T.ACQUIRE_LOCK, T.ABORT, T.COMMIT_PRIM, T.COMMIT_BCK], n, p=[0.3, 0.35, 0.15, 0.12, 0.08])
+    req["val"] = rng.integers(0, 256, (n, 40), dtype=np.uint8)
+    req["ver"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype("<u4")
+    for flags in (0, 1):
+        eng = _engine(W.TATP, n_rows=n_sub, flags=flags)
+        eng.populate(n_sub)
+        oo = orc.TatpOracle(n_sub, populate_n=n_sub)
+        want = oo.replay(req)
+        got = eng.submit(req)
+        assert got.tobytes() == want.tobytes()
+        assert (want["type"] == T.REJECT_LOCK).sum() > n // 20 and (want["type"] == T.GRANT_LOCK).sum() > n // 50
+        assert _same_rows(eng.dump_rows(0), oo.dump(0))
+        _tatp_locks(eng, oo)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Big-bin statistics of tatp passes (DINT_KV_TRACE=1): per pass, how many bins went to k_kv_resolve_big, how many
+records they hold, and how long the slowest one took.  usage: exp_big.py [clients] [theta]"""
+import os
+import sys
+import time
+
+os.environ["DINT_KV_TRACE"] = "1"
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dint_amd import wire  # noqa: E402
+from dint_amd.driver import Driver  # noqa: E402
+from dint_amd.replay import Replay, ShardGroup, record  # noqa: E402
+
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
+theta = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
+n_sub, E = 1_000_000, 16
+grp = ShardGroup(wire.Workload.TATP, n_sub)
+grp.sync(); grp.snapshot()
+d = Driver(wire.Workload.TATP, C, n_sub, zipf_theta=theta if theta > 0 else None)
+trace, done = record(d, grp, E)
+grp.sync(); grp.restore()
+rp = Replay(trace, grp.msg)
+torch.cuda.synchronize()
+eng = grp.engines[0]
+print("per pass: n, wall_us, n_big, records in big bins, max c, slowest big: us / c / windows / rounds, sum of big us, top-5 c")
+for e in range(E):
+    grp.sync(); t0 = time.perf_counter()
+    eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
+    grp.sync(); wall = (time.perf_counter() - t0) * 1e6
+    tt = eng.kv_trace().astype(np.int64)
+    bg = tt[:, 14] > 64
+    if bg.any():
+        du = (tt[bg, 9] - tt[bg, 8]) / 100
+        i = int(np.argmax(du))
+        b = tt[bg]
+        print("  ", rp.counts[e][0], round(wall), int(bg.sum()), int(b[:, 14].sum()), int(b[:, 14].max()),
+              round(float(du.max()), 1), int(b[i, 14]), int(b[i, 13]), int(b[i, 12]), round(float(du.sum())),
+              sorted(b[:, 14].tolist())[-5:])
+    tt[:, 14] = 0
+grp.restore()
+eng.timing_enable(True)
+for e in range(E):
+    eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
+grp.sync()
+print({k: round(v["avg_us"], 2) for k, v in eng.timing_read().items()})
+# timeline of the last traced pass (10 ns ticks of s_memrealtime): big bins and small waves relative to the first start
+grp.restore(); grp.sync()
+for e in range(E):
+    eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
+    grp.sync()
+tt = eng.kv_trace().astype(np.int64)
+small = (tt[:, 15] > 0) & (tt[:, 15] <= 64) & (tt[:, 11] > 0)
+s0 = tt[small, 10].min()
+bg = (tt[:, 14] > 64) & (tt[:, 8] >= s0 - 100000)
+t0 = min(s0, tt[bg, 8].min()) if bg.any() else s0
+print("small waves: start p50 %.1f us p99 %.1f | end p50 %.1f p99 %.1f max %.1f" % tuple(
+    x / 100 for x in (np.median(tt[small, 10] - t0), np.percentile(tt[small, 10] - t0, 99), np.median(tt[small, 11] - t0),
+                      np.percentile(tt[small, 11] - t0, 99), (tt[small, 11] - t0).max())))
+rows = sorted(((int(r[14]), round((r[8] - t0) / 100, 1), round((r[9] - t0) / 100, 1), int(r[13]), int(r[12])) for r in tt[bg]), key=lambda r: -r[2])
+print("big bins (c, start_us, end_us, stretches, rounds), latest end first:", rows[:12])
