@@ -503,8 +503,9 @@ int dint_kv_trace_read(dint_engine_t *e, uint64_t *out, uint64_t cap) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
-  const uint64_t words = std::min<uint64_t>(cap, (uint64_t)DINT_KV_PMAX * 16);
+  const uint64_t words = std::min<uint64_t>(cap, (uint64_t)DINT_KV_TRACE_WORDS);
   HIP_TRY(hipMemcpy(out, e->kv.d_trace, words * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(e->kv.d_trace, 0, DINT_KV_TRACE_WORDS * 8));  // the next read sees one launch only
   return (int)DINT_KV_PMAX;
 }
 

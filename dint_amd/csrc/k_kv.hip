@@ -790,8 +790,8 @@ __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const k
   kv_stamp(tr, 0);
   const uint64_t r0 = bins[(size_t)bin * DINT_KV_BINCAP + lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
-  if (tr && lane == 0 && c) { tr[15] = c; tr[14] = 0; }
   if (c == 0 || c > DINT_KV_BINCAP) return;  // larger bins are on the big-bin list
+  if (tr && lane == 0) { tr[15] = c; tr[14] = 0; }
   if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
   kv_stamp(tr, 1);
   // Sort the records by (bucket group, key hash, idx) in registers: groups commute, so any order that keeps each
@@ -833,7 +833,7 @@ __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const k
 // stretch precedes every request of the next one) and the stretches run one after the other.
 #define KVB_T 512u
 #define KVB_W (KVB_T / 64u)
-#define KVB_GRID 128u              // workgroups that walk the big-bin list
+#define KVB_GRID 512u              // workgroups that walk the big-bin list (most exit at once)
 #define KVB_NMAX 4096u             // requests resolved together (one stretch of a bin)
 #define KVB_NW (KVB_NMAX / 64u)    // mask words of a stretch = lanes of one wave
 #define KVB_NBK 2048u              // request-index buckets that cut a longer bin into stretches
@@ -1006,22 +1006,47 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     const uint32_t m = Swn;
     __syncthreads();  // Swn is reset at the top of the next stretch
     if (m == 0) continue;  // workgroup-uniform
-    uint32_t N = KVB_T;
+    if (tr && t == 0 && win == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+    uint32_t N = 64;
     while (N < m) N <<= 1;
-    for (uint32_t k = m + t; k < N; k += KVB_T) Sk[k] = ~0ull;  // empty slots sort last
+    for (uint32_t k = m + t; k < max(N, KVB_T); k += KVB_T) Sk[k] = ~0ull;  // empty slots sort last
     __syncthreads();
-    // ---- sort: bitonic network over N keys in LDS (N / 2 compare-exchanges per step)
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        for (uint32_t i = t; i < N / 2; i += KVB_T) {
-          const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1)), b = a | j;
-          const uint64_t x = Sk[a], y = Sk[b];
-          if ((x > y) == ((a & k) == 0)) { Sk[a] = y; Sk[b] = x; }
+    if (N <= KVB_T) {
+      // ---- sort, one key per thread: bitonic network, in-wave steps by shuffle, the wide ones through LDS
+      uint64_t v = Sk[t];
+      for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          uint64_t o;
+          if (j < 64) {
+            const uint32_t lo = __shfl_xor((uint32_t)v, (int)j, 64), hi = __shfl_xor((uint32_t)(v >> 32), (int)j, 64);
+            o = ((uint64_t)hi << 32) | lo;
+          } else {
+            Sk[t] = v;
+            __syncthreads();
+            o = Sk[t ^ j];
+            __syncthreads();
+          }
+          const bool up = (t & k) == 0, low = (t & j) == 0;
+          v = (low == up) ? (v < o ? v : o) : (v < o ? o : v);
         }
-        __syncthreads();
+      }
+      Sk[t] = v;
+      __syncthreads();
+    } else {
+      // ---- sort: bitonic network over N keys in LDS (N / 2 compare-exchanges per step)
+      for (uint32_t k = 2; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          for (uint32_t i = t; i < N / 2; i += KVB_T) {
+            const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1)), b = a | j;
+            const uint64_t x = Sk[a], y = Sk[b];
+            if ((x > y) == ((a & k) == 0)) { Sk[a] = y; Sk[b] = x; }
+          }
+          __syncthreads();
+        }
       }
     }
     const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
+    if (tr && t == 0 && win == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- pass A: segment heads (key hash changes), bucket-run heads (group changes), op classes
     for (uint32_t j = 0; j < ntile; j++) {
@@ -1047,6 +1072,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     if (wave == 4) kvb_build_pop(Mhead, Phead);
     __syncthreads();
     const uint32_t nseg = Phead.below[KVB_NW];
+    if (tr && t == 0 && win == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
     // ---- pass B: a segment must be one key (9 hash bits can collide) and carry only ops the closed form knows
     for (uint32_t j = 0; j < ntile; j++) {
       const uint32_t p = j * KVB_T + t;
@@ -1062,6 +1088,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     __syncthreads();
     if (wave == 0) kvb_build_pop(Mbad, Pbad);
     __syncthreads();
+    if (tr && t == 0 && win == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
     // ---- pass C: key segments that carry lock ops, per lock quadrant (two on one lock word make the bucket run
     // non-simple); key segments that insert / delete
     for (uint32_t j = 0; j < ntile; j++) {
@@ -1114,6 +1141,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     if (wave == 1) kvb_build_edge(Mwr, Ewr);
     if (wave == 2) kvb_build_edge(Mlk, Elk);
     __syncthreads();
+    if (tr && t == 0 && win == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
 
     // ---- leaders: one thread per simple key segment loads the bucket's inline header (+ smallbank counters) and
     // locates the row; every segment of the stretch at once
@@ -1154,6 +1182,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     // ---- tiles: outcomes and replies of the simple segments, 512 requests at a time.  Nothing a tile reads from
     // the table is written before the last tile is done, so the tiles' loads and stores stream back to back.
     const bool walks = WL == DINT_WL_SMALLBANK || Sany;  // workgroup-uniform
+    if (tr && t == 0 && win == 0) tr[5] = __builtin_amdgcn_s_memrealtime();
     for (uint32_t j = 0; j < ntile; j++) {
       const uint32_t lo = j * KVB_T, hi = min(lo + KVB_T, m), p = lo + t;
       const bool valid = p < m;
@@ -1312,6 +1341,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();  // every table read of the stretch precedes the write-backs
+    if (tr && t == 0 && win == 0) tr[6] = __builtin_amdgcn_s_memrealtime();
 
     // ---- write-back: one thread per simple key segment
     if (t < nseg && nseg <= KVB_T) {
@@ -1378,6 +1408,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     // ---- every other bucket run: request by request.  Position inside the run = number of its requests that come
     // earlier in request order (the run is sorted by key first); the k-th request executes in round k.
     uint16_t *Rpos = (uint16_t *)Lead;  // by sorted position; Lead is free now
+    if (tr && t == 0 && win == 0) tr[7] = __builtin_amdgcn_s_memrealtime();
     uint32_t mylen = 0, tot;
     for (uint32_t j = 0; j < ntile; j++) {
       const uint32_t p = j * KVB_T + t;
@@ -1433,11 +1464,18 @@ k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict_
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
+  // tracing: per workgroup {first wave in, last wave out} after the per-bin rows (10 ns ticks)
+  unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 2 * blockIdx.x : nullptr;
+  if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
   if (blockIdx.x < KVB_GRID) {
     kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_rounds, trace);
   } else {
     const uint32_t bin = (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
     if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_rounds, trace);
+  }
+  if (wg && (threadIdx.x & 63) == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    atomicMax(&wg[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
 }
 
@@ -1552,8 +1590,8 @@ int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard s
     gk += tb.n_local;
   }
   if (getenv("DINT_KV_TRACE")) {
-    if (hipMalloc((void **)&kv->d_trace, (size_t)DINT_KV_PMAX * 16 * 8) != hipSuccess) return DINT_ENOMEM;
-    hipMemset(kv->d_trace, 0, (size_t)DINT_KV_PMAX * 16 * 8);
+    if (hipMalloc((void **)&kv->d_trace, (size_t)DINT_KV_TRACE_WORDS * 8) != hipSuccess) return DINT_ENOMEM;
+    hipMemset(kv->d_trace, 0, (size_t)DINT_KV_TRACE_WORDS * 8);
   }
   if (hipMalloc((void **)&kv->d_dev, sizeof(kv_dev)) != hipSuccess) return DINT_ENOMEM;
   if (hipMemcpy(kv->d_dev, &kv->h, sizeof(kv_dev), hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;

@@ -114,11 +114,13 @@ class Engine:
     def timing_enable(self, on: bool = True):
         _lib.check(self._L.dint_timing_enable(self._h, int(on)))
 
-    def kv_trace(self) -> np.ndarray:
-        """[2048, 16] u64 per-wave timeline of the last resolve launch (needs DINT_KV_TRACE=1)."""
-        out = np.zeros((2048, 16), "<u8")
+    def kv_trace(self, workgroups: bool = False):
+        """DINT_KV_TRACE=1: [32768, 16] u64 per-bin timeline of the resolve launches since the last read; with
+        workgroups=True also [8192, 2] {first wave in, last wave out} per workgroup (10 ns ticks)."""
+        out = np.zeros(32768 * 16 + 2 * 8192, "<u8")
         _lib.check(self._L.dint_kv_trace_read(self._h, out.ctypes.data, out.size))
-        return out
+        bins = out[:32768 * 16].reshape(32768, 16)
+        return (bins, out[32768 * 16:].reshape(8192, 2)) if workgroups else bins
 
     def timing_read(self) -> dict:
         names = (C.c_char_p * 8)(); us = (C.c_double * 8)(); cnt = (C.c_uint64 * 8)()

@@ -33,13 +33,17 @@ for e in range(E):
     tt = eng.kv_trace().astype(np.int64)
     bg = tt[:, 14] > 64
     if bg.any():
+        sm = (tt[:, 15] > 0) & (tt[:, 11] > 0)
+        t0 = min(tt[sm, 10].min(), tt[bg, 8].min())
+        print("     timeline us: small end p50 %.0f max %.0f | big start max %.0f end max %.0f" % (
+            np.median(tt[sm, 11] - t0) / 100, (tt[sm, 11] - t0).max() / 100, (tt[bg, 8] - t0).max() / 100, (tt[bg, 9] - t0).max() / 100))
         du = (tt[bg, 9] - tt[bg, 8]) / 100
         i = int(np.argmax(du))
         b = tt[bg]
         print("  ", rp.counts[e][0], round(wall), int(bg.sum()), int(b[:, 14].sum()), int(b[:, 14].max()),
               round(float(du.max()), 1), int(b[i, 14]), int(b[i, 13]), int(b[i, 12]), round(float(du.sum())),
-              sorted(b[:, 14].tolist())[-5:])
-    tt[:, 14] = 0
+              sorted(b[:, 14].tolist())[-5:], "bins with rounds (c, rounds, us):",
+              [(int(r[14]), int(r[12]), round((r[9] - r[8]) / 100, 1)) for r in b if r[12] > 0][:6])
 grp.restore()
 eng.timing_enable(True)
 for e in range(E):
@@ -49,9 +53,21 @@ print({k: round(v["avg_us"], 2) for k, v in eng.timing_read().items()})
 # timeline of the last traced pass (10 ns ticks of s_memrealtime): big bins and small waves relative to the first start
 grp.restore(); grp.sync()
 for e in range(E):
+    if e == E - 1:
+        eng.kv_trace()
     eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
     grp.sync()
-tt = eng.kv_trace().astype(np.int64)
+tt, wg = eng.kv_trace(workgroups=True)
+tt, wg = tt.astype(np.int64), wg.astype(np.int64)
+live = wg[:, 0] > 0
+w0 = wg[live, 0].min()
+dur = (wg[live, 1] - wg[live, 0]) / 100
+print("workgroups: %d, start p50 %.1f max %.1f us, end p50 %.1f p99 %.1f max %.1f us" % (
+    live.sum(), np.median(wg[live, 0] - w0) / 100, (wg[live, 0] - w0).max() / 100, np.median(wg[live, 1] - w0) / 100,
+    np.percentile(wg[live, 1] - w0, 99) / 100, (wg[live, 1] - w0).max() / 100))
+idx = np.nonzero(live)[0]
+o = np.argsort(wg[live, 1])[-10:]
+print("last workgroups out (block, start_us, end_us):", [(int(idx[i]), round((wg[idx[i], 0] - w0) / 100, 1), round((wg[idx[i], 1] - w0) / 100, 1)) for i in o])
 small = (tt[:, 15] > 0) & (tt[:, 15] <= 64) & (tt[:, 11] > 0)
 s0 = tt[small, 10].min()
 bg = (tt[:, 14] > 64) & (tt[:, 8] >= s0 - 100000)
@@ -61,3 +77,8 @@ print("small waves: start p50 %.1f us p99 %.1f | end p50 %.1f p99 %.1f max %.1f"
                       np.percentile(tt[small, 11] - t0, 99), (tt[small, 11] - t0).max())))
 rows = sorted(((int(r[14]), round((r[8] - t0) / 100, 1), round((r[9] - t0) / 100, 1), int(r[13]), int(r[12])) for r in tt[bg]), key=lambda r: -r[2])
 print("big bins (c, start_us, end_us, stretches, rounds), latest end first:", rows[:12])
+
+names = ["gather", "sort", "A", "B", "C+D", "leaders", "tiles", "wb", "rounds+end"]
+for r in sorted(tt[bg], key=lambda r: -r[14])[:3] + sorted(tt[bg], key=lambda r: r[14])[:2]:
+    st = [r[8]] + [r[k] for k in range(8)] + [r[9]]
+    print("  c=%d first-stretch phases us:" % r[14], {names[i]: round((st[i + 1] - st[i]) / 100, 1) for i in range(9)})
