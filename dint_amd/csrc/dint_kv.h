@@ -8,7 +8,7 @@
 
 #define DINT_KV_MAX_TABLES 5
 #define DINT_KV_CTL_BYTES (64 + 16 * KV_NLISTS)  // per table: pool_top, free_head[], pend_head[]
-#define DINT_KV_TRACE_WORDS ((size_t)DINT_KV_PMAX * 16 + 2 * 8192)  // per bin 16 words, then per workgroup 2
+#define DINT_KV_TRACE_WORDS ((size_t)DINT_KV_PMAX * 16 + 16 * 8192)  // per bin 16 words, then per workgroup 16
 #define DINT_KV_LOAD_OP 0xF0u  // internal request type: insert a row with the version carried in msg.ver
 
 // everything the kernels need about the tables; lives in device memory (d_dev) and in a host mirror

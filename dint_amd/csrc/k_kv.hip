@@ -897,6 +897,59 @@ __device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, 
   return cnt;
 }
 
+// Bitonic sort of KVB_T * R keys held R per thread (thread t owns positions R*t .. R*t + R - 1): the steps with a
+// partner inside the thread run in registers, those inside the wave by shuffle, and only the few with a partner in
+// another wave go through LDS (the key array itself is the staging area -- every key is in a register by then --
+// laid out [r][t] so the exchange is conflict-free).
+template <int R>
+__device__ __attribute__((noinline)) static void kvb_sort_blocked(uint64_t *Sk) {
+  uint64_t *X = Sk;
+  const uint32_t t = threadIdx.x;
+  uint64_t v[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) v[r] = Sk[R * t + r];
+  auto cmpx = [](uint64_t &a, uint64_t &b, bool up) {  // up: a <= b afterwards
+    const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = up ? lo : hi; b = up ? hi : lo;
+  };
+  for (uint32_t k = 2; k <= KVB_T * R; k <<= 1) {
+    for (uint32_t j = k >> 1; j >= (uint32_t)R; j >>= 1) {  // partner in thread t ^ (j / R), same register
+      const uint32_t tj = j / R;
+      const bool low = (t & tj) == 0;
+      if (tj >= 64) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++) X[r * KVB_T + t] = v[r];
+        __syncthreads();
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        uint64_t o;
+        if (tj < 64) {
+          const uint32_t lo = __shfl_xor((uint32_t)v[r], (int)tj, 64), hi = __shfl_xor((uint32_t)(v[r] >> 32), (int)tj, 64);
+          o = ((uint64_t)hi << 32) | lo;
+        } else {
+          o = X[r * KVB_T + (t ^ tj)];
+        }
+        const bool up = ((R * t + r) & k) == 0;
+        v[r] = (low == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+      }
+    }
+#pragma unroll
+    for (int jj = R / 2; jj > 0; jj >>= 1) {  // partner in the same thread
+      if ((uint32_t)jj < k) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if ((r & jj) == 0) cmpx(v[r], v[r | jj], ((R * t + r) & k) == 0);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; r++) Sk[R * t + r] = v[r];
+  __syncthreads();
+}
+
 template <int WL>
 __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *kv, uint32_t first,
                                           uint32_t stride, uint32_t *__restrict__ bin_cnt,
@@ -908,7 +961,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   __shared__ uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
   __shared__ uint16_t Bwin[KVB_NBK];          // stretch each idx bucket belongs to
   __shared__ uint64_t Mhead[KVB_NW], Mbh[KVB_NW], Mbad[KVB_NW], Mlop[KVB_NW], Mst[KVB_NW], Mlkseg[4][KVB_NW],
-      Mstseg[KVB_NW], Msimple[KVB_NW], Mwr[KVB_NW], Mlk[KVB_NW], Macq[KVB_NW];
+      Mstseg[KVB_NW], Mrs[KVB_NW], Msimple[KVB_NW], Mwr[KVB_NW], Mlk[KVB_NW], Macq[KVB_NW];
   __shared__ kvb_pop Pbad, Plop, Pst, Plkseg[4], Pstseg, Pwr;
   __shared__ kvb_edge Ehead, Ebh, Ewr, Elk;
   __shared__ uint64_t Mbail[KVB_W];           // tile-local
@@ -994,19 +1047,30 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     if (t == 0) Swn = 0;
     __syncthreads();
     // ---- gather the stretch (any order) as sort keys
-    for (uint32_t k = t; k < c; k += KVB_T) {
-      const uint64_t r = rec_at(k);
-      const uint32_t idx = kv_rec_idx(r, pbits);
-      if (c <= KVB_NMAX || Bwin[idx >> bs] == win) {
-        const uint32_t pay = kv_rec_pay(r);
-        Sk[atomicAdd(&Swn, 1u)] = ((r >> sh_g) << sh_g) | ((uint64_t)pay_kh(pay) << sh_k) | ((uint64_t)idx << 7) | (pay & 0x7Fu);
+    auto sort_key = [&](uint64_t r) -> uint64_t {
+      const uint32_t pay = kv_rec_pay(r);
+      return ((r >> sh_g) << sh_g) | ((uint64_t)pay_kh(pay) << sh_k) | ((uint64_t)kv_rec_idx(r, pbits) << 7) | (pay & 0x7Fu);
+    };
+    if (c <= KVB_NMAX) {  // the whole bin
+      for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = sort_key(rec_at(k));
+      if (t == 0) Swn = c;
+    } else {
+      for (uint32_t k0 = 0; k0 < c; k0 += KVB_T) {  // one slot reservation per wave and step
+        const uint32_t k = k0 + t;
+        const uint64_t r = k < c ? rec_at(k) : 0;
+        const bool in = k < c && Bwin[kv_rec_idx(r, pbits) >> bs] == win;
+        const uint64_t im = __ballot(in);
+        uint32_t base = 0;
+        if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (in) Sk[base + (uint32_t)__popcll(im & lanemask_lt())] = sort_key(r);
       }
     }
     __syncthreads();
     const uint32_t m = Swn;
     __syncthreads();  // Swn is reset at the top of the next stretch
     if (m == 0) continue;  // workgroup-uniform
-    if (tr && t == 0 && win == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     uint32_t N = 64;
     while (N < m) N <<= 1;
     for (uint32_t k = m + t; k < max(N, KVB_T); k += KVB_T) Sk[k] = ~0ull;  // empty slots sort last
@@ -1032,21 +1096,15 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       }
       Sk[t] = v;
       __syncthreads();
+    } else if (N == 2 * KVB_T) {
+      kvb_sort_blocked<2>(Sk);
+    } else if (N == 4 * KVB_T) {
+      kvb_sort_blocked<4>(Sk);
     } else {
-      // ---- sort: bitonic network over N keys in LDS (N / 2 compare-exchanges per step)
-      for (uint32_t k = 2; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-          for (uint32_t i = t; i < N / 2; i += KVB_T) {
-            const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1)), b = a | j;
-            const uint64_t x = Sk[a], y = Sk[b];
-            if ((x > y) == ((a & k) == 0)) { Sk[a] = y; Sk[b] = x; }
-          }
-          __syncthreads();
-        }
-      }
+      kvb_sort_blocked<8>(Sk);
     }
     const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
-    if (tr && t == 0 && win == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 
     // ---- pass A: segment heads (key hash changes), bucket-run heads (group changes), op classes
     for (uint32_t j = 0; j < ntile; j++) {
@@ -1061,8 +1119,10 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       if (lane == 0) { Mhead[p >> 6] = m1; Mbh[p >> 6] = m2; Mlop[p >> 6] = m3; Mst[p >> 6] = m4; }
     }
     for (uint32_t w = ntile * KVB_W + t; w < KVB_NW; w += KVB_T) {
-      Mhead[w] = 0; Mbh[w] = 0; Mlop[w] = 0; Mst[w] = 0; Mbad[w] = 0; Mstseg[w] = 0; Msimple[w] = 0; Mwr[w] = 0; Mlk[w] = 0; Macq[w] = 0;
-      Mlkseg[0][w] = 0; Mlkseg[1][w] = 0; Mlkseg[2][w] = 0; Mlkseg[3][w] = 0;
+      Mhead[w] = 0; Mbh[w] = 0; Mlop[w] = 0; Mst[w] = 0; Mbad[w] = 0; Msimple[w] = 0; Mwr[w] = 0; Mlk[w] = 0; Macq[w] = 0;
+    }
+    for (uint32_t w = t; w < KVB_NW; w += KVB_T) {  // set bit by bit below
+      Mstseg[w] = 0; Mrs[w] = 0; Mlkseg[0][w] = 0; Mlkseg[1][w] = 0; Mlkseg[2][w] = 0; Mlkseg[3][w] = 0;
     }
     __syncthreads();
     if (wave == 0) kvb_build_edge(Mhead, Ehead);
@@ -1072,13 +1132,17 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     if (wave == 4) kvb_build_pop(Mhead, Phead);
     __syncthreads();
     const uint32_t nseg = Phead.below[KVB_NW];
-    if (tr && t == 0 && win == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
-    // ---- pass B: a segment must be one key (9 hash bits can collide) and carry only ops the closed form knows
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
+    // ---- pass B: a segment must be one key (9 hash bits can collide) and carry only ops the closed form knows;
+    // list the segment heads
     for (uint32_t j = 0; j < ntile; j++) {
       const uint32_t p = j * KVB_T + t;
       const uint64_t cur = Sk[p];
       const bool valid = p < m;
       const uint32_t type = k_type(cur);
+      const uint32_t sn = valid ? kvb_below(Mhead, Phead, p + 1) - 1 : 0;  // my segment's number
+      const bool head = valid && kvb_bit(Mhead, p);
+      if (head && sn < KVB_T) HeadPos[sn] = (uint16_t)p;
       const uint32_t seg_a = valid ? (uint32_t)kvb_last(Mhead, Ehead, 0, p + 1) : 0;
       const uint64_t key = valid ? ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY) : 0;
       const uint64_t hkey = valid ? ld_u64(rep + (size_t)k_idx(Sk[seg_a]) * F::MSG + F::KEY) : 0;
@@ -1087,49 +1151,41 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     }
     __syncthreads();
     if (wave == 0) kvb_build_pop(Mbad, Pbad);
-    __syncthreads();
-    if (tr && t == 0 && win == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
-    // ---- pass C: key segments that carry lock ops, per lock quadrant (two on one lock word make the bucket run
-    // non-simple); key segments that insert / delete
-    for (uint32_t j = 0; j < ntile; j++) {
-      const uint32_t p = j * KVB_T + t;
-      const bool valid = p < m;
-      const uint32_t q = k_q(Sk[p]);
-      const bool head = valid && kvb_bit(Mhead, p);
-      uint32_t seg_b = m;
-      if (head) { const int nx = kvb_first(Mhead, Ehead, p + 1); if (nx >= 0) seg_b = (uint32_t)nx; }
-      if (head) { const uint32_t sn = kvb_below(Mhead, Phead, p); if (sn < KVB_T) HeadPos[sn] = (uint16_t)p; }
-      const bool lkseg = head && kvb_popc(Mlop, Plop, p, seg_b) != 0;
-      const bool stseg = head && kvb_popc(Mst, Pst, p, seg_b) != 0;
-#pragma unroll
-      for (uint32_t k = 0; k < 4; k++) {
-        const uint64_t sm = __ballot(lkseg && q == k);
-        if (lane == 0) Mlkseg[k][p >> 6] = sm;
-      }
-      const uint64_t ss = __ballot(stseg);
-      if (lane == 0) Mstseg[p >> 6] = ss;
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+    // ---- pass C, one thread per key segment: segments that carry lock ops, per lock quadrant (smallbank: two on one
+    // lock word make the bucket run non-simple); segments that insert / delete
+    const bool closed = !force_rounds && nseg <= KVB_T;  // else: every request of the stretch runs on its own, in rounds
+    const bool mine = closed && t < nseg;
+    uint32_t ha = 0, hb = 0;  // my segment = sorted positions [ha, hb)
+    if (mine) {
+      ha = HeadPos[t];
+      hb = t + 1 < nseg ? HeadPos[t + 1] : m;
+      if (kvb_popc(Mlop, Plop, ha, hb) != 0) atomicOr((unsigned long long *)&Mlkseg[k_q(Sk[ha])][ha >> 6], 1ull << (ha & 63));
+      if (kvb_popc(Mst, Pst, ha, hb) != 0) atomicOr((unsigned long long *)&Mstseg[ha >> 6], 1ull << (ha & 63));
     }
     __syncthreads();
     if (wave < 4) kvb_build_pop(Mlkseg[wave], Plkseg[wave]);
     if (wave == 4) kvb_build_pop(Mstseg, Pstseg);
     __syncthreads();
-    // ---- pass D: simple bucket runs; their writers and lock ops
+    // ---- pass D, one thread per bucket run: is it simple?
+    if (mine && kvb_bit(Mbh, ha)) {
+      const int bx = kvb_first(Mbh, Ebh, ha + 1);
+      const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m;
+      bool clash = false;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) clash |= WL != DINT_WL_TATP && kvb_popc(Mlkseg[k], Plkseg[k], ha, bk_b) > 1;
+      const uint32_t nst = kvb_popc(Mstseg, Pstseg, ha, bk_b);
+      const bool spans = ha / KVB_T != (bk_b - 1) / KVB_T;  // a run with an insert / delete stays inside one tile
+      if (kvb_popc(Mbad, Pbad, ha, bk_b) == 0 && !clash && nst <= 1 && !(nst && spans))
+        atomicOr((unsigned long long *)&Mrs[ha >> 6], 1ull << (ha & 63));
+    }
+    __syncthreads();
+    // ---- ... and every request: in a simple run?  the writers and lock ops of the simple runs
     for (uint32_t j = 0; j < ntile; j++) {
       const uint32_t p = j * KVB_T + t;
       const bool valid = p < m;
       const uint32_t type = k_type(Sk[p]);
-      bool simple = false;
-      if (valid && !force_rounds && nseg <= KVB_T) {
-        const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, p + 1);
-        const int bx = kvb_first(Mbh, Ebh, p + 1);
-        const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m;
-        bool clash = false;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) clash |= WL != DINT_WL_TATP && kvb_popc(Mlkseg[k], Plkseg[k], bk_a, bk_b) > 1;
-        const uint32_t nst = kvb_popc(Mstseg, Pstseg, bk_a, bk_b);
-        const bool spans = bk_a / KVB_T != (bk_b - 1) / KVB_T;  // a run with an insert / delete stays inside one tile
-        simple = kvb_popc(Mbad, Pbad, bk_a, bk_b) == 0 && !clash && nst <= 1 && !(nst && spans);
-      }
+      const bool simple = valid && closed && kvb_bit(Mrs, (uint32_t)kvb_last(Mbh, Ebh, 0, p + 1));
       const uint64_t m0 = __ballot(simple);
       const uint64_t m1 = __ballot(simple && is_writer(type));
       const uint64_t m2 = __ballot(simple && WL == DINT_WL_TATP && kv_lock_op<WL>(type));
@@ -1141,14 +1197,14 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     if (wave == 1) kvb_build_edge(Mwr, Ewr);
     if (wave == 2) kvb_build_edge(Mlk, Elk);
     __syncthreads();
-    if (tr && t == 0 && win == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
 
     // ---- leaders: one thread per simple key segment loads the bucket's inline header (+ smallbank counters) and
     // locates the row; every segment of the stretch at once
     if (t == 0) Sany = 0;
     __syncthreads();
-    if (t < nseg && nseg <= KVB_T) {
-      const uint32_t a = HeadPos[t];
+    if (mine) {
+      const uint32_t a = ha;
       if (kvb_bit(Msimple, a)) {
         const uint64_t cur = Sk[a];
         const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk), q = k_q(cur);
@@ -1169,8 +1225,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         Lead[t].slot = wh.slot; Lead[t].ver0 = wh.ver; Lead[t].la0 = la0; Lead[t].lb0 = lb0;
         if (WL == DINT_WL_SMALLBANK) { Carry[t].la = la0; Carry[t].lb = lb0; Carry[t].ver = wh.ver; Carry[t].src = -1; Carry[t].miss = 0; }
         if (WL != DINT_WL_SMALLBANK) {
-          const int nx = kvb_first(Mhead, Ehead, a + 1);
-          if (kvb_popc(Mst, Pst, a, nx >= 0 ? (uint32_t)nx : m) != 0) {  // the segment inserts / deletes
+          if (kvb_bit(Mstseg, a)) {  // the segment inserts / deletes
             Crow[t].exists = wh.found; Crow[t].ver = wh.ver; Crow[t].toggles = 0; Crow[t].miss = 0; Crow[t].bail = 0; Crow[t].src = -1;
             Sany = 1;
           }
@@ -1182,8 +1237,9 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     // ---- tiles: outcomes and replies of the simple segments, 512 requests at a time.  Nothing a tile reads from
     // the table is written before the last tile is done, so the tiles' loads and stores stream back to back.
     const bool walks = WL == DINT_WL_SMALLBANK || Sany;  // workgroup-uniform
-    if (tr && t == 0 && win == 0) tr[5] = __builtin_amdgcn_s_memrealtime();
-    for (uint32_t j = 0; j < ntile; j++) {
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+    struct kvb_out { uint8_t *msg; const uint8_t *from; uint32_t ver, code; bool simple, get; };
+    auto outcome = [&](uint32_t j, kvb_out &o) {  // tile j: what each request answers, and where a read finds its value
       const uint32_t lo = j * KVB_T, hi = min(lo + KVB_T, m), p = lo + t;
       const bool valid = p < m;
       const uint64_t cur = Sk[p];
@@ -1192,13 +1248,8 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
       uint8_t *msg = rep + (size_t)idx * F::MSG;
       bool simple = valid && kvb_bit(Msimple, p);
-      uint32_t seg_a = 0, seg_b = m;  // my key segment = sorted positions [a, b)
-      if (valid) {
-        seg_a = (uint32_t)kvb_last(Mhead, Ehead, 0, p + 1);
-        const int nx = kvb_first(Mhead, Ehead, p + 1);
-        if (nx >= 0) seg_b = (uint32_t)nx;
-      }
       const uint32_t si = simple ? kvb_below(Mhead, Phead, p + 1) - 1 : 0;  // my segment's number = its Lead / Carry slot
+      const uint32_t seg_a = simple ? HeadPos[si] : 0;                       // my key segment starts here
       uint32_t found = 0, link = 0, slot = 0, ver0 = 0, la0 = 0;
       if (simple) {
         const kvb_lead L = Lead[si];
@@ -1242,7 +1293,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         // in sorted order, wave after wave, with the state carried through Crow[segment] (as kv_chunk; rare, so
         // the whole step is skipped when the stretch has no such segment)
         if (walks) {
-          const bool structural = simple && kvb_popc(Mst, Pst, seg_a, seg_b) != 0;
+          const bool structural = simple && kvb_bit(Mstseg, seg_a);
           if (t < KVB_W) Mbail[t] = 0;
           __syncthreads();
           for (uint32_t wv = 0; wv < KVB_W; wv++) {
@@ -1327,33 +1378,50 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           __syncthreads();
         }
       }
-      // ---- replies
-      if (simple) {
-        if (my_get) {
-          const kv_tab tb = kv->tab[table];
-          const uint8_t *row = kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS;
-          const uint8_t *from = my_src >= 0 ? rep + (size_t)k_idx(Sk[my_src]) * F::MSG + F::VAL : row;
-          kv_copy_words(msg + F::VAL, from, F::VS);
-          st_u32(msg + F::VER, my_ver);
-        }
-        msg[F::TYPE] = (uint8_t)my_code;
+      o.msg = msg; o.simple = simple; o.get = simple && my_get != 0; o.code = my_code; o.ver = my_ver; o.from = nullptr;
+      if (o.get) {
+        const kv_tab tb = kv->tab[table];
+        o.from = my_src >= 0 ? rep + (size_t)k_idx(Sk[my_src]) * F::MSG + F::VAL
+                             : kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS;
       }
+    };
+    auto fetch = [&](const kvb_out &o, uint32_t (&w)[10]) {
+      if (o.get) {
+#pragma unroll
+        for (uint32_t k = 0; k < F::VS / 4; k++) w[k] = ld_u32(o.from + 4 * k);
+      }
+    };
+    auto reply = [&](const kvb_out &o, const uint32_t (&w)[10]) {
+      if (o.simple) {
+        if (o.get) {
+#pragma unroll
+          for (uint32_t k = 0; k < F::VS / 4; k++) st_u32(o.msg + F::VAL + 4 * k, w[k]);
+          st_u32(o.msg + F::VER, o.ver);
+        }
+        o.msg[F::TYPE] = (uint8_t)o.code;
+      }
+    };
+    for (uint32_t j = 0; j < ntile; j++) {
+      kvb_out o;
+      uint32_t w[10];
+      outcome(j, o);
+      fetch(o, w);
+      reply(o, w);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();  // every table read of the stretch precedes the write-backs
-    if (tr && t == 0 && win == 0) tr[6] = __builtin_amdgcn_s_memrealtime();
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 8] = __builtin_amdgcn_s_memrealtime();
 
     // ---- write-back: one thread per simple key segment
-    if (t < nseg && nseg <= KVB_T) {
-      const uint32_t a = HeadPos[t];
+    if (mine) {
+      const uint32_t a = ha;
       if (kvb_bit(Msimple, a)) {
         const uint64_t cur = Sk[a];
         const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk), q = k_q(cur);
         const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
         const kv_tab tb = kv->tab[table];
         uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
-        const int nx = kvb_first(Mhead, Ehead, a + 1);
-        const uint32_t seg_b = nx >= 0 ? (uint32_t)nx : m;
+        const uint32_t seg_b = hb;
         const kvb_lead L = Lead[t];
         const uint32_t found0 = L.found_link >> 31, link = L.found_link & 0x7FFFFFFFu, slot = L.slot, la0 = L.la0, lb0 = L.lb0;
         uint32_t exists1 = found0, fin_ver = L.ver0, fin_la = la0, fin_lb = lb0, nmiss = 0;
@@ -1361,7 +1429,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         if (WL == DINT_WL_SMALLBANK) {
           const kvb_carry st = Carry[t];
           fin_la = st.la; fin_lb = st.lb; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
-        } else if (kvb_popc(Mst, Pst, a, seg_b) != 0) {
+        } else if (kvb_bit(Mstseg, a)) {
           const kv_rowst st = Crow[t];
           exists1 = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
         } else {
@@ -1408,7 +1476,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     // ---- every other bucket run: request by request.  Position inside the run = number of its requests that come
     // earlier in request order (the run is sorted by key first); the k-th request executes in round k.
     uint16_t *Rpos = (uint16_t *)Lead;  // by sorted position; Lead is free now
-    if (tr && t == 0 && win == 0) tr[7] = __builtin_amdgcn_s_memrealtime();
+    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 9] = __builtin_amdgcn_s_memrealtime();
     uint32_t mylen = 0, tot;
     for (uint32_t j = 0; j < ntile; j++) {
       const uint32_t p = j * KVB_T + t;
@@ -1465,7 +1533,7 @@ k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict_
   for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
   // tracing: per workgroup {first wave in, last wave out} after the per-bin rows (10 ns ticks)
-  unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 2 * blockIdx.x : nullptr;
+  unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
   if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
   if (blockIdx.x < KVB_GRID) {
     kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_rounds, trace);

@@ -116,11 +116,12 @@ class Engine:
 
     def kv_trace(self, workgroups: bool = False):
         """DINT_KV_TRACE=1: [32768, 16] u64 per-bin timeline of the resolve launches since the last read; with
-        workgroups=True also [8192, 2] {first wave in, last wave out} per workgroup (10 ns ticks)."""
-        out = np.zeros(32768 * 16 + 2 * 8192, "<u8")
+        workgroups=True also [8192, 16] per workgroup: {first wave in, last wave out, phase stamps of its first big bin}
+        (10 ns ticks)."""
+        out = np.zeros(32768 * 16 + 16 * 8192, "<u8")
         _lib.check(self._L.dint_kv_trace_read(self._h, out.ctypes.data, out.size))
         bins = out[:32768 * 16].reshape(32768, 16)
-        return (bins, out[32768 * 16:].reshape(8192, 2)) if workgroups else bins
+        return (bins, out[32768 * 16:].reshape(8192, 16)) if workgroups else bins
 
     def timing_read(self) -> dict:
         names = (C.c_char_p * 8)(); us = (C.c_double * 8)(); cnt = (C.c_uint64 * 8)()

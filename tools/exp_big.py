@@ -78,7 +78,9 @@ print("small waves: start p50 %.1f us p99 %.1f | end p50 %.1f p99 %.1f max %.1f"
 rows = sorted(((int(r[14]), round((r[8] - t0) / 100, 1), round((r[9] - t0) / 100, 1), int(r[13]), int(r[12])) for r in tt[bg]), key=lambda r: -r[2])
 print("big bins (c, start_us, end_us, stretches, rounds), latest end first:", rows[:12])
 
-names = ["gather", "sort", "A", "B", "C+D", "leaders", "tiles", "wb", "rounds+end"]
-for r in sorted(tt[bg], key=lambda r: -r[14])[:3] + sorted(tt[bg], key=lambda r: r[14])[:2]:
-    st = [r[8]] + [r[k] for k in range(8)] + [r[9]]
-    print("  c=%d first-stretch phases us:" % r[14], {names[i]: round((st[i + 1] - st[i]) / 100, 1) for i in range(9)})
+names = ["gather", "sort", "A", "B", "C+D", "leaders", "tiles", "wb"]
+big_wg = [i for i in range(512) if wg[i, 2] > 0]
+for i in sorted(big_wg, key=lambda i: -(wg[i, 1] - wg[i, 0]))[:4] + sorted(big_wg, key=lambda i: wg[i, 1] - wg[i, 0])[:2]:
+    st = [wg[i, 0]] + [wg[i, k] for k in range(2, 10)]
+    print("  workgroup %d, %.1f us in all; first stretch of its bin, phases us:" % (i, (wg[i, 1] - wg[i, 0]) / 100),
+          {names[k]: round((st[k + 1] - st[k]) / 100, 1) for k in range(8)})
