@@ -37,13 +37,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("DINT_BENCH_WORKLOAD", "tatp"), choices=["tatp", "fasst"])
     ap.add_argument("--slots", type=int, default=1 << 20, help="lock_fasst table slots (BASELINE configs[1]: 1M)")
     ap.add_argument("--theta", type=float, default=0.8, help="Zipf skew of the key stream; 0 = the reference's own distribution")
     ap.add_argument("--subscribers", type=int, default=1_000_000, help="tatp subscribers (BASELINE configs[3]: 1M)")
-    ap.add_argument("--clients", type=int, default=131072, help="tatp virtual clients per GPU")
+    ap.add_argument("--clients", type=int, default=524288,
+                    help="tatp closed-loop clients per GPU (one outstanding request each: a shard server sees ~clients * 0.46 "
+                         "requests per epoch, all resolved in one kernel pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rand64", action="store_true")
     return ap.parse_args()

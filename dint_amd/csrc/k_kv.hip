@@ -640,9 +640,10 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         }
       }
       // key segments with an INSERT / DELETE: the row machine {exists, version, last writer} is walked once per
-      // segment with wave-uniform registers.  Two toggles of `exists` (delete then re-insert: the row may move to
-      // another slot) or an INSERT of an existing key (a duplicate row) send the bucket run to the rounds.
-      uint32_t fin_exists = found, my_bail = 0;
+      // segment with wave-uniform registers.  A row that is deleted and inserted again may move to another slot:
+      // the write-back then deletes and re-inserts once (further pairs leave the row where the first put it).  An
+      // INSERT of an existing key (a duplicate row) sends the bucket run to the rounds.
+      uint32_t fin_exists = found, fin_multi = 0, my_bail = 0;
       uint64_t stm = __ballot(leader && structural);
       while (stm) {
         const int L = __ffsll((unsigned long long)stm) - 1;
@@ -666,12 +667,14 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         }
         if (lane == L) {
           fin_exists = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
-          my_bail = st.bail | (st.toggles > 1);
+          fin_multi = st.toggles > 1;
+          my_bail = st.bail;
         }
       }
       const uint64_t m_bail = __ballot(head && my_bail);
       if (m_bail & run) { simple = false; leader = false; }
-      found = simple && structural ? (found | (fin_exists << 1)) : found;  // bit 1: exists after the segment (head lane)
+      // head lane: bit 1 = the row exists after the segment, bit 2 = it was deleted and inserted on the way
+      found = simple && structural ? (found | (fin_exists << 1) | (fin_multi << 2)) : found;
     } else {
       // smallbank.  cnt = {la: num_ex, lb: num_sh}
       auto sb_step = [](uint32_t op, uint32_t fnd, uint32_t &la, uint32_t &lb, uint32_t &get, uint32_t &miss,
@@ -736,12 +739,18 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   // segment of the bucket that carries lock ops (fin_la / fin_lb differ from la0 / lb0 only there).
   if (leader) {
     const uint32_t found0 = found & 1u, exists1 = structural ? (found >> 1) & 1u : found0;
-    if (found0 && exists1) {          // the row stays where it is: value / version of the last writer
+    const bool redo = structural && found0 && exists1 && ((found >> 2) & 1u);  // deleted and inserted again
+    if (found0 && exists1 && !redo) {  // the row stays where it is: value / version of the last writer
       if (fin_src >= 0) {
         kv_copy_words(row, rep + (size_t)fin_idx * F::MSG + F::VAL, F::VS);
         kv_entry_hdr(t, bucket, link)->ver[slot] = fin_ver;
       }
-    } else if (found0 != exists1) {   // one INSERT or one DELETE took effect: apply it to the chain once
+    } else if (found0 != exists1 || redo) {  // apply the net INSERT / DELETE (or DELETE + INSERT) to the chain once
+      if (redo) {
+        kv_apply<kv_dev_mem>(t, bucket, H, KV_ACT_DEL, key, nullptr, 0, blockIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        kv_hdr_copy(H, *(const kv_hdr *)ie);
+      }
       const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key,
                                             rep + (size_t)fin_idx * F::MSG + F::VAL, fin_ver, blockIdx.x);
       if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
@@ -1323,11 +1332,11 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
             }
             __syncthreads();
           }
-          // a segment whose walk bailed out (insert of an existing row, several toggles) sends its bucket run to the
+          // a segment whose walk bailed out (insert of an existing row) sends its bucket run to the
           // request-by-request path
           const bool bhead = valid && kvb_bit(Mhead, p) && structural;
           uint32_t my_bail = 0;
-          if (bhead) { const kv_rowst st = Crow[si]; my_bail = st.bail | (st.toggles > 1); }
+          if (bhead) { const kv_rowst st = Crow[si]; my_bail = st.bail; }
           const uint64_t bm = __ballot(my_bail != 0);
           if (lane == 0) Mbail[wave] = bm;
           __syncthreads();
@@ -1426,12 +1435,14 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         const uint32_t found0 = L.found_link >> 31, link = L.found_link & 0x7FFFFFFFu, slot = L.slot, la0 = L.la0, lb0 = L.lb0;
         uint32_t exists1 = found0, fin_ver = L.ver0, fin_la = la0, fin_lb = lb0, nmiss = 0;
         int fin_src = -1;
+        bool redo = false;  // the row was deleted and inserted again: it may have moved
         if (WL == DINT_WL_SMALLBANK) {
           const kvb_carry st = Carry[t];
           fin_la = st.la; fin_lb = st.lb; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
         } else if (kvb_bit(Mstseg, a)) {
           const kv_rowst st = Crow[t];
           exists1 = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
+          redo = found0 && exists1 && st.toggles > 1;
         } else {
           const uint32_t nw = kvb_popc(Mwr, Pwr, a, seg_b);
           fin_ver = L.ver0 + (found0 ? nw : 0);
@@ -1452,15 +1463,20 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           if (lk >= 0) fin_la = (uint32_t)lk;
         }
         const uint8_t *fin_val = fin_src >= 0 ? rep + (size_t)k_idx(Sk[fin_src]) * F::MSG + F::VAL : nullptr;
-        if (found0 && exists1) {          // the row stays where it is: value / version of the last writer
+        if (found0 && exists1 && !redo) {  // the row stays where it is: value / version of the last writer
           if (fin_src >= 0) {
             kv_copy_words(kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS, fin_val, F::VS);
             kv_entry_hdr(tb, bucket, link)->ver[slot] = fin_ver;
           }
-        } else if (found0 != exists1) {   // one INSERT or one DELETE took effect: apply it to the chain once
+        } else if (found0 != exists1 || redo) {  // apply the net INSERT / DELETE (or DELETE + INSERT) to the chain once
           kv_hdr H;
           kv_hdr_copy(H, *(const kv_hdr *)ie);
           const uint64_t key = ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY);
+          if (redo) {
+            kv_apply<kv_dev_mem>(tb, bucket, H, KV_ACT_DEL, key, nullptr, 0, blockIdx.x);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            kv_hdr_copy(H, *(const kv_hdr *)ie);
+          }
           const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key, (uint8_t *)fin_val,
                                                 fin_ver, blockIdx.x);
           if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);

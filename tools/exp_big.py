@@ -30,7 +30,14 @@ for e in range(E):
     grp.sync(); t0 = time.perf_counter()
     eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
     grp.sync(); wall = (time.perf_counter() - t0) * 1e6
-    tt = eng.kv_trace().astype(np.int64)
+    tt, wgp = eng.kv_trace(workgroups=True)
+    tt, wgp = tt.astype(np.int64), wgp.astype(np.int64)
+    lv = wgp[:, 0] > 0
+    wd = np.where(lv, wgp[:, 1] - wgp[:, 0], 0)
+    wi = int(np.argmax(wd))
+    print("   slowest workgroup: block %d (%s), %.1f us; kernel span %.1f us" % (
+        wi, "big-bin list" if wi < 512 else "bins %d..%d" % ((wi - 512) * 8, (wi - 512) * 8 + 7), wd[wi] / 100,
+        (wgp[lv, 1].max() - wgp[lv, 0].min()) / 100), [int(x) for x in tt[(wi - 512) * 8:(wi - 512) * 8 + 8, 15]] if wi >= 512 else "")
     bg = tt[:, 14] > 64
     if bg.any():
         sm = (tt[:, 15] > 0) & (tt[:, 11] > 0)

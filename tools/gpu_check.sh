@@ -12,7 +12,7 @@ echo "== bench" ; timeout 900 python bench.py "$@" > "$OUT/bench.json" 2> "$OUT/
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel trace"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- python "$ROOT/bench.py" "$@" --no-cpu-baseline --no-rand64 > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
-python "$ROOT/tools/pmc_summary.py" "$OUT/trace" | tee "$OUT/trace_summary.txt"
+python "$ROOT/tools/pmc_summary.py" --last ${DINT_TIMED_LAUNCHES:-330} "$OUT/trace" | tee "$OUT/trace_summary.txt"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_')
   echo "== rocprof pmc $C"

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) result directories.
 
-    pmc_summary.py <dir> [<dir> ...]
+    pmc_summary.py [--last N] <dir> [<dir> ...]
 
 For a --kernel-trace --stats run: the top_kernels view (calls, total/avg duration in us).
 For a --pmc run: per kernel and counter, the mean counter value per dispatch.
+--last N: also summarise only the last N dispatches of every kernel -- bench.py's event-timed replay is the last thing
+that launches kernels, so with N = its launch count these rows are the launches bench.py's `kernels_us` times (the
+rows over all calls also contain the population and recording passes).
 """
 import glob
 import os
@@ -16,7 +19,12 @@ def short(name: str) -> str:
     return name.split("(")[0].replace("void ", "")[:70]
 
 
-for d in sys.argv[1:]:
+args = sys.argv[1:]
+last = 0
+if args and args[0] == "--last":
+    last = int(args[1])
+    args = args[2:]
+for d in args:
     for db in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
         c = sqlite3.connect(db)
         print(f"# {os.path.relpath(db)}")
@@ -28,6 +36,15 @@ for d in sys.argv[1:]:
                     print(f"{short(n):70s} {calls:8d} {tot:12.2f} {avg:10.3f} {pct:7.2f}")
         except sqlite3.Error as e:
             print("top_kernels:", e)
+        if last:
+            try:
+                names = [r[0] for r in c.execute("select distinct name from kernels")]
+                print(f"{'kernel (last %d dispatches)' % last:70s} {'calls':>8s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s}")
+                for n in names:
+                    du = [r[0] for r in c.execute("select end - start from kernels where name = ? order by start desc limit ?", (n, last))]
+                    print(f"{short(n):70s} {len(du):8d} {sum(du) / len(du) / 1e3:10.3f} {min(du) / 1e3:10.3f} {max(du) / 1e3:10.3f}")
+            except sqlite3.Error as e:
+                print("kernels:", e)
         try:
             rows = c.execute(
                 "select kernel_name,counter_name,count(*),avg(value),sum(value),avg(duration) "
