@@ -101,16 +101,21 @@ def sum_over_ranks(x, world):
 def pmc_traffic(kernels):
     """HBM bytes per launch of `kernels` from the committed rocprofv3 --pmc summary of this same command
     (profiles/r01_tatp_rocprofv3_summary.txt: FETCH_SIZE + WRITE_SIZE, KiB per dispatch, separate passes as
-    MI355X_MICROARCH.md prescribes).  Raw counter values: the guide's x2 FETCH_SIZE correction applies to wide
-    coalesced streams, the resolve kernels issue 8..64-byte random accesses, for which it is uncalibrated."""
+    MI355X_MICROARCH.md prescribes; the rows over the last dispatches = the replayed epochs, without the population
+    passes).  Raw counter values: the guide's x2 FETCH_SIZE correction applies to wide coalesced streams, the
+    resolve kernel issues 8..64-byte random accesses, for which it is uncalibrated."""
     path = os.path.join(ROOT, "profiles", "r01_tatp_rocprofv3_summary.txt")
     try:
-        tot = 0.0
+        tot = {False: 0.0, True: 0.0}  # [rows over all dispatches, rows over the last dispatches]
+        last = False
         for line in open(path):
+            if line.startswith("kernel"):
+                last = "(last" in line
             f = line.split()
             if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE") and f[0].split("<")[0] in kernels:
-                tot += float(f[3]) * 1024.0
-        return int(tot) if tot else None
+                tot[last] += float(f[3]) * 1024.0
+        t = tot[True] or tot[False]
+        return int(t) if t else None
     except OSError:
         return None
 
@@ -323,12 +328,11 @@ def bench_tatp(args, world, rank, dev):
         names = list(tims[0].keys())
         avg = {k: float(np.mean([t[k]["avg_us"] for t in tims])) for k in names}
         extra["kernels_us"] = {k: round(v, 3) for k, v in avg.items()}
-        # The table requests of a pass are resolved by two kernels that own disjoint bins (> 64 records / the rest)
-        # and run back to back: they are one unit for the roofline -- algorithmic bytes of the table requests
-        # over the sum of the two durations.  Log requests are finished by k_kv_place.
-        resolve_us = avg.get("k_kv_resolve_big", 0.0) + avg.get("k_kv_resolve", 0.0)
+        # The table requests of a pass are resolved by k_kv_resolve (every bin of the pass, one launch): algorithmic
+        # bytes of the table requests over its duration.  Log requests are finished by k_kv_place.
+        resolve_us = avg.get("k_kv_resolve", 0.0)
         scatter_us = avg.get("k_kv_count", 0.0) + avg.get("k_kv_scan", 0.0) + avg.get("k_kv_place", 0.0)
-        dom = "k_kv_resolve_big+k_kv_resolve" if resolve_us >= scatter_us else "k_kv_count+k_kv_scan+k_kv_place"
+        dom = "k_kv_resolve" if resolve_us >= scatter_us else "k_kv_count+k_kv_scan+k_kv_place"
         dom_us = max(resolve_us, scatter_us)
         tot_b, launches = 0.0, 0
         for e in range(n_t):

@@ -17,6 +17,6 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_')
   echo "== rocprof pmc $C"
   timeout 900 rocprofv3 --pmc $C --kernel-trace -d "$OUT/pmc_$N" -o pmc -- python "$ROOT/bench.py" "$@" --steps 40 --warmup 5 --no-cpu-baseline --no-rand64 > /dev/null 2> "$OUT/pmc_$N.err"
-  python "$ROOT/tools/pmc_summary.py" "$OUT/pmc_$N" > "$OUT/pmc_$N.txt" 2>&1; cat "$OUT/pmc_$N.txt"
+  python "$ROOT/tools/pmc_summary.py" --last ${DINT_PMC_LAUNCHES:-135} "$OUT/pmc_$N" > "$OUT/pmc_$N.txt" 2>&1; cat "$OUT/pmc_$N.txt"
 done
 echo "== done"

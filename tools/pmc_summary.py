@@ -53,5 +53,11 @@ for d in args:
                 print(f"{'kernel':70s} {'counter':16s} {'dispatches':>10s} {'mean/dispatch':>16s} {'avg_ns':>10s}")
                 for n, cn, k, av, sm, du in rows:
                     print(f"{short(n):70s} {cn:16s} {k:10d} {av:16.2f} {du:10.0f}")
+            if rows and last:
+                print(f"{'kernel (last %d dispatches)' % last:70s} {'counter':16s} {'dispatches':>10s} {'mean/dispatch':>16s} {'avg_ns':>10s}")
+                for n, cn in sorted({(r[0], r[1]) for r in rows}):
+                    v = c.execute("select value,duration from counters_collection where kernel_name = ? and counter_name = ? "
+                                  "order by start desc limit ?", (n, cn, last)).fetchall()
+                    print(f"{short(n):70s} {cn:16s} {len(v):10d} {sum(x[0] for x in v) / len(v):16.2f} {sum(x[1] for x in v) / len(v):10.0f}")
         except sqlite3.Error as e:
             print("counters_collection:", e)
