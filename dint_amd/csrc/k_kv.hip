@@ -7,21 +7,23 @@
 // Every request touches exactly one bucket of one table (lock_hash % hash_size == kvs bucket), or only
 // the log ring.  Requests on different buckets commute; requests on one bucket apply in request order.
 //
-// One pass (n <= 65,536 requests) = up to three kernels:
-//   k_kv_prepass (tatp / smallbank): per-block count of log requests, publishes the ring tail.
-//   k_kv_scatter : one thread per request -- copy the message to the reply array, classify, hash, and
-//                  either append the canonical 64-byte log record at ring position
-//                  tail + (#log requests below i)   [deterministic: an exclusive scan, not an atomic], or
-//                  append a {bucket group, idx, type, table|quadrant} record to bin = group & (P-1).
-//   k_kv_resolve : one wave per bin.  A bin of <= 64 records (the common case: ~32 per bin) is sorted by
-//                  (bucket group, idx) in registers and handled as one chunk.  Larger bins (hot keys) restore
-//                  request order with a bitmap rank over idx, group each window of 512 records by bucket in
-//                  an LDS hash and walk it 64 at a time.  Inside a chunk, lanes whose bucket is unique run at
-//                  once; several requests on ONE key are resolved in closed form (ballots: version = v0 +
-//                  #writers below, value = message of the last writer below, lock = last lock op below); any
-//                  other same-bucket group runs in rounds (k-th request in round k, workgroup fence between
-//                  rounds), so every request sees the table exactly as the serial reference would.  The table
-//                  is the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
+// One pass (n <= 2^20 requests) = four kernels:
+//   k_kv_count   : one thread per request -- copy the message to the reply array, classify, hash, reserve a position
+//                  in bin = group & (P-1) (P ~ n / 32) -- merged per workgroup in an LDS hash, so a hot key costs one
+//                  device atomic per workgroup -- and store the {bucket group, idx, type | quadrant | key-hash bits}
+//                  record in place (positions < 64) or on the pass's overflow list; count the log requests.
+//   k_kv_scan    : give every bin with more than 64 records (the big-bin list) a range of the overflow area.
+//   k_kv_place   : move the overflow records there; append the canonical 64-byte log records at ring position
+//                  tail + (#log requests below i)   [deterministic: an exclusive scan, not an atomic].
+//   k_kv_resolve : every bin, one launch.  A bin of <= 64 records (the common case: ~32 per bin) is one wave: sorted
+//                  by (bucket group, key hash, idx) in registers and handled as one chunk (kv_chunk).  A bigger bin
+//                  (hot keys) is one 512-thread workgroup: sorted in LDS, ballot masks over the whole sorted stretch
+//                  with O(1) range tables, then leaders / 512-request tiles / write-back (kv_big_bins).  Inside a
+//                  chunk or stretch, several requests on ONE key are resolved in closed form (version = v0 + #writers
+//                  below, value = message of the last writer below, lock = last lock op below); what the closed
+//                  forms do not cover runs in rounds (k-th request of a bucket run in round k, workgroup fence
+//                  between rounds), so every request sees the table exactly as the serial reference would.  The
+//                  table is the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
