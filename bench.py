@@ -120,6 +120,27 @@ def pmc_traffic(kernels):
         return None
 
 
+def rocprof_avg_us(kernels):
+    """Average begin->end duration of `kernels` over the same launches in the committed rocprofv3 --kernel-trace summary
+    (first block of profiles/r01_tatp_rocprofv3_summary.txt, rows over the last dispatches).  The live HIP-event interval
+    (`kernel_avg_us`) additionally contains the dispatch gap on a stream that shares the GPU with two other engines."""
+    path = os.path.join(ROOT, "profiles", "r01_tatp_rocprofv3_summary.txt")
+    try:
+        tot, last, seen = 0.0, False, set()
+        for line in open(path):
+            if line.startswith("#") and seen:
+                break  # only the kernel-trace block
+            if line.startswith("kernel"):
+                last = "(last" in line
+            f = line.split()
+            if last and len(f) == 5 and f[0].split("<")[0] in kernels and f[0] not in seen:
+                seen.add(f[0])
+                tot += float(f[2])
+        return round(tot, 3) if seen else None
+    except (OSError, ValueError):
+        return None
+
+
 def rand64(extra, value_ops_per_s, dev):
     """Measured random-64B HBM roofline: gathers over an 8 GiB table."""
     from dint_amd.engine import bench_rand64
@@ -348,7 +369,8 @@ def bench_tatp(args, world, rank, dev):
         achieved = alg / (dom_us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom.split("+")),
-                "alg_bytes_per_launch": int(alg), "kernel_avg_us": round(dom_us, 3)}
+                "alg_bytes_per_launch": int(alg), "kernel_avg_us": round(dom_us, 3),
+                "kernel_avg_us_rocprofv3": rocprof_avg_us(dom.split("+"))}
     if rank != 0:
         return None
     if not args.no_rand64 and world == 1:

@@ -66,9 +66,11 @@ enum {
   DINT_ESTATE = -5    /* call not valid for this engine's workload */
 };
 
-/* The largest request count one kernel pass handles; dint_submit splits larger
- * arrays into consecutive micro-batches (correct by the serial-order contract). */
+/* The largest request count one kernel pass handles: dint_submit splits larger
+ * arrays into consecutive passes (correct by the serial-order contract).  FASST / 2PL /
+ * LOG engines; STORE / TATP / SMALLBANK engines take DINT_KV_PASS_MAX (see max_pass). */
 #define DINT_MICRO_BATCH 65536u
+#define DINT_KV_PASS_MAX 1048576u
 
 typedef struct dint_config {
   uint32_t abi_version;  /* DINT_ABI_VERSION */
