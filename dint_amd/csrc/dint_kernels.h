@@ -18,11 +18,12 @@ struct dint_scratch {
   uint32_t *bin_cnt;   // [DINT_PMAX | DINT_KV_PMAX]   zero between passes (the resolve kernels re-zero their own)
   uint64_t *bins;      // locks: [DINT_PMAX][DINT_MICRO];  kv: [DINT_KV_PMAX][DINT_KV_BINCAP]
   dint_dev_stats *stats;
-  uint32_t *blk_cnt;   // per-block counts of the log scan: [256], kv [1024]
+  uint32_t *blk_cnt;   // per-block counts of the log scan [256]  (lock_2pl / lock_fasst / log)
   // ---- store / tatp / smallbank only (k_kv.hip) ----
-  uint32_t *blk_off;   // [1024] exclusive scan of blk_cnt
-  uint32_t *big;       // [2 + DINT_KV_PMAX]: big[0] = number of bins with more than DINT_KV_BINCAP records in this
-                       // pass, big[1] = number of overflow records, then the ids of those bins
+  uint32_t *blk_pub;   // [1024] log requests per 1024-request slice of the pass, bit 31 = published
+  uint32_t *blk_pub_next;  // ... of the next pass (two arrays, used alternately)
+  uint32_t *big;       // [4 + DINT_KV_PMAX]: big[0] = number of bins with more than DINT_KV_BINCAP records in this
+                       // pass, big[1] = number of overflow records, big[2] = slices handed out, then the bin ids
   uint32_t *big_next;  // the list of the next pass (two lists, used alternately)
   uint32_t *bin_off;   // [DINT_KV_PMAX] start of a big bin's records DINT_KV_BINCAP.. in `ovf`
   uint4 *ovl;          // [pass_max] overflow records as counted: {record lo, record hi, bin, position in bin}

@@ -135,7 +135,8 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
       dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names));
-      std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists alternate between passes
+      std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
+      std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
     default:
       return fail(DINT_EINVAL, "bad workload");
@@ -168,6 +169,7 @@ int load_rows_locked(dint_engine *e, uint32_t table, const uint64_t *keys, const
     HIP_TRY(hipMemcpyAsync(e->d_stage_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
     dint_launch_kv(e->d_stage_req, e->d_stage_req, m, e->kv, e->log, e->scratch, 1, e->stream, nullptr);
     std::swap(e->scratch.big, e->scratch.big_next);
+    std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -230,10 +232,10 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   if (is_kv) {
     TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
-    TRY(dev_alloc((void **)&e->scratch.blk_cnt, 1024 * sizeof(uint32_t)));
-    TRY(dev_alloc((void **)&e->scratch.blk_off, 1024 * sizeof(uint32_t)));
-    TRY(dev_alloc((void **)&e->scratch.big, 2 * (2 + DINT_KV_PMAX) * sizeof(uint32_t)));
-    e->scratch.big_next = e->scratch.big + (2 + DINT_KV_PMAX);
+    TRY(dev_alloc((void **)&e->scratch.blk_pub, 2 * 1024 * sizeof(uint32_t)));
+    e->scratch.blk_pub_next = e->scratch.blk_pub + 1024;
+    TRY(dev_alloc((void **)&e->scratch.big, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
+    e->scratch.big_next = e->scratch.big + (4 + DINT_KV_PMAX);
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
@@ -286,7 +288,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bins);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
-  hipFree(e->scratch.blk_off);
+  hipFree(std::min(e->scratch.blk_pub, e->scratch.blk_pub_next));
   hipFree(std::min(e->scratch.big, e->scratch.big_next));
   hipFree(e->scratch.bin_off);
   hipFree(e->scratch.ovl);

@@ -154,25 +154,44 @@ static_assert(KV_TB == 1024, "block_hash_insert assumes 2048 slots");
 // DINT_KV_BINCAP are stored in place; the others are listed for k_kv_place.
 template <int WL>
 __global__ void __launch_bounds__(KV_TB)
-k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, uint32_t *tail,
+k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
            uint32_t pbits, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
-           uint4 *__restrict__ ovl, uint32_t *__restrict__ blk_cnt, dint_dev_stats *__restrict__ stats, int load_mode) {
+           uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode) {
   using F = Fmt<WL>;
   __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
   __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
   __shared__ uint32_t Sov[2];         // overflow records of the workgroup; their place in the pass's list
-  const uint32_t t = threadIdx.x, lane = t & 63;
-  const uint32_t i = blockIdx.x * KV_TB + t;
-  if (blockIdx.x == 0 && t == 0 && tail) tail[0] = tail[1];
+  __shared__ uint32_t Stile;
+  __shared__ uint32_t Swl[KV_TB / 64], Swp[KV_TB / 64];
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  // The workgroup's slice of the pass is handed out in start order (a ticket, not blockIdx), so the slices before
+  // mine belong to workgroups that are already running: what the log-position look-back below waits for.
+  if (t == 0) Stile = atomicAdd(&big[2], 1u);
   if (blockIdx.x == 0 && t < KV_NLISTS)  // entries freed by earlier passes become reusable
     for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t);
   Hb[t] = KV_NONE; Hb[t + KV_TB] = KV_NONE;
   Hc[t] = 0; Hc[t + KV_TB] = 0;
+  __syncthreads();
+  const uint32_t tile = Stile;
+  const uint32_t i = tile * KV_TB + t;
+  const uint8_t *m = req + (size_t)i * F::MSG;
+  const kv_reqinfo r = kv_read_request<WL>(m, i < n, kv, load_mode);
+  // log requests of this slice: publish the count at once (tatp / smallbank)
+  const uint64_t lm = __ballot(r.cls == 2);
+  if (WL != DINT_WL_STORE) {
+    if (lane == 0) Swl[wv] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    if (t == 0) {
+      uint32_t c = 0;
+      for (uint32_t w = 0; w < KV_TB / 64; w++) c += Swl[w];
+      __hip_atomic_store(&blk_pub[tile], 0x80000000u | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
-  // copy this workgroup's messages to the reply array (replies are the request mutated in place).  All loads of a
-  // thread are issued before its first store: one memory round trip for the KV_TB * MSG <= 55 KiB of the workgroup.
+  // copy this slice's messages to the reply array (replies are the request mutated in place).  All loads of a
+  // thread are issued before its first store: one memory round trip for the KV_TB * MSG <= 55 KiB of the slice.
   if (rep != req) {
-    const size_t lo = (size_t)blockIdx.x * KV_TB * F::MSG;
+    const size_t lo = (size_t)tile * KV_TB * F::MSG;
     const size_t hi = min((size_t)n * F::MSG, lo + (size_t)KV_TB * F::MSG);
     if ((((uintptr_t)req | (uintptr_t)rep) & 15) == 0) {
       const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 3520 vectors
@@ -191,8 +210,6 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
       for (size_t k = lo + t; k < hi; k += KV_TB) rep[k] = req[k];
     }
   }
-
-  const kv_reqinfo r = kv_read_request<WL>(req + (size_t)i * F::MSG, i < n, kv, load_mode);
   if (i < n && !r.cls) atomicAdd(&stats->bad_requests, 1ULL);
 
   uint32_t bin = KV_NONE, gk = 0, pay = 0;
@@ -215,23 +232,21 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
       pay = kv_pay(r.type, q, (uint32_t)(h >> 40) & 511u);  // the table is implied by the group key
     }
   }
-  __syncthreads();
   uint32_t e = 0, mypos = 0;
   if (bin != KV_NONE) {
     e = block_hash_insert(Hb, bin);
     mypos = atomicAdd(&Hc[e], 1u);
   }
-  const uint32_t nlog = __syncthreads_count(r.cls == 2);
-  if (t == 0 && blk_cnt) blk_cnt[blockIdx.x] = nlog;
   if (t == 0) Sov[0] = 0;
+  __syncthreads();
 #pragma unroll
   for (uint32_t k = 0; k < 2; k++) {
     const uint32_t sl = t + k * KV_TB;
     if (Hb[sl] != KV_NONE) {
       const uint32_t cnt = Hc[sl], base = atomicAdd(&bin_cnt[Hb[sl]], cnt);
       Hc[sl] = base;
-      // the workgroup whose records cross position DINT_KV_BINCAP lists the bin for k_kv_resolve_big
-      if (base <= DINT_KV_BINCAP && base + cnt > DINT_KV_BINCAP) big[2 + atomicAdd(&big[0], 1u)] = Hb[sl];
+      // the workgroup whose records cross position DINT_KV_BINCAP lists the bin for the big-bin workgroups
+      if (base <= DINT_KV_BINCAP && base + cnt > DINT_KV_BINCAP) big[4 + atomicAdd(&big[0], 1u)] = Hb[sl];
     }
   }
   __syncthreads();
@@ -248,21 +263,72 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
     __syncthreads();
     if (over) ovl[Sov[1] + orank] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
   }
+
+  // ---- log requests: the canonical 64-byte record at ring position tail + (#log requests below i)
+  // [deterministic: an exclusive scan, not an atomic].  The slices before mine published their counts long ago
+  // (first thing they did); one count per thread, polled until it is there.
+  if (WL != DINT_WL_STORE) {
+    uint32_t part = 0;
+    if (t < tile) {
+      uint32_t v;
+      do { v = __hip_atomic_load(&blk_pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 31));
+      part = v & 0x7FFFFFFFu;
+    }
+    uint32_t tot;
+    wave_excl_scan_u32(part, &tot);
+    if (lane == 0) Swp[wv] = tot;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < KV_TB / 64; w++) base += Swp[w] + (w < wv ? Swl[w] : 0);
+    if (tile == gridDim.x - 1 && t == 0) {  // the pass's new tail (k_kv_scan makes it current)
+      uint32_t total = base;
+      for (uint32_t w = 0; w < KV_TB / 64; w++) total += Swl[w];
+      log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
+    }
+    if (r.cls == 2) {
+      const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
+      const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
+      uint8_t *e8 = log.ring + (size_t)pos * 64;
+      const uint32_t ver = ld_u32(m + F::VER);
+      uint8_t *rp = rep + (size_t)i * F::MSG;
+      if (WL == DINT_WL_TATP && r.type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
+        *(uint64_t *)e8 = r.key;
+        *(uint2 *)(e8 + 48) = make_uint2(ver, 1u | (r.table << 8));
+        rp[F::TYPE] = 27;
+      } else {  // kCommitLog  (tatp server_shard.cc:182-194, smallbank server_shard.cc:175-186)
+        uint32_t w[16];
+        __builtin_memcpy(&w[0], &r.key, 8);
+#pragma unroll
+        for (uint32_t k = 0; k < F::VS / 4; k++) w[2 + k] = ld_u32(m + F::VAL + 4 * k);
+        uint4 *e4 = (uint4 *)e8;
+        e4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (F::VS == 40) {
+          e4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+          e4[2] = make_uint4(w[8], w[9], w[10], w[11]);
+        }
+        *(uint2 *)(e8 + 48) = make_uint2(ver, r.table << 8);
+        rp[F::TYPE] = (WL == DINT_WL_TATP) ? 17 : 15;
+      }
+    }
+  }
 }
 
 // ---- k_kv_scan: one workgroup ---------------------------------------------------------------------------
-// Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area; clear the counters of the
-// list the next pass will use (the lists alternate, so nothing has to be reset behind the resolve kernel).
+// Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area; make the pass's log tail
+// current; clear the counters the next pass will use (the big-bin lists and the published log counts alternate
+// between passes, so nothing has to be reset behind the resolve kernel).
 __global__ void __launch_bounds__(256)
 k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
-          uint32_t *__restrict__ big_next) {
+          uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail) {
   __shared__ uint32_t Sw[4];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t < 2) big_next[t] = 0;  // the next pass counts into the other list (this one is read until the pass ends)
+  if (t < 4) big_next[t] = 0;
+  for (uint32_t k = t; k < 1024; k += 256) blk_pub_next[k] = 0;
+  if (t == 0 && tail) tail[0] = tail[1];
   const uint32_t nbig = big[0];
   uint32_t run = 0;
   for (uint32_t lo = 0; lo < nbig; lo += 256) {  // workgroup-uniform trip count; one trip unless the pass is very skewed
-    const uint32_t bin = lo + t < nbig ? big[2 + lo + t] : KV_NONE;
+    const uint32_t bin = lo + t < nbig ? big[4 + lo + t] : KV_NONE;
     const uint32_t extra = bin != KV_NONE ? bin_cnt[bin] - DINT_KV_BINCAP : 0;
     uint32_t tot, x = wave_excl_scan_u32(extra, &tot);
     __syncthreads();
@@ -275,65 +341,15 @@ k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, 
 }
 
 // ---- k_kv_place ----------------------------------------------------------------------------------------
-// Log requests: the canonical 64-byte record at ring position tail + (#log requests below i) [deterministic: an
-// exclusive scan, not an atomic].  Overflow records: into their bin's range of the overflow area.
-template <int WL>
+// Overflow records (positions DINT_KV_BINCAP.. of a bin): from the pass's list into their bin's range.
+#define KV_PLACE_GRID 64u
 __global__ void __launch_bounds__(KV_TB)
-k_kv_place(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
-           const uint32_t *__restrict__ blk_cnt, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-           const uint4 *__restrict__ ovl, uint64_t *__restrict__ ovf, int load_mode) {
-  using F = Fmt<WL>;
-  __shared__ uint32_t wcnt[KV_TB / 64], wpre[KV_TB / 64];
-  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint32_t i = blockIdx.x * KV_TB + t;
-  if (i < big[1]) {
+k_kv_place(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off, const uint4 *__restrict__ ovl,
+           uint64_t *__restrict__ ovf) {
+  const uint32_t novl = big[1];
+  for (uint32_t i = blockIdx.x * KV_TB + threadIdx.x; i < novl; i += KV_PLACE_GRID * KV_TB) {
     const uint4 o = ovl[i];
     ovf[bin_off[o.z] + o.w - DINT_KV_BINCAP] = ((uint64_t)o.y << 32) | o.x;
-  }
-  if (WL == DINT_WL_STORE) return;
-  const uint8_t *m = req + (size_t)i * F::MSG;
-  const kv_reqinfo r = kv_read_request<WL>(m, i < n, kv, load_mode);
-  // ring position = tail + (log requests below i): the workgroups before this one (<= 1023 counts, one per
-  // thread) + the waves before this one + the lanes before this one
-  {
-    uint32_t part = t < blockIdx.x ? blk_cnt[t] : 0, tot;
-    wave_excl_scan_u32(part, &tot);
-    if (lane == 0) wpre[wv] = tot;
-  }
-  const uint64_t lm = __ballot(r.cls == 2);
-  if (lane == 0) wcnt[wv] = (uint32_t)__popcll(lm);
-  __syncthreads();
-  uint32_t base = 0;
-  for (uint32_t w = 0; w < KV_TB / 64; w++) base += wpre[w] + (w < wv ? wcnt[w] : 0);
-  if (blockIdx.x == gridDim.x - 1 && t == 0) {  // the pass's new tail
-    uint32_t total = base;
-    for (uint32_t w = 0; w < KV_TB / 64; w++) total += wcnt[w];
-    log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
-  }
-  if (r.cls == 2) {
-    const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
-    const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
-    uint8_t *e = log.ring + (size_t)pos * 64;
-    const uint32_t ver = ld_u32(m + F::VER);
-    uint8_t *rp = rep + (size_t)i * F::MSG;
-    if (WL == DINT_WL_TATP && r.type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
-      *(uint64_t *)e = r.key;
-      *(uint2 *)(e + 48) = make_uint2(ver, 1u | (r.table << 8));
-      rp[F::TYPE] = 27;
-    } else {  // kCommitLog  (tatp server_shard.cc:182-194, smallbank server_shard.cc:175-186)
-      uint32_t w[16];
-      __builtin_memcpy(&w[0], &r.key, 8);
-#pragma unroll
-      for (uint32_t k = 0; k < F::VS / 4; k++) w[2 + k] = ld_u32(m + F::VAL + 4 * k);
-      uint4 *e4 = (uint4 *)e;
-      e4[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      if (F::VS == 40) {
-        e4[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        e4[2] = make_uint4(w[8], w[9], w[10], w[11]);
-      }
-      *(uint2 *)(e + 48) = make_uint2(ver, r.table << 8);
-      rp[F::TYPE] = (WL == DINT_WL_TATP) ? 17 : 15;
-    }
   }
 }
 
@@ -1016,7 +1032,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     return kind;
   };
   for (uint32_t bi = first; bi < nbig; bi += stride) {
-  const uint32_t bin = big[2 + bi];
+  const uint32_t bin = big[4 + bi];
   __syncthreads();  // the previous bin's LDS is free
   const uint32_t c = bin_cnt[bin];
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;  // [8] start, [9] end (10 ns), [12] rounds, [13] stretches, [14] c
@@ -1576,15 +1592,13 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   const bool has_log = WL != DINT_WL_STORE;
   if (ev) hipEventRecord(ev[0], st);
   hipLaunchKernelGGL((k_kv_count<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
-                     has_log ? log.tail : nullptr, pbits, s.bin_cnt, s.bins, s.big, s.ovl, has_log ? s.blk_cnt : nullptr,
-                     s.stats, load_mode);
+                     log, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode);
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
-                     s.big_next);
+                     s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr);
   if (ev) hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL((k_kv_place<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
-                     log, (const uint32_t *)s.blk_cnt, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
-                     (const uint4 *)s.ovl, s.ovf, load_mode);
+  hipLaunchKernelGGL(k_kv_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.big,
+                     (const uint32_t *)s.bin_off, (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[3], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
                      pbits, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
