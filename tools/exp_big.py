@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Big-bin statistics of tatp passes (DINT_KV_TRACE=1): per pass, how many bins went to k_kv_resolve_big, how many
+"""Big-bin statistics of tatp passes (DINT_KV_TRACE=1): per pass, how many bins went to the big-bin workgroups of k_kv_resolve, how many
 records they hold, and how long the slowest one took.  usage: exp_big.py [clients] [theta]"""
 import os
 import sys
