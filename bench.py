@@ -2,7 +2,7 @@
 """bench.py -- the DINT server hot path on MI355X, one step = one batch of synthetic wire messages
 already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tatp|fasst] ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload tatp|smallbank|store|fasst] ...
 
 Default workload (BASELINE.json metric "Mtxn/s ... TATP Zipf-0.8", configs[3]): the TATP transaction
 mix against 1M subscribers.  W virtual clients run the reference client's seven transactions in lock
@@ -10,17 +10,23 @@ step (dint_amd/csrc/txn_driver.cc); one step = one EPOCH = every client's curren
 request batches (one per replicated shard server, as in the reference's 3-server deployment), which the
 three engines of the GPU process.  The closed loop is first run once and recorded; the timed region
 replays the recorded batches from HBM (no host work, no PCIe) and the replies are checked byte for byte
-against the recorded run.  `--workload fasst` = BASELINE configs[1] (lock_fasst, 1M slots, 64k batches).
+against the recorded run -- and, in the cpu_baseline leg, against the CPU oracle on the same stream.
+Other workloads: `smallbank` (BASELINE configs[4], same machinery), `store` (configs[2]: 16.8M keys, 95/5
+read/write), `fasst` (configs[1]: lock_fasst, 64k batches; `--slots 36000000` = the reference's table).
 
-Rank 0 prints ONE JSON line; DESIGN.md "Measurement" defines every field.  For N > 1 this file is
-launched by torch.distributed.run, one rank per GPU: every logical shard server is hash-partitioned
-over the ranks and requests are routed to their home GPU with an all-to-all over RCCL.
+`--gpus N` with N > 1 and no torchrun environment re-launches this file under torch.distributed.run, one rank
+per GPU (RCCL); if fewer than N GPUs are visible the ranks share them and the exchange is staged through the
+host over gloo -- a functional run, labelled as such.  Rank 0 prints ONE JSON line; DESIGN.md "Measurement"
+defines every field.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,32 +45,60 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=os.environ.get("DINT_BENCH_WORKLOAD", "tatp"), choices=["tatp", "fasst"])
-    ap.add_argument("--slots", type=int, default=1 << 20, help="lock_fasst table slots (BASELINE configs[1]: 1M)")
-    ap.add_argument("--theta", type=float, default=0.8, help="Zipf skew of the key stream; 0 = the reference's own distribution")
+    ap.add_argument("--workload", default=os.environ.get("DINT_BENCH_WORKLOAD", "tatp"),
+                    choices=["tatp", "smallbank", "store", "fasst"])
+    ap.add_argument("--slots", type=int, default=1 << 20, help="lock_fasst table slots (BASELINE configs[1]: 1M; reference 36000000)")
+    ap.add_argument("--theta", type=float, default=None,
+                    help="Zipf skew of the key stream (default 0.8; smallbank 0.99); 0 = the reference's own distribution")
     ap.add_argument("--subscribers", type=int, default=1_000_000, help="tatp subscribers (BASELINE configs[3]: 1M)")
+    ap.add_argument("--accounts", type=int, default=0,
+                    help="smallbank accounts in total over all GPUs (default 10M per GPU: BASELINE configs[4] = 80M on 8)")
+    ap.add_argument("--keys", type=int, default=16_777_216, help="store keys (BASELINE configs[2]: 16M)")
     ap.add_argument("--clients", type=int, default=524288,
-                    help="tatp closed-loop clients per GPU (one outstanding request each: a shard server sees ~clients * 0.46 "
+                    help="closed-loop clients per GPU (one outstanding phase each: a tatp shard server sees ~clients * 0.46 "
                          "requests per epoch, all resolved in one kernel pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rand64", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive dint_submit_async measurement")
+    ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the multi-GPU exchange (self all-to-all)")
     return ap.parse_args()
 
 
-def init_dist():
+# --------------------------------------------------------------------------------------------- launch / dist
+def respawn_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this same file."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def init_dist(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    transport = "self"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank % ndev)
+        if ndev >= world:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            transport = "nccl"
+        else:  # several ranks per GPU: RCCL refuses that; functional run over gloo, exchange staged through the host
+            dist.init_process_group("gloo")
+            transport = "host"
     else:
         torch.cuda.set_device(0)
-    return world, rank, torch.cuda.current_device()
+    return world, rank, torch.cuda.current_device(), transport
 
 
 def barrier(world):
@@ -76,69 +110,77 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-def max_over_ranks(dt, world):
+def _reduce(x, world, op, transport):
     import torch
     import torch.distributed as dist
 
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
-
-
-def sum_over_ranks(x, world):
-    import torch
-    import torch.distributed as dist
-
-    if world > 1:
-        t = torch.tensor([float(x)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = torch.tensor([float(x)], device="cuda" if transport == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=op)
         x = float(t.item())
     return x
 
 
-def pmc_traffic(kernels):
-    """HBM bytes per launch of `kernels` from the committed rocprofv3 --pmc summary of this same command
-    (profiles/r01_tatp_rocprofv3_summary.txt: FETCH_SIZE + WRITE_SIZE, KiB per dispatch, separate passes as
-    MI355X_MICROARCH.md prescribes; the rows over the last dispatches = the replayed epochs, without the population
-    passes).  Raw counter values: the guide's x2 FETCH_SIZE correction applies to wide coalesced streams, the
-    resolve kernel issues 8..64-byte random accesses, for which it is uncalibrated."""
-    path = os.path.join(ROOT, "profiles", "r01_tatp_rocprofv3_summary.txt")
+def max_over_ranks(dt, world, transport="nccl"):
+    import torch.distributed as dist
+
+    return _reduce(dt, world, dist.ReduceOp.MAX, transport)
+
+
+def sum_over_ranks(x, world, transport="nccl"):
+    import torch.distributed as dist
+
+    return _reduce(x, world, dist.ReduceOp.SUM, transport)
+
+
+# --------------------------------------------------------------------------------------------- helpers
+def host_cpu():
+    model = "unknown"
     try:
-        tot = {False: 0.0, True: 0.0}  # [rows over all dispatches, rows over the last dispatches]
-        last = False
-        for line in open(path):
-            if line.startswith("kernel"):
-                last = "(last" in line
-            f = line.split()
-            if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE") and f[0].split("<")[0] in kernels:
-                tot[last] += float(f[3]) * 1024.0
-        t = tot[True] or tot[False]
-        return int(t) if t else None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
     except OSError:
-        return None
+        pass
+    return {"model": model, "logical_cores": os.cpu_count()}
 
 
-def rocprof_avg_us(kernels):
-    """Average begin->end duration of `kernels` over the same launches in the committed rocprofv3 --kernel-trace summary
-    (first block of profiles/r01_tatp_rocprofv3_summary.txt, rows over the last dispatches).  The live HIP-event interval
-    (`kernel_avg_us`) additionally contains the dispatch gap on a stream that shares the GPU with two other engines."""
-    path = os.path.join(ROOT, "profiles", "r01_tatp_rocprofv3_summary.txt")
+def kernel_source_hash():
+    """sha256 over the kernel sources: profiles/ counters are only quoted for the build they were taken from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dint_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_counters(workload, kernels):
+    """HBM-side bytes per launch of `kernels` (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) and their
+    rocprofv3 begin->end duration, from profiles/traffic_<workload>.json -- written by tools/profile_bench.py from
+    rocprofv3 runs of this same command.  Quoted only when the file was taken from the kernel sources this run
+    uses; otherwise (None, None, reason).  Not measured in this run: the field name in the JSON line says so."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
     try:
-        tot, last, seen = 0.0, False, set()
-        for line in open(path):
-            if line.startswith("#") and seen:
-                break  # only the kernel-trace block
-            if line.startswith("kernel"):
-                last = "(last" in line
-            f = line.split()
-            if last and len(f) == 5 and f[0].split("<")[0] in kernels and f[0] not in seen:
-                seen.add(f[0])
-                tot += float(f[2])
-        return round(tot, 3) if seen else None
+        p = json.load(open(path))
     except (OSError, ValueError):
         return None
+    if p.get("kernel_source_hash") != kernel_source_hash():
+        return {"stale": True, "file": os.path.relpath(path, ROOT), "profiled_sources": p.get("kernel_source_hash")}
+    tot_b, tot_us, seen = 0.0, 0.0, 0
+    for k in kernels:
+        e = p.get("kernels", {}).get(k)
+        if e is None:
+            continue
+        seen += 1
+        tot_b += e.get("fetch_bytes", 0.0) + e.get("write_bytes", 0.0)
+        tot_us += e.get("avg_us", 0.0)
+    if not seen:
+        return None
+    return {"traffic_bytes": int(tot_b), "kernel_avg_us": round(tot_us, 3), "file": os.path.relpath(path, ROOT),
+            "command": p.get("command"), "launches": p.get("launches"), "commit": p.get("commit")}
 
 
 def rand64(extra, value_ops_per_s, dev):
@@ -155,36 +197,46 @@ def rand64(extra, value_ops_per_s, dev):
         extra["rand64_error"] = str(ex)
 
 
+def pct(a, q):
+    return round(float(np.percentile(a, q)), 2)
+
+
 # ------------------------------------------------------------------------------------------- lock_fasst
-def cpu_baseline_fasst(sample: np.ndarray, nslots: int):
+def cpu_baseline_fasst(sample: np.ndarray, nslots: int, want: bytes):
     """The CPU baseline on rank 0's host cores over a bounded sample of the same stream: the unmodified
-    reference server when its replay binary is present (kind "reference"), else the C restatement."""
+    reference server when its replay binary is present and the table has the reference's size (kind "reference"),
+    else the C restatement.  Its replies must equal the GPU's on the same requests (`want`)."""
     from oracle import oracle as orc
 
     if nslots == 36_000_000 and orc.ref_available("lock_fasst"):
-        _, st = orc.ref_replay("lock_fasst", sample)
-        return {"value": st["ops_per_s"] / 1e6, "unit": "Mtxn/s", "cores": 1, "kind": "reference",
-                "sample": f"{len(sample)} requests of the bench stream, unmodified lock_fasst/udp/server.cc, sockets interposed"}
-    o = orc.FasstOracle(nslots)
-    t = time.perf_counter()
-    o.replay(sample)
-    dt = time.perf_counter() - t
-    return {"value": len(sample) / dt / 1e6, "unit": "Mtxn/s", "cores": 1, "kind": "port",
-            "sample": f"{len(sample)} requests of the bench stream, oracle/dint_oracle.c ({nslots} slots)"}
+        rep, st = orc.ref_replay("lock_fasst", sample)
+        out = {"value": st["ops_per_s"] / 1e6, "unit": "Mtxn/s", "cores": 1, "kind": "reference",
+               "sample": f"{len(sample)} requests of the bench stream, unmodified lock_fasst/udp/server.cc, sockets interposed"}
+    else:
+        o = orc.FasstOracle(nslots)
+        t = time.perf_counter()
+        rep = o.replay(sample)
+        dt = time.perf_counter() - t
+        out = {"value": len(sample) / dt / 1e6, "unit": "Mtxn/s", "cores": 1, "kind": "port",
+               "sample": f"{len(sample)} requests of the bench stream, oracle/dint_oracle.c ({nslots} slots)"}
+    out["host_cpu"] = host_cpu()
+    out["oracle_parity"] = {"requests": len(sample), "ok": rep.tobytes() == want}
+    return out
 
 
-def bench_fasst(args, world, rank, dev):
+def bench_fasst(args, world, rank, dev, transport):
     import torch
 
     from dint_amd import wire, workloads
     from dint_amd.engine import Engine
-    from dint_amd.sharded import ShardedEngine
+    from dint_amd.sharded import Router
 
     K, W = args.steps, args.warmup
+    theta = 0.8 if args.theta is None else args.theta
     # FaSST-client-shaped stream, Zipf(theta) keys over 24M lids, 4096 interleaved virtual clients;
     # every rank ingests its own slice
     n_req = BATCH * (K + W)
-    stream = workloads.fasst_stream(n_req, key_space=24_000_000, theta=args.theta, seed=1234 + rank)
+    stream = workloads.fasst_stream(n_req, key_space=24_000_000, theta=theta, seed=1234 + rank)
     stream = workloads.interleave(stream, 4096)
     n_req = len(stream) // BATCH * BATCH
     assert n_req // BATCH >= K + W
@@ -193,40 +245,50 @@ def bench_fasst(args, world, rank, dev):
     msg = wire.FASST_MSG.itemsize
 
     eng = Engine(wire.Workload.FASST, n_slots=args.slots, device=dev, shard_index=rank, shard_count=world)
-    sh = ShardedEngine(eng, world, rank) if world > 1 else None
-    st = torch.cuda.current_stream().cuda_stream
+    rt = Router([eng], world, rank, transport=None if world > 1 else "self", n_max=BATCH) if (world > 1 or args.force_exchange) else None
+    torch.cuda.synchronize()
 
     def step(b):
         lo = b * BATCH * msg
-        if sh is None:
-            eng.submit_device(d_req.data_ptr() + lo, BATCH, d_rep.data_ptr() + lo, st)
+        if rt is None:
+            eng.submit_device(d_req.data_ptr() + lo, BATCH, d_rep.data_ptr() + lo, 0)
         else:
-            sh.submit_device(d_req[lo:lo + BATCH * msg], BATCH, d_rep[lo:lo + BATCH * msg])
+            rt.step([d_req.data_ptr() + lo], [BATCH], [d_rep.data_ptr() + lo])
+
+    def sync():
+        if rt is not None:
+            rt.sync()
+        eng.sync()
+        torch.cuda.synchronize()
 
     for b in range(W):
         step(b)
+    sync()
     barrier(world)
     t0 = time.perf_counter()
     for b in range(W, W + K):
         step(b)
+    sync()
     barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, transport)
+    got0 = d_rep[0:min(n_req, 4_000_000 // BATCH * BATCH) * msg].cpu().numpy().tobytes()  # replies of the first batches
+    overflow = rt.overflow() if rt is not None else 0
 
     lat = []
     for b in range(W, W + min(K, 100)):
-        torch.cuda.synchronize()
+        sync()
         t = time.perf_counter()
         step(b)
-        torch.cuda.synchronize()
+        sync()
         lat.append((time.perf_counter() - t) * 1e6)
     lat = np.array(lat)
 
     roof, extra = None, {}
-    if sh is None:
+    if rt is None:
         eng.timing_enable(True)
         for b in range(W, W + min(K, 200)):
             step(b)
-        torch.cuda.synchronize()
+        sync()
         tim = eng.timing_read()
         eng.timing_enable(False)
         extra["kernels_us"] = {k: round(v["avg_us"], 3) for k, v in tim.items()}
@@ -237,57 +299,234 @@ def bench_fasst(args, world, rank, dev):
         achieved = alg_bytes / (dom[1]["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(dom[1]["avg_us"], 3)}
+                "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(dom[1]["avg_us"], 3),
+                "from_profile": profile_counters("fasst", [dom[0]])}
 
     value = world * K * BATCH / dt / 1e6
     if rank != 0:
         return None
-    if not args.no_rand64 and sh is None:
+    if not args.no_rand64 and rt is None:
         rand64(extra, value * 1e6, dev)
-    cpu = None if args.no_cpu_baseline else cpu_baseline_fasst(stream[W * BATCH:W * BATCH + 4_000_000].copy(), args.slots)
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        # the engine state at the first batch is the empty table: the first batches' replies are checkable as a unit
+        n_s = len(got0) // msg
+        cpu = cpu_baseline_fasst(stream[:n_s].copy(), args.slots, got0)
     return {
         "metric": "Mtxn/s (lock_fasst: 1 txn = 1 request) + p50/p99 batch latency",
         "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"lock_fasst on {world} MI355X: {args.slots}-slot lock table, 64k-request batches, "
-                               f"Zipf-{args.theta} over 24M lids, FaSST client op mix (read proportion 0.8)",
-                   "batch": BATCH, "slots": args.slots, "parallelism": f"hash-shard x{world}"},
-        "latency_us": {"p50": round(float(np.percentile(lat, 50)), 2), "p99": round(float(np.percentile(lat, 99)), 2)},
+                               f"Zipf-{theta} over 24M lids, FaSST client op mix (read proportion 0.8)",
+                   "batch": BATCH, "slots": args.slots, "parallelism": f"hash-shard x{world}", "transport": transport},
+        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99)}, "route_overflow": overflow,
         "roofline": roof, "cpu_baseline": cpu, **extra,
     }
 
 
-# ------------------------------------------------------------------------------------------------ tatp
-# algorithmic bytes per request: 55 (request) + 55 (reply) + the row / lock bytes the op needs
+# -------------------------------------------------------------------------------------------------- store
+STORE_ALG = {0: 158, 1: 162}  # READ 53 + 53 + 52, SET 53 + 53 + 12 + 44
+
+
+def store_stream(n, n_sub, theta, seed):
+    """store/caladan/client_udp.cc:135-147 key shape {s_id, sf_type 1..4, start_time 0/8/16}, s_id ~ Zipf(theta) over
+    the populated subscribers, 95 % READ / 5 % SET (BASELINE configs[2]); SET value {end_time, 0x5a} (:56-66)"""
+    from dint_amd import wire, workloads
+
+    rng = np.random.default_rng(seed)
+    z = workloads.Zipf(n_sub, theta, seed + 1)
+    m = np.zeros(n, wire.STORE_MSG)
+    s_id = z.sample(n).astype(np.uint64)
+    m["key"] = s_id | (rng.integers(1, 5, n).astype(np.uint64) << np.uint64(32)) | (
+        (rng.integers(0, 3, n) * 8).astype(np.uint64) << np.uint64(40))
+    m["type"] = (rng.random(n) < 0.05).astype(np.uint8)
+    m["val"][:, 0] = rng.integers(0, 24, n)
+    m["val"][:, 1] = 0x5A
+    return m
+
+
+def bench_store(args, world, rank, dev, transport):
+    import torch
+
+    from dint_amd import wire
+    from dint_amd.engine import Engine
+    from dint_amd.sharded import Router
+
+    K, W = args.steps, args.warmup
+    theta = 0.8 if args.theta is None else args.theta
+    n_sub = args.keys // 12  # 12 rows per subscriber (store/udp/tatp.h:44-66)
+    NB = 262144            # requests per step
+    eng = Engine(wire.Workload.STORE, n_rows=n_sub, device=dev, shard_index=rank, shard_count=world)
+    t_setup = time.perf_counter()
+    eng.populate(n_sub)
+    eng.sync()
+    t_setup = time.perf_counter() - t_setup
+    stream = store_stream(NB * (K + W), n_sub, theta, 77 + rank)
+    d_req = torch.from_numpy(np.frombuffer(stream.tobytes(), np.uint8).copy()).cuda()
+    d_rep = torch.empty_like(d_req)
+    msg = wire.STORE_MSG.itemsize
+    rt = Router([eng], world, rank, n_max=NB) if world > 1 else None
+    torch.cuda.synchronize()
+
+    def step(b):
+        lo = b * NB * msg
+        if rt is None:
+            eng.submit_device(d_req.data_ptr() + lo, NB, d_rep.data_ptr() + lo, 0)
+        else:
+            rt.step([d_req.data_ptr() + lo], [NB], [d_rep.data_ptr() + lo])
+
+    def sync():
+        if rt is not None:
+            rt.sync()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    for b in range(W):
+        step(b)
+    sync()
+    barrier(world)
+    t0 = time.perf_counter()
+    for b in range(W, W + K):
+        step(b)
+    sync()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, transport)
+    got = d_rep.cpu().numpy().tobytes()
+    lat = []
+    for b in range(W, W + min(K, 100)):
+        sync()
+        t = time.perf_counter()
+        step(b)
+        sync()
+        lat.append((time.perf_counter() - t) * 1e6)
+    lat = np.array(lat)
+    roof, extra, cpu = None, {}, None
+    if rt is None:
+        eng.timing_enable(True)
+        for b in range(W, W + min(K, 200)):
+            step(b)
+        sync()
+        tim = eng.timing_read()
+        eng.timing_enable(False)
+        extra["kernels_us"] = {k: round(v["avg_us"], 3) for k, v in tim.items()}
+        ty = stream[W * NB:(W + K) * NB]["type"]
+        alg = NB * (STORE_ALG[0] * float((ty == 0).mean()) + STORE_ALG[1] * float((ty == 1).mean()))
+        us = tim["k_kv_resolve"]["avg_us"]
+        ach = alg / (us * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_kv_resolve", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(alg),
+                "kernel_avg_us": round(us, 3), "from_profile": profile_counters("store", ["k_kv_resolve"])}
+    value = world * K * NB / dt / 1e6
+    if rank != 0:
+        return None
+    if not args.no_rand64 and rt is None:
+        rand64(extra, value * 1e6, dev)
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import oracle as orc
+
+        o = orc.StoreOracle(n_sub * 18 // 4, n_sub)
+        n_s = min(len(stream), 8 * NB)
+        t = time.perf_counter()
+        rep = o.replay(stream[:n_s].copy())
+        dtc = time.perf_counter() - t
+        cpu = {"value": round(n_s / dtc / 1e6, 4), "unit": "Mtxn/s", "cores": 1, "kind": "port", "host_cpu": host_cpu(),
+               "sample": f"the first {n_s} requests of the bench stream, oracle/dint_oracle.c ({n_sub * 12} keys), 1 thread",
+               "oracle_parity": {"requests": n_s, "ok": rep.tobytes() == got[:n_s * msg]}}
+    return {
+        "metric": "Mtxn/s (store: 1 txn = 1 request) + p50/p99 batch latency",
+        "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"store KV on {world} MI355X: {n_sub * 12} keys x 40-B values (64-B slots), 95/5 read/write, "
+                               f"s_id ~ Zipf-{theta}, {NB}-request batches", "keys": n_sub * 12, "batch": NB,
+                   "parallelism": f"hash-shard x{world}", "transport": transport},
+        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99)},
+        "roofline": roof, "cpu_baseline": cpu, "setup_s": round(t_setup, 2), **extra,
+    }
+
+
+# ----------------------------------------------------------------------------------- tatp / smallbank
+# algorithmic bytes per request (SURVEY.md 8d): request + reply + the row / lock bytes the op needs
 TATP_ALG = {0: 162, 1: 126, 2: 126, 12: 170, 18: 170, 22: 170, 13: 162, 19: 162, 23: 162, 14: 174, 24: 174}
 TATP_LOG_TYPES = (14, 24)
+SB_ALG = {0: 78, 1: 78, 2: 58, 3: 58, 4: 66, 5: 66, 6: 78}  # 23 + 23 + {20 row + 12 counters | 12 | 20 | 32 log}
+SB_LOG_TYPES = (6,)
 
 
-def cpu_baseline_tatp(trace, done, n_sub, lo, hi):
-    """Shard server 0's recorded request stream of epochs [lo, hi) replayed on one host core by the CPU
-    port (oracle/dint_oracle.c).  A transaction costs `ops_per_txn` requests over the three servers, so one
-    core serving all three streams back to back completes (ops/s) / ops_per_txn transactions per second."""
+def cpu_baseline_txn(kind, trace, done, n_rows, lo, hi):
+    """Shard server 0's recorded request stream of epochs [0, hi) replayed on one host core by the CPU port
+    (oracle/dint_oracle.c); epochs [lo, hi) are timed.  Every reply must equal what the GPU engine answered when the
+    stream was recorded (oracle parity on the exact bench stream).  A transaction costs `ops_per_txn` requests over
+    the three servers, so one core serving all three streams back to back completes (ops/s) / ops_per_txn
+    transactions per second."""
     from oracle import oracle as orc
 
-    o = orc.TatpOracle(n_sub)
-    for e in range(lo):  # bring the replica to the state at the start of the sample (not timed)
-        o.replay(trace[e][0][0])
-    n = 0
-    t = time.perf_counter()
-    for e in range(lo, hi):
-        o.replay(trace[e][0][0])
-        n += len(trace[e][0][0])
-    dt = time.perf_counter() - t
+    o = orc.TatpOracle(n_rows) if kind == "tatp" else orc.SmallbankOracle(n_rows)
+    ok, checked = True, 0
+    n, dt = 0, 0.0
+    for e in range(hi):
+        req = trace[e][0][0]
+        t = time.perf_counter()
+        rep = o.replay(req)
+        if e >= lo:
+            dt += time.perf_counter() - t
+            n += len(req)
+        ok = ok and rep.tobytes() == trace[e][1][0].tobytes()
+        checked += len(req)
     ops_all = sum(sum(len(r) for r in trace[e][0]) for e in range(lo, hi))
     ops_per_txn = ops_all / max(1, sum(done[lo:hi]))
     return {"value": round(n / dt / ops_per_txn / 1e6, 4), "unit": "Mtxn/s", "cores": 1, "kind": "port",
-            "ops_per_s": round(n / dt), "ops_per_txn": round(ops_per_txn, 3),
+            "ops_per_s": round(n / dt), "ops_per_txn": round(ops_per_txn, 3), "host_cpu": host_cpu(),
             "sample": f"{n} requests = shard server 0's stream of {hi - lo} bench epochs, oracle/dint_oracle.c "
-                      f"({n_sub} subscribers), 1 thread"}
+                      f"({n_rows} rows), 1 thread",
+            "oracle_parity": {"epochs": hi, "requests": checked, "ok": ok,
+                              "what": "GPU replies of shard server 0 vs the CPU oracle, every byte, on the bench stream"}}
 
 
-def bench_tatp(args, world, rank, dev):
+def host_path(grp, trace, lo, hi):
+    """The boundary the reference's servers sit behind hands over HOST buffers: the same recorded batches through
+    dint_submit_async / dint_wait from page-locked memory (H2D + kernels + D2H, three staging slots per engine).
+    Returns per-epoch latency (submit of the three batches -> all replies in host memory) and the pipelined rate."""
+    from dint_amd.engine import Pinned
+
+    msg = grp.msg
+    bufs = []
+    for e in range(lo, hi):
+        row = []
+        for s in range(3):
+            b = trace[e][0][s].tobytes()
+            pin, pout = Pinned(max(len(b), 1)), Pinned(max(len(b), 1))
+            pin.array[:len(b)] = np.frombuffer(b, np.uint8)
+            row.append((pin, pout, len(b) // msg))
+        bufs.append(row)
+    grp.sync()
+    lat = []
+    for row in bufs:  # one epoch at a time: latency
+        t = time.perf_counter()
+        tk = [grp.engines[s].submit_async(row[s][0].ptr, row[s][2], row[s][1].ptr) for s in range(3)]
+        for s in range(3):
+            grp.engines[s].wait(tk[s])
+        lat.append((time.perf_counter() - t) * 1e6)
+    ok = all(row[s][1].array[:row[s][2] * msg].tobytes() == trace[lo + i][1][s].tobytes()
+             for i, row in enumerate(bufs) for s in range(3))
+    return np.array(lat), bufs, ok
+
+
+def host_path_rate(grp, bufs):
+    """all epochs submitted back to back (the engines pipeline copies and kernels), one wait at the end"""
+    grp.sync()
+    t = time.perf_counter()
+    tk = [0, 0, 0]
+    for row in bufs:
+        for s in range(3):
+            tk[s] = grp.engines[s].submit_async(row[s][0].ptr, row[s][2], row[s][1].ptr)
+    for s in range(3):
+        grp.engines[s].wait(tk[s])
+    return time.perf_counter() - t
+
+
+def bench_txn(args, world, rank, dev, transport, kind):
     import torch
 
     from dint_amd import wire
@@ -295,16 +534,25 @@ def bench_tatp(args, world, rank, dev):
     from dint_amd.replay import Replay, ShardGroup, record
 
     K, W = args.steps, args.warmup
-    n_sub, C = args.subscribers, args.clients
-    theta = args.theta if args.theta > 0 else None
+    C = args.clients
+    if kind == "tatp":
+        wl, n_rows, theta = wire.Workload.TATP, args.subscribers, (0.8 if args.theta is None else args.theta)
+        alg_tab, log_types, dtype = TATP_ALG, TATP_LOG_TYPES, "u64"
+    else:
+        wl, theta = wire.Workload.SMALLBANK, (0.99 if args.theta is None else args.theta)
+        n_rows = args.accounts if args.accounts else 10_000_000 * world
+        alg_tab, log_types, dtype = SB_ALG, SB_LOG_TYPES, "u64"
+    zipf = theta if theta > 0 else None
     t_setup = time.perf_counter()
-    grp = ShardGroup(wire.Workload.TATP, n_sub, device=dev, rank=rank, world=world)
+    grp = ShardGroup(wl, n_rows, device=dev, rank=rank, world=world, transport=None if world > 1 else "self",
+                     force_exchange=args.force_exchange, n_max=KV_PASS)
     grp.sync()
     grp.snapshot()
-    drv = Driver(wire.Workload.TATP, C, n_sub, first_client=rank * C, zipf_theta=theta)
+    drv = Driver(wl, C, n_rows, first_client=rank * C, zipf_theta=zipf)
     trace, done = record(drv, grp, W + K)  # the closed loop, once, through the real engines
     stats = drv.stats()
     grp.sync()
+    caps = grp.router.tighten_caps() if grp.router is not None else None  # slot capacities from the recorded maxima
     grp.restore()
     rp = Replay(trace, grp.msg)
     torch.cuda.synchronize()
@@ -317,14 +565,28 @@ def bench_tatp(args, world, rank, dev):
     rp.run(grp, W, W + K)
     grp.sync()
     barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, transport)
     rp.check(0, W + K)  # parity with the recorded closed-loop run, every reply byte
+    overflow = grp.router.overflow() if grp.router is not None else 0
 
-    txns = sum_over_ranks(sum(done[W:W + K]), world)
-    ops = sum_over_ranks(rp.ops(W, W + K), world)
+    txns = sum_over_ranks(sum(done[W:W + K]), world, transport)
+    ops = sum_over_ranks(rp.ops(W, W + K), world, transport)
     value = txns / dt / 1e6
 
-    # per-epoch latency: submit of the three batches -> all replies visible in HBM
+    # run-to-run spread of the same K steps (state restored before each): the driver's 20-step run is a few ms
+    repeats = []
+    for _ in range(4):
+        grp.restore()
+        rp.run(grp, 0, W)
+        grp.sync()
+        barrier(world)
+        t1 = time.perf_counter()
+        rp.run(grp, W, W + K)
+        grp.sync()
+        barrier(world)
+        repeats.append(txns / max_over_ranks(time.perf_counter() - t1, world, transport) / 1e6)
+
+    # per-epoch latency, device side: submit of the three batches -> all replies visible in HBM
     grp.restore()
     lat = []
     for e in range(min(W + K, 120)):
@@ -336,7 +598,7 @@ def bench_tatp(args, world, rank, dev):
     lat = np.array(lat[min(W, len(lat) // 2):])
 
     roof, extra = None, {}
-    if world == 1:
+    if world == 1 and grp.router is None:
         grp.restore()
         for e in grp.engines:
             e.timing_enable(True)
@@ -350,7 +612,7 @@ def bench_tatp(args, world, rank, dev):
         avg = {k: float(np.mean([t[k]["avg_us"] for t in tims])) for k in names}
         extra["kernels_us"] = {k: round(v, 3) for k, v in avg.items()}
         # The table requests of a pass are resolved by k_kv_resolve (every bin of the pass, one launch): algorithmic
-        # bytes of the table requests over its duration.  Log requests are finished by k_kv_place.
+        # bytes of the table requests over its duration.  Log requests are finished by k_kv_count.
         resolve_us = avg.get("k_kv_resolve", 0.0)
         scatter_us = avg.get("k_kv_count", 0.0) + avg.get("k_kv_scan", 0.0) + avg.get("k_kv_place", 0.0)
         dom = "k_kv_resolve" if resolve_us >= scatter_us else "k_kv_count+k_kv_scan+k_kv_place"
@@ -362,47 +624,87 @@ def bench_tatp(args, world, rank, dev):
                 if len(ty) == 0:
                     continue
                 launches += -(-len(ty) // KV_PASS)
-                for code, b in TATP_ALG.items():
-                    if resolve_us < scatter_us or code not in TATP_LOG_TYPES:
+                for code, b in alg_tab.items():
+                    if resolve_us < scatter_us or code not in log_types:
                         tot_b += b * int((ty == code).sum())
         alg = tot_b / max(1, launches)
         achieved = alg / (dom_us * 1e-6) / 1e9
+        # `traffic` is not measured inside this run (rocprofv3 cannot attach to itself): null here; the PMC figures of
+        # the same command live in profiles/ and are quoted under from_profile only for the same kernel sources
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom.split("+")),
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "alg_bytes_per_launch": int(alg), "kernel_avg_us": round(dom_us, 3),
-                "kernel_avg_us_rocprofv3": rocprof_avg_us(dom.split("+"))}
+                "from_profile": profile_counters(kind, dom.split("+"))}
+        fp = roof["from_profile"]
+        if fp and fp.get("traffic_bytes"):
+            roof["traffic"] = fp["traffic_bytes"]
+            roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, alg), 3)
+
+    host = {}
+    if world == 1 and grp.router is None and not args.no_host_path:
+        grp.restore()
+        n_h = min(W + K, 24)
+        hl, bufs, ok = host_path(grp, trace, 0, n_h)
+        grp.restore()
+        dth = host_path_rate(grp, bufs)
+        tx_h, ops_h = sum(done[:n_h]), sum(sum(len(r) for r in trace[e][0]) for e in range(n_h))
+        host = {"latency_host_us": {"p50": pct(hl[n_h // 4:], 50), "p99": pct(hl[n_h // 4:], 99),
+                                    "what": "dint_submit_async x3 + dint_wait from page-locked host buffers: H2D + kernels + D2H"},
+                "value_pcie": round(tx_h / dth / 1e6, 3), "Mops_s_pcie": round(ops_h / dth / 1e6, 3),
+                "pcie_parity_ok": bool(ok)}
     if rank != 0:
         return None
-    if not args.no_rand64 and world == 1:
+    if not args.no_rand64 and world == 1 and grp.router is None:
         rand64(extra, ops / dt, dev)
     cpu = None
-    if not args.no_cpu_baseline:
-        cpu = cpu_baseline_tatp(trace, done, n_sub, W, W + min(K, 60))
-    dist_name = f"Zipf-{args.theta}" if theta else "tatp_nurand (reference)"
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline_txn(kind, trace, done, n_rows, W, W + min(K, 60))
+    if kind == "tatp":
+        dist_name = f"Zipf-{theta}" if zipf else "tatp_nurand (reference)"
+        what = (f"TATP full txn mix (35/35/10/2/14/2/2) on {world} MI355X: {n_rows} subscribers, 3 replicated "
+                f"shard servers per GPU group, {C} closed-loop clients per GPU, s_id ~ {dist_name}; "
+                f"1 step = 1 epoch = 3 request batches")
+        metric = "Mtxn/s + p50/p99 batch latency, TATP"
+        rows_key = "subscribers"
+    else:
+        dist_name = f"Zipf-{theta}" if zipf else "90% of txns on the 4% hot accounts (reference)"
+        what = (f"SmallBank (6 txns, 15/15/15/25/15/15, 2PL) on {world} MI355X: {n_rows} accounts hash-sharded, 3 replicated "
+                f"shard servers per GPU group, {C} closed-loop clients per GPU, accounts ~ {dist_name}; "
+                f"1 step = 1 epoch = 3 request batches")
+        metric = "Mtxn/s + p50/p99 batch latency, SmallBank"
+        rows_key = "accounts"
+    nt = 7 if kind == "tatp" else 6
     return {
-        "metric": "Mtxn/s + p50/p99 batch latency, TATP",
+        "metric": metric,
         "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"TATP full txn mix (35/35/10/2/14/2/2) on {world} MI355X: {n_sub} subscribers, 3 replicated "
-                               f"shard servers per GPU group, {C} closed-loop clients per GPU, s_id ~ {dist_name}; "
-                               f"1 step = 1 epoch = 3 request batches",
-                   "subscribers": n_sub, "clients_per_gpu": C, "requests_per_step": round(ops / K / world),
-                   "parallelism": f"3 shard servers x hash-shard x{world}"},
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": what, rows_key: n_rows, "clients_per_gpu": C, "requests_per_step": round(ops / K / world),
+                   "parallelism": f"3 shard servers x hash-shard x{world}", "transport": transport,
+                   "exchange_slot_caps": caps},
         "Mops_s": round(ops / dt / 1e6, 3), "ops_per_txn": round(ops / max(1.0, txns), 3),
         "abort_rate": round(1.0 - stats["committed"] / max(1, stats["txns"]), 5),
-        "txns_by_type": stats["by_type"][:7], "committed_by_type": stats["committed_by_type"][:7],
-        "latency_us": {"p50": round(float(np.percentile(lat, 50)), 2), "p99": round(float(np.percentile(lat, 99)), 2)},
+        "txns_by_type": stats["by_type"][:nt], "committed_by_type": stats["committed_by_type"][:nt],
+        "value_repeats": [round(v, 1) for v in repeats],
+        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "device side: 3 batches submitted -> replies in HBM"},
+        **host, "route_overflow": overflow,
         "roofline": roof, "cpu_baseline": cpu, "setup_s": round(t_setup, 2), **extra,
     }
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     import torch.distributed as dist
 
-    world, rank, dev = init_dist()
-    out = bench_tatp(args, world, rank, dev) if args.workload == "tatp" else bench_fasst(args, world, rank, dev)
+    world, rank, dev, transport = init_dist(args)
+    if args.workload == "fasst":
+        out = bench_fasst(args, world, rank, dev, transport)
+    elif args.workload == "store":
+        out = bench_store(args, world, rank, dev, transport)
+    else:
+        out = bench_txn(args, world, rank, dev, transport, args.workload)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

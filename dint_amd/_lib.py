@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdint.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MICRO_BATCH = 65536
 
 #: every symbol include/dint_abi.h declares (checked by tests/test_abi.py)
@@ -20,6 +20,8 @@ SYMBOLS = [
     "dint_submit_device", "dint_sync", "dint_load_rows", "dint_populate", "dint_hash_size", "dint_dump_rows",
     "dint_read_locks", "dint_read_log", "dint_get_stats", "dint_reset", "dint_snapshot", "dint_restore",
     "dint_home_shard", "dint_bench_rand64", "dint_timing_enable", "dint_timing_read", "dint_kv_trace_read",
+    "dint_submit_async", "dint_wait", "dint_alloc_pinned", "dint_free_pinned", "dint_engine_stream", "dint_max_pass",
+    "dint_stream_wait", "dint_stream_signal", "dint_route_pack", "dint_route_unpack", "dint_submit_segments",
 ]
 
 
@@ -28,7 +30,7 @@ class Config(C.Structure):
         ("abi_version", C.c_uint32), ("workload", C.c_uint32), ("device", C.c_int32), ("flags", C.c_uint32),
         ("n_slots", C.c_uint64), ("n_rows", C.c_uint64), ("log_entries", C.c_uint32),
         ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("max_pass", C.c_uint32),
-        ("reserved", C.c_uint32 * 4),
+        ("pool_entries", C.c_uint32), ("reserved", C.c_uint32 * 3),
     ]
 
 
@@ -36,7 +38,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("batches", C.c_uint64), ("requests", C.c_uint64), ("bad_requests", C.c_uint64),
         ("missing_keys", C.c_uint64), ("foreign_requests", C.c_uint64), ("pool_exhausted", C.c_uint64),
-        ("reserved", C.c_uint64 * 2),
+        ("route_overflow", C.c_uint64), ("reserved", C.c_uint64 * 1),
     ]
 
 
@@ -82,6 +84,17 @@ def load() -> C.CDLL:
         "dint_kv_trace_read": (C.c_int, [vp, vp, u64]),
         "dint_timing_enable": (C.c_int, [vp, C.c_int]),
         "dint_timing_read": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(u64), C.c_int]),
+        "dint_submit_async": (C.c_int, [vp, vp, u32, vp, C.POINTER(u64)]),
+        "dint_wait": (C.c_int, [vp, u64]),
+        "dint_alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+        "dint_free_pinned": (None, [vp]),
+        "dint_engine_stream": (vp, [vp]),
+        "dint_max_pass": (u32, [vp]),
+        "dint_stream_wait": (C.c_int, [vp, vp]),
+        "dint_stream_signal": (C.c_int, [vp, vp]),
+        "dint_route_pack": (C.c_int, [vp, vp, u32, vp, u32, u64, vp, u64, vp, vp]),
+        "dint_route_unpack": (C.c_int, [vp, vp, u32, u64, vp, vp, u32, vp, vp]),
+        "dint_submit_segments": (C.c_int, [vp, vp, u32, u32, u64, vp, u64, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)  # AttributeError here = the .so does not export the ABI

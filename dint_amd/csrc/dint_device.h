@@ -66,6 +66,49 @@ __host__ __device__ static inline uint64_t dint_fastmod(uint64_t h, dint_mod f) 
   return r;
 }
 
+// ---- where request i of a pass lives ------------------------------------------------------
+// A pass is either one contiguous array of wire messages (request i at byte i * msg), or -- for batches that
+// arrived through the multi-GPU exchange -- n_seg SEGMENTS of seg_cap message slots each, one per source rank,
+// seg_stride bytes apart, of which only the first cnt[k] slots of segment k hold a request (the senders pad
+// their slots to a fixed capacity so the all-to-all needs no split sizes on the host).  Request index
+// i = k * seg_cap + j is then the serial position "source rank k, j-th request it sent here".
+struct dint_view {
+  uint32_t seg_cap;     // 0 = contiguous
+  uint32_t n_seg;
+  dint_mod seg;         // division by seg_cap
+  uint64_t seg_stride;  // bytes between segment starts
+  const uint8_t *cnt;   // u32 live count of segment k at cnt + k * cnt_stride (device memory)
+  uint64_t cnt_stride;
+};
+static inline dint_view dint_flat_view() {
+  dint_view v;
+  v.seg_cap = 0; v.n_seg = 0; v.seg.d = 0; v.seg.m = 0; v.seg_stride = 0; v.cnt = nullptr; v.cnt_stride = 0;
+  return v;
+}
+static inline dint_view dint_seg_view(uint32_t n_seg, uint32_t seg_cap, uint64_t seg_stride, const void *cnt,
+                                      uint64_t cnt_stride) {
+  dint_view v;
+  v.seg_cap = seg_cap; v.n_seg = n_seg; v.seg = dint_make_mod(seg_cap); v.seg_stride = seg_stride;
+  v.cnt = (const uint8_t *)cnt; v.cnt_stride = cnt_stride;
+  return v;
+}
+// byte offset of request i; *live = the slot holds a request (always true for a contiguous pass)
+__host__ __device__ static inline size_t dint_view_off(const dint_view &v, uint32_t i, uint32_t msg, bool *live = nullptr) {
+  if (v.seg_cap == 0) {
+    if (live) *live = true;
+    return (size_t)i * msg;
+  }
+#ifdef __HIP_DEVICE_COMPILE__
+  uint32_t q = (uint32_t)__umul64hi((uint64_t)i, v.seg.m);
+#else
+  uint32_t q = (uint32_t)(((unsigned __int128)i * v.seg.m) >> 64);
+#endif
+  uint32_t r = i - q * v.seg_cap;
+  if (r >= v.seg_cap) { q++; r -= v.seg_cap; }
+  if (live) *live = q < v.n_seg && r < *(const uint32_t *)(v.cnt + (size_t)q * v.cnt_stride);
+  return (size_t)q * v.seg_stride + (size_t)r * msg;
+}
+
 // ---- batch record: one 64-bit word per request --------------------------------------------
 //   bits  0..31  group key (local lock slot, or table_base + local bucket)
 //   bits 32..47  request index inside the micro-batch

@@ -11,6 +11,7 @@ struct dint_dev_stats {
   unsigned long long missing_keys;
   unsigned long long foreign_requests;
   unsigned long long pool_exhausted;
+  unsigned long long route_overflow;  // requests dropped by dint_route_pack: a destination slot was full
 };
 
 // scratch shared by every workload: bins of batch records
@@ -50,9 +51,11 @@ static inline uint32_t dint_pick_bins_kv(uint32_t n) {
 // ---- lock tables (lock_fasst, lock_2pl): k_locks.hip ----------------------------------------
 // table entry: uint2 {a, b} = fasst {lock, ver} / 2pl {num_ex, num_sh}
 void dint_launch_fasst(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots,
-                       dint_shard shard, dint_scratch s, hipStream_t st, hipEvent_t *ev);
+                       dint_shard shard, dint_scratch s, hipStream_t st, hipEvent_t *ev,
+                       const dint_view &view = dint_flat_view());
 void dint_launch_2pl(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots,
-                     dint_shard shard, dint_scratch s, hipStream_t st, hipEvent_t *ev);
+                     dint_shard shard, dint_scratch s, hipStream_t st, hipEvent_t *ev,
+                     const dint_view &view = dint_flat_view());
 void dint_launch_home_lid(const void *d_req, uint32_t msg_size, uint32_t n, dint_mod slots, uint32_t shard_count,
                           uint8_t *d_home, hipStream_t st);
 

@@ -34,7 +34,7 @@ struct dint_kv {
   size_t entry_bytes[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
 };
 
-int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard);
+int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard, uint32_t pool_entries = 0);
 void dint_kv_destroy(dint_kv *kv);
 std::vector<std::pair<void *, size_t>> dint_kv_regions(dint_kv *kv);
 // valid rows of `table` in bucket order, chain order inside a bucket; returns the row count
@@ -43,11 +43,28 @@ int64_t dint_kv_dump_rows(dint_kv *kv, uint32_t table, uint64_t *keys, uint32_t 
 int64_t dint_kv_read_locks(dint_kv *kv, uint32_t table, uint32_t *a, uint32_t *b, uint64_t cap);
 // one pass (n <= DINT_MICRO and, when a log is attached, n <= log.cap).  load_mode: accept DINT_KV_LOAD_OP
 // rows and ignore rows of other shards silently.
+// `view`: where request i lives (contiguous array, or the segments of a multi-GPU exchange buffer)
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
-                    int load_mode, hipStream_t st, hipEvent_t *ev);
+                    int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view = dint_flat_view());
 void dint_launch_home_kv(const void *d_req, uint32_t n, const dint_kv &kv, uint8_t *d_home, hipStream_t st);
 // wire message size / field offsets of a kv workload
 struct dint_kv_fmt {
   uint32_t msg, type, table, key, val, ver, val_size;  // table == 0xFFFFFFFF: no table field
 };
 dint_kv_fmt dint_kv_format(uint32_t workload);
+
+// ---- multi-GPU routing (k_route.hip) --------------------------------------------------------------------------
+#define DINT_ROUTE_MAXW 64u        // ranks a batch can be routed to
+#define DINT_ROUTE_MAXN 1048576u   // requests per dint_route_pack call
+struct dint_route_scratch {
+  uint8_t *home;   // [DINT_ROUTE_MAXN] home rank of each request
+  uint32_t *blk;   // [1024][world] requests per destination and 1024-request block, then their exclusive scan
+};
+// stable partition of n contiguous requests by home rank into `shard.count` slots of `cap` messages, slot w at
+// d_send + w * stride, its live count (u32) at d_cnt + w * cnt_stride; d_slot[i] = home * cap + position (or ~0u)
+void dint_launch_route_pack(uint32_t workload, uint32_t msg, dint_mod slots, const dint_kv *kv, dint_shard shard,
+                            const void *d_req, uint32_t n, void *d_send, uint32_t cap, uint64_t stride, void *d_cnt,
+                            uint64_t cnt_stride, uint32_t *d_slot, dint_route_scratch rs, dint_dev_stats *stats,
+                            hipStream_t st);
+void dint_launch_route_unpack(const void *d_back, uint32_t cap, uint64_t stride, const uint32_t *d_slot,
+                              const void *d_req, uint32_t n, uint32_t msg, void *d_rep, hipStream_t st);

@@ -61,8 +61,27 @@ struct dint_engine {
 
   // batch scratch
   dint_scratch scratch{};
-  uint8_t *d_stage_req = nullptr, *d_stage_rep = nullptr;  // host path staging (DINT_MICRO msgs)
-  uint8_t *h_pinned = nullptr;                             // pinned bounce buffer
+  dint_route_scratch route{};                              // dint_route_pack (allocated on first use)
+  uint8_t *h_pinned = nullptr;                             // pinned buffer of dint_load_rows / dint_populate
+
+  // host path: kNSlot staging slots {device request / reply buffers of one pass}; chunk k of a host submission
+  // uses slot k % kNSlot, so the H2D copy of chunk k+1 and the D2H copy of chunk k-1 overlap the kernels of
+  // chunk k (three streams, ordered by events).  Tickets are chunk sequence numbers.
+  static const int kNSlot = 3;
+  struct Slot {
+    uint8_t *d_req = nullptr, *d_rep = nullptr;
+    hipEvent_t h2d = nullptr, comp = nullptr, done = nullptr;
+    uint64_t seq = 0;  // sequence number of the chunk that used the slot last (0 = never)
+  } slot[kNSlot];
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  uint64_t next_seq = 1;
+  uint64_t pool_seen = 0;  // pool_exhausted at the last host-path check
+  unsigned long long *h_pool = nullptr;  // pinned: pool_exhausted counter read back with each host chunk
+
+  // stream ordering: passes share one scratch set, so a pass enqueued on another stream than the previous one
+  // first waits for it (dint_submit_device with a caller stream)
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev_order = nullptr;
 
   // lock tables (fasst / 2pl)
   uint2 *d_lock_tbl = nullptr;
@@ -98,6 +117,30 @@ int dev_alloc(void **p, size_t bytes, bool zero = true) {
 
 void add_region(dint_engine *e, void *p, size_t bytes) { e->regions.push_back({p, bytes}); }
 
+// Every enqueue on behalf of the engine goes through here: work on `st` is ordered after whatever the engine
+// enqueued last on another stream.
+int order_stream(dint_engine *e, hipStream_t st) {
+  if (e->last_stream && e->last_stream != st) {
+    HIP_TRY(hipEventRecord(e->ev_order, e->last_stream));
+    HIP_TRY(hipStreamWaitEvent(st, e->ev_order, 0));
+  }
+  e->last_stream = st;
+  return 0;
+}
+
+int slot_alloc(dint_engine *e, int k) {
+  dint_engine::Slot &sl = e->slot[k];
+  if (sl.d_req) return 0;
+  const size_t bytes = (size_t)e->pass_max * e->msg_size + 64;
+  int rc = dev_alloc((void **)&sl.d_req, bytes, false);
+  if (!rc) rc = dev_alloc((void **)&sl.d_rep, bytes, false);
+  if (rc) return rc;
+  HIP_TRY(hipEventCreateWithFlags(&sl.h2d, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&sl.comp, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  return 0;
+}
+
 hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names) {
   KernelTimer &t = e->timer;
   if (!t.on || t.passes >= KernelTimer::kMaxLaunch) return nullptr;
@@ -115,26 +158,29 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 }
 
 // one micro-batch (n <= DINT_MICRO) on device buffers
-int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0) {
+int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0,
+             const dint_view &view = dint_flat_view()) {
+  if (int rc = order_stream(e, st)) return rc;
   static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
   static const char *const kv_names[] = {"k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                        timer_events(e, 2, lock_names));
+                        timer_events(e, 2, lock_names), view);
       break;
     case DINT_WL_2PL:
       dint_launch_2pl(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                      timer_events(e, 2, lock_names));
+                      timer_events(e, 2, lock_names), view);
       break;
     case DINT_WL_LOG:
+      if (view.seg_cap) return fail(DINT_ESTATE, "the log workload is not sharded by key");
       dint_launch_log(d_req, d_rep, n, e->log, e->scratch, st, timer_events(e, 2, log_names));
       break;
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names));
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
@@ -166,12 +212,11 @@ int load_rows_locked(dint_engine *e, uint32_t table, const uint64_t *keys, const
       const uint32_t ver = vers ? vers[off + i] : 0;
       memcpy(msg + f.ver, &ver, 4);
     }
-    HIP_TRY(hipMemcpyAsync(e->d_stage_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
-    dint_launch_kv(e->d_stage_req, e->d_stage_req, m, e->kv, e->log, e->scratch, 1, e->stream, nullptr);
-    std::swap(e->scratch.big, e->scratch.big_next);
-    std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+    if (int rc = order_stream(e, e->stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(e->slot[0].d_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
+    if (int rc = run_pass(e, e->slot[0].d_req, m, e->slot[0].d_req, e->stream, 1)) return rc;
+    e->batches--;  // population passes are not request batches
+    e->requests -= m;
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
   return 0;
@@ -212,8 +257,11 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     delete e;
     return fail(DINT_EINVAL, "shard %u of %u", cfg->shard_index, cfg->shard_count);
   }
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete e;
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->s_h2d, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&e->s_d2h, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) != hipSuccess) {
+    dint_engine_destroy(e);
     return fail(DINT_EHIP, "hipStreamCreate");
   }
   const uint32_t wl = cfg->workload;
@@ -241,15 +289,17 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
   } else {
     TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_PMAX * sizeof(uint32_t)));
-    TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_PMAX * DINT_MICRO * sizeof(uint64_t), false));
+    if (wl != DINT_WL_LOG)  // the log append has no bins
+      TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_PMAX * DINT_MICRO * sizeof(uint64_t), false));
     TRY(dev_alloc((void **)&e->scratch.blk_cnt, 256 * sizeof(uint32_t)));
   }
-  TRY(dev_alloc((void **)&e->d_stage_req, (size_t)e->pass_max * e->msg_size + 64, false));
-  TRY(dev_alloc((void **)&e->d_stage_rep, (size_t)e->pass_max * e->msg_size + 64, false));
-  if (hipHostMalloc((void **)&e->h_pinned, (size_t)e->pass_max * e->msg_size + 64, hipHostMallocDefault) != hipSuccess) {
+  TRY(slot_alloc(e, 0));
+  if (hipHostMalloc((void **)&e->h_pinned, (size_t)e->pass_max * e->msg_size + 64, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void **)&e->h_pool, 64, hipHostMallocDefault) != hipSuccess) {
     dint_engine_destroy(e);
     return fail(DINT_ENOMEM, "hipHostMalloc");
   }
+  *e->h_pool = 0;
 
   if (wl == DINT_WL_FASST || wl == DINT_WL_2PL) {
     e->n_slots = cfg->n_slots ? cfg->n_slots : 36000000ull;  // lock_fasst/udp/utils.h:12
@@ -267,13 +317,16 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     add_region(e, e->log.tail, 2 * sizeof(uint32_t));
   }
   if (is_kv) {
-    rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard);
+    rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard, cfg->pool_entries);
     if (rc) { dint_engine_destroy(e); return fail(rc, "kv table allocation failed (%s)", g_err.c_str()); }
     e->kv.force_rounds = (cfg->flags & DINT_FLAG_KV_ROUNDS) ? 1 : 0;
     for (auto &r : dint_kv_regions(&e->kv)) add_region(e, r.first, r.second);
   }
+  if (hipDeviceSynchronize() != hipSuccess) {
+    dint_engine_destroy(e);
+    return fail(DINT_EHIP, "hipDeviceSynchronize after engine set-up");
+  }
 #undef TRY
-  HIP_TRY(hipDeviceSynchronize());
   *out = e;
   return 0;
 }
@@ -293,9 +346,20 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bin_off);
   hipFree(e->scratch.ovl);
   hipFree(e->scratch.ovf);
-  hipFree(e->d_stage_req);
-  hipFree(e->d_stage_rep);
+  for (auto &sl : e->slot) {
+    hipFree(sl.d_req);
+    hipFree(sl.d_rep);
+    if (sl.h2d) hipEventDestroy(sl.h2d);
+    if (sl.comp) hipEventDestroy(sl.comp);
+    if (sl.done) hipEventDestroy(sl.done);
+  }
+  hipFree(e->route.home);
+  hipFree(e->route.blk);
   if (e->h_pinned) hipHostFree(e->h_pinned);
+  if (e->h_pool) hipHostFree(e->h_pool);
+  if (e->ev_order) hipEventDestroy(e->ev_order);
+  if (e->s_h2d) hipStreamDestroy(e->s_h2d);
+  if (e->s_d2h) hipStreamDestroy(e->s_d2h);
   hipFree(e->d_lock_tbl);
   hipFree(e->log.ring);
   hipFree(e->log.tail);
@@ -319,23 +383,163 @@ int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d
   return 0;
 }
 
-int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies) {
-  if (!e || (n && (!reqs || !replies))) return fail(DINT_EINVAL, "null argument");
+int dint_submit_segments(dint_engine_t *e, void *d_base, uint32_t n_seg, uint32_t seg_cap, uint64_t seg_stride,
+                         const void *d_cnt, uint64_t cnt_stride, void *stream) {
+  if (!e || (n_seg && (!d_base || !d_cnt))) return fail(DINT_EINVAL, "null argument");
+  if (seg_cap < 2 || seg_cap > e->pass_max) return fail(DINT_EINVAL, "seg_cap %u outside [2, %u]", seg_cap, e->pass_max);
+  if (seg_stride < (uint64_t)seg_cap * e->msg_size) return fail(DINT_EINVAL, "seg_stride smaller than a segment");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  const uint32_t per_pass = e->pass_max / seg_cap;  // whole segments per kernel pass
+  for (uint32_t k0 = 0; k0 < n_seg; k0 += per_pass) {
+    const uint32_t ns = std::min(per_pass, n_seg - k0);
+    uint8_t *base = (uint8_t *)d_base + (size_t)k0 * seg_stride;
+    const dint_view v = dint_seg_view(ns, seg_cap, seg_stride, (const uint8_t *)d_cnt + (size_t)k0 * cnt_stride, cnt_stride);
+    int rc = run_pass(e, base, ns * seg_cap, base, st, 0, v);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ---- host buffers: pipelined H2D / kernels / D2H ---------------------------------------------------------------
+namespace {
+// enqueue chunk [off, off + m) of a host submission; returns its sequence number in *seq
+int enqueue_chunk(dint_engine *e, const uint8_t *rq, uint8_t *rp, uint32_t m, uint64_t *seq) {
+  const uint64_t sq = e->next_seq;
+  const int k = (int)(sq % dint_engine::kNSlot);
+  if (int rc = slot_alloc(e, k)) return rc;
+  dint_engine::Slot &sl = e->slot[k];
+  if (sl.seq) HIP_TRY(hipEventSynchronize(sl.done));  // the slot's previous chunk has left the GPU
+  const size_t bytes = (size_t)m * e->msg_size;
+  HIP_TRY(hipMemcpyAsync(sl.d_req, rq, bytes, hipMemcpyHostToDevice, e->s_h2d));
+  HIP_TRY(hipEventRecord(sl.h2d, e->s_h2d));
+  HIP_TRY(hipStreamWaitEvent(e->stream, sl.h2d, 0));
+  if (int rc = run_pass(e, sl.d_req, m, sl.d_rep, e->stream)) return rc;
+  HIP_TRY(hipEventRecord(sl.comp, e->stream));
+  HIP_TRY(hipStreamWaitEvent(e->s_d2h, sl.comp, 0));
+  HIP_TRY(hipMemcpyAsync(rp, sl.d_rep, bytes, hipMemcpyDeviceToHost, e->s_d2h));
+  if (e->kv.n_tables)  // the overflow-pool counter travels with the replies (see dint_wait)
+    HIP_TRY(hipMemcpyAsync(e->h_pool, &e->scratch.stats->pool_exhausted, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->s_d2h));
+  HIP_TRY(hipEventRecord(sl.done, e->s_d2h));
+  sl.seq = sq;
+  e->next_seq++;
+  *seq = sq;
+  return 0;
+}
+int wait_seq(dint_engine *e, uint64_t seq) {
+  if (seq == 0 || seq >= e->next_seq) return fail(DINT_EINVAL, "unknown ticket");
+  dint_engine::Slot &sl = e->slot[seq % dint_engine::kNSlot];
+  if (sl.seq == seq) HIP_TRY(hipEventSynchronize(sl.done));  // else: the slot was reused, so the chunk finished long ago
+  if (*e->h_pool > e->pool_seen) {
+    const unsigned long long lost = *e->h_pool - e->pool_seen;
+    e->pool_seen = *e->h_pool;
+    return fail(DINT_ENOMEM, "%llu INSERTs found the overflow-entry pool full (dint_config.pool_entries); "
+                             "they were answered with a reject code and stored nothing", lost);
+  }
+  return 0;
+}
+}  // namespace
+
+int dint_submit_async(dint_engine_t *e, const void *reqs, uint32_t n, void *replies, dint_ticket *ticket) {
+  if (!e || !ticket || (n && (!reqs || !replies))) return fail(DINT_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
   const uint8_t *rq = (const uint8_t *)reqs;
   uint8_t *rp = (uint8_t *)replies;
+  uint64_t seq = e->next_seq - 1;  // n == 0: the ticket of whatever was submitted last
   for (uint32_t off = 0; off < n; off += e->pass_max) {
-    uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
-    size_t bytes = (size_t)m * e->msg_size;
-    memcpy(e->h_pinned, rq + (size_t)off * e->msg_size, bytes);
-    HIP_TRY(hipMemcpyAsync(e->d_stage_req, e->h_pinned, bytes, hipMemcpyHostToDevice, e->stream));
-    int rc = run_pass(e, e->d_stage_req, m, e->d_stage_rep, e->stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_stage_rep, bytes, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    memcpy(rp + (size_t)off * e->msg_size, e->h_pinned, bytes);
+    const uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
+    if (int rc = enqueue_chunk(e, rq + (size_t)off * e->msg_size, rp + (size_t)off * e->msg_size, m, &seq)) return rc;
   }
+  *ticket = seq;
+  return 0;
+}
+
+int dint_wait(dint_engine_t *e, dint_ticket ticket) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  if (ticket == 0) return 0;  // nothing was ever submitted
+  return wait_seq(e, ticket);
+}
+
+int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies) {
+  dint_ticket t = 0;
+  if (int rc = dint_submit_async(e, reqs, n, replies, &t)) return rc;
+  return n ? dint_wait(e, t) : 0;
+}
+
+int dint_alloc_pinned(size_t bytes, void **out) {
+  if (!out) return fail(DINT_EINVAL, "null argument");
+  if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return fail(DINT_ENOMEM, "hipHostMalloc(%zu)", bytes);
+  return 0;
+}
+void dint_free_pinned(void *p) {
+  if (p) hipHostFree(p);
+}
+
+// ---- multi-GPU routing ---------------------------------------------------------------------------------------
+int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_send, uint32_t seg_cap,
+                    uint64_t seg_stride, void *d_cnt, uint64_t cnt_stride, uint32_t *d_slot, void *stream) {
+  if (!e || !d_send || !d_cnt || (n && (!d_reqs || !d_slot))) return fail(DINT_EINVAL, "null argument");
+  if (e->cfg.workload == DINT_WL_LOG) return fail(DINT_ESTATE, "workload is not sharded by key");
+  if (n > DINT_ROUTE_MAXN) return fail(DINT_EINVAL, "at most %u requests per dint_route_pack", DINT_ROUTE_MAXN);
+  if (e->shard.count > DINT_ROUTE_MAXW) return fail(DINT_EINVAL, "at most %u shards can be routed to", DINT_ROUTE_MAXW);
+  if (seg_cap == 0 || (uint64_t)seg_cap * e->shard.count > 0xFFFFFFF0ull) return fail(DINT_EINVAL, "bad seg_cap");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->route.home) {
+    if (int rc = dev_alloc((void **)&e->route.home, DINT_ROUTE_MAXN, false)) return rc;
+    if (int rc = dev_alloc((void **)&e->route.blk, (size_t)(DINT_ROUTE_MAXN / 1024) * DINT_ROUTE_MAXW * 4)) return rc;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  if (int rc = order_stream(e, st)) return rc;  // the routing scratch is per engine too
+  dint_launch_route_pack(e->cfg.workload, e->msg_size, e->slots_mod, &e->kv, e->shard, d_reqs, n, d_send, seg_cap,
+                         seg_stride, d_cnt, cnt_stride, d_slot, e->route, e->scratch.stats, st);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  return 0;
+}
+
+int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, uint64_t seg_stride,
+                      const uint32_t *d_slot, const void *d_reqs, uint32_t n, void *d_replies, void *stream) {
+  if (!e || (n && (!d_back || !d_slot || !d_reqs || !d_replies))) return fail(DINT_EINVAL, "null argument");
+  if (seg_cap == 0) return fail(DINT_EINVAL, "bad seg_cap");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+  dint_launch_route_unpack(d_back, seg_cap, seg_stride, d_slot, d_reqs, n, e->msg_size, d_replies, st);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  return 0;
+}
+
+void *dint_engine_stream(dint_engine_t *e) { return e ? (void *)e->stream : nullptr; }
+uint32_t dint_max_pass(dint_engine_t *e) { return e ? e->pass_max : 0; }
+
+int dint_stream_wait(dint_engine_t *e, void *other_stream) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t r = hipEventRecord(ev, (hipStream_t)other_stream);
+  if (r == hipSuccess) r = hipStreamWaitEvent(e->stream, ev, 0);
+  hipEventDestroy(ev);  // released by the runtime once the wait has been satisfied
+  if (r != hipSuccess) return fail(DINT_EHIP, "dint_stream_wait: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int dint_stream_signal(dint_engine_t *e, void *other_stream) {
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t r = hipEventRecord(ev, e->stream);
+  if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)other_stream, ev, 0);
+  hipEventDestroy(ev);
+  if (r != hipSuccess) return fail(DINT_EHIP, "dint_stream_signal: %s", hipGetErrorString(r));
   return 0;
 }
 
@@ -343,6 +547,7 @@ int dint_sync(dint_engine_t *e) {
   if (!e) return fail(DINT_EINVAL, "null engine");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipStreamSynchronize(e->s_d2h));
   return 0;
 }
 
@@ -396,6 +601,7 @@ int dint_get_stats(dint_engine_t *e, dint_stats *out) {
   out->missing_keys = d.missing_keys;
   out->foreign_requests = d.foreign_requests;
   out->pool_exhausted = d.pool_exhausted;
+  out->route_overflow = d.route_overflow;
   return 0;
 }
 
@@ -406,6 +612,8 @@ int dint_reset(dint_engine_t *e) {
   HIP_TRY(hipDeviceSynchronize());
   for (auto &r : e->regions) HIP_TRY(hipMemset(r.first, 0, r.second));
   e->batches = e->requests = 0;
+  e->pool_seen = 0;
+  *e->h_pool = 0;
   HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
@@ -438,6 +646,8 @@ int dint_restore(dint_engine_t *e) {
   for (size_t i = 0; i < e->regions.size(); i++)
     HIP_TRY(hipMemcpy(e->regions[i].first, e->snap[i], e->regions[i].second, hipMemcpyDeviceToDevice));
   HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(e->h_pool, &e->scratch.stats->pool_exhausted, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  e->pool_seen = *e->h_pool;
   return 0;
 }
 

@@ -156,7 +156,7 @@ template <int WL>
 __global__ void __launch_bounds__(KV_TB)
 k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
            uint32_t pbits, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
-           uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode) {
+           uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode, dint_view V) {
   using F = Fmt<WL>;
   __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
   __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
@@ -174,8 +174,11 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
   __syncthreads();
   const uint32_t tile = Stile;
   const uint32_t i = tile * KV_TB + t;
-  const uint8_t *m = req + (size_t)i * F::MSG;
-  const kv_reqinfo r = kv_read_request<WL>(m, i < n, kv, load_mode);
+  bool live;  // a segmented pass (multi-GPU exchange) has padding slots: they are no requests at all
+  const size_t moff = dint_view_off(V, i < n ? i : 0, F::MSG, &live);
+  live = live && i < n;
+  const uint8_t *m = req + moff;
+  const kv_reqinfo r = kv_read_request<WL>(m, live, kv, load_mode);
   // log requests of this slice: publish the count at once (tatp / smallbank)
   const uint64_t lm = __ballot(r.cls == 2);
   if (WL != DINT_WL_STORE) {
@@ -210,7 +213,7 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
       for (size_t k = lo + t; k < hi; k += KV_TB) rep[k] = req[k];
     }
   }
-  if (i < n && !r.cls) atomicAdd(&stats->bad_requests, 1ULL);
+  if (live && !r.cls) atomicAdd(&stats->bad_requests, 1ULL);
 
   uint32_t bin = KV_NONE, gk = 0, pay = 0;
   if (r.cls == 1) {
@@ -290,7 +293,7 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
       const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
       uint8_t *e8 = log.ring + (size_t)pos * 64;
       const uint32_t ver = ld_u32(m + F::VER);
-      uint8_t *rp = rep + (size_t)i * F::MSG;
+      uint8_t *rp = rep + moff;
       if (WL == DINT_WL_TATP && r.type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
         *(uint64_t *)e8 = r.key;
         *(uint2 *)(e8 + 48) = make_uint2(ver, 1u | (r.table << 8));
@@ -429,6 +432,13 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
 
   // ---- act phase
   const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, act, key, val, ins_ver, blockIdx.x);
+  if (act == KV_ACT_INS && !r.ok && type != DINT_KV_LOAD_OP) {
+    // the overflow-entry pool is full: nothing was stored and the request is refused -- store kRejectInsert
+    // (store/udp/net.h:28), tatp REJECT_COMMIT, the eBPF flavour's "send again" (tatp/ebpf/shard_kern.c:509-514,
+    // taken there before the lock word is touched)
+    code = WL == DINT_WL_STORE ? 9 : 11;
+    lock_store = -1;
+  }
   if (WL == DINT_WL_TATP && lock_store >= 0) ie[KV_LOCKB_OFF + q] = (uint8_t)lock_store;
   if (WL == DINT_WL_SMALLBANK && cnt_store) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = cnt;
   if (act == KV_ACT_GET && r.ok) st_u32(msg + F::VER, r.ver);
@@ -537,11 +547,11 @@ __device__ static inline uint64_t run_mask(uint64_t heads, uint64_t le, uint64_t
 template <int WL>
 __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t gk, uint32_t kh, uint32_t type,
                                        uint32_t table, uint32_t q, const kv_dev *kv, dint_dev_stats *__restrict__ stats,
-                                       int force_rounds, bool last_chunk, uint64_t *tr = nullptr) {
+                                       int force_rounds, bool last_chunk, const dint_view &V, uint64_t *tr = nullptr) {
   using F = Fmt<WL>;
   const int lane = (int)lane_id();
   const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
-  uint8_t *msg = rep + (size_t)idx * F::MSG;
+  uint8_t *msg = rep + dint_view_off(V, idx, F::MSG);
   const uint64_t key = valid ? ld_u64(msg + F::KEY) : 0;
   const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
 
@@ -745,7 +755,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   if (simple) {
     row = kv_entry_ptr(t, bucket, link) + KV_VAL_OFF + slot * F::VS;  // meaningful when the row was found
     if (my_get) {
-      const uint8_t *from = my_src >= 0 ? rep + (size_t)src_idx * F::MSG + F::VAL : row;
+      const uint8_t *from = my_src >= 0 ? rep + dint_view_off(V, src_idx, F::MSG) + F::VAL : row;
       kv_copy_words(msg + F::VAL, from, F::VS);
       st_u32(msg + F::VER, my_ver);
     }
@@ -760,7 +770,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
     const bool redo = structural && found0 && exists1 && ((found >> 2) & 1u);  // deleted and inserted again
     if (found0 && exists1 && !redo) {  // the row stays where it is: value / version of the last writer
       if (fin_src >= 0) {
-        kv_copy_words(row, rep + (size_t)fin_idx * F::MSG + F::VAL, F::VS);
+        kv_copy_words(row, rep + dint_view_off(V, fin_idx, F::MSG) + F::VAL, F::VS);
         kv_entry_hdr(t, bucket, link)->ver[slot] = fin_ver;
       }
     } else if (found0 != exists1 || redo) {  // apply the net INSERT / DELETE (or DELETE + INSERT) to the chain once
@@ -770,7 +780,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         kv_hdr_copy(H, *(const kv_hdr *)ie);
       }
       const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key,
-                                            rep + (size_t)fin_idx * F::MSG + F::VAL, fin_ver, blockIdx.x);
+                                            rep + dint_view_off(V, fin_idx, F::MSG) + F::VAL, fin_ver, blockIdx.x);
       if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
     }
     if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
@@ -810,7 +820,8 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 template <int WL>
 __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const kv_dev *kv, uint32_t bin,
                                            uint32_t *__restrict__ bin_cnt, const uint64_t *__restrict__ bins,
-                                           dint_dev_stats *__restrict__ stats, int kv_force_rounds, uint64_t *trace) {
+                                           dint_dev_stats *__restrict__ stats, int kv_force_rounds, const dint_view &V,
+                                           uint64_t *trace) {
   const uint32_t lane = threadIdx.x & 63;
   uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
   kv_stamp_real(tr, 10);
@@ -839,7 +850,7 @@ __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const k
   const uint32_t idx = (uint32_t)(w >> 7) & ((1u << (16 + pbits)) - 1u);
   const uint32_t pay = (uint32_t)w & 0x7Fu;
   kv_chunk<WL>(rep, valid, valid ? idx : 0, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), kv, stats,
-               kv_force_rounds, true, tr);
+               kv_force_rounds, true, V, tr);
   kv_stamp(tr, 9);
   kv_stamp_real(tr, 11);
 }
@@ -982,7 +993,8 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
                                           uint32_t stride, uint32_t *__restrict__ bin_cnt,
                                           const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big,
                                           const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
-                                          dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace) {
+                                          dint_dev_stats *__restrict__ stats, int force_rounds, const dint_view &V,
+                                          uint64_t *trace) {
   using F = Fmt<WL>;
   __shared__ uint64_t Sk[KVB_NMAX];           // the stretch: group >> pbits | key-hash bits | idx | type, quadrant
   __shared__ uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
@@ -1171,8 +1183,8 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const bool head = valid && kvb_bit(Mhead, p);
       if (head && sn < KVB_T) HeadPos[sn] = (uint16_t)p;
       const uint32_t seg_a = valid ? (uint32_t)kvb_last(Mhead, Ehead, 0, p + 1) : 0;
-      const uint64_t key = valid ? ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY) : 0;
-      const uint64_t hkey = valid ? ld_u64(rep + (size_t)k_idx(Sk[seg_a]) * F::MSG + F::KEY) : 0;
+      const uint64_t key = valid ? ld_u64(rep + dint_view_off(V, k_idx(cur), F::MSG) + F::KEY) : 0;
+      const uint64_t hkey = valid ? ld_u64(rep + dint_view_off(V, k_idx(Sk[seg_a]), F::MSG) + F::KEY) : 0;
       const uint64_t bm = __ballot(valid && !(key == hkey && (kv_simple_op<WL>(type) || kv_struct_op<WL>(type))));
       if (lane == 0) Mbad[p >> 6] = bm;
     }
@@ -1240,7 +1252,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         const uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
         kv_hdr H;
         kv_hdr_copy(H, *(const kv_hdr *)ie);
-        const uint64_t key = ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY);
+        const uint64_t key = ld_u64(rep + dint_view_off(V, k_idx(cur), F::MSG) + F::KEY);
         uint32_t la0 = 0, lb0 = 0;
         if (WL == DINT_WL_SMALLBANK) {
           const uint2 cc = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);
@@ -1273,7 +1285,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const uint32_t gk = valid ? ((uint32_t)(cur >> sh_g) << pbits) | bin : 0, idx = valid ? k_idx(cur) : 0;
       const uint32_t type = k_type(cur), table = valid ? kv_table_of(kv, gk) : 0;
       const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
-      uint8_t *msg = rep + (size_t)idx * F::MSG;
+      uint8_t *msg = rep + dint_view_off(V, idx, F::MSG);
       bool simple = valid && kvb_bit(Msimple, p);
       const uint32_t si = simple ? kvb_below(Mhead, Phead, p + 1) - 1 : 0;  // my segment's number = its Lead / Carry slot
       const uint32_t seg_a = simple ? HeadPos[si] : 0;                       // my key segment starts here
@@ -1408,7 +1420,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       o.msg = msg; o.simple = simple; o.get = simple && my_get != 0; o.code = my_code; o.ver = my_ver; o.from = nullptr;
       if (o.get) {
         const kv_tab tb = kv->tab[table];
-        o.from = my_src >= 0 ? rep + (size_t)k_idx(Sk[my_src]) * F::MSG + F::VAL
+        o.from = my_src >= 0 ? rep + dint_view_off(V, k_idx(Sk[my_src]), F::MSG) + F::VAL
                              : kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS;
       }
     };
@@ -1480,7 +1492,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           }
           if (lk >= 0) fin_la = (uint32_t)lk;
         }
-        const uint8_t *fin_val = fin_src >= 0 ? rep + (size_t)k_idx(Sk[fin_src]) * F::MSG + F::VAL : nullptr;
+        const uint8_t *fin_val = fin_src >= 0 ? rep + dint_view_off(V, k_idx(Sk[fin_src]), F::MSG) + F::VAL : nullptr;
         if (found0 && exists1 && !redo) {  // the row stays where it is: value / version of the last writer
           if (fin_src >= 0) {
             kv_copy_words(kv_entry_ptr(tb, bucket, link) + KV_VAL_OFF + slot * F::VS, fin_val, F::VS);
@@ -1489,7 +1501,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         } else if (found0 != exists1 || redo) {  // apply the net INSERT / DELETE (or DELETE + INSERT) to the chain once
           kv_hdr H;
           kv_hdr_copy(H, *(const kv_hdr *)ie);
-          const uint64_t key = ld_u64(rep + (size_t)k_idx(cur) * F::MSG + F::KEY);
+          const uint64_t key = ld_u64(rep + dint_view_off(V, k_idx(cur), F::MSG) + F::KEY);
           if (redo) {
             kv_apply<kv_dev_mem>(tb, bucket, H, KV_ACT_DEL, key, nullptr, 0, blockIdx.x);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1540,7 +1552,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         if (p < m && Rpos[p] == r) {
           const uint64_t cur = Sk[p];
           const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk);
-          kv_do_request<WL>(rep + (size_t)k_idx(cur) * F::MSG, k_type(cur), table, k_q(cur),
+          kv_do_request<WL>(rep + dint_view_off(V, k_idx(cur), F::MSG), k_type(cur), table, k_q(cur),
                             (uint64_t)(gk - kv->gk_base[table]), kv, stats);
         }
       }
@@ -1562,7 +1574,8 @@ template <int WL>
 __global__ void __launch_bounds__(KVB_T, 4)
 k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
              const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace) {
+             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace,
+             dint_view V) {
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
@@ -1570,10 +1583,10 @@ k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict_
   unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
   if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
   if (blockIdx.x < KVB_GRID) {
-    kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_rounds, trace);
+    kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_rounds, V, trace);
   } else {
     const uint32_t bin = (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
-    if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_rounds, trace);
+    if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_rounds, V, trace);
   }
   if (wg && (threadIdx.x & 63) == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1584,7 +1597,7 @@ k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict_
 // ---- launch -------------------------------------------------------------------------------------------
 template <int WL>
 static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
-                      int load_mode, hipStream_t st, hipEvent_t *ev) {
+                      int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
   const uint32_t P = dint_pick_bins_kv(n);
   uint32_t pbits = 0;
   while ((1u << pbits) < P) pbits++;
@@ -1592,7 +1605,7 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   const bool has_log = WL != DINT_WL_STORE;
   if (ev) hipEventRecord(ev[0], st);
   hipLaunchKernelGGL((k_kv_count<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
-                     log, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode);
+                     log, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode, view);
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
                      s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr);
@@ -1602,17 +1615,17 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   if (ev) hipEventRecord(ev[3], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
                      pbits, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
-                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace);
+                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace, view);
   if (ev) hipEventRecord(ev[4], st);
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
-                    int load_mode, hipStream_t st, hipEvent_t *ev) {
+                    int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
   if (n == 0) return;
   switch (kv.workload) {
-    case DINT_WL_STORE: launch_kv<DINT_WL_STORE>(d_req, d_rep, n, kv, log, s, load_mode, st, ev); break;
-    case DINT_WL_TATP: launch_kv<DINT_WL_TATP>(d_req, d_rep, n, kv, log, s, load_mode, st, ev); break;
-    default: launch_kv<DINT_WL_SMALLBANK>(d_req, d_rep, n, kv, log, s, load_mode, st, ev); break;
+    case DINT_WL_STORE: launch_kv<DINT_WL_STORE>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
+    case DINT_WL_TATP: launch_kv<DINT_WL_TATP>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
+    default: launch_kv<DINT_WL_SMALLBANK>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
   }
 }
 
@@ -1635,7 +1648,7 @@ void dint_launch_home_kv(const void *d_req, uint32_t n, const dint_kv &kv, uint8
 }
 
 // ---- table management (host) ------------------------------------------------------------------------------
-int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard) {
+int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard, uint32_t pool_entries) {
   *kv = dint_kv();
   kv->workload = workload;
   uint64_t hs[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
@@ -1670,7 +1683,8 @@ int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard s
     kv->hash_size[t] = hs[t];
     kv_tab &tb = kv->h.tab[t];
     tb.n_local = (hs[t] + count - 1) / count;
-    const uint64_t pool = tb.n_local / 4 + 4096;  // expected overflow at the reference's 2.67 rows/bucket: 0.14/bucket
+    // expected overflow at the reference's 2.67 rows/bucket: 0.14 entries per bucket
+    const uint64_t pool = pool_entries ? pool_entries : tb.n_local / 4 + 4096;
     if (pool > 0xFFFFFFF0ull || gk + tb.n_local > 0xFFFFFFF0ull) return DINT_EINVAL;
     tb.pool_cap = (uint32_t)pool;
     tb.stride = stride;

@@ -37,20 +37,23 @@ template <int WL>  // 0 = lock_fasst, 1 = lock_2pl
 __global__ void __launch_bounds__(256)
 k_lock_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod slots, dint_shard shard,
                uint32_t pmask, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins,
-               dint_dev_stats *__restrict__ stats) {
+               dint_dev_stats *__restrict__ stats, dint_view V) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
+  bool live;
+  const size_t off = dint_view_off(V, i, WL == 0 ? sizeof(fasst_msg) : sizeof(tpl_msg), &live);
+  if (!live) return;  // padding slot of a segmented pass
   uint32_t lid, op;
   bool ok;
   if (WL == 0) {
-    fasst_msg m = ((const fasst_msg *)req)[i];
-    if (rep != req) ((fasst_msg *)rep)[i] = m;
+    fasst_msg m = *(const fasst_msg *)(req + off);
+    if (rep != req) *(fasst_msg *)(rep + off) = m;
     lid = m.lid;
     op = m.type;  // 0 READ, 1 ACQUIRE_LOCK, 2 ABORT, 3 COMMIT
     ok = op <= 3;
   } else {
-    tpl_msg m = ((const tpl_msg *)req)[i];
-    if (rep != req) ((tpl_msg *)rep)[i] = m;
+    tpl_msg m = *(const tpl_msg *)(req + off);
+    if (rep != req) *(tpl_msg *)(rep + off) = m;
     lid = m.lid;
     if (m.action == 0) {  // ACQUIRE: op 0 shared, 1 exclusive; any other lock type panics in the reference
       ok = m.type <= 1;
@@ -144,8 +147,8 @@ struct FasstOps {
     fin.y = st0.y + (uint32_t)__popcll(m_com);
     dirty = fin.x != st0.x || fin.y != st0.y;
   }
-  __device__ static void write_reply(uint8_t *rep, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
-    fasst_msg *m = (fasst_msg *)rep + idx;
+  __device__ static void write_reply(uint8_t *rep, const dint_view &V, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
+    fasst_msg *m = (fasst_msg *)(rep + dint_view_off(V, idx, sizeof(fasst_msg)));
     m->type = (uint8_t)code;
     if (op == 0) m->ver = rv;  // ver is echoed on every non-READ reply
   }
@@ -217,16 +220,16 @@ struct TplOps {
       if ((int)lane == L) { fin = st; dirty = wr; }
     }
   }
-  __device__ static void write_reply(uint8_t *rep, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
+  __device__ static void write_reply(uint8_t *rep, const dint_view &V, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
     (void)op; (void)rv;
-    ((tpl_msg *)rep + idx)->action = (uint8_t)code;
+    ((tpl_msg *)(rep + dint_view_off(V, idx, sizeof(tpl_msg))))->action = (uint8_t)code;
   }
 };
 
 template <class Ops>
 __global__ void __launch_bounds__(64)
 k_lock_resolve(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
-               const uint64_t *__restrict__ bins) {
+               const uint64_t *__restrict__ bins, dint_view V) {
   __shared__ dint_rank_lds R;
   __shared__ uint32_t Srec[DINT_WCAP];  // idx | entry << 16 | op << 26, in request order
   __shared__ uint32_t Hk[DINT_HSIZE];   // slot of each hash entry
@@ -264,7 +267,7 @@ k_lock_resolve(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__
     uint2 fin = st0;
     bool dirty = false;
     Ops::resolve_sorted(valid, seg, op, st0, code, rv, fin, dirty);
-    if (valid) Ops::write_reply(rep, idx, op, code, rv);
+    if (valid) Ops::write_reply(rep, V, idx, op, code, rv);
     if (head && dirty) table[slot] = fin;
     return;
   }
@@ -324,7 +327,7 @@ k_lock_resolve(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__
       __syncthreads();
       if (valid) {
         atomicAnd(&Hfl[e], 0x80000000u);
-        Ops::write_reply(rep, idx, op, code, rv);
+        Ops::write_reply(rep, V, idx, op, code, rv);
       }
       __syncthreads();
     }
@@ -344,25 +347,25 @@ k_lock_resolve(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__
 // ------------------------------------------------------------------------------------------
 template <int WL, class Ops>
 static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,
-                         dint_scratch s, hipStream_t st, hipEvent_t *ev) {
+                         dint_scratch s, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
   if (n == 0) return;
   const uint32_t P = dint_pick_bins(n);
   if (ev) hipEventRecord(ev[0], st);
   hipLaunchKernelGGL((k_lock_scatter<WL>), dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t *)d_req,
-                     (uint8_t *)d_rep, n, slots, shard, P - 1, s.bin_cnt, s.bins, s.stats);
+                     (uint8_t *)d_rep, n, slots, shard, P - 1, s.bin_cnt, s.bins, s.stats, view);
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, table, s.bin_cnt,
-                     (const uint64_t *)s.bins);
+                     (const uint64_t *)s.bins, view);
   if (ev) hipEventRecord(ev[2], st);
 }
 
 void dint_launch_fasst(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,
-                       dint_scratch s, hipStream_t st, hipEvent_t *ev) {
-  launch_locks<0, FasstOps>(d_req, d_rep, n, table, slots, shard, s, st, ev);
+                       dint_scratch s, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
+  launch_locks<0, FasstOps>(d_req, d_rep, n, table, slots, shard, s, st, ev, view);
 }
 void dint_launch_2pl(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,
-                     dint_scratch s, hipStream_t st, hipEvent_t *ev) {
-  launch_locks<1, TplOps>(d_req, d_rep, n, table, slots, shard, s, st, ev);
+                     dint_scratch s, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
+  launch_locks<1, TplOps>(d_req, d_rep, n, table, slots, shard, s, st, ev, view);
 }
 
 // home shard of each lock request (multi-GPU routing): global slot % shard_count

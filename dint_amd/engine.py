@@ -23,21 +23,51 @@ def _ptr(x):
     return x.data_ptr()
 
 
+def _hptr(x):
+    """Host pointer of a numpy array / pinned torch tensor / int."""
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()
+
+
+class Pinned:
+    """A page-locked host buffer from dint_alloc_pinned, viewed as a numpy uint8 array."""
+
+    def __init__(self, nbytes: int):
+        self._L = _lib.load()
+        p = C.c_void_p()
+        _lib.check(self._L.dint_alloc_pinned(nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.array = np.frombuffer((C.c_uint8 * nbytes).from_address(self.ptr), np.uint8)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self._L.dint_free_pinned(self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+
 class Engine:
     def __init__(self, workload: Workload, *, n_slots: int = 0, n_rows: int = 0, log_entries: int = 0,
-                 device: int = -1, shard_index: int = 0, shard_count: int = 1, flags: int = 0, max_pass: int = 0):
+                 device: int = -1, shard_index: int = 0, shard_count: int = 1, flags: int = 0, max_pass: int = 0,
+                 pool_entries: int = 0):
         self._L = _lib.load()
         self.workload = Workload(workload)
         self.msg_dtype = MSG_DTYPE[self.workload]
         self.msg_size = self.msg_dtype.itemsize
         cfg = _lib.Config(abi_version=_lib.ABI_VERSION, workload=int(workload), device=device, flags=flags, n_slots=n_slots,
                           n_rows=n_rows, log_entries=log_entries, shard_index=shard_index, shard_count=shard_count,
-                          max_pass=max_pass)
+                          max_pass=max_pass, pool_entries=pool_entries)
         h = C.c_void_p()
         _lib.check(self._L.dint_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self.shard_index, self.shard_count = shard_index, max(1, shard_count)
         self.val_size = 8 if self.workload == Workload.SMALLBANK else 40
+        self.pass_max = int(self._L.dint_max_pass(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -61,8 +91,41 @@ class Engine:
         d_replies = d_reqs if d_replies is None else d_replies
         _lib.check(self._L.dint_submit_device(self._h, _ptr(d_reqs), n, _ptr(d_replies), stream))
 
+    def submit_async(self, reqs, n: int, replies) -> int:
+        """Pipelined host submit on raw host pointers (page-locked for real overlap); returns the ticket."""
+        t = C.c_uint64()
+        _lib.check(self._L.dint_submit_async(self._h, _hptr(reqs), n, _hptr(replies), C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int):
+        _lib.check(self._L.dint_wait(self._h, ticket))
+
     def sync(self):
         _lib.check(self._L.dint_sync(self._h))
+
+    # ---- streams / multi-GPU routing (dint_amd.sharded.Router) ------------------------------------------
+    @property
+    def stream(self) -> int:
+        return self._L.dint_engine_stream(self._h) or 0
+
+    def stream_wait(self, other_stream: int):
+        _lib.check(self._L.dint_stream_wait(self._h, other_stream))
+
+    def stream_signal(self, other_stream: int):
+        _lib.check(self._L.dint_stream_signal(self._h, other_stream))
+
+    def route_pack(self, d_reqs, n: int, d_send, seg_cap: int, seg_stride: int, d_cnt, cnt_stride: int, d_slot,
+                   stream: int = 0):
+        _lib.check(self._L.dint_route_pack(self._h, _ptr(d_reqs), n, _ptr(d_send), seg_cap, seg_stride, _ptr(d_cnt),
+                                           cnt_stride, _ptr(d_slot), stream))
+
+    def route_unpack(self, d_back, seg_cap: int, seg_stride: int, d_slot, d_reqs, n: int, d_replies, stream: int = 0):
+        _lib.check(self._L.dint_route_unpack(self._h, _ptr(d_back), seg_cap, seg_stride, _ptr(d_slot), _ptr(d_reqs), n,
+                                             _ptr(d_replies), stream))
+
+    def submit_segments(self, d_base, n_seg: int, seg_cap: int, seg_stride: int, d_cnt, cnt_stride: int, stream: int = 0):
+        _lib.check(self._L.dint_submit_segments(self._h, _ptr(d_base), n_seg, seg_cap, seg_stride, _ptr(d_cnt),
+                                                cnt_stride, stream))
 
     def home_shard(self, d_reqs, n: int, d_home, stream: int = 0) -> None:
         _lib.check(self._L.dint_home_shard(self._h, _ptr(d_reqs), n, _ptr(d_home), stream))

@@ -3,7 +3,8 @@
 The reference deployment is three `server_shard <id>` processes (tatp/udp/server_shard.cc:279-285),
 3-way replicated.  A :class:`ShardGroup` is those three servers on one GPU (three engines, each on
 its own HIP stream so their kernel chains overlap) -- or, with world > 1, on N GPUs: every logical
-shard server is hash-partitioned over the ranks and fronted by a :class:`ShardedEngine`.
+shard server is hash-partitioned over the ranks and the three batches of an epoch cross the node in one
+all-to-all each way (:class:`dint_amd.sharded.Router`).
 
 `record()` runs a :class:`Driver` closed loop through the group and keeps every epoch's per-shard
 request and reply batches; `Replay` uploads them to HBM and re-submits them without any host work,
@@ -18,49 +19,44 @@ import torch
 
 from .driver import N_SHARDS, Driver
 from .engine import Engine
-from .sharded import ShardedEngine
+from .sharded import Router
 from .wire import Workload
 
 
 class ShardGroup:
     def __init__(self, workload: Workload, n_rows: int, *, device: int = -1, rank: int = 0, world: int = 1,
-                 log_entries: int = 0, populate: Optional[int] = None):
+                 log_entries: int = 0, populate: Optional[int] = None, transport: Optional[str] = None,
+                 force_exchange: bool = False, n_max: int = 1 << 20):
         self.workload, self.world, self.rank = Workload(workload), world, rank
         self.engines = [Engine(workload, n_rows=n_rows, device=device, shard_index=rank, shard_count=world,
                                log_entries=log_entries) for _ in range(N_SHARDS)]
         self.msg = self.engines[0].msg_size
-        self.sharded = [ShardedEngine(e, world, rank) for e in self.engines] if world > 1 else None
-        self.last_splits = None  # multi GPU: all-to-all split sizes of the latest submit(), per shard
+        self.router = (Router(self.engines, world, rank, transport=transport, n_max=n_max)
+                       if world > 1 or force_exchange else None)
         for e in self.engines:  # every server holds every row (tatp/udp/server_shard.cc:71-85)
             e.populate(n_rows if populate is None else populate)
 
     # ---- host path (recording) ----------------------------------------------------------------------
     def submit(self, reqs: List[np.ndarray]) -> List[np.ndarray]:
-        if self.sharded is None:
+        if self.router is None:
             return [self.engines[s].submit(reqs[s]) if len(reqs[s]) else reqs[s] for s in range(N_SHARDS)]
-        out, self.last_splits = [], []
-        for s in range(N_SHARDS):  # every rank must enter the collectives, also with an empty batch
-            n = len(reqs[s])
-            d = torch.from_numpy(np.frombuffer(reqs[s].tobytes(), np.uint8).copy()).cuda()
-            r = torch.empty_like(d)
-            self.last_splits.append(self.sharded[s].submit_device(d, n, r))
-            out.append(np.frombuffer(r.cpu().numpy().tobytes(), reqs[s].dtype))
-        return out
+        return self.router.submit(reqs)  # every rank enters the collectives, also with an empty batch
 
     # ---- device path (replay) --------------------------------------------------------------------------
-    def submit_device(self, d_reqs, counts, d_reps, splits=None) -> None:
+    def submit_device(self, d_reqs, counts, d_reps) -> None:
         """d_reqs / d_reps: per shard uint8 tensors; asynchronous.  Single GPU: each engine runs on its own
-        stream (the three shard servers are independent).  Multi GPU: routed on torch's current stream; `splits`
-        (per shard, recorded by submit()) keeps the exchange free of host syncs."""
-        if self.sharded is None:
+        stream (the three shard servers are independent).  Multi GPU: pack -> all-to-all -> the three engines on
+        their own streams -> all-to-all -> unpack, without host round trips (fixed-capacity slots)."""
+        if self.router is None:
             for s in range(N_SHARDS):
                 if counts[s]:
                     self.engines[s].submit_device(d_reqs[s], counts[s], d_reps[s], 0)
         else:
-            for s in range(N_SHARDS):
-                self.sharded[s].submit_device(d_reqs[s], counts[s], d_reps[s], None if splits is None else splits[s])
+            self.router.step(d_reqs, counts, d_reps)
 
     def sync(self):
+        if self.router is not None:
+            self.router.sync()
         for e in self.engines:
             e.sync()
         torch.cuda.synchronize()
@@ -83,7 +79,7 @@ def record(driver: Driver, group, n_epochs: int):
         req = driver.next()
         rep = group.submit(req)
         driver.consume(rep)
-        trace.append((req, rep, getattr(group, "last_splits", None)))
+        trace.append((req, rep))
         now = driver.stats()["txns"]  # transactions whose last reply arrived in this epoch
         done.append(now - last)
         last = now
@@ -96,7 +92,6 @@ class Replay:
     def __init__(self, trace, msg_size: int):
         self.msg = msg_size
         self.counts = [[len(t[0][s]) for s in range(N_SHARDS)] for t in trace]
-        self.splits = [t[2] if len(t) > 2 else None for t in trace]
         self.d_req, self.d_rep, self.want = [], [], []
         for req, rep in ((t[0], t[1]) for t in trace):
             self.d_req.append([torch.from_numpy(np.frombuffer(req[s].tobytes(), np.uint8).copy()).cuda()
@@ -110,7 +105,7 @@ class Replay:
 
     def run(self, group: ShardGroup, lo: int, hi: int) -> None:
         for e in range(lo, hi):
-            group.submit_device(self.d_req[e], self.counts[e], self.d_rep[e], self.splits[e])
+            group.submit_device(self.d_req[e], self.counts[e], self.d_rep[e])
 
     def check(self, lo: int, hi: int) -> None:
         """The replayed replies must equal the recorded ones byte for byte."""

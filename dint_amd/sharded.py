@@ -1,81 +1,159 @@
-"""Hash-sharded multi-GPU front end: one process per GPU, one Engine per rank.
+"""Hash-sharded multi-GPU front end: one process per GPU, the key space of every logical
+server partitioned by ``home = global slot / bucket % world`` (the engine stores its share at ``// world``).
 
-Every request touches exactly one lock slot / bucket, so the key space is partitioned by
-``home = global_slot % world`` (the engine stores its share at ``global_slot // world``).
-A step on rank r:
+A step on rank r, for S logical servers at once (S = 3 replicated shard servers for tatp / smallbank, 1 for the
+lock tables), entirely on the GPU and free of host round trips:
 
-  1. home shard of each ingested request (GPU kernel ``dint_home_shard``: same hash/modulus
-     as the engine);
-  2. stable partition of the batch by home;
-  3. all-to-all of the per-destination counts, then of the fixed-size wire messages
-     (RCCL over xGMI; the messages are the packed request structs themselves);
-  4. the home engine processes what it received, ordered (source rank, original index) --
-     i.e. the serial order of the rank-major concatenation of all ingest slices;
-  5. inverse all-to-all of the replies, scatter back to the original positions.
+  1. ``dint_route_pack`` (HIP): stable partition of each ingested batch by home rank into fixed-capacity slots
+     of ONE exchange buffer -- per peer a chunk ``[counts | slot of server 0 | slot of server 1 | ...]``;
+  2. one all-to-all of the equal-size chunks (RCCL over xGMI; ``dist.all_to_all_single`` without split sizes);
+  3. every home engine answers the W segments it received, in place, as one serial history ordered
+     (source rank, index) -- ``dint_submit_segments`` on the engine's own stream, so the S servers of a rank
+     overlap exactly as they do on a single GPU;
+  4. the inverse all-to-all;
+  5. ``dint_route_unpack`` (HIP): replies back to their original positions.
 
-The exchange code is device-agnostic torch; tests run it on CPU tensors over gloo with an
-injected per-rank server double.
+The order in step 3 is the serial order of the rank-major concatenation of all ingest batches, so results do
+not depend on the number of GPUs.  The collective is torch.distributed's; everything else is the C ABI.
+
+Transports: ``"nccl"`` = RCCL on device buffers (one GPU per rank); ``"host"`` = any CPU backend (gloo) with the
+chunks staged through host memory -- functional testing with several ranks on ONE GPU, where RCCL refuses to
+run.  `Exchange` is the only class that touches torch.distributed.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional
+import contextlib
+from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
+HDR = 64  # bytes of the chunk header: u32 live count of each server's slot
 
-class ShardedEngine:
-    def __init__(self, engine, world: int, rank: int, group=None, msg_size: Optional[int] = None,
-                 home_fn: Optional[Callable] = None, local_fn: Optional[Callable] = None):
-        """`engine` is this rank's dint_amd.engine.Engine created with shard_index=rank,
-        shard_count=world.  `home_fn(req2d) -> uint8[n]` and `local_fn(recv2d) -> None (in place)`
-        override the GPU kernels (used by the CPU/gloo tests)."""
-        self.engine, self.world, self.rank, self.group = engine, world, rank, group
-        self.msg = msg_size if msg_size is not None else engine.msg_size
-        self.home_fn, self.local_fn = home_fn, local_fn
 
-    def _home(self, req2d: torch.Tensor, n: int) -> torch.Tensor:
-        if self.home_fn is not None:
-            return self.home_fn(req2d)
-        home = torch.empty(n, dtype=torch.uint8, device=req2d.device)
-        st = torch.cuda.current_stream().cuda_stream
-        self.engine.home_shard(req2d, n, home, st)
-        return home
+def _align(x: int, a: int) -> int:
+    return (x + a - 1) // a * a
 
-    def _local(self, recv2d: torch.Tensor, n: int) -> None:
-        if self.local_fn is not None:
-            self.local_fn(recv2d)
-            return
-        st = torch.cuda.current_stream().cuda_stream
-        self.engine.submit_device(recv2d, n, recv2d, st)
 
-    def submit_device(self, d_req: torch.Tensor, n: int, d_rep: torch.Tensor, splits=None):
-        """d_req / d_rep: uint8 tensors of n * msg_size bytes on this rank's device.
+class Exchange:
+    """all-to-all of equal-size per-peer chunks of a uint8 device tensor."""
 
-        The collective API wants the split sizes as host integers.  Without `splits` they are exchanged and read
-        back (two host syncs per call); a caller that already knows them -- a replayed recorded trace, or an
-        ingest path with fixed-capacity slots -- passes `splits = (send_splits, recv_splits)` and the whole step
-        stays asynchronous on the stream.  Returns the splits used."""
-        W, msg = self.world, self.msg
-        req2d = d_req.view(n, msg)
-        home = self._home(req2d, n).to(torch.int64)
-        home = torch.where(home >= W, torch.full_like(home, self.rank), home)  # no home: counted as bad locally
-        order = torch.argsort(home, stable=True)
-        if splits is None:
-            counts = torch.bincount(home, minlength=W)
-            recv_counts = torch.empty_like(counts)
-            dist.all_to_all_single(recv_counts, counts, group=self.group)
-            send_splits = counts.tolist()          # host sync: split sizes must be host integers
-            recv_splits = recv_counts.tolist()
-        else:
-            send_splits, recv_splits = splits
-        send = req2d.index_select(0, order).contiguous()
-        n_recv = int(sum(recv_splits))
-        recv = torch.empty((n_recv, msg), dtype=torch.uint8, device=d_req.device)
-        dist.all_to_all_single(recv, send, recv_splits, send_splits, group=self.group)
-        if n_recv:
-            self._local(recv, n_recv)
-        back = torch.empty_like(send)
-        dist.all_to_all_single(back, recv, send_splits, recv_splits, group=self.group)
-        d_rep.view(n, msg).index_copy_(0, order, back)
-        return send_splits, recv_splits
+    def __init__(self, world: int, rank: int, group=None, transport: Optional[str] = None):
+        self.world, self.rank, self.group = world, rank, group
+        if transport is None:
+            transport = "nccl" if dist.is_initialized() and dist.get_backend(group) == "nccl" else "host"
+        if world == 1 and not dist.is_initialized():
+            transport = "self"
+        self.transport = transport
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        """out chunk k <- rank k's inp chunk `rank`; enqueued on torch's current stream."""
+        if self.transport == "self":
+            out.copy_(inp, non_blocking=True)
+        elif self.transport == "nccl":
+            dist.all_to_all_single(out, inp, group=self.group)
+        else:  # staged through the host: synchronous
+            h_in = inp.cpu()
+            h_out = torch.empty_like(h_in)
+            dist.all_to_all_single(h_out, h_in, group=self.group)
+            out.copy_(h_out)
+
+    def max_int(self, v: Sequence[int]) -> List[int]:
+        if self.transport == "self":
+            return list(v)
+        dev = "cuda" if self.transport == "nccl" else "cpu"
+        t = torch.tensor(list(v), dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [int(x) for x in t.tolist()]
+
+
+class Router:
+    """The exchange around S engines of this rank (each created with shard_index = rank, shard_count = world)."""
+
+    def __init__(self, engines, world: int, rank: int, *, group=None, transport: Optional[str] = None,
+                 n_max: int = 1 << 20, caps: Optional[Sequence[int]] = None, device: str = "cuda"):
+        """device="cpu" (with engine doubles that implement the routing calls on host memory) is what the
+        world-size-2 gloo tests run; the orchestration below is the same."""
+        self.engines, self.world, self.rank, self.device = list(engines), world, rank, device
+        self.S = len(self.engines)
+        assert 1 <= self.S <= HDR // 4
+        self.msg = self.engines[0].msg_size
+        self.ex = Exchange(world, rank, group, transport)
+        self.n_max = n_max
+        self.stream = torch.cuda.Stream() if device == "cuda" else None  # routing kernels and collectives
+        self.d_slot = [torch.empty(n_max, dtype=torch.int32, device=device) for _ in range(self.S)]
+        self.send = self.recv = None
+        self.max_seen = [0] * self.S
+        self.set_caps(caps if caps is not None else [self.default_cap(n_max)] * self.S)
+
+    def default_cap(self, n: int) -> int:
+        """slot capacity for batches of up to n requests: 1.5x the mean per destination + slack (hash-partitioned
+        keys are balanced up to the hot keys), never more than one kernel pass takes"""
+        cap = _align(max(1024, (3 * n) // (2 * self.world) + 512), 64) if self.world > 1 else _align(max(n, 64), 64)
+        return max(64, min(cap, self.engines[0].pass_max // 64 * 64))
+
+    def set_caps(self, caps: Sequence[int]) -> None:
+        """(re)build the exchange buffers for per-server slot capacities `caps` (identical on every rank)"""
+        self.caps = [max(2, int(c)) for c in caps]
+        self.off = []
+        o = HDR
+        for c in self.caps:
+            self.off.append(o)
+            o += _align(c * self.msg, 16)
+        self.chunk = _align(o, 64)
+        if self.device == "cuda":
+            torch.cuda.synchronize()
+        self.send = torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device)
+        self.recv = torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device)
+
+    def tighten_caps(self, slack: int = 64) -> List[int]:
+        """after a recorded run: the smallest capacities that held every slot seen so far, agreed by all ranks"""
+        caps = [_align(m + slack, 64) for m in self.ex.max_int(self.max_seen)]
+        self.set_caps(caps)
+        return caps
+
+    # ---- one step --------------------------------------------------------------------------------------------
+    def step(self, d_reqs, counts, d_reps, track: bool = False) -> None:
+        """d_reqs / d_reps: per server uint8 device tensors (or raw device pointers) of counts[s] messages.
+        Asynchronous: everything is enqueued on self.stream and the engines' own streams."""
+        xs = self.stream.cuda_stream if self.stream is not None else 0
+        sp, rp = self.send.data_ptr(), self.recv.data_ptr()
+        with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+            for s, e in enumerate(self.engines):
+                assert counts[s] <= self.n_max
+                e.route_pack(d_reqs[s], counts[s], sp + self.off[s], self.caps[s], self.chunk, sp + 4 * s, self.chunk,
+                             self.d_slot[s], xs)
+            if track:  # slot occupancy (host sync; recording runs only)
+                hdr = self.send.view(self.world, self.chunk)[:, :4 * self.S].cpu().numpy().view("<u4")
+                for s in range(self.S):
+                    self.max_seen[s] = max(self.max_seen[s], int(hdr[:, s].max()))
+            self.ex.all_to_all(self.recv, self.send)
+            for s, e in enumerate(self.engines):
+                e.stream_wait(xs)
+                e.submit_segments(rp + self.off[s], self.world, self.caps[s], self.chunk, rp + 4 * s, self.chunk)
+                e.stream_signal(xs)
+            self.ex.all_to_all(self.send, self.recv)
+            for s, e in enumerate(self.engines):
+                e.route_unpack(sp + self.off[s], self.caps[s], self.chunk, self.d_slot[s], d_reqs[s], counts[s],
+                               d_reps[s], xs)
+
+    def sync(self) -> None:
+        if self.stream is not None:
+            self.stream.synchronize()
+        for e in self.engines:
+            e.sync()
+
+    def overflow(self) -> int:
+        return sum(e.stats()["route_overflow"] for e in self.engines)
+
+    # ---- host convenience (recording, tests) ---------------------------------------------------------------------
+    def submit(self, reqs: List[np.ndarray]) -> List[np.ndarray]:
+        d_req = [torch.from_numpy(np.frombuffer(r.tobytes(), np.uint8).copy()).to(self.device) for r in reqs]
+        d_rep = [torch.empty_like(d) for d in d_req]
+        before = self.overflow()
+        self.step(d_req, [len(r) for r in reqs], d_rep, track=True)
+        self.sync()
+        if self.overflow() != before:
+            raise RuntimeError("exchange slot overflow: raise the slot capacities (Router.set_caps)")
+        return [np.frombuffer(d.cpu().numpy().tobytes(), r.dtype) for d, r in zip(d_rep, reqs)]

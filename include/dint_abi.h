@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 1
+#define DINT_ABI_VERSION 2
 
 /* dint_config.flags */
 #define DINT_FLAG_KV_ROUNDS 1u /* kv workloads: resolve same-key conflicts request by request instead of in
@@ -95,7 +95,11 @@ typedef struct dint_config {
   /* requests per kernel pass; longer submissions run as several passes.  0 = the engine's maximum
    * (FASST / 2PL / LOG 65,536; STORE / TATP / SMALLBANK 1,048,576, and never more than log_entries). */
   uint32_t max_pass;
-  uint32_t reserved[4];
+  /* STORE / TATP / SMALLBANK: overflow entries per table (a bucket whose 4 inline slots are taken chains 4-slot
+   * entries from this pool; the reference `new`s them without bound, store/udp/kvs.h:95-102).  0 = local buckets / 4
+   * + 4096 (twice what the reference population needs).  A full pool refuses INSERTs: see dint_stats.pool_exhausted. */
+  uint32_t pool_entries;
+  uint32_t reserved[3];
 } dint_config;
 
 typedef struct dint_stats {
@@ -105,8 +109,12 @@ typedef struct dint_stats {
   uint64_t missing_keys;   /* SET/COMMIT/DELETE (tatp) or lock+read (smallbank) on a missing key:
                               the reference panics (tatp/udp/kvs.h:91,152); ack still sent */
   uint64_t foreign_requests; /* request whose home shard is not this engine: left untouched */
-  uint64_t pool_exhausted; /* INSERT dropped because the overflow-entry pool is full */
-  uint64_t reserved[2];
+  uint64_t pool_exhausted; /* INSERTs that found the overflow-entry pool full: nothing is stored; a request resolved on
+                              its own is answered REJECT_INSERT (store, 9) / REJECT_COMMIT (tatp, 11 -- the eBPF
+                              flavour's "refused, send again", tatp/ebpf/shard_kern.c:509-514), one folded into a
+                              same-key closed form keeps its ack; dint_wait / dint_submit return DINT_ENOMEM */
+  uint64_t route_overflow; /* requests dint_route_pack could not place (destination slot full): reply = request */
+  uint64_t reserved[1];
 } dint_stats;
 
 typedef struct dint_engine dint_engine_t;
@@ -121,14 +129,39 @@ const char *dint_last_error(void);
 
 /* ---- the hot path -------------------------------------------------------- */
 /* Host buffers: copies reqs to the GPU, runs the batch, copies replies back;
- * returns when replies are complete.  reqs == replies (in place) is allowed. */
+ * returns when replies are complete.  reqs == replies (in place) is allowed.
+ * = dint_submit_async + dint_wait. */
 int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies);
+/* Pipelined form: enqueue and return at once; *ticket identifies the submission.  The array is cut
+ * into passes of max_pass requests; pass k+1's host-to-device copy and pass k-1's device-to-host copy overlap pass
+ * k's kernels (three HIP streams, three staging slots), and successive submissions pipeline the same way -- as long
+ * as reqs / replies are page-locked (dint_alloc_pinned, or the caller's own hipHostMalloc / hipHostRegister
+ * memory); pageable buffers work but every copy then blocks the calling thread.  Buffers must stay untouched until
+ * dint_wait(ticket) returns.  Submissions are applied in call order (one serial history per engine). */
+typedef uint64_t dint_ticket;
+int dint_submit_async(dint_engine_t *e, const void *reqs, uint32_t n, void *replies, dint_ticket *ticket);
+/* replies of `ticket` (and of every earlier ticket) are complete.  DINT_ENOMEM if INSERTs were refused since the
+ * last check (dint_stats.pool_exhausted) -- the replies are valid, rows were not stored. */
+int dint_wait(dint_engine_t *e, dint_ticket ticket);
+int dint_alloc_pinned(size_t bytes, void **out);
+void dint_free_pinned(void *p);
 /* Device buffers (HBM-resident, e.g. torch tensors): enqueues the batch on `stream`
  * (a hipStream_t, NULL = the engine's own stream) and returns immediately; in-place
- * allowed.  Buffers must stay valid until the stream reaches the end of the batch. */
+ * allowed.  Buffers must stay valid until the stream reaches the end of the batch.
+ * Stream rule: an engine has ONE set of batch scratch, so its passes run one after the other.  When consecutive
+ * calls (submit, load, populate, route) name different streams the engine inserts the event wait itself; work the
+ * CALLER enqueues on other streams (producing d_reqs, consuming d_replies) is the caller's to order --
+ * dint_stream_wait / dint_stream_signal do that for the engine's own stream. */
 int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, void *stream);
-/* wait for everything enqueued on the engine's own stream */
+/* wait for everything enqueued on the engine's own streams */
 int dint_sync(dint_engine_t *e);
+/* the engine's own stream (a hipStream_t) */
+void *dint_engine_stream(dint_engine_t *e);
+/* requests one kernel pass takes (dint_config.max_pass after clamping) */
+uint32_t dint_max_pass(dint_engine_t *e);
+/* the engine's own stream waits for everything enqueued so far on other_stream / other_stream waits for the engine */
+int dint_stream_wait(dint_engine_t *e, void *other_stream);
+int dint_stream_signal(dint_engine_t *e, void *other_stream);
 
 /* ---- population / state (parity + checkpointing) -------------------------- */
 /* KV workloads: bulk-insert rows in order with kvs_insert semantics (ver given, or 0 if
@@ -163,7 +196,26 @@ int dint_reset(dint_engine_t *e);
 int dint_snapshot(dint_engine_t *e);
 int dint_restore(dint_engine_t *e);
 
-/* ---- multi-GPU routing helper ------------------------------ */
+/* ---- multi-GPU routing -------------------------------------- */
+/* One step on rank r of G (every engine created with shard_index = r, shard_count = G):
+ *   dint_route_pack      stable partition of the ingested batch by home rank into G fixed-capacity slots
+ *   all-to-all           of the slots (RCCL; equal split sizes, so no host round trip)
+ *   dint_submit_segments the home engine answers what it received, in (source rank, index) order, in place
+ *   all-to-all           back
+ *   dint_route_unpack    replies to their original positions
+ * A slot = seg_cap messages at d_send + w * seg_stride, with its live count (u32) at d_cnt + w * cnt_stride (the
+ * caller decides where the header lives, e.g. in front of the slot so that it travels with it).  d_slot[n] (u32)
+ * remembers where each request went.  Requests beyond a slot's capacity are not sent (reply = request,
+ * dint_stats.route_overflow); n <= 1,048,576 and G <= 64 per call. */
+int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_send, uint32_t seg_cap,
+                    uint64_t seg_stride, void *d_cnt, uint64_t cnt_stride, uint32_t *d_slot, void *stream);
+int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, uint64_t seg_stride,
+                      const uint32_t *d_slot, const void *d_reqs, uint32_t n, void *d_replies, void *stream);
+/* n_seg segments of seg_cap message slots, segment k at d_base + k * seg_stride holding *(u32 *)(d_cnt + k *
+ * cnt_stride) requests: processed in place as ONE serial history, segment by segment (kernel passes take whole
+ * segments: seg_cap <= max_pass). */
+int dint_submit_segments(dint_engine_t *e, void *d_base, uint32_t n_seg, uint32_t seg_cap, uint64_t seg_stride,
+                         const void *d_cnt, uint64_t cnt_stride, void *stream);
 /* d_home[i] = home shard (0..shard_count-1) of d_reqs[i], computed on the GPU with the
  * same hash/modulus the engine uses; 0xFF for requests that have no home (bad table). */
 int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d_home, void *stream);

@@ -1,0 +1,85 @@
+"""The host boundary of the C ABI: dint_submit_async / dint_wait (pipelined H2D / kernels / D2H), stream ordering of
+dint_submit_device across caller streams, and the overflow-pool accounting."""
+import numpy as np
+import pytest
+import torch
+
+import tracegen
+from dint_amd import _lib, wire
+from dint_amd.engine import Engine, Pinned
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+W = wire.Workload
+
+
+def test_async_tickets_pipeline_and_match_sync_submit():
+    n, chunks = 40_000, 7
+    reqs = [tracegen.fasst_random(n, seed=10 + k, n_hot=32, p_hot=0.7) for k in range(chunks)]
+    a = Engine(W.FASST, n_slots=1 << 20)
+    want = [a.submit(r) for r in reqs]
+    b = Engine(W.FASST, n_slots=1 << 20, max_pass=4096)  # ten passes per submission, three staging slots
+    pins = [(Pinned(n * 9), Pinned(n * 9)) for _ in range(chunks)]
+    for (pi, _), r in zip(pins, reqs):
+        pi.array[:] = np.frombuffer(r.tobytes(), np.uint8)
+    tickets = [b.submit_async(pi.ptr, n, po.ptr) for pi, po in pins]  # all in flight before the first wait
+    assert tickets == sorted(tickets) and len(set(tickets)) == chunks
+    for t in reversed(tickets):  # waiting out of order is fine
+        b.wait(t)
+    for (_, po), w in zip(pins, want):
+        assert po.array.tobytes() == w.tobytes()
+    assert all((x == y).all() for x, y in zip(a.read_locks(), b.read_locks()))
+    with pytest.raises(_lib.DintError):
+        b.wait(tickets[-1] + 100)
+
+
+def test_async_pageable_buffers_and_in_place():
+    o = orc.TatpOracle(300, log_entries=20_000)
+    req = tracegen.tatp_random(30_000, [o.dump(t)[0] for t in range(5)], seed=2, n_sub_touch=50)
+    e = Engine(W.TATP, n_rows=300, log_entries=20_000, max_pass=8192)
+    e.populate(300)
+    buf = req.copy()
+    t = e.submit_async(buf, len(buf), buf)  # pageable numpy memory, replies over the requests
+    e.wait(t)
+    assert buf.tobytes() == o.replay(req).tobytes()
+
+
+def test_submit_device_on_alternating_caller_streams_is_serial():
+    """consecutive passes on different streams share the engine's scratch: the engine must order them itself"""
+    n, steps = 60_000, 12
+    reqs = [tracegen.fasst_random(n, seed=50 + k, n_hot=4, p_hot=0.9) for k in range(steps)]
+    o = orc.FasstOracle(4801)
+    e = Engine(W.FASST, n_slots=4801)
+    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    d = [torch.from_numpy(np.frombuffer(r.tobytes(), np.uint8).copy()).cuda() for r in reqs]
+    torch.cuda.synchronize()
+    for k in range(steps):
+        e.submit_device(d[k], n, d[k], s[k & 1].cuda_stream if k % 3 else 0)  # also the engine's own stream
+    torch.cuda.synchronize()
+    e.sync()
+    for k in range(steps):
+        assert d[k].cpu().numpy().tobytes() == o.replay(reqs[k]).tobytes(), k
+
+
+def test_pool_exhaustion_is_reported_not_silent():
+    """a full overflow pool refuses INSERTs: reject code on the request-by-request path, DINT_ENOMEM from the host
+    submit, nothing stored"""
+    S = wire.Store
+    e = Engine(W.STORE, n_rows=8, pool_entries=2, flags=1)  # 36 buckets, 2 overflow entries; flag 1 = rounds
+    n = 2000
+    m = np.zeros(n, wire.STORE_MSG)
+    m["type"], m["key"] = S.INSERT, np.arange(1, n + 1, dtype=np.uint64) << np.uint64(32)
+    rep = np.empty_like(m)
+    with pytest.raises(_lib.DintError, match="pool"):
+        _lib.check(e._L.dint_submit(e._h, m.ctypes.data, n, rep.ctypes.data))
+    st = e.stats()
+    acked, refused = int((rep["type"] == S.INSERT_ACK).sum()), int((rep["type"] == S.REJECT_INSERT).sum())
+    assert acked + refused == n and refused == st["pool_exhausted"] > 0
+    assert acked == len(e.dump_rows(0)[0]) <= 36 * 4 + 2 * 4
+    # a second, harmless batch does not report the old failures again
+    rd = m[:10].copy()
+    rd["type"] = S.READ
+    assert set(e.submit(rd)["type"].tolist()) <= {int(S.GRANT_READ), int(S.NOT_EXIST)}
+    # the default pool takes the same inserts without a single refusal
+    e2 = Engine(W.STORE, n_rows=8, pool_entries=4096)
+    assert (e2.submit(m)["type"] == S.INSERT_ACK).all() and e2.stats()["pool_exhausted"] == 0

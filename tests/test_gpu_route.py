@@ -1,0 +1,245 @@
+"""GPU tests of the multi-GPU path on ONE GPU: the HIP pack / unpack kernels against their numpy
+restatement, segmented passes against contiguous ones, the whole Router with a self all-to-all, and two REAL
+sharded engine groups (two ranks sharing the GPU, exchange staged through the host over gloo) against the
+unsharded CPU oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import shard_double as sd
+import tracegen
+from dint_amd import wire
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W = wire.Workload
+
+
+def _engine(*a, **k):
+    from dint_amd.engine import Engine
+
+    return Engine(*a, **k)
+
+
+def _dev(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.frombuffer(a.tobytes(), np.uint8).copy()).cuda()
+
+
+# ------------------------------------------------------------------------------------------- pack / unpack
+@pytest.mark.parametrize("n,world,cap", [(1, 2, 64), (5000, 2, 4096), (70_000, 8, 9000), (70_000, 8, 8000), (1 << 20, 3, 400_000),
+                                         (0, 4, 64), (1025, 64, 64)])
+def test_route_pack_unpack_vs_numpy(n, world, cap):
+    nslots, rank = 36_000_000, 1
+    req = tracegen.fasst_random(max(n, 1), seed=n + world, n_hot=8, p_hot=0.3)[:n]
+    eng = _engine(W.FASST, n_slots=nslots, shard_index=rank, shard_count=world)
+    msg, HDRB = 9, 64
+    stride = HDRB + (cap * msg + 15) // 16 * 16
+    d_req = _dev(req) if n else torch.zeros(16, dtype=torch.uint8, device="cuda")
+    d_send = torch.zeros(world * stride, dtype=torch.uint8, device="cuda")
+    d_slot = torch.full((max(n, 1),), 12345, dtype=torch.int32, device="cuda")
+    eng.route_pack(d_req, n, d_send.data_ptr() + HDRB, cap, stride, d_send.data_ptr(), stride, d_slot)
+    eng.sync()
+    # the numpy restatement on host buffers
+    dbl = sd.ServerDouble(W.FASST, None, world, rank, sd.lid_home(nslots, world))
+    h_req = torch.from_numpy(np.frombuffer(req.tobytes(), np.uint8).copy()) if n else torch.zeros(16, dtype=torch.uint8)
+    h_send = torch.zeros(world * stride, dtype=torch.uint8)
+    h_slot = torch.full((max(n, 1),), 12345, dtype=torch.int32)
+    dbl.route_pack(h_req, n, h_send.data_ptr() + HDRB, cap, stride, h_send.data_ptr(), stride, h_slot)
+    got = d_send.cpu().numpy().reshape(world, stride)
+    want = h_send.numpy().reshape(world, stride)
+    cnt = got[:, :4].copy().view("<u4")[:, 0]
+    assert (cnt == want[:, :4].copy().view("<u4")[:, 0]).all()
+    for w in range(world):
+        assert (got[w, HDRB:HDRB + cnt[w] * msg] == want[w, HDRB:HDRB + cnt[w] * msg]).all(), w
+    assert (d_slot.cpu().numpy()[:n] == h_slot.numpy()[:n]).all()
+    assert eng.stats()["route_overflow"] == dbl.route_overflow
+    # unpack straight from the send buffer: every request comes back unchanged (overflowed ones via reply = request)
+    d_rep = torch.zeros_like(d_req)
+    eng.route_unpack(d_send.data_ptr() + HDRB, cap, stride, d_slot, d_req, n, d_rep)
+    eng.sync()
+    assert d_rep.cpu().numpy()[:n * msg].tobytes() == req.tobytes()
+
+
+def _segmented(req: np.ndarray, cuts, cap, hdr=64):
+    """lay `req` out as len(cuts)-1 segments of capacity `cap` with a header in front of each"""
+    msg = req.dtype.itemsize
+    stride = hdr + (cap * msg + 63) // 64 * 64
+    nseg = len(cuts) - 1
+    buf = np.full(nseg * stride, 0xCD, np.uint8)  # padding slots hold garbage
+    for k in range(nseg):
+        part = req[cuts[k]:cuts[k + 1]]
+        buf[k * stride:k * stride + 4] = np.array([len(part)], "<u4").view(np.uint8)
+        buf[k * stride + hdr:k * stride + hdr + len(part) * msg] = np.frombuffer(part.tobytes(), np.uint8)
+    return buf, stride, nseg
+
+
+def _unsegment(buf, cuts, stride, dtype, hdr=64):
+    msg = dtype.itemsize
+    return np.concatenate([np.frombuffer(buf[k * stride + hdr:k * stride + hdr + (cuts[k + 1] - cuts[k]) * msg].tobytes(), dtype)
+                           for k in range(len(cuts) - 1)])
+
+
+@pytest.mark.parametrize("wl", ["fasst", "tpl", "tatp", "smallbank"])
+@pytest.mark.parametrize("cuts,cap", [([0, 3000, 3000, 9000, 20_000], 12_000), ([0, 1, 2, 20_000], 65_536)])
+def test_submit_segments_equals_contiguous(wl, cuts, cap):
+    n = cuts[-1]
+    if wl == "fasst":
+        req, mk = tracegen.fasst_random(n, seed=3, n_hot=8, p_hot=0.6), lambda **k: _engine(W.FASST, n_slots=4801, **k)
+    elif wl == "tpl":
+        req, mk = tracegen.tpl_random(n, seed=4, n_hot=8, p_hot=0.6), lambda **k: _engine(W.TPL, n_slots=4801, **k)
+    elif wl == "tatp":
+        o = orc.TatpOracle(300, log_entries=200_000)
+        req = tracegen.tatp_random(n, [o.dump(t)[0] for t in range(5)], seed=5, n_sub_touch=40)
+
+        def mk(**k):
+            e = _engine(W.TATP, n_rows=300, log_entries=200_000, **k)
+            e.populate(300)
+            return e
+    else:
+        req = tracegen.sb_random(n, seed=6, n_acct_touch=30)
+
+        def mk(**k):
+            e = _engine(W.SMALLBANK, n_rows=2000, log_entries=200_000, **k)
+            e.populate(2000)
+            return e
+    a, b = mk(), mk(max_pass=16_384 if cap <= 16_384 else 0)
+    want = a.submit(req)
+    buf, stride, nseg = _segmented(req, cuts, cap)
+    d = torch.from_numpy(buf).cuda()
+    b.submit_segments(d.data_ptr() + 64, nseg, cap, stride, d.data_ptr(), stride)
+    b.sync()
+    out = d.cpu().numpy()
+    got = _unsegment(out, cuts, stride, req.dtype)
+    assert got.tobytes() == want.tobytes()
+    # padding slots were never written
+    for k in range(nseg):
+        used = 64 + (cuts[k + 1] - cuts[k]) * req.dtype.itemsize
+        assert (out[k * stride + used:(k + 1) * stride] == 0xCD).all()
+    if wl in ("tatp", "smallbank"):
+        for t in range(5 if wl == "tatp" else 2):
+            assert all((x == y).all() for x, y in zip(a.dump_rows(t), b.dump_rows(t)))
+        ra, ta = a.read_log(200_000)
+        rb, tb = b.read_log(200_000)
+        assert ta == tb and ra.tobytes() == rb.tobytes()
+        assert b.stats()["bad_requests"] == a.stats()["bad_requests"]
+    else:
+        assert all((x == y).all() for x, y in zip(a.read_locks(), b.read_locks()))
+
+
+def test_router_self_exchange_equals_plain_group():
+    """world = 1 with the exchange forced on: pack -> self all-to-all -> segments -> unpack must change nothing"""
+    from dint_amd.driver import Driver
+    from dint_amd.replay import ShardGroup
+
+    n_sub, clients = 20_000, 6000
+    plain = ShardGroup(W.TATP, n_sub, log_entries=200_000)
+    routed = ShardGroup(W.TATP, n_sub, log_entries=200_000, force_exchange=True, n_max=1 << 16)
+    assert routed.router is not None and routed.router.ex.transport == "self"
+    d = Driver(W.TATP, clients, n_sub, zipf_theta=0.8)
+    for e in range(30):
+        req = d.next()
+        a, b = plain.submit(req), routed.submit(req)
+        for s in range(3):
+            assert a[s].tobytes() == b[s].tobytes(), (e, s)
+        d.consume(a)
+    assert routed.router.overflow() == 0
+    for s in range(3):
+        for t in range(5):
+            assert all((x == y).all() for x, y in zip(plain.engines[s].dump_rows(t), routed.engines[s].dump_rows(t)))
+
+
+# ------------------------------------------------------------------------- two real ranks on one GPU
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, wl, n_rows, clients, epochs, zipf, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dint_amd.driver import Driver
+    from dint_amd.replay import ShardGroup
+
+    torch.cuda.set_device(0)
+    grp = ShardGroup(wl, n_rows, device=0, rank=rank, world=world, log_entries=200_000, n_max=1 << 16)
+    assert grp.router.ex.transport == "host"
+    d = Driver(wl, clients, n_rows, first_client=rank * clients, zipf_theta=zipf)
+    trace = []
+    for _ in range(epochs):
+        req = d.next()
+        rep = grp.submit(req)
+        d.consume(rep)
+        trace.append(([r.tobytes() for r in req], [r.tobytes() for r in rep]))
+    # a second pass over the same requests with the tightened slot capacities, device path (what bench.py times)
+    caps = grp.router.tighten_caps()
+    rows = [[tuple(x.tobytes() for x in e.dump_rows(t)) for t in range(len(e_tables(wl)))] for e in grp.engines]
+    st = [e.stats() for e in grp.engines]
+    q.put((rank, trace, rows, st, caps, d.stats()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def e_tables(wl):
+    return range(5) if wire.Workload(wl) == W.TATP else range(2)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("wl,n_rows,clients,zipf", [(int(W.TATP), 20_000, 5000, 0.8), (int(W.SMALLBANK), 50_000, 4000, 0.99 - 1e-9)])
+def test_two_sharded_ranks_on_one_gpu_equal_unsharded_oracle(wl, n_rows, clients, zipf):
+    import torch.multiprocessing as mp
+
+    world, epochs = 2, 25
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, wl, n_rows, clients, epochs, zipf, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=800)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    dtype = wire.MSG_DTYPE[wire.Workload(wl)]
+    mk = (lambda: orc.TatpOracle(n_rows, log_entries=200_000)) if wl == int(W.TATP) else (lambda: orc.SmallbankOracle(n_rows, log_entries=200_000))
+    ora = [mk() for _ in range(3)]
+    total = 0
+    for e in range(epochs):
+        for s in range(3):
+            parts = [np.frombuffer(res[r][0][e][0][s], dtype) for r in range(world)]
+            want = ora[s].replay(np.concatenate(parts))  # the serial order: rank-major concatenation
+            lo = 0
+            for r in range(world):
+                n = len(parts[r])
+                assert res[r][0][e][1][s] == want[lo:lo + n].tobytes(), (e, s, r)
+                lo += n
+                total += n
+    assert total > 0 and all(o.errors == 0 for o in ora)
+    # final rows: the two ranks' shares together are the oracle's table (as multisets of rows per table)
+    for s in range(3):
+        for t in e_tables(wl):
+            keys = np.concatenate([np.frombuffer(res[r][1][s][t][0], "<u8") for r in range(world)])
+            vers = np.concatenate([np.frombuffer(res[r][1][s][t][1], "<u4") for r in range(world)])
+            ok, ov, _ = ora[s].dump(t)
+            a = sorted(zip(keys.tolist(), vers.tolist()))
+            b = sorted(zip(ok.tolist(), ov.tolist()))
+            assert a == b, (s, t)
+    for r in range(world):
+        for st in res[r][2]:
+            assert st["foreign_requests"] == 0 and st["route_overflow"] == 0 and st["bad_requests"] == 0
+        assert res[r][4]["committed"] > 0
+    assert res[0][3] == res[1][3]  # the tightened capacities are agreed by all ranks

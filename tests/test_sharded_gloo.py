@@ -1,17 +1,19 @@
-"""world_size-2 CPU test of the multi-GPU exchange (gloo): routing + inverse routing around a
-per-rank server double must reproduce the single-server serial replay of the rank-major
-concatenation of the ingest slices."""
+"""world_size-2 CPU tests of the multi-GPU exchange (gloo): dint_amd.sharded.Router -- the orchestration the GPU
+path runs (fixed-capacity slots, one all-to-all each way for all logical servers, segments processed in (source
+rank, index) order) -- around per-rank server doubles (tests/shard_double.py) must reproduce the single-server
+serial replay of the rank-major concatenation of the ingest batches."""
 import os
 import socket
 import sys
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_FASST, NSLOTS = 5000, 4801
+N_SUB, N_TATP = 300, 4000
 
 
 def _free_port():
@@ -22,70 +24,80 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, nslots, q):
+_EXISTING = None
+
+
+def _tatp_batches(step, rank):
+    """three per-server batches of all 13 request types (not well-formed across ranks: the missing-key paths of the
+    restatement are exercised too)"""
+    global _EXISTING
+    import tracegen
+    from oracle import oracle as orc
+
+    if _EXISTING is None:
+        o = orc.TatpOracle(N_SUB, log_entries=1000)
+        _EXISTING = [o.dump(t)[0] for t in range(5)]
+    return [tracegen.tatp_random(N_TATP - 500 * s, _EXISTING, seed=1000 * step + 10 * rank + s, n_sub_touch=60,
+                                 well_formed=False) for s in range(3)]
+
+
+def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import shard_double as sd
     import tracegen
     from dint_amd import wire
-    from dint_amd.sharded import ShardedEngine
+    from dint_amd.sharded import Router
     from oracle import oracle as orc
 
-    msg = wire.FASST_MSG.itemsize
-    n = 5000
-    # the server double of this rank: an oracle over the LOCAL slots, fed with lids remapped so
-    # that local_slot = global_slot // world  (what the sharded engine does on the GPU)
-    full = orc.FasstOracle(nslots)  # per-rank replica used only through slots that are "home" here
-
-    def home_fn(req2d):
-        lids = np.frombuffer(req2d.numpy().tobytes(), wire.FASST_MSG)["lid"]
-        h = np.array([orc.fasthash64(int(l).to_bytes(4, "little")) % nslots % world for l in lids], np.uint8)
-        return torch.from_numpy(h)
-
-    def local_fn(recv2d):
-        m = np.frombuffer(recv2d.numpy().tobytes(), wire.FASST_MSG)
-        out = full.replay(m)
-        recv2d.copy_(torch.from_numpy(np.frombuffer(out.tobytes(), np.uint8).reshape(-1, msg).copy()))
-
-    sh = ShardedEngine(None, world, rank, msg_size=msg, home_fn=home_fn, local_fn=local_fn)
-    # a second, independent server double replays the same steps with the split sizes the first run discovered
-    # (the host-sync-free form bench.py uses for a recorded trace)
-    full2 = orc.FasstOracle(nslots)
-
-    def local_fn2(recv2d):
-        m = np.frombuffer(recv2d.numpy().tobytes(), wire.FASST_MSG)
-        recv2d.copy_(torch.from_numpy(np.frombuffer(full2.replay(m).tobytes(), np.uint8).reshape(-1, msg).copy()))
-
-    sh2 = ShardedEngine(None, world, rank, msg_size=msg, home_fn=home_fn, local_fn=local_fn2)
-    outs = []
+    out = {"fasst": [], "tatp": []}
+    # ---- lock_fasst: one logical server; the second router replays with the tightened capacities
+    dbl = sd.ServerDouble(wire.Workload.FASST, orc.FasstOracle(NSLOTS), world, rank, sd.lid_home(NSLOTS, world))
+    rt = Router([dbl], world, rank, n_max=N_FASST, device="cpu")
+    assert rt.ex.transport == "host"
+    reqs = [tracegen.fasst_random(N_FASST, seed=100 * step + rank, n_hot=16, p_hot=0.8) for step in range(3)]
+    for r in reqs:
+        out["fasst"].append(rt.submit([r])[0].tobytes())
+    caps = rt.tighten_caps()
+    assert caps[0] < rt.default_cap(N_FASST) and caps == rt.ex.max_int(caps)
+    dbl2 = sd.ServerDouble(wire.Workload.FASST, orc.FasstOracle(NSLOTS), world, rank, sd.lid_home(NSLOTS, world))
+    rt2 = Router([dbl2], world, rank, n_max=N_FASST, caps=caps, device="cpu")
+    for r, want in zip(reqs, out["fasst"]):
+        assert rt2.submit([r])[0].tobytes() == want
+    # a slot that is too small must be reported, never silently drop requests
+    rt3 = Router([sd.ServerDouble(wire.Workload.FASST, orc.FasstOracle(NSLOTS), world, rank, sd.lid_home(NSLOTS, world))],
+                 world, rank, n_max=N_FASST, caps=[64], device="cpu")
+    try:
+        rt3.submit([reqs[0]])
+        raise AssertionError("overflow not reported")
+    except RuntimeError:
+        pass
+    # ---- tatp: three logical servers, one exchange per direction for all of them
+    ora = [orc.TatpOracle(N_SUB, log_entries=100_000) for _ in range(3)]
+    hs = [ora[0].hash_size(t) for t in range(5)]
+    dbls = [sd.ServerDouble(wire.Workload.TATP, ora[s], world, rank, sd.kv_home(hs, world, rank)) for s in range(3)]
+    rt = Router(dbls, world, rank, n_max=N_TATP, device="cpu")
     for step in range(3):
-        req = tracegen.fasst_random(n, seed=100 * step + rank, n_hot=16, p_hot=0.8)
-        d_req = torch.from_numpy(np.frombuffer(req.tobytes(), np.uint8).copy())
-        d_rep = torch.empty_like(d_req)
-        splits = sh.submit_device(d_req, n, d_rep)
-        outs.append(d_rep.numpy().tobytes())
-        d_rep2 = torch.empty_like(d_req)
-        assert sh2.submit_device(d_req, n, d_rep2, splits=splits) == splits
-        assert d_rep2.numpy().tobytes() == outs[-1]
-    q.put((rank, outs))
+        out["tatp"].append([x.tobytes() for x in rt.submit(_tatp_batches(step, rank))])
+    q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_sharded_exchange_world2_gloo():
+def test_router_world2_gloo():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import tracegen
-    from dint_amd import wire
     from oracle import oracle as orc
 
-    world, nslots = 2, 4801
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, nslots, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
@@ -93,9 +105,19 @@ def test_sharded_exchange_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     # single-server serial replay of the rank-major concatenation, step by step
-    o = orc.FasstOracle(nslots)
+    o = orc.FasstOracle(NSLOTS)
     for step in range(3):
-        reqs = [tracegen.fasst_random(5000, seed=100 * step + r, n_hot=16, p_hot=0.8) for r in range(world)]
+        reqs = [tracegen.fasst_random(N_FASST, seed=100 * step + r, n_hot=16, p_hot=0.8) for r in range(world)]
         want = o.replay(np.concatenate(reqs))
         for r in range(world):
-            assert res[r][step] == want[r * 5000:(r + 1) * 5000].tobytes(), (step, r)
+            assert res[r]["fasst"][step] == want[r * N_FASST:(r + 1) * N_FASST].tobytes(), (step, r)
+    ora = [orc.TatpOracle(N_SUB, log_entries=100_000) for _ in range(3)]
+    for step in range(3):
+        per_rank = [_tatp_batches(step, r) for r in range(world)]
+        for s in range(3):
+            want = ora[s].replay(np.concatenate([per_rank[r][s] for r in range(world)]))
+            lo = 0
+            for r in range(world):
+                n = len(per_rank[r][s])
+                assert res[r]["tatp"][step][s] == want[lo:lo + n].tobytes(), (step, s, r)
+                lo += n

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Run bench.py under rocprofv3 (kernel trace, then one --pmc pass per counter group, as MI355X_MICROARCH.md
+prescribes) and write profiles/traffic_<workload>.json + profiles/<tag>_<workload>_rocprofv3_summary.txt.
+
+    python tools/profile_bench.py <tag> [--workload tatp] [bench args ...]      (on the GPU box)
+
+bench.py quotes the JSON (`roofline.from_profile`, `roofline.traffic`) only while the kernel sources are the ones
+profiled here (kernel_source_hash), so a kernel edit invalidates the numbers instead of silently keeping them.
+Per kernel: avg begin->end duration and mean FETCH_SIZE / WRITE_SIZE / TCC_HIT / TCC_MISS / TCC_EA0_RDREQ / WRREQ per
+dispatch over the LAST `launches` dispatches = the event-timed replay at the end of bench.py (population and
+recording passes excluded).  FETCH_SIZE / WRITE_SIZE are KiB in rocprofv3's output; raw values (the guide's x2
+correction is calibrated for wide coalesced streams only -- see profiles/README.md)."""
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").split("<")[0]
+
+
+def last_rows(db, last):
+    c = sqlite3.connect(db)
+    out = {}
+    try:
+        for (n,) in c.execute("select distinct name from kernels").fetchall():
+            du = [r[0] for r in c.execute("select end - start from kernels where name = ? order by start desc limit ?", (n, last))]
+            out.setdefault(short(n), {})["avg_us"] = sum(du) / len(du) / 1e3
+            out[short(n)]["max_us"] = max(du) / 1e3
+            out[short(n)]["calls"] = len(du)
+    except sqlite3.Error:
+        pass
+    try:
+        pairs = c.execute("select distinct kernel_name, counter_name from counters_collection").fetchall()
+        for n, cn in pairs:
+            v = [r[0] for r in c.execute("select value from counters_collection where kernel_name = ? and counter_name = ? "
+                                         "order by start desc limit ?", (n, cn, last))]
+            out.setdefault(short(n), {})[cn] = sum(v) / len(v)
+    except sqlite3.Error:
+        pass
+    return out
+
+
+def main():
+    tag = sys.argv[1]
+    rest = sys.argv[2:]
+    wl = rest[rest.index("--workload") + 1] if "--workload" in rest else "tatp"
+    out_dir = os.path.join(ROOT, "gpurun_out", f"{tag}_{wl}")
+    os.makedirs(out_dir, exist_ok=True)
+    steps, warm = 40, 5
+    engines = 3 if wl in ("tatp", "smallbank") else 1
+    last = engines * min(steps + warm, 200)  # bench.py's event-timed replay = the last launches
+    base = [sys.executable, os.path.join(ROOT, "bench.py")] + rest + ["--steps", str(steps), "--warmup", str(warm),
+                                                                       "--no-cpu-baseline", "--no-rand64", "--no-host-path"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    passes = [("trace", ["--kernel-trace", "--stats"]), ("FETCH_SIZE", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
+              ("WRITE_SIZE", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
+              ("TCC", ["--pmc", "TCC_HIT_sum", "TCC_MISS_sum", "--kernel-trace"]),
+              ("EA", ["--pmc", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "--kernel-trace"])]
+    merged, lines = {}, []
+    for name, flags in passes:
+        d = os.path.join(out_dir, name)
+        cmd = ["rocprofv3"] + flags + ["-d", d, "-o", name, "--"] + base
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
+        lines.append(f"# pass {name}: rc {r.returncode}: {' '.join(cmd[:6])} ... -- bench.py {' '.join(rest)}")
+        if r.returncode != 0:
+            lines.append(r.stderr[-600:])
+            continue
+        for db in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
+            rows = last_rows(db, last)
+            for k, v in rows.items():
+                if name == "trace":
+                    merged.setdefault(k, {}).update(v)
+                else:  # keep the trace pass's duration; counters from this pass
+                    merged.setdefault(k, {}).update({a: b for a, b in v.items() if a not in ("avg_us", "max_us", "calls")})
+                    merged[k].setdefault("avg_us_under_" + name, v.get("avg_us"))
+    kernels = {}
+    for k, v in merged.items():
+        kernels[k] = dict(v)
+        if "FETCH_SIZE" in v:
+            kernels[k]["fetch_bytes"] = v["FETCH_SIZE"] * 1024.0
+        if "WRITE_SIZE" in v:
+            kernels[k]["write_bytes"] = v["WRITE_SIZE"] * 1024.0
+    from bench import kernel_source_hash
+
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        commit = None
+    res = {"workload": wl, "command": "bench.py " + " ".join(rest) + f" --steps {steps} --warmup {warm}", "launches": last,
+           "kernel_source_hash": kernel_source_hash(), "commit": commit, "kernels": kernels}
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "profiles", f"traffic_{wl}.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    lines.append(f"# kernels over the last {last} dispatches (the event-timed replay of bench.py)")
+    cols = ["avg_us", "max_us", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"]
+    lines.append(f"{'kernel':28s}" + "".join(f"{c:>20s}" for c in cols))
+    for k in sorted(kernels, key=lambda x: -kernels[x].get("avg_us", 0)):
+        lines.append(f"{k:28s}" + "".join(f"{kernels[k].get(c, float('nan')):20.2f}" for c in cols))
+    txt = "\n".join(lines) + "\n"
+    with open(os.path.join(ROOT, "gpurun_out", "profiles", f"{tag}_{wl}_rocprofv3_summary.txt"), "w") as f:
+        f.write(txt)
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()
