@@ -257,9 +257,10 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     delete e;
     return fail(DINT_EINVAL, "shard %u of %u", cfg->shard_index, cfg->shard_count);
   }
+  // (the copy streams of the host path are created on first use: every stream beyond GPU_MAX_HW_QUEUES -- 4 by
+  // default -- shares a hardware queue with another one, and engines that only serve device buffers must not
+  // pay for that with their kernel chains serialised behind each other)
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&e->s_h2d, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&e->s_d2h, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) != hipSuccess) {
     dint_engine_destroy(e);
     return fail(DINT_EHIP, "hipStreamCreate");
@@ -409,6 +410,10 @@ int enqueue_chunk(dint_engine *e, const uint8_t *rq, uint8_t *rp, uint32_t m, ui
   const uint64_t sq = e->next_seq;
   const int k = (int)(sq % dint_engine::kNSlot);
   if (int rc = slot_alloc(e, k)) return rc;
+  if (!e->s_h2d) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&e->s_d2h, hipStreamNonBlocking));
+  }
   dint_engine::Slot &sl = e->slot[k];
   if (sl.seq) HIP_TRY(hipEventSynchronize(sl.done));  // the slot's previous chunk has left the GPU
   const size_t bytes = (size_t)m * e->msg_size;
@@ -547,7 +552,7 @@ int dint_sync(dint_engine_t *e) {
   if (!e) return fail(DINT_EINVAL, "null engine");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipStreamSynchronize(e->s_d2h));
+  if (e->s_d2h) HIP_TRY(hipStreamSynchronize(e->s_d2h));
   return 0;
 }
 

@@ -17,6 +17,7 @@
 
 #include "../../include/dint_abi.h"
 #include "../../include/dint_driver.h"
+#include "zipf_table.h"
 
 namespace {
 
@@ -28,36 +29,12 @@ struct Lcg {  // fastrand, tatp/caladan/tatp.h:31-34
   }
 };
 
-// Zipf(theta) over [0, n) by the closed-form inverse of Gray et al. (SIGMOD'94); ranks are scattered over
-// the key space with a multiplicative hash so that hot rows do not share buckets by construction.
+// Zipf(theta) over [0, n): exact inverse CDF over an integer threshold table (zipf_table.h), so that the GPU-resident
+// driver (k_txn.hip) draws the same keys from the same random words.
 struct Zipf {
-  uint64_t n = 1;
-  double theta = 0, zetan = 1, zeta2 = 1, alpha = 1, eta = 1;
-  void init(uint64_t n_, double th) {
-    n = n_ ? n_ : 1;
-    theta = th;
-    double z = 0;
-    const uint64_t direct = n < 2000000 ? n : 2000000;
-    for (uint64_t k = 1; k <= direct; k++) z += pow((double)k, -theta);
-    if (n > direct) {  // Euler-Maclaurin tail
-      const double a = (double)direct, b = (double)n;
-      z += (pow(b, 1 - theta) - pow(a, 1 - theta)) / (1 - theta) + 0.5 * (pow(b, -theta) - pow(a, -theta));
-    }
-    zetan = z;
-    zeta2 = 1.0 + pow(0.5, theta);
-    alpha = 1.0 / (1.0 - theta);
-    eta = (1 - pow(2.0 / (double)n, 1 - theta)) / (1 - zeta2 / zetan);
-  }
-  uint64_t sample(Lcg &g) const {
-    const double u = ((double)g.next() + 0.5) / 4294967296.0;
-    const double uz = u * zetan;
-    uint64_t r;
-    if (uz < 1.0) r = 0;
-    else if (uz < zeta2) r = 1;
-    else r = (uint64_t)((double)n * pow(eta * u - eta + 1.0, alpha));
-    if (r >= n) r = n - 1;
-    return (r * 0x9E3779B97F4A7C15ull >> 11) % n;
-  }
+  ZipfTable t;
+  void init(uint64_t n, double th) { t.init(n, th); }
+  uint64_t sample(Lcg &g) const { return zipf_lookup(t.cdf.data(), t.n, g.next()); }
 };
 
 // ---- wire messages ----------------------------------------------------------------------------------

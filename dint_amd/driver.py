@@ -92,6 +92,82 @@ class Driver:
                 "by_type": list(s.by_type), "committed_by_type": list(s.committed_by_type)}
 
 
+class FasstClientConfig(C.Structure):
+    _fields_ = [("n_workers", C.c_uint32), ("first_worker", C.c_uint32), ("key_space", C.c_uint32),
+                ("read_pct", C.c_uint32), ("key_dist", C.c_uint32), ("reserved0", C.c_uint32),
+                ("zipf_theta", C.c_double), ("reserved", C.c_uint32 * 8)]
+
+
+class FasstClientStats(C.Structure):
+    _fields_ = [("requests", C.c_uint64), ("epochs", C.c_uint64), ("committed", C.c_uint64), ("rejects", C.c_uint64),
+                ("rollbacks", C.c_uint64), ("protocol_errors", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+
+
+class FasstClient:
+    """The lock_fasst load generator (lock_fasst/caladan/client.cc:183-280 restated, csrc/fasst_client.cc): W
+    workers in lock step, ``next()`` = one 9-byte request per worker, ``consume(replies)`` advances them."""
+
+    def __init__(self, n_workers: int = 4096, key_space: int = 24_000_000, *, read_pct: int = 80,
+                 zipf_theta: float | None = 0.8, first_worker: int = 0):
+        from .wire import FASST_MSG
+
+        L = self._L = _lib.load()
+        vp = C.c_void_p
+        L.dint_fasst_client_create.restype, L.dint_fasst_client_create.argtypes = C.c_int, [C.POINTER(FasstClientConfig), C.POINTER(vp)]
+        L.dint_fasst_client_destroy.restype, L.dint_fasst_client_destroy.argtypes = None, [vp]
+        L.dint_fasst_client_next.restype, L.dint_fasst_client_next.argtypes = vp, [vp]
+        L.dint_fasst_client_consume.restype, L.dint_fasst_client_consume.argtypes = C.c_int, [vp, vp]
+        L.dint_fasst_client_get_stats.restype, L.dint_fasst_client_get_stats.argtypes = C.c_int, [vp, C.POINTER(FasstClientStats)]
+        self.dtype, self.n = FASST_MSG, n_workers
+        cfg = FasstClientConfig(n_workers=n_workers, first_worker=first_worker, key_space=key_space, read_pct=read_pct,
+                                key_dist=0 if zipf_theta is None else 1, zipf_theta=zipf_theta or 0.0)
+        h = vp()
+        rc = L.dint_fasst_client_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise _lib.DintError(f"dint_fasst_client_create failed: {rc}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dint_fasst_client_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def next(self) -> np.ndarray:
+        p = self._L.dint_fasst_client_next(self._h)
+        if not p:
+            raise _lib.DintError("dint_fasst_client_next: replies of the previous epoch are still outstanding")
+        return np.frombuffer((C.c_uint8 * (self.n * 9)).from_address(p), self.dtype).copy()
+
+    def consume(self, replies: np.ndarray):
+        replies = np.ascontiguousarray(replies)
+        _lib.check(self._L.dint_fasst_client_consume(self._h, replies.ctypes.data))
+
+    def stats(self) -> dict:
+        s = FasstClientStats()
+        _lib.check(self._L.dint_fasst_client_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+
+
+def fasst_trace(server, n_requests: int = 24_000_000, **kw):
+    """The lock_fasst request trace: closed loop of a FasstClient against `server` (an object with
+    submit(ndarray) -> ndarray) until n_requests requests were issued.  Returns (requests, replies, client stats);
+    the trace is a function of the client parameters alone as long as the server is correct."""
+    c = FasstClient(**kw)
+    reqs, reps, n = [], [], 0
+    while n < n_requests:
+        r = c.next()[:n_requests - n]  # the last epoch is cut: the server sees exactly n_requests requests
+        p = server.submit(r)
+        if len(r) == c.n:
+            c.consume(p)
+        reqs.append(r)
+        reps.append(p)
+        n += len(r)
+    st = c.stats()
+    return np.concatenate(reqs), np.concatenate(reps), st
+
+
 def run_epochs(driver: Driver, servers, n_epochs: int, record: bool = False):
     """Closed loop: `servers` = 3 objects with submit(ndarray) -> ndarray (one per shard).
     Returns the recorded [(requests[3], replies[3])] per epoch when record=True."""

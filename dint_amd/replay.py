@@ -104,6 +104,9 @@ class Replay:
         return len(self.counts)
 
     def run(self, group: ShardGroup, lo: int, hi: int) -> None:
+        if group.router is not None:  # the epochs of a recorded trace are independent batches: pipelined exchange
+            group.router.run([(self.d_req[e], self.counts[e], self.d_rep[e]) for e in range(lo, hi)])
+            return
         for e in range(lo, hi):
             group.submit_device(self.d_req[e], self.counts[e], self.d_rep[e])
 

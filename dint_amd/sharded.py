@@ -82,7 +82,10 @@ class Router:
         self.ex = Exchange(world, rank, group, transport)
         self.n_max = n_max
         self.stream = torch.cuda.Stream() if device == "cuda" else None  # routing kernels and collectives
-        self.d_slot = [torch.empty(n_max, dtype=torch.int32, device=device) for _ in range(self.S)]
+        # the engines' own streams, as torch streams (event waits / records only; kernels are launched by the ABI)
+        self.estream = [torch.cuda.ExternalStream(e.stream) for e in self.engines] if device == "cuda" else None
+        self.NBUF = 2  # exchange buffer sets: step k uses set k % 2 (see run())
+        self.d_slot = [[torch.empty(n_max, dtype=torch.int32, device=device) for _ in range(self.S)] for _ in range(self.NBUF)]
         self.send = self.recv = None
         self.max_seen = [0] * self.S
         self.set_caps(caps if caps is not None else [self.default_cap(n_max)] * self.S)
@@ -104,8 +107,8 @@ class Router:
         self.chunk = _align(o, 64)
         if self.device == "cuda":
             torch.cuda.synchronize()
-        self.send = torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device)
-        self.recv = torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device)
+        self.send = [torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device) for _ in range(self.NBUF)]
+        self.recv = [torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device) for _ in range(self.NBUF)]
 
     def tighten_caps(self, slack: int = 64) -> List[int]:
         """after a recorded run: the smallest capacities that held every slot seen so far, agreed by all ranks"""
@@ -113,30 +116,83 @@ class Router:
         self.set_caps(caps)
         return caps
 
-    # ---- one step --------------------------------------------------------------------------------------------
-    def step(self, d_reqs, counts, d_reps, track: bool = False) -> None:
-        """d_reqs / d_reps: per server uint8 device tensors (or raw device pointers) of counts[s] messages.
-        Asynchronous: everything is enqueued on self.stream and the engines' own streams."""
+    # ---- the exchange ------------------------------------------------------------------------------------------
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _forward(self, k: int, d_reqs, counts, track: bool):
+        """pack + all-to-all of step k into buffer set k % 2; returns the event the engines wait for"""
+        b = k % self.NBUF
         xs = self.stream.cuda_stream if self.stream is not None else 0
-        sp, rp = self.send.data_ptr(), self.recv.data_ptr()
-        with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
-            for s, e in enumerate(self.engines):
-                assert counts[s] <= self.n_max
-                e.route_pack(d_reqs[s], counts[s], sp + self.off[s], self.caps[s], self.chunk, sp + 4 * s, self.chunk,
-                             self.d_slot[s], xs)
-            if track:  # slot occupancy (host sync; recording runs only)
-                hdr = self.send.view(self.world, self.chunk)[:, :4 * self.S].cpu().numpy().view("<u4")
-                for s in range(self.S):
-                    self.max_seen[s] = max(self.max_seen[s], int(hdr[:, s].max()))
-            self.ex.all_to_all(self.recv, self.send)
-            for s, e in enumerate(self.engines):
-                e.stream_wait(xs)
-                e.submit_segments(rp + self.off[s], self.world, self.caps[s], self.chunk, rp + 4 * s, self.chunk)
-                e.stream_signal(xs)
-            self.ex.all_to_all(self.send, self.recv)
-            for s, e in enumerate(self.engines):
-                e.route_unpack(sp + self.off[s], self.caps[s], self.chunk, self.d_slot[s], d_reqs[s], counts[s],
-                               d_reps[s], xs)
+        sp = self.send[b].data_ptr()
+        for s, e in enumerate(self.engines):
+            assert counts[s] <= self.n_max
+            e.route_pack(d_reqs[s], counts[s], sp + self.off[s], self.caps[s], self.chunk, sp + 4 * s, self.chunk,
+                         self.d_slot[b][s], xs)
+        if track:  # slot occupancy (host sync; recording runs only)
+            hdr = self.send[b].view(self.world, self.chunk)[:, :4 * self.S].cpu().numpy().view("<u4")
+            for s in range(self.S):
+                self.max_seen[s] = max(self.max_seen[s], int(hdr[:, s].max()))
+        self.ex.all_to_all(self.recv[b], self.send[b])
+        if self.stream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def _engines(self, k: int, ev_fwd):
+        """every home engine answers its W segments of step k on its own stream; returns their completion events"""
+        b = k % self.NBUF
+        rp = self.recv[b].data_ptr()
+        done = []
+        for s, e in enumerate(self.engines):
+            if self.estream is not None:
+                self.estream[s].wait_event(ev_fwd)
+            e.submit_segments(rp + self.off[s], self.world, self.caps[s], self.chunk, rp + 4 * s, self.chunk)
+            if self.estream is not None:
+                ev = torch.cuda.Event()
+                ev.record(self.estream[s])
+                done.append(ev)
+        return done
+
+    def _backward(self, k: int, ev_done, d_reqs, counts, d_reps):
+        b = k % self.NBUF
+        xs = self.stream.cuda_stream if self.stream is not None else 0
+        for ev in ev_done:
+            self.stream.wait_event(ev)
+        self.ex.all_to_all(self.send[b], self.recv[b])
+        sp = self.send[b].data_ptr()
+        for s, e in enumerate(self.engines):
+            e.route_unpack(sp + self.off[s], self.caps[s], self.chunk, self.d_slot[b][s], d_reqs[s], counts[s],
+                           d_reps[s], xs)
+
+    def run(self, steps, track: bool = False) -> None:
+        """steps: [(d_reqs[S], counts[S], d_reps[S])] -- independent batches (a recorded trace).  Asynchronous.
+
+        Software pipeline over two buffer sets: the forward exchange of step k+1 is issued BEFORE the backward
+        exchange of step k, so on the exchange stream (and on RCCL's, which runs collectives in issue order) step
+        k+1's requests travel while the engines work on step k, and step k's replies travel while they work on step
+        k+1.  Every rank issues the same sequence, so the collectives match up."""
+        if not steps:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())  # the caller's uploads of the request tensors
+        with self._on_stream():
+            ev = self._forward(0, steps[0][0], steps[0][1], track)
+            done = self._engines(0, ev)
+            for k in range(len(steps)):
+                nxt = None
+                if k + 1 < len(steps):
+                    ev = self._forward(k + 1, steps[k + 1][0], steps[k + 1][1], track)
+                    nxt = ev
+                self._backward(k, done, *steps[k])
+                if k + 1 < len(steps):
+                    done = self._engines(k + 1, nxt)
+
+    def step(self, d_reqs, counts, d_reps, track: bool = False) -> None:
+        """one batch per server: d_reqs / d_reps are per server uint8 device tensors (or raw device pointers) of
+        counts[s] messages"""
+        self.run([(d_reqs, counts, d_reps)], track)
 
     def sync(self) -> None:
         if self.stream is not None:

@@ -66,6 +66,36 @@ const void *dint_driver_batch(dint_driver_t *d, uint32_t shard);
 int dint_driver_consume(dint_driver_t *d, const void *const replies[DINT_N_SHARDS]);
 int dint_driver_get_stats(const dint_driver_t *d, dint_driver_stats *out);
 
+/* ---- lock_fasst load generator ---------------------------------------------------------------------------
+ * lock_fasst/caladan/client.cc:183-280 (ClientLoop) over transactions shaped like lock_fasst/caladan/trace_init.sh
+ * :6-27, W workers in lock step, one outstanding request each.  dint_fasst_client_next returns the epoch's W 9-byte
+ * requests (worker order), dint_fasst_client_consume takes the W replies.  Epochs laid end to end = the request trace
+ * (the "24M-op trace": 4096 workers, 24,000,000 keys, read_pct 80, Zipf 0.8 or uniform). */
+typedef struct dint_fasst_client dint_fasst_client_t;
+typedef struct dint_fasst_client_config {
+  uint32_t n_workers;     /* W virtual workers */
+  uint32_t first_worker;  /* seed of worker i = 0xdeadbeef + first_worker + i */
+  uint32_t key_space;     /* lids are drawn from [0, key_space) */
+  uint32_t read_pct;      /* a key of a transaction is read-only with this probability (80) */
+  uint32_t key_dist;      /* 0 = uniform (the reference's traces), 1 = Zipf(zipf_theta) */
+  uint32_t reserved0;
+  double zipf_theta;
+  uint32_t reserved[8];
+} dint_fasst_client_config;
+typedef struct dint_fasst_client_stats {
+  uint64_t requests, epochs;
+  uint64_t committed;        /* transactions that reached COMMIT (or finished read-only) */
+  uint64_t rejects;          /* REJECT_LOCK replies: abort what was locked, restart the transaction */
+  uint64_t rollbacks;        /* validation failures: abort every write key, restart */
+  uint64_t protocol_errors;  /* a reply the reference client would assert / panic on */
+  uint64_t reserved[2];
+} dint_fasst_client_stats;
+int dint_fasst_client_create(const dint_fasst_client_config *cfg, dint_fasst_client_t **out);
+void dint_fasst_client_destroy(dint_fasst_client_t *c);
+const void *dint_fasst_client_next(dint_fasst_client_t *c);
+int dint_fasst_client_consume(dint_fasst_client_t *c, const void *replies);
+int dint_fasst_client_get_stats(const dint_fasst_client_t *c, dint_fasst_client_stats *out);
+
 #ifdef __cplusplus
 }
 #endif
