@@ -34,10 +34,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP gives a process 4 hardware queues by default and lets further streams share them; three engines, the
-# exchange stream, RCCL's stream and the copy streams of the host path are more than four, and two engines sharing a
-# queue run their kernel chains one after the other.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+# HIP gives a process 4 hardware queues by default and lets further streams share them.  N = 1 uses exactly four
+# streams (three engines + torch's); with N > 1 the exchange stream and RCCL's stream come on top, and an engine sharing
+# a queue with them would serialise the exchange behind its kernels.  Must be set before the HIP runtime initialises.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 BATCH = 65536
 KV_PASS = 1 << 20  # requests per kernel pass of the store / tatp / smallbank engines (dint_config.max_pass = 0)
@@ -660,6 +661,33 @@ def bench_txn(args, world, rank, dev, transport, kind):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, alg), 3)
 
+    # ---- the closed loop itself, resident on the GPU: the same clients as device code emit the same
+    # stream (tests/test_gpu_gdriver.py), the engines read the batch sizes on the device, nothing crosses PCIe
+    closed = None
+    if world == 1 and grp.router is None:
+        from dint_amd.driver import GpuDriver
+        from dint_amd.replay import GpuLoop
+
+        grp.restore()
+        cap = min(min(e.pass_max for e in grp.engines), int(1.25 * max(max(c) for c in rp.counts)) + 4096)
+        gd = GpuDriver(wl, C, n_rows, cap, first_client=rank * C, zipf_theta=zipf)
+        loop = GpuLoop(grp, gd)
+        loop.epochs(W)
+        loop.sync()
+        tx0 = gd.stats()["txns"]
+        t1 = time.perf_counter()
+        loop.epochs(K)
+        loop.sync()
+        dtc = time.perf_counter() - t1
+        gs = gd.stats()
+        # same seeds, same servers => the device clients must have finished exactly the transactions the host
+        # driver finished while the trace was recorded
+        same = all(gs[k] == stats[k] for k in ("txns", "committed", "by_type", "committed_by_type"))
+        closed = {"value": round((gs["txns"] - tx0) / dtc / 1e6, 3), "unit": "Mtxn/s", "ms_per_epoch": round(dtc / K * 1e3, 5),
+                  "epochs": K, "equals_host_driver_run": bool(same), "overflow": gs["overflow"],
+                  "what": "GPU-resident clients (k_txn_emit / k_txn_consume) + the three shard servers, closed loop, no host round trip"}
+        del loop, gd
+
     host = {}
     if world == 1 and grp.router is None and not args.no_host_path:
         grp.restore()
@@ -705,7 +733,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
         "Mops_s": round(ops / dt / 1e6, 3), "ops_per_txn": round(ops / max(1.0, txns), 3),
         "abort_rate": round(1.0 - stats["committed"] / max(1, stats["txns"]), 5),
         "txns_by_type": stats["by_type"][:nt], "committed_by_type": stats["committed_by_type"][:nt],
-        "value_repeats": [round(v, 1) for v in repeats],
+        "value_repeats": [round(v, 1) for v in repeats], "closed_loop": closed,
         "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "device side: 3 batches submitted -> replies in HBM"},
         **host, "route_overflow": overflow,
         "roofline": roof, "cpu_baseline": cpu, "setup_s": round(t_setup, 2), **extra,

@@ -22,6 +22,7 @@ SYMBOLS = [
     "dint_home_shard", "dint_bench_rand64", "dint_timing_enable", "dint_timing_read", "dint_kv_trace_read",
     "dint_submit_async", "dint_wait", "dint_alloc_pinned", "dint_free_pinned", "dint_engine_stream", "dint_max_pass",
     "dint_stream_wait", "dint_stream_signal", "dint_route_pack", "dint_route_unpack", "dint_submit_segments",
+    "dint_log_drain", "dint_refuse",
 ]
 
 
@@ -95,6 +96,8 @@ def load() -> C.CDLL:
         "dint_route_pack": (C.c_int, [vp, vp, u32, vp, u32, u64, vp, u64, vp, vp]),
         "dint_route_unpack": (C.c_int, [vp, vp, u32, u64, vp, vp, u32, vp, vp]),
         "dint_submit_segments": (C.c_int, [vp, vp, u32, u32, u64, vp, u64, vp]),
+        "dint_log_drain": (i64, [vp, vp, u64, C.POINTER(u64)]),
+        "dint_refuse": (C.c_int, [u32, vp, u32, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)  # AttributeError here = the .so does not export the ABI

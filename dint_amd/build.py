@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdint.so")
-SOURCES = ["engine.hip", "k_locks.hip", "k_log.hip", "k_kv.hip", "k_route.hip", "k_bench.hip", "txn_driver.cc", "fasst_client.cc"]
+SOURCES = ["engine.hip", "k_locks.hip", "k_log.hip", "k_kv.hip", "k_route.hip", "k_bench.hip", "k_txn.hip", "txn_driver.cc", "fasst_client.cc"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SHIM = os.path.join(HERE, "dint_udp_server")
 ROCM_LIB = os.environ.get("ROCM_LIB", "/opt/rocm/lib")

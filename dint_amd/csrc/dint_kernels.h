@@ -62,7 +62,8 @@ void dint_launch_home_lid(const void *d_req, uint32_t msg_size, uint32_t n, dint
 // ---- log append: k_log.hip ---------------------------------------------------------------------
 struct dint_log {
   uint8_t *ring;        // [cap][64] canonical records
-  uint32_t *tail;       // device word
+  uint32_t *tail;       // device words {cur, next, appended lo, appended hi}: ring position before / after the pass in
+                        // flight, and the number of records ever appended
   uint32_t cap;
 };
 void dint_launch_log(const void *d_req, void *d_rep, uint32_t n, dint_log log, dint_scratch s, hipStream_t st,

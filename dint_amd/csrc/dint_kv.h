@@ -19,6 +19,7 @@ struct kv_dev {
   uint32_t gk_base[DINT_KV_MAX_TABLES];  // group key of local bucket 0 of each table
   uint32_t n_tables;
   uint32_t shard_index, shard_count;
+  uint32_t same_key;  // tatp, DINT_FLAG_LOCK_SAME_KEY: lock slots remember their owner's key (tatp/ebpf/lock_kern.c)
 };
 
 struct dint_kv {
@@ -34,7 +35,8 @@ struct dint_kv {
   size_t entry_bytes[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
 };
 
-int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard, uint32_t pool_entries = 0);
+int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard, uint32_t pool_entries = 0,
+                   uint32_t flags = 0);
 void dint_kv_destroy(dint_kv *kv);
 std::vector<std::pair<void *, size_t>> dint_kv_regions(dint_kv *kv);
 // valid rows of `table` in bucket order, chain order inside a bucket; returns the row count

@@ -56,6 +56,7 @@ static_assert(sizeof(kv_hdr) == 64, "header must be one 64-byte sector");
 #define KV_VALID_OFF 48u     // byte offset of validw in a header
 #define KV_LOCKB_OFF 60u     // byte offset of lockw in the inline header
 #define KV_SB_LOCK_OFF 96u  // smallbank: 4 x {u32 num_ex, u32 num_sh}
+#define KV_OWNER_OFF 224u   // tatp (256-byte entries), DINT_FLAG_LOCK_SAME_KEY: 4 x u64 key the quadrant's lock was granted to
 
 // device view of one table (plain pointers, passed to kernels by value)
 struct kv_tab {

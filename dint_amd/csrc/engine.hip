@@ -90,6 +90,7 @@ struct dint_engine {
 
   // log
   dint_log log{};
+  uint64_t log_drained = 0;  // records handed out (or given up as lost) by dint_log_drain
 
   // kv workloads (store / tatp / smallbank)
   dint_kv kv{};
@@ -257,9 +258,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     delete e;
     return fail(DINT_EINVAL, "shard %u of %u", cfg->shard_index, cfg->shard_count);
   }
-  // (the copy streams of the host path are created on first use: every stream beyond GPU_MAX_HW_QUEUES -- 4 by
-  // default -- shares a hardware queue with another one, and engines that only serve device buffers must not
-  // pay for that with their kernel chains serialised behind each other)
+  // (the copy streams of the host path exist only with DINT_FLAG_COPY_STREAMS, and are created on first use)
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) != hipSuccess) {
     dint_engine_destroy(e);
@@ -313,14 +312,15 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   if (wl == DINT_WL_LOG || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
     e->log.cap = cfg->log_entries ? cfg->log_entries : 1000000u;  // log_server/udp/utils.h:16
     TRY(dev_alloc((void **)&e->log.ring, (size_t)e->log.cap * 64));
-    TRY(dev_alloc((void **)&e->log.tail, 2 * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->log.tail, 4 * sizeof(uint32_t)));
     add_region(e, e->log.ring, (size_t)e->log.cap * 64);
-    add_region(e, e->log.tail, 2 * sizeof(uint32_t));
+    add_region(e, e->log.tail, 4 * sizeof(uint32_t));
   }
   if (is_kv) {
-    rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard, cfg->pool_entries);
+    rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard, cfg->pool_entries, cfg->flags);
     if (rc) { dint_engine_destroy(e); return fail(rc, "kv table allocation failed (%s)", g_err.c_str()); }
-    e->kv.force_rounds = (cfg->flags & DINT_FLAG_KV_ROUNDS) ? 1 : 0;
+    // the owner-key comparison of DINT_FLAG_LOCK_SAME_KEY exists on the request-by-request path only
+    e->kv.force_rounds = (cfg->flags & (DINT_FLAG_KV_ROUNDS | DINT_FLAG_LOCK_SAME_KEY)) ? 1 : 0;
     for (auto &r : dint_kv_regions(&e->kv)) add_region(e, r.first, r.second);
   }
   if (hipDeviceSynchronize() != hipSuccess) {
@@ -359,8 +359,8 @@ void dint_engine_destroy(dint_engine_t *e) {
   if (e->h_pinned) hipHostFree(e->h_pinned);
   if (e->h_pool) hipHostFree(e->h_pool);
   if (e->ev_order) hipEventDestroy(e->ev_order);
-  if (e->s_h2d) hipStreamDestroy(e->s_h2d);
-  if (e->s_d2h) hipStreamDestroy(e->s_d2h);
+  if (e->s_h2d && e->s_h2d != e->stream) hipStreamDestroy(e->s_h2d);
+  if (e->s_d2h && e->s_d2h != e->stream) hipStreamDestroy(e->s_d2h);
   hipFree(e->d_lock_tbl);
   hipFree(e->log.ring);
   hipFree(e->log.tail);
@@ -411,8 +411,16 @@ int enqueue_chunk(dint_engine *e, const uint8_t *rq, uint8_t *rp, uint32_t m, ui
   const int k = (int)(sq % dint_engine::kNSlot);
   if (int rc = slot_alloc(e, k)) return rc;
   if (!e->s_h2d) {
-    HIP_TRY(hipStreamCreateWithFlags(&e->s_h2d, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&e->s_d2h, hipStreamNonBlocking));
+    if (!(e->cfg.flags & DINT_FLAG_COPY_STREAMS)) {
+      // default: copies on the engine's own stream.  Measured on MI355X (tools/gpu_ab.sh, r02): with three engines
+      // in one process, two more streams per engine push the process past HIP's 4 hardware queues and -- depending on
+      // which queues end up shared -- serialise the engines' kernel chains (TATP replay 1.2 instead of 1.7 G txn/s).
+      // Several engines overlap each other's copies anyway; one engine alone wants DINT_FLAG_COPY_STREAMS.
+      e->s_h2d = e->s_d2h = e->stream;
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&e->s_h2d, hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&e->s_d2h, hipStreamNonBlocking));
+    }
   }
   dint_engine::Slot &sl = e->slot[k];
   if (sl.seq) HIP_TRY(hipEventSynchronize(sl.done));  // the slot's previous chunk has left the GPU
@@ -592,6 +600,67 @@ int64_t dint_read_log(dint_engine_t *e, void *records, uint64_t cap) {
   return (int64_t)t[1];
 }
 
+int64_t dint_log_drain(dint_engine_t *e, void *records, uint64_t cap, uint64_t *lost) {
+  if (!e || (cap && !records)) return fail(DINT_EINVAL, "null argument");
+  if (!e->log.ring) return fail(DINT_ESTATE, "workload has no log");
+  std::lock_guard<std::mutex> lk(e->mu);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t t[4];
+  HIP_TRY(hipMemcpy(t, e->log.tail, sizeof t, hipMemcpyDeviceToHost));
+  const uint64_t total = (uint64_t)t[2] | ((uint64_t)t[3] << 32);
+  if (e->log_drained > total) e->log_drained = total;  // the engine was reset / restored to an earlier state
+  uint64_t pending = total - e->log_drained, gone = 0;
+  if (pending > e->log.cap) {  // the ring lapped the reader: the oldest records are overwritten
+    gone = pending - e->log.cap;
+    pending = e->log.cap;
+  }
+  if (lost) *lost = gone;
+  e->log_drained += gone;
+  const uint64_t n = std::min<uint64_t>(pending, cap);
+  uint64_t pos = e->log_drained % e->log.cap;  // record k of the stream lives at ring slot k % cap
+  uint8_t *out = (uint8_t *)records;
+  for (uint64_t done = 0; done < n;) {
+    const uint64_t run = std::min<uint64_t>(n - done, e->log.cap - pos);
+    HIP_TRY(hipMemcpy(out + done * 64, e->log.ring + pos * 64, run * 64, hipMemcpyDeviceToHost));
+    done += run;
+    pos = (pos + run) % e->log.cap;
+  }
+  e->log_drained += n;
+  return (int64_t)n;
+}
+
+int dint_refuse(uint32_t workload, const void *reqs, uint32_t n, void *replies) {
+  if (workload >= DINT_WL_COUNT || (n && (!reqs || !replies))) return fail(DINT_EINVAL, "bad argument");
+  const uint32_t msg = kMsgSize[workload];
+  const uint8_t *rq = (const uint8_t *)reqs;
+  uint8_t *rp = (uint8_t *)replies;
+  if (rp != rq) memcpy(rp, rq, (size_t)n * msg);
+  for (uint32_t i = 0; i < n; i++) {
+    uint8_t *m = rp + (size_t)i * msg;
+    switch (workload) {
+      case DINT_WL_2PL:  // RETRY, lock_2pl/ebpf/ls_kern.c:59-64
+        m[0] = 4;
+        break;
+      case DINT_WL_STORE:  // kRejectRead / kRejectSet / kRejectInsert, store/ebpf/store_kern.c:57-62
+        if (m[0] <= 2) m[0] = (uint8_t)(4 + 2 * m[0] + (m[0] == 2));  // 0 -> 4, 1 -> 6, 2 -> 9
+        break;
+      case DINT_WL_TATP:  // REJECT_READ / REJECT_LOCK / REJECT_COMMIT, tatp/ebpf/shard_kern.c:173-178,289-293,371-376
+        if (m[1] == 0) m[1] = 5;
+        else if (m[1] == 1) m[1] = 8;
+        else if (m[1] == 12 || m[1] == 13 || m[1] == 18 || m[1] == 19 || m[1] == 22 || m[1] == 23) m[1] = 11;
+        break;  // ABORT and the log appends are never refused by the eBPF server either
+      case DINT_WL_SMALLBANK:  // RETRY, smallbank/ebpf/shard_kern.c:96-110,603-608
+        if (m[1] <= 5 || m[1] == 17) m[1] = 16;
+        break;
+      default:  // lock_fasst: REJECT_LOCK is the only "not now" a client understands; the log server has none
+        if (workload == DINT_WL_FASST && m[0] == 1) m[0] = 6;
+        break;
+    }
+  }
+  return 0;
+}
+
 int dint_get_stats(dint_engine_t *e, dint_stats *out) {
   if (!e || !out) return fail(DINT_EINVAL, "null argument");
   std::lock_guard<std::mutex> lk(e->mu);
@@ -617,6 +686,7 @@ int dint_reset(dint_engine_t *e) {
   HIP_TRY(hipDeviceSynchronize());
   for (auto &r : e->regions) HIP_TRY(hipMemset(r.first, 0, r.second));
   e->batches = e->requests = 0;
+  e->log_drained = 0;
   e->pool_seen = 0;
   *e->h_pool = 0;
   HIP_TRY(hipDeviceSynchronize());

@@ -70,7 +70,7 @@ __device__ static inline uint32_t kv_class(uint32_t type, int load_mode) {
       default: return 0;
     }
   }
-  return type <= 5 ? 1 : (type == 6 ? 2 : 0);
+  return (type <= 5 || type == 17) ? 1 : (type == 6 ? 2 : 0);  // 17 = WARMUP_READ (eBPF flavour)
 }
 
 // 16-bit request descriptor carried from the scatter kernel to the resolve kernels
@@ -287,6 +287,7 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
       uint32_t total = base;
       for (uint32_t w = 0; w < KV_TB / 64; w++) total += Swl[w];
       log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
+      *(unsigned long long *)(log.tail + 2) += total;  // records ever appended (dint_log_drain)
     }
     if (r.cls == 2) {
       const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
@@ -409,7 +410,10 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
     const uint32_t lk = (H.lockw >> (8 * q)) & 0xFFu;
     switch (type) {
       case 0: act = KV_ACT_GET; break;                                                    // kRead  server_shard.cc:116-121
-      case 1: if (lk == 0) { lock_store = 1; code = 7; } else code = 8; break;           // kAcquireLock  :123-132
+      case 1:                                                                             // kAcquireLock  :123-132
+        if (lk == 0) { lock_store = 1; code = 7; }
+        else code = (kv->same_key && *(const uint64_t *)(ie + KV_OWNER_OFF + 8 * q) == key) ? 28 : 8;  // lock_kern.c:289-298
+        break;
       case 2: lock_store = 0; code = 9; break;                                            // kAbort  :134-138
       case 12: act = KV_ACT_SET; miss_counts = true; lock_store = 0; code = 15; break;    // kCommitPrim  :140-146
       case 18: act = KV_ACT_INS; lock_store = 0; code = 20; break;                        // kInsertPrim  :148-154
@@ -426,6 +430,7 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
       case 2: cnt.y--; cnt_store = true; code = 11; break;
       case 3: cnt.x--; cnt_store = true; code = 12; break;
       case 4: act = KV_ACT_SET; miss_counts = true; code = 13; break;
+      case 17: act = KV_ACT_GET; code = 18; break;  // WARMUP_READ (eBPF flavour): kvs_get, ack whether found or not
       default: act = KV_ACT_SET; miss_counts = true; code = 14; break;  // 5 kCommitBck
     }
   }
@@ -440,6 +445,7 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
     lock_store = -1;
   }
   if (WL == DINT_WL_TATP && lock_store >= 0) ie[KV_LOCKB_OFF + q] = (uint8_t)lock_store;
+  if (WL == DINT_WL_TATP && kv->same_key && type == 1 && code == 7) *(uint64_t *)(ie + KV_OWNER_OFF + 8 * q) = key;
   if (WL == DINT_WL_SMALLBANK && cnt_store) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = cnt;
   if (act == KV_ACT_GET && r.ok) st_u32(msg + F::VER, r.ver);
   if (act != KV_ACT_NONE && !r.ok) {
@@ -477,7 +483,7 @@ template <int WL>
 __device__ static inline bool kv_simple_op(uint32_t type) {
   if (WL == DINT_WL_STORE) return type <= 1;                                   // READ, SET
   if (WL == DINT_WL_TATP) return type <= 2 || type == 12 || type == 13;        // READ, ACQUIRE, ABORT, COMMIT_PRIM/BCK
-  return type <= 5;                                                            // every smallbank table op
+  return type <= 5 || type == 17;                                              // every smallbank table op
 }
 template <int WL>
 __device__ static inline bool kv_struct_op(uint32_t type) {  // inserts / deletes a row (changes the chain)
@@ -713,6 +719,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
           case 2: lb--; return 11;
           case 3: la--; return 12;
           case 4: wr = fnd; miss += !fnd; return 13;
+          case 17: get = fnd; return 18;  // WARMUP_READ -> WARMUP_READ_ACK: a plain read (smallbank/ebpf/shard_user.c:179-186)
           default: wr = fnd; miss += !fnd; return 14;  // 5 kCommitBck
         }
       };
@@ -1406,6 +1413,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
                   case 2: st.lb--; code = 11; break;
                   case 3: st.la--; code = 12; break;
                   case 4: wr = fnd; st.miss += !fnd; code = 13; break;
+                  case 17: get = fnd; code = 18; break;  // WARMUP_READ
                   default: wr = fnd; st.miss += !fnd; code = 14; break;  // 5 kCommitBck
                 }
                 if (wr) { st.ver++; st.src = (int)(lo + wv * 64 + l); }
@@ -1648,9 +1656,11 @@ void dint_launch_home_kv(const void *d_req, uint32_t n, const dint_kv &kv, uint8
 }
 
 // ---- table management (host) ------------------------------------------------------------------------------
-int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard, uint32_t pool_entries) {
+int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard, uint32_t pool_entries,
+                   uint32_t flags) {
   *kv = dint_kv();
   kv->workload = workload;
+  kv->h.same_key = (workload == DINT_WL_TATP && (flags & DINT_FLAG_LOCK_SAME_KEY)) ? 1 : 0;
   uint64_t hs[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
   if (workload == DINT_WL_STORE) {
     const uint64_t n = n_rows ? n_rows : 2000000ull;  // store/udp/tatp.h:10

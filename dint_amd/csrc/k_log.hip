@@ -86,6 +86,7 @@ k_log_write(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const uin
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
     const uint32_t total = pos_in_batch + (valid ? 1u : 0u);
     log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
+    *(unsigned long long *)(log.tail + 2) += total;  // records ever appended (dint_log_drain)
   }
 }
 

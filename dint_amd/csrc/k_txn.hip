@@ -1,0 +1,293 @@
+// k_txn.hip -- the GPU-resident closed-loop transaction driver (include/dint_driver.h dint_gdriver_*).
+//
+// The callers of the hot path -- the reference's TATP / SmallBank clients, tatp/caladan/client_udp_shard.cc:177-1185,
+// smallbank/caladan/client_udp_shard.cc:169-1240 -- as device code: the SAME state machines the host driver runs
+// (txn_clients.h is compiled for both), one lane per client, client state resident in HBM.  No NIC can offer the
+// > 10^9 requests/s one MI355X absorbs, and a host-side generator caps the loop at PCIe speed; with the clients on
+// the GPU the closed loop {emit -> three shard servers -> consume} never leaves the device.
+//
+//   k_txn_emit    : every client runs one phase (finishing / starting transactions on the way) and emits its <= 9
+//                   messages into the three per-shard request arrays at EXACTLY the positions the host driver uses
+//                   -- batch s is ordered by client id, then send order -- so the request stream is bit-identical
+//                   to the host driver's: position = messages of smaller client ids to that shard (a workgroup scan
+//                   + a decoupled look-back over the workgroups before mine, which are handed out by ticket and
+//                   publish their totals first thing) + msg.ord.  The last workgroup writes the three batch sizes
+//                   for the engines (dint_submit_segments reads them on the device: no host round trip).
+//   k_txn_consume : every client copies the replies it waits for out of the (in place) reply arrays.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/dint_abi.h"
+#include "../../include/dint_driver.h"
+#include "dint_device.h"
+#include "txn_clients.h"
+
+#define TXG_TB 256u  // clients per workgroup
+
+struct txg_stats {
+  unsigned long long txns, committed, messages, by_type[8], committed_by_type[8], overflow;
+};
+#define TXG_NSTAT (sizeof(txg_stats) / 8)
+
+void dint_driver_params(const dint_driver_config &c, TxParams *P, ZipfTable *zipf);  // txn_driver.cc
+
+template <class T>
+__global__ void __launch_bounds__(TXG_TB)
+k_txn_emit(typename T::Client *cl, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1, uint8_t *out2,
+           uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t *counts, txg_stats *st) {
+  typedef typename T::Msg Msg;
+  __shared__ uint32_t Stile, Sw[3][TXG_TB / 64], Sbase[3], Sred[3][TXG_TB / 64];
+  __shared__ unsigned long long Sst[TXG_NSTAT];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) Stile = atomicAdd(ticket, 1u);
+  if (t < TXG_NSTAT) Sst[t] = 0;
+  __syncthreads();
+  const uint32_t tile = Stile, i = tile * TXG_TB + t, ntiles = gridDim.x;
+  const bool valid = i < n_clients;
+
+  typename T::Out o;
+  o.clear();
+  if (valid) T::run(cl[i], P, o);
+  uint32_t c[3] = {0, 0, 0};
+  for (uint8_t k = 0; k < o.n; k++) c[o.shard[k]]++;
+
+  // ---- my messages' positions: workgroup scan per shard ...
+  uint32_t x[3], tot[3];
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    uint32_t wt;
+    x[s] = wave_excl_scan_u32(c[s], &wt);
+    if (lane == 0) Sw[s][wave] = wt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    tot[s] = 0;
+    for (uint32_t w = 0; w < TXG_TB / 64; w++) {
+      if (w < wave) x[s] += Sw[s][w];
+      tot[s] += Sw[s][w];
+    }
+  }
+  if (t < 3) __hip_atomic_store(&pub[tile * 4 + t], 0x80000000u | tot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- ... + the totals of the workgroups before mine (published long ago: they started earlier)
+  uint32_t part[3] = {0, 0, 0};
+  for (uint32_t k = t; k < tile; k += TXG_TB) {
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      uint32_t v;
+      do { v = __hip_atomic_load(&pub[k * 4 + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 31));
+      part[s] += v & 0x7FFFFFFFu;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 3; s++) {
+    uint32_t v = part[s];
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane == 0) Sred[s][wave] = v;
+  }
+  __syncthreads();
+  if (t < 3) {
+    uint32_t b = 0;
+    for (uint32_t w = 0; w < TXG_TB / 64; w++) b += Sred[t][w];
+    Sbase[t] = b;
+    if (tile == ntiles - 1) counts[t] = min(b + tot[t], cap);  // batch sizes of this epoch (read by the engines)
+  }
+  __syncthreads();
+
+  // ---- emit
+  uint8_t *outs[3] = {out0, out1, out2};
+  uint32_t lost = 0;
+  for (uint8_t k = 0; k < o.n; k++) {
+    const uint32_t s = o.shard[k], pos = Sbase[s] + x[s] + o.msg[k].ord;
+    cl[i].out_pos[k] = pos;
+    if (pos < cap) *(Msg *)(outs[s] + (size_t)pos * sizeof(Msg)) = o.msg[k];
+    else lost++;
+  }
+  // ---- statistics: LDS first, then one device atomic per counter and workgroup
+  if (valid) {
+    atomicAdd(&Sst[offsetof(txg_stats, messages) / 8], (unsigned long long)o.n);
+    if (lost) atomicAdd(&Sst[offsetof(txg_stats, overflow) / 8], (unsigned long long)lost);
+    for (uint8_t k = 0; k < o.n_fin && k < 2; k++) {
+      atomicAdd(&Sst[offsetof(txg_stats, txns) / 8], 1ull);
+      atomicAdd(&Sst[offsetof(txg_stats, by_type) / 8 + o.fin_txn[k]], 1ull);
+      if (o.fin_ok[k]) {
+        atomicAdd(&Sst[offsetof(txg_stats, committed) / 8], 1ull);
+        atomicAdd(&Sst[offsetof(txg_stats, committed_by_type) / 8 + o.fin_txn[k]], 1ull);
+      }
+    }
+  }
+  __syncthreads();
+  if (t < TXG_NSTAT && Sst[t]) atomicAdd((unsigned long long *)st + t, Sst[t]);
+}
+
+template <class T>
+__global__ void __launch_bounds__(TXG_TB)
+k_txn_consume(typename T::Client *cl, uint32_t n_clients, const uint8_t *rep0, const uint8_t *rep1, const uint8_t *rep2,
+              uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t ntiles) {
+  typedef typename T::Msg Msg;
+  const uint32_t i = blockIdx.x * TXG_TB + threadIdx.x;
+  // leave the look-back words clean for the next emit (nothing else runs between consume and the next emit)
+  if (i < ntiles * 4) pub[i] = 0;
+  if (i == 0) *ticket = 0;
+  if (i >= n_clients) return;
+  const uint8_t *reps[3] = {rep0, rep1, rep2};
+  typename T::Client &c = cl[i];
+  const uint8_t n = c.n_out;
+  for (uint8_t k = 0; k < n; k++) {
+    const uint8_t d = c.out_dst[k];
+    const uint32_t pos = c.out_pos[k];
+    if (d != TX_NO_DST && pos < cap) c.m[d] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+struct dint_gdriver {
+  dint_driver_config cfg{};
+  int device = 0;
+  uint32_t cap = 0, ntiles = 0, msg = 0;
+  bool awaiting = false;
+  uint64_t epochs = 0;
+  void *d_clients = nullptr;
+  uint8_t *d_batch[DINT_N_SHARDS] = {nullptr, nullptr, nullptr};
+  uint32_t *d_counts = nullptr, *d_pub = nullptr, *d_ticket = nullptr, *d_zipf = nullptr;
+  txg_stats *d_stats = nullptr;
+  TxParams P{};
+};
+
+namespace {
+template <class Client>
+int upload_clients(dint_gdriver *g) {
+  std::vector<Client> h(g->cfg.n_clients);
+  for (uint32_t i = 0; i < g->cfg.n_clients; i++) {
+    memset(&h[i], 0, sizeof(Client));
+    h[i].rng.s = 0xdeadbeefull + g->cfg.first_client + i;  // ClientLoop :1122
+  }
+  const size_t bytes = h.size() * sizeof(Client);
+  if (hipMalloc(&g->d_clients, bytes) != hipSuccess) return DINT_ENOMEM;
+  if (hipMemcpy(g->d_clients, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t cap_per_shard, dint_gdriver_t **out) {
+  if (!cfg || !out || cfg->n_clients == 0 || cfg->n_rows == 0 || cap_per_shard < 2) return DINT_EINVAL;
+  if (cfg->workload != DINT_WL_TATP && cfg->workload != DINT_WL_SMALLBANK) return DINT_EINVAL;
+  if (cfg->key_dist > 1 || (cfg->key_dist == 1 && !(cfg->zipf_theta > 0 && cfg->zipf_theta < 1))) return DINT_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DINT_ENODEV;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return DINT_ENODEV;
+  if (device >= ndev || hipSetDevice(device) != hipSuccess) return DINT_ENODEV;
+  dint_gdriver *g = new (std::nothrow) dint_gdriver();
+  if (!g) return DINT_ENOMEM;
+  g->cfg = *cfg;
+  g->device = device;
+  g->cap = cap_per_shard;
+  g->msg = cfg->workload == DINT_WL_TATP ? 55 : 23;
+  g->ntiles = (cfg->n_clients + TXG_TB - 1) / TXG_TB;
+  int rc = 0;
+  try {
+    ZipfTable zipf;
+    dint_driver_params(*cfg, &g->P, &zipf);
+    if (cfg->key_dist == 1) {
+      if (hipMalloc((void **)&g->d_zipf, zipf.cdf.size() * 4) != hipSuccess) rc = DINT_ENOMEM;
+      else if (hipMemcpy(g->d_zipf, zipf.cdf.data(), zipf.cdf.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = DINT_EHIP;
+      g->P.zipf_cdf = g->d_zipf;
+    }
+    if (!rc) rc = cfg->workload == DINT_WL_TATP ? upload_clients<TatpClient>(g) : upload_clients<SbClient>(g);
+  } catch (const std::bad_alloc &) {
+    rc = DINT_ENOMEM;
+  }
+  for (int s = 0; s < DINT_N_SHARDS && !rc; s++)
+    if (hipMalloc((void **)&g->d_batch[s], (size_t)g->cap * g->msg + 64) != hipSuccess) rc = DINT_ENOMEM;
+  if (!rc && (hipMalloc((void **)&g->d_counts, 16) != hipSuccess || hipMalloc((void **)&g->d_ticket, 4) != hipSuccess ||
+              hipMalloc((void **)&g->d_pub, (size_t)g->ntiles * 16) != hipSuccess ||
+              hipMalloc((void **)&g->d_stats, sizeof(txg_stats)) != hipSuccess))
+    rc = DINT_ENOMEM;
+  if (!rc && (hipMemset(g->d_counts, 0, 16) != hipSuccess || hipMemset(g->d_ticket, 0, 4) != hipSuccess ||
+              hipMemset(g->d_pub, 0, (size_t)g->ntiles * 16) != hipSuccess ||
+              hipMemset(g->d_stats, 0, sizeof(txg_stats)) != hipSuccess || hipDeviceSynchronize() != hipSuccess))
+    rc = DINT_EHIP;
+  if (rc) {
+    dint_gdriver_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return 0;
+}
+
+void dint_gdriver_destroy(dint_gdriver_t *g) {
+  if (!g) return;
+  hipSetDevice(g->device);
+  hipDeviceSynchronize();
+  hipFree(g->d_clients);
+  for (auto p : g->d_batch) hipFree(p);
+  hipFree(g->d_counts); hipFree(g->d_pub); hipFree(g->d_ticket); hipFree(g->d_zipf); hipFree(g->d_stats);
+  delete g;
+}
+
+int dint_gdriver_next(dint_gdriver_t *g, void *stream) {
+  if (!g) return DINT_EINVAL;
+  if (g->awaiting) return DINT_ESTATE;
+  if (hipSetDevice(g->device) != hipSuccess) return DINT_EHIP;
+  hipStream_t st = (hipStream_t)stream;
+  if (g->cfg.workload == DINT_WL_TATP)
+    hipLaunchKernelGGL((k_txn_emit<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (TatpClient *)g->d_clients,
+                       g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
+                       g->d_counts, g->d_stats);
+  else
+    hipLaunchKernelGGL((k_txn_emit<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (SbClient *)g->d_clients,
+                       g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
+                       g->d_counts, g->d_stats);
+  if (hipGetLastError() != hipSuccess) return DINT_EHIP;
+  g->awaiting = true;
+  g->epochs++;
+  return 0;
+}
+
+int dint_gdriver_consume(dint_gdriver_t *g, void *stream) {
+  if (!g) return DINT_EINVAL;
+  if (!g->awaiting) return DINT_ESTATE;
+  if (hipSetDevice(g->device) != hipSuccess) return DINT_EHIP;
+  hipStream_t st = (hipStream_t)stream;
+  if (g->cfg.workload == DINT_WL_TATP)
+    hipLaunchKernelGGL((k_txn_consume<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (TatpClient *)g->d_clients,
+                       g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
+  else
+    hipLaunchKernelGGL((k_txn_consume<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (SbClient *)g->d_clients,
+                       g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
+  if (hipGetLastError() != hipSuccess) return DINT_EHIP;
+  g->awaiting = false;
+  return 0;
+}
+
+void *dint_gdriver_batch(dint_gdriver_t *g, uint32_t shard) { return (g && shard < DINT_N_SHARDS) ? g->d_batch[shard] : nullptr; }
+const void *dint_gdriver_counts(dint_gdriver_t *g) { return g ? g->d_counts : nullptr; }
+uint32_t dint_gdriver_cap(const dint_gdriver_t *g) { return g ? g->cap : 0; }
+
+int64_t dint_gdriver_read_batch(dint_gdriver_t *g, uint32_t shard, void *host, uint64_t cap_msgs) {
+  if (!g || shard >= DINT_N_SHARDS) return DINT_EINVAL;
+  if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return DINT_EHIP;
+  uint32_t cnt[3];
+  if (hipMemcpy(cnt, g->d_counts, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) return DINT_EHIP;
+  const uint64_t n = cnt[shard] < cap_msgs ? cnt[shard] : cap_msgs;
+  if (host && n && hipMemcpy(host, g->d_batch[shard], n * g->msg, hipMemcpyDeviceToHost) != hipSuccess) return DINT_EHIP;
+  return (int64_t)cnt[shard];
+}
+
+int dint_gdriver_get_stats(dint_gdriver_t *g, dint_driver_stats *out, uint64_t *overflow) {
+  if (!g || !out) return DINT_EINVAL;
+  if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return DINT_EHIP;
+  txg_stats s;
+  if (hipMemcpy(&s, g->d_stats, sizeof s, hipMemcpyDeviceToHost) != hipSuccess) return DINT_EHIP;
+  memset(out, 0, sizeof *out);
+  out->txns = s.txns; out->committed = s.committed; out->messages = s.messages; out->epochs = g->epochs;
+  for (int k = 0; k < 8; k++) { out->by_type[k] = s.by_type[k]; out->committed_by_type[k] = s.committed_by_type[k]; }
+  if (overflow) *overflow = s.overflow;
+  return 0;
+}
+
+}  // extern "C"

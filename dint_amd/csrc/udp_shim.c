@@ -10,20 +10,28 @@
  * One datagram = one packed request struct; the reply is the same struct, sent to the datagram's source.
  * Datagrams of the wrong size are dropped (the reference would read garbage).
  *
- * Batching: recvmmsg() drains the socket into a batch; the batch closes when it holds `--batch` requests
- * or `--deadline-us` after its first request, whichever comes first, then dint_submit() runs it on the GPU
- * and sendmmsg() returns the replies.  Arrival order in the socket = request order in the batch, so the
- * engine's serial-equivalence contract gives clients exactly the semantics of a single-threaded reference
- * server.  Port+1 answers the clients' end-of-run CPU-usage query (16 bytes {double ucores, kcores},
- * tatp/caladan/client_udp_shard.cc:75-92) so unmodified clients do not hang in CollectStat.
+ * Threads: `--threads` socket threads (default 2), each with its own SO_REUSEPORT socket on the same port exactly as
+ * the reference's workers (lock_fasst/udp/server.cc:54-73,136-146); the kernel spreads client flows over them.
+ * Batching: recvmmsg() drains a socket into a page-locked batch buffer; the batch closes when it holds `--batch`
+ * requests or `--deadline-us` after its first request, whichever comes first, and goes to the GPU with
+ * dint_submit_async().  Every thread keeps two batches: while one is on the GPU the next one is being received, and
+ * its replies leave with sendmmsg() as soon as dint_wait() returns.  Arrival order in a socket = request order in
+ * the batch, and the engine applies submissions in call order, so clients see one serial server.  `--shed`: a batch
+ * that closes while both of the thread's batches are still busy is answered at once with the eBPF servers'
+ * "not now" replies (dint_refuse: REJECT_READ / REJECT_LOCK / REJECT_COMMIT / RETRY ...) instead of waiting; requests
+ * that have no such reply (ABORT, log appends) stay queued.  Port+1 answers the clients' end-of-run CPU-usage query
+ * (16 bytes {double ucores, kcores}, tatp/caladan/client_udp_shard.cc:75-92) so unmodified clients do not hang in
+ * CollectStat.
  *
  *   dint_udp_server --workload {fasst|2pl|log|store|tatp|smallbank} [--rows N] [--slots N] [--populate N]
- *                   [--bind 10.10.1.1] [--port 20230] [--batch 4096] [--deadline-us 100] [--device 0]
+ *                   [--bind 10.10.1.1] [--port 20230] [--batch 4096] [--deadline-us 100] [--threads 2] [--shed]
+ *                   [--device 0]
  */
 #define _GNU_SOURCE
 #include <arpa/inet.h>
 #include <errno.h>
 #include <netinet/in.h>
+#include <poll.h>
 #include <pthread.h>
 #include <signal.h>
 #include <stdint.h>
@@ -56,7 +64,8 @@ struct options {
   int have_populate;
   const char *bind_ip;
   int port, device;
-  uint32_t batch, deadline_us;
+  uint32_t batch, deadline_us, threads;
+  int shed;
 };
 
 static int parse_workload(const char *s, uint32_t *out) {
@@ -105,8 +114,144 @@ static void *monitor_thread(void *p) {
   return NULL;
 }
 
+/* ---- socket threads ------------------------------------------------------------------------------------- */
+struct batch_slot {
+  uint8_t *reqs, *reps;          /* page-locked (dint_alloc_pinned) */
+  struct sockaddr_in *peers;
+  uint32_t n;
+  dint_ticket ticket;
+  int busy;
+};
+struct worker {
+  pthread_t th;
+  int id, fd, msg_size;
+  const struct options *o;
+  dint_engine_t *eng;
+  struct batch_slot slot[2];
+  uint64_t requests, batches, dropped, refused, send_dropped;
+};
+
+/* replies [0, n) to their peers; would-block -> wait for the socket, a dead destination -> skip that one reply */
+static void send_replies(struct worker *w, const uint8_t *reps, const struct sockaddr_in *peers, uint32_t n,
+                         struct mmsghdr *mm, struct iovec *iov) {
+  for (uint32_t off = 0; off < n && !g_stop;) {
+    const uint32_t cnt = (n - off) < VLEN ? (n - off) : VLEN;
+    for (uint32_t k = 0; k < cnt; k++) {
+      iov[k].iov_base = (void *)(reps + (size_t)(off + k) * w->msg_size);
+      iov[k].iov_len = (size_t)w->msg_size;
+      memset(&mm[k].msg_hdr, 0, sizeof mm[k].msg_hdr);
+      mm[k].msg_hdr.msg_iov = &iov[k];
+      mm[k].msg_hdr.msg_iovlen = 1;
+      mm[k].msg_hdr.msg_name = (void *)&peers[off + k];
+      mm[k].msg_hdr.msg_namelen = sizeof peers[off + k];
+    }
+    const int sent = sendmmsg(w->fd, mm, cnt, 0);
+    if (sent > 0) { off += (uint32_t)sent; continue; }
+    if (sent < 0 && errno == EINTR) continue;
+    if (sent == 0 || errno == EAGAIN || errno == EWOULDBLOCK || errno == ENOBUFS) {
+      struct pollfd pf = {w->fd, POLLOUT, 0};
+      poll(&pf, 1, 100);
+      continue;
+    }
+    w->send_dropped++;  /* per-destination error (e.g. ECONNREFUSED from an earlier ICMP): give up on this reply only */
+    off++;
+  }
+}
+
+static void complete(struct worker *w, struct batch_slot *b, struct mmsghdr *mm, struct iovec *iov) {
+  if (dint_wait(w->eng, b->ticket)) fprintf(stderr, "dint_wait: %s\n", dint_last_error());  /* replies are valid */
+  send_replies(w, b->reps, b->peers, b->n, mm, iov);
+  w->requests += b->n;
+  w->batches++;
+  b->busy = 0;
+}
+
+static void *socket_thread(void *arg) {
+  struct worker *w = (struct worker *)arg;
+  const struct options *o = w->o;
+  const int msg_size = w->msg_size;
+  uint8_t (*rx)[MAX_MSG] = malloc((size_t)VLEN * MAX_MSG);
+  struct mmsghdr *mm = (struct mmsghdr *)calloc(VLEN, sizeof *mm);
+  struct iovec *iov = (struct iovec *)calloc(VLEN, sizeof *iov);
+  struct sockaddr_in *from = (struct sockaddr_in *)calloc(VLEN, sizeof *from);
+  uint8_t *shed_tmp = (uint8_t *)malloc((size_t)o->batch * MAX_MSG);
+  struct sockaddr_in *shed_peers = (struct sockaddr_in *)malloc((size_t)o->batch * sizeof *shed_peers);
+  if (!rx || !mm || !iov || !from || !shed_tmp || !shed_peers) { fprintf(stderr, "out of memory\n"); g_stop = 1; return NULL; }
+  int cur = 0;
+  while (!g_stop) {
+    struct batch_slot *b = &w->slot[cur], *other = &w->slot[cur ^ 1];
+    if (b->busy) complete(w, b, mm, iov);
+    uint32_t n = 0;
+    uint64_t t_first = 0;
+    while (n < o->batch && !g_stop) {
+      const uint32_t want = (o->batch - n) < VLEN ? (o->batch - n) : VLEN;
+      for (uint32_t k = 0; k < want; k++) {
+        iov[k].iov_base = rx[k];
+        iov[k].iov_len = MAX_MSG;
+        memset(&mm[k].msg_hdr, 0, sizeof mm[k].msg_hdr);
+        mm[k].msg_hdr.msg_iov = &iov[k];
+        mm[k].msg_hdr.msg_iovlen = 1;
+        mm[k].msg_hdr.msg_name = &from[k];
+        mm[k].msg_hdr.msg_namelen = sizeof from[k];
+      }
+      /* first datagram of a batch: block -- unless the other batch is on the GPU, whose replies must not wait for
+       * new traffic; afterwards only take what is already queued */
+      const int flags = (n == 0 && !other->busy) ? MSG_WAITFORONE : MSG_DONTWAIT;
+      const int got = recvmmsg(w->fd, mm, want, flags, NULL);
+      if (got <= 0) {
+        if (n == 0) {
+          if (other->busy) complete(w, other, mm, iov);       /* idle socket: finish what is in flight */
+          continue;
+        }
+        if (now_us() - t_first >= o->deadline_us) break;      /* deadline: close the batch */
+        continue;
+      }
+      if (n == 0) t_first = now_us();
+      for (int k = 0; k < got; k++) {
+        if ((int)mm[k].msg_len != msg_size) { w->dropped++; continue; }
+        memcpy(b->reqs + (size_t)n * msg_size, rx[k], (size_t)msg_size);
+        b->peers[n] = from[k];
+        n++;
+      }
+      if (now_us() - t_first >= o->deadline_us) break;
+    }
+    if (n == 0) continue;
+    if (o->shed && other->busy) {
+      /* both batches would be in flight: tell the senders "not now" (they resend) rather than queue behind the GPU;
+       * requests that have no such reply stay in the batch */
+      dint_refuse(o->workload, b->reqs, n, shed_tmp);
+      uint32_t keep = 0, ref = 0;
+      for (uint32_t k = 0; k < n; k++) {
+        if (memcmp(shed_tmp + (size_t)k * msg_size, b->reqs + (size_t)k * msg_size, (size_t)msg_size) != 0) {
+          memmove(shed_tmp + (size_t)ref * msg_size, shed_tmp + (size_t)k * msg_size, (size_t)msg_size);
+          shed_peers[ref++] = b->peers[k];
+        } else {
+          memmove(b->reqs + (size_t)keep * msg_size, b->reqs + (size_t)k * msg_size, (size_t)msg_size);
+          b->peers[keep++] = b->peers[k];
+        }
+      }
+      send_replies(w, shed_tmp, shed_peers, ref, mm, iov);
+      w->refused += ref;
+      n = keep;
+      if (n == 0) continue;
+    }
+    b->n = n;
+    if (dint_submit_async(w->eng, b->reqs, n, b->reps, &b->ticket)) {
+      fprintf(stderr, "dint_submit_async: %s\n", dint_last_error());
+      g_stop = 1;
+      break;
+    }
+    b->busy = 1;
+    cur ^= 1;
+  }
+  for (int k = 0; k < 2; k++)
+    if (w->slot[k].busy) complete(w, &w->slot[k], mm, iov);
+  free(rx); free(mm); free(iov); free(from); free(shed_tmp); free(shed_peers);
+  return NULL;
+}
+
 int main(int argc, char **argv) {
-  struct options o = {DINT_WL_FASST, 0, 0, 0, 0, "10.10.1.1", 20230, 0, 4096, 100};
+  struct options o = {DINT_WL_FASST, 0, 0, 0, 0, "10.10.1.1", 20230, 0, 4096, 100, 2, 0};
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i], *v = (i + 1 < argc) ? argv[i + 1] : NULL;
 #define NEED_V if (!v) { fprintf(stderr, "%s needs a value\n", a); return 2; } i++
@@ -119,9 +264,13 @@ int main(int argc, char **argv) {
     else if (!strcmp(a, "--device")) { NEED_V; o.device = atoi(v); }
     else if (!strcmp(a, "--batch")) { NEED_V; o.batch = (uint32_t)strtoul(v, NULL, 10); }
     else if (!strcmp(a, "--deadline-us")) { NEED_V; o.deadline_us = (uint32_t)strtoul(v, NULL, 10); }
+    else if (!strcmp(a, "--threads")) { NEED_V; o.threads = (uint32_t)strtoul(v, NULL, 10); }
+    else if (!strcmp(a, "--shed")) { o.shed = 1; }
     else { fprintf(stderr, "unknown option %s\n", a); return 2; }
   }
-  if (o.batch == 0 || o.batch > DINT_MICRO_BATCH) o.batch = DINT_MICRO_BATCH;
+  const uint32_t batch_max = o.workload >= DINT_WL_STORE ? DINT_KV_PASS_MAX : DINT_MICRO_BATCH;  /* one kernel pass */
+  if (o.batch == 0 || o.batch > batch_max) o.batch = batch_max;
+  if (o.threads == 0 || o.threads > 64) o.threads = 2;
 
   dint_config cfg;
   memset(&cfg, 0, sizeof cfg);
@@ -130,6 +279,7 @@ int main(int argc, char **argv) {
   cfg.device = o.device;
   cfg.n_slots = o.slots;
   cfg.n_rows = o.rows;
+  cfg.flags = DINT_FLAG_COPY_STREAMS;  /* one engine in this process: overlap its copies with its kernels */
   dint_engine_t *eng = NULL;
   if (dint_engine_create(&cfg, &eng)) { fprintf(stderr, "dint_engine_create: %s\n", dint_last_error()); return 1; }
   const int msg_size = dint_msg_size(o.workload);
@@ -138,96 +288,65 @@ int main(int argc, char **argv) {
                      : (o.rows ? o.rows : (o.workload == DINT_WL_STORE ? 2000000ull : o.workload == DINT_WL_TATP ? 7000000ull : 24000000ull));
     if (n && dint_populate(eng, n)) { fprintf(stderr, "dint_populate: %s\n", dint_last_error()); return 1; }
   }
-
-  int fd = socket(AF_INET, SOCK_DGRAM, 0);
-  if (fd < 0) { perror("socket"); return 1; }
-  int one = 1, buf = 64 << 20;
-  setsockopt(fd, SOL_SOCKET, SO_REUSEPORT, &one, sizeof one);  /* as the reference: lock_fasst/udp/server.cc:57-58 */
-  setsockopt(fd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
-  setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
   struct sockaddr_in addr;
   memset(&addr, 0, sizeof addr);
   addr.sin_family = AF_INET;
   addr.sin_port = htons((uint16_t)o.port);
   if (inet_pton(AF_INET, o.bind_ip, &addr.sin_addr) != 1) { fprintf(stderr, "bad --bind %s\n", o.bind_ip); return 2; }
-  if (bind(fd, (struct sockaddr *)&addr, sizeof addr) < 0) { perror("bind"); return 1; }
-  struct timeval tv = {0, 100000};  /* wake up to notice signals */
-  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
 
   signal(SIGINT, on_signal);
   signal(SIGTERM, on_signal);
+  struct worker *ws = (struct worker *)calloc(o.threads, sizeof *ws);
+  if (!ws) { fprintf(stderr, "out of memory\n"); return 1; }
+  for (uint32_t t = 0; t < o.threads; t++) {
+    struct worker *w = &ws[t];
+    w->id = (int)t; w->o = &o; w->eng = eng; w->msg_size = msg_size;
+    w->fd = socket(AF_INET, SOCK_DGRAM, 0);
+    if (w->fd < 0) { perror("socket"); return 1; }
+    int one = 1, buf = 64 << 20;
+    setsockopt(w->fd, SOL_SOCKET, SO_REUSEPORT, &one, sizeof one);  /* as the reference: lock_fasst/udp/server.cc:57-58 */
+    setsockopt(w->fd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
+    setsockopt(w->fd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
+    if (bind(w->fd, (struct sockaddr *)&addr, sizeof addr) < 0) { perror("bind"); return 1; }
+    struct timeval tv = {0, 100000};  /* wake up to notice signals */
+    setsockopt(w->fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    for (int k = 0; k < 2; k++) {
+      void *a = NULL, *b = NULL;
+      if (dint_alloc_pinned((size_t)o.batch * MAX_MSG, &a) || dint_alloc_pinned((size_t)o.batch * MAX_MSG, &b)) {
+        fprintf(stderr, "dint_alloc_pinned: %s\n", dint_last_error());
+        return 1;
+      }
+      w->slot[k].reqs = (uint8_t *)a;
+      w->slot[k].reps = (uint8_t *)b;
+      w->slot[k].peers = (struct sockaddr_in *)malloc((size_t)o.batch * sizeof(struct sockaddr_in));
+      if (!w->slot[k].peers) { fprintf(stderr, "out of memory\n"); return 1; }
+    }
+  }
   pthread_t mon;
   struct mon_arg ma = {o.bind_ip, o.port + 1};
   pthread_create(&mon, NULL, monitor_thread, &ma);
+  for (uint32_t t = 0; t < o.threads; t++) pthread_create(&ws[t].th, NULL, socket_thread, &ws[t]);
 
-  uint8_t *reqs = (uint8_t *)malloc((size_t)o.batch * MAX_MSG);
-  uint8_t *reps = (uint8_t *)malloc((size_t)o.batch * MAX_MSG);
-  struct sockaddr_in *peers = (struct sockaddr_in *)malloc((size_t)o.batch * sizeof *peers);
-  uint8_t (*rx)[MAX_MSG] = malloc((size_t)VLEN * MAX_MSG);
-  struct mmsghdr *mm = (struct mmsghdr *)calloc(VLEN, sizeof *mm);
-  struct iovec *iov = (struct iovec *)calloc(VLEN, sizeof *iov);
-  struct sockaddr_in *from = (struct sockaddr_in *)calloc(VLEN, sizeof *from);
-  if (!reqs || !reps || !peers || !rx || !mm || !iov || !from) { fprintf(stderr, "out of memory\n"); return 1; }
-
-  fprintf(stdout, "dint_udp_server ready workload=%u msg=%d %s:%d batch=%u deadline_us=%u\n", o.workload, msg_size,
-          o.bind_ip, o.port, o.batch, o.deadline_us);
+  fprintf(stdout, "dint_udp_server ready workload=%u msg=%d %s:%d batch=%u deadline_us=%u threads=%u shed=%d\n", o.workload,
+          msg_size, o.bind_ip, o.port, o.batch, o.deadline_us, o.threads, o.shed);
   fflush(stdout);
 
-  uint64_t total = 0, batches = 0, dropped = 0;
-  while (!g_stop) {
-    uint32_t n = 0;
-    uint64_t t_first = 0;
-    while (n < o.batch && !g_stop) {
-      const uint32_t want = (o.batch - n) < VLEN ? (o.batch - n) : VLEN;
-      for (uint32_t k = 0; k < want; k++) {
-        iov[k].iov_base = rx[k];
-        iov[k].iov_len = MAX_MSG;
-        memset(&mm[k].msg_hdr, 0, sizeof mm[k].msg_hdr);
-        mm[k].msg_hdr.msg_iov = &iov[k];
-        mm[k].msg_hdr.msg_iovlen = 1;
-        mm[k].msg_hdr.msg_name = &from[k];
-        mm[k].msg_hdr.msg_namelen = sizeof from[k];
-      }
-      /* first datagram of a batch: block; afterwards only take what is already queued */
-      const int got = recvmmsg(fd, mm, want, n == 0 ? MSG_WAITFORONE : MSG_DONTWAIT, NULL);
-      if (got <= 0) {
-        if (n == 0) continue;                                   /* idle: keep waiting */
-        if (now_us() - t_first >= o.deadline_us) break;         /* deadline: close the batch */
-        continue;
-      }
-      if (n == 0) t_first = now_us();
-      for (int k = 0; k < got; k++) {
-        if ((int)mm[k].msg_len != msg_size) { dropped++; continue; }
-        memcpy(reqs + (size_t)n * msg_size, rx[k], (size_t)msg_size);
-        peers[n] = from[k];
-        n++;
-      }
-      if (now_us() - t_first >= o.deadline_us) break;
-    }
-    if (n == 0) continue;
-    if (dint_submit(eng, reqs, n, reps)) { fprintf(stderr, "dint_submit: %s\n", dint_last_error()); break; }
-    for (uint32_t off = 0; off < n;) {
-      const uint32_t cnt = (n - off) < VLEN ? (n - off) : VLEN;
-      for (uint32_t k = 0; k < cnt; k++) {
-        iov[k].iov_base = reps + (size_t)(off + k) * msg_size;
-        iov[k].iov_len = (size_t)msg_size;
-        memset(&mm[k].msg_hdr, 0, sizeof mm[k].msg_hdr);
-        mm[k].msg_hdr.msg_iov = &iov[k];
-        mm[k].msg_hdr.msg_iovlen = 1;
-        mm[k].msg_hdr.msg_name = &peers[off + k];
-        mm[k].msg_hdr.msg_namelen = sizeof peers[off + k];
-      }
-      int sent = sendmmsg(fd, mm, cnt, 0);
-      if (sent < 0) { if (errno == EINTR) continue; perror("sendmmsg"); sent = (int)cnt; }
-      off += (uint32_t)sent;
-    }
-    total += n;
-    batches++;
+  uint64_t total = 0, batches = 0, dropped = 0, refused = 0, send_dropped = 0;
+  for (uint32_t t = 0; t < o.threads; t++) {
+    pthread_join(ws[t].th, NULL);
+    total += ws[t].requests; batches += ws[t].batches; dropped += ws[t].dropped; refused += ws[t].refused;
+    send_dropped += ws[t].send_dropped;
   }
-  fprintf(stdout, "dint_udp_server exit requests=%llu batches=%llu dropped=%llu\n", (unsigned long long)total,
-          (unsigned long long)batches, (unsigned long long)dropped);
+  g_stop = 1;
+  fprintf(stdout, "dint_udp_server exit requests=%llu batches=%llu dropped=%llu refused=%llu send_dropped=%llu\n",
+          (unsigned long long)total, (unsigned long long)batches, (unsigned long long)dropped, (unsigned long long)refused,
+          (unsigned long long)send_dropped);
   pthread_join(mon, NULL);
+  for (uint32_t t = 0; t < o.threads; t++) {
+    close(ws[t].fd);
+    for (int k = 0; k < 2; k++) { dint_free_pinned(ws[t].slot[k].reqs); dint_free_pinned(ws[t].slot[k].reps); free(ws[t].slot[k].peers); }
+  }
   dint_engine_destroy(eng);
-  close(fd);
+  free(ws);
   return 0;
 }

@@ -92,6 +92,74 @@ class Driver:
                 "by_type": list(s.by_type), "committed_by_type": list(s.committed_by_type)}
 
 
+class GpuDriver:
+    """The same closed-loop clients resident on the GPU (csrc/k_txn.hip, include/dint_driver.h dint_gdriver_*):
+    ``next(stream)`` emits the epoch's three request batches into device arrays (``batch(s)``, live sizes at
+    ``counts_ptr``), the shard servers answer in place, ``consume(stream)`` feeds the replies back.  The request
+    stream is bit-identical to :class:`Driver`'s."""
+
+    def __init__(self, workload: Workload, n_clients: int, n_rows: int, cap: int, *, first_client: int = 0,
+                 zipf_theta: float | None = None, device: int = -1):
+        L = self._L = _lib.load()
+        vp, u32 = C.c_void_p, C.c_uint32
+        L.dint_gdriver_create.restype, L.dint_gdriver_create.argtypes = C.c_int, [C.POINTER(DriverConfig), C.c_int32, u32, C.POINTER(vp)]
+        L.dint_gdriver_destroy.restype, L.dint_gdriver_destroy.argtypes = None, [vp]
+        L.dint_gdriver_next.restype, L.dint_gdriver_next.argtypes = C.c_int, [vp, vp]
+        L.dint_gdriver_consume.restype, L.dint_gdriver_consume.argtypes = C.c_int, [vp, vp]
+        L.dint_gdriver_batch.restype, L.dint_gdriver_batch.argtypes = vp, [vp, u32]
+        L.dint_gdriver_counts.restype, L.dint_gdriver_counts.argtypes = vp, [vp]
+        L.dint_gdriver_get_stats.restype, L.dint_gdriver_get_stats.argtypes = C.c_int, [vp, C.POINTER(DriverStats), C.POINTER(C.c_uint64)]
+        L.dint_gdriver_read_batch.restype, L.dint_gdriver_read_batch.argtypes = C.c_int64, [vp, u32, vp, C.c_uint64]
+        self.workload = Workload(workload)
+        self.dtype = MSG_DTYPE[self.workload]
+        self.cap = cap
+        cfg = DriverConfig(workload=int(workload), n_clients=n_clients, n_rows=n_rows, first_client=first_client,
+                           key_dist=0 if zipf_theta is None else 1, zipf_theta=zipf_theta or 0.0)
+        h = vp()
+        rc = L.dint_gdriver_create(C.byref(cfg), device, cap, C.byref(h))
+        if rc:
+            raise _lib.DintError(f"dint_gdriver_create failed: {rc}")
+        self._h = h
+        self.batch_ptr = [L.dint_gdriver_batch(h, s) for s in range(N_SHARDS)]
+        self.counts_ptr = L.dint_gdriver_counts(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dint_gdriver_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def next(self, stream: int = 0):
+        rc = self._L.dint_gdriver_next(self._h, stream)
+        if rc:
+            raise _lib.DintError(f"dint_gdriver_next failed: {rc}")
+
+    def consume(self, stream: int = 0):
+        rc = self._L.dint_gdriver_consume(self._h, stream)
+        if rc:
+            raise _lib.DintError(f"dint_gdriver_consume failed: {rc}")
+
+    def stats(self) -> dict:
+        s, ov = DriverStats(), C.c_uint64()
+        rc = self._L.dint_gdriver_get_stats(self._h, C.byref(s), C.byref(ov))
+        if rc:
+            raise _lib.DintError(f"dint_gdriver_get_stats failed: {rc}")
+        return {"txns": s.txns, "committed": s.committed, "messages": s.messages, "epochs": s.epochs,
+                "by_type": list(s.by_type), "committed_by_type": list(s.committed_by_type), "overflow": ov.value}
+
+    def read_batches(self):
+        """host copies of the current epoch's three batches (synchronises; tests and debugging)"""
+        out = []
+        for s in range(N_SHARDS):
+            buf = np.zeros(self.cap, self.dtype)
+            n = self._L.dint_gdriver_read_batch(self._h, s, buf.ctypes.data, self.cap)
+            if n < 0:
+                raise _lib.DintError(f"dint_gdriver_read_batch failed: {n}")
+            out.append(buf[:n].copy())
+        return out
+
+
 class FasstClientConfig(C.Structure):
     _fields_ = [("n_workers", C.c_uint32), ("first_worker", C.c_uint32), ("key_space", C.c_uint32),
                 ("read_pct", C.c_uint32), ("key_dist", C.c_uint32), ("reserved0", C.c_uint32),

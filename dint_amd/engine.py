@@ -164,6 +164,13 @@ class Engine:
         tail = _lib.check(self._L.dint_read_log(self._h, rec.ctypes.data, cap))
         return rec, tail
 
+    def log_drain(self, cap: int = 1 << 20):
+        """records appended since the previous drain (oldest first) and how many were lost to ring overwrite"""
+        rec = np.zeros(cap, LOG_REC)
+        lost = C.c_uint64()
+        n = _lib.check(self._L.dint_log_drain(self._h, rec.ctypes.data, cap, C.byref(lost)))
+        return rec[:n], lost.value
+
     def stats(self) -> dict:
         s = _lib.Stats()
         _lib.check(self._L.dint_get_stats(self._h, C.byref(s)))
@@ -198,3 +205,12 @@ def bench_rand64(bytes_: int, n_access: int, write_back: bool = False, device: i
     aps = C.c_double(); sec = C.c_double()
     _lib.check(L.dint_bench_rand64(device, bytes_, n_access, int(write_back), C.byref(aps), C.byref(sec)))
     return aps.value, sec.value
+
+
+def refuse(workload, reqs: np.ndarray) -> np.ndarray:
+    """the back-pressure replies of the eBPF-flavour servers (REJECT_* / RETRY) for a batch that is not taken"""
+    L = _lib.load()
+    reqs = np.ascontiguousarray(reqs)
+    out = np.empty_like(reqs)
+    _lib.check(L.dint_refuse(int(workload), reqs.ctypes.data, len(reqs), out.ctypes.data))
+    return out

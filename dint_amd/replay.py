@@ -120,3 +120,31 @@ class Replay:
 
     def ops(self, lo: int, hi: int) -> int:
         return sum(sum(c) for c in self.counts[lo:hi])
+
+
+class GpuLoop:
+    """The closed loop that never leaves the GPU: a :class:`dint_amd.driver.GpuDriver` and the three shard servers of a
+    single-GPU :class:`ShardGroup`.  One epoch = emit kernel -> the three engines on their own streams, each answering
+    its batch in place (the batch size is read on the device) -> consume kernel; no host round trip, no PCIe."""
+
+    def __init__(self, group: ShardGroup, gdriver):
+        assert group.router is None, "single GPU (the exchange needs host-known batch sizes)"
+        assert gdriver.cap <= min(e.pass_max for e in group.engines)
+        self.g, self.d = group, gdriver
+        self.stream = torch.cuda.Stream()
+        self.msg = group.msg
+
+    def epochs(self, n: int) -> None:
+        xs = self.stream.cuda_stream
+        cap, msg, d = self.d.cap, self.msg, self.d
+        for _ in range(n):
+            d.next(xs)
+            for s, e in enumerate(self.g.engines):
+                e.stream_wait(xs)
+                e.submit_segments(d.batch_ptr[s], 1, cap, cap * msg, d.counts_ptr + 4 * s, 0)
+                e.stream_signal(xs)
+            d.consume(xs)
+
+    def sync(self):
+        self.stream.synchronize()
+        self.g.sync()

@@ -45,6 +45,17 @@ extern "C" {
 #define DINT_FLAG_KV_ROUNDS 1u /* kv workloads: resolve same-key conflicts request by request instead of in
                                   closed form (slow; identical results -- used for A/B runs and parity tests) */
 
+#define DINT_FLAG_COPY_STREAMS 2u /* host path: dedicated H2D / D2H streams, so that one engine overlaps the copies of
+                                     neighbouring passes with its kernels.  Off by default: a process that runs several
+                                     engines has them overlap each other, and every extra stream beyond HIP's hardware
+                                     queues (GPU_MAX_HW_QUEUES, 4) can serialise two engines behind one queue */
+
+#define DINT_FLAG_LOCK_SAME_KEY 4u /* tatp: the eBPF ablation build tatp/ebpf/lock_kern.c -- a lock slot remembers the key it
+                                     was granted to and a rejected ACQUIRE_LOCK for that same key is answered
+                                     REJECT_LOCK_SAME_KEY (28) instead of REJECT_LOCK (:289-298; counted by
+                                     tatp/caladan/client_lock.cc:762-771 to tell true conflicts from slot aliasing).
+                                     Diagnostic: requests are resolved one by one (as DINT_FLAG_KV_ROUNDS) */
+
 /* workloads (dint_config.workload) */
 enum {
   DINT_WL_FASST = 0,     /* lock_fasst: 9-byte {u8 type; u32 lid; u32 ver}            net.h:23-29 */
@@ -52,7 +63,8 @@ enum {
   DINT_WL_LOG = 2,       /* log_server: 53-byte {u8 type; u64 key; u8 val[40]; u32 ver}           */
   DINT_WL_STORE = 3,     /* store:      53-byte, same layout                                      */
   DINT_WL_TATP = 4,      /* tatp:       55-byte {u8 ord,type,table; u64 key; u8 val[40]; u32 ver} */
-  DINT_WL_SMALLBANK = 5, /* smallbank:  23-byte {u8 ord,type,table; u64 key; u8 val[8]; u32 ver}  */
+  DINT_WL_SMALLBANK = 5, /* smallbank:  23-byte {u8 ord,type,table; u64 key; u8 val[8]; u32 ver};
+                            the udp server's 7 request types + WARMUP_READ (17 -> 18) of the eBPF flavour */
   DINT_WL_COUNT = 6
 };
 
@@ -134,7 +146,7 @@ const char *dint_last_error(void);
 int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies);
 /* Pipelined form: enqueue and return at once; *ticket identifies the submission.  The array is cut
  * into passes of max_pass requests; pass k+1's host-to-device copy and pass k-1's device-to-host copy overlap pass
- * k's kernels (three HIP streams, three staging slots), and successive submissions pipeline the same way -- as long
+ * k's kernels (DINT_FLAG_COPY_STREAMS: three HIP streams; three staging slots), and successive submissions pipeline the same way -- as long
  * as reqs / replies are page-locked (dint_alloc_pinned, or the caller's own hipHostMalloc / hipHostRegister
  * memory); pageable buffers work but every copy then blocks the calling thread.  Buffers must stay untouched until
  * dint_wait(ticket) returns.  Submissions are applied in call order (one serial history per engine). */
@@ -163,6 +175,13 @@ uint32_t dint_max_pass(dint_engine_t *e);
 int dint_stream_wait(dint_engine_t *e, void *other_stream);
 int dint_stream_signal(dint_engine_t *e, void *other_stream);
 
+/* Back-pressure: the reply the reference's eBPF servers give when they cannot take a request right
+ * now -- REJECT_READ / REJECT_LOCK / REJECT_COMMIT (tatp), RETRY (smallbank, lock_2pl), kReject* (store) -- which every
+ * client answers by sending the request again (e.g. tatp/caladan/client_ebpf_shard.cc:434-442).  A front end that must
+ * shed load (the UDP shim with its submission queue full) fills replies with this instead of queueing; no GPU work,
+ * no state change.  Request types that the eBPF servers never refuse are left as they are (= not answered). */
+int dint_refuse(uint32_t workload, const void *reqs, uint32_t n, void *replies);
+
 /* ---- population / state (parity + checkpointing) -------------------------- */
 /* KV workloads: bulk-insert rows in order with kvs_insert semantics (ver given, or 0 if
  * vers == NULL).  val_size is 40 (store/tatp) or 8 (smallbank).  Host pointers. */
@@ -189,6 +208,11 @@ int64_t dint_read_locks(dint_engine_t *e, uint32_t table, uint32_t *a, uint32_t 
 /* log ring: copies up to cap canonical 64-byte records
  * {u64 key; u8 val[40]; u32 ver; u8 is_del; u8 table; u8 pad[10]} and returns the tail index */
 int64_t dint_read_log(dint_engine_t *e, void *records, uint64_t cap);
+/* Log drain (the reference writes its logs and never reads them, tatp/udp/server_shard.cc:182-207): copies
+ * the records appended since the previous call, oldest first, up to cap; returns how many.  *lost (may be NULL) = records
+ * the ring overwrote before they were drained (drain at least once per log_entries appended).  The stream position
+ * survives ring wrap-around; dint_reset rewinds it.  dint_amd/recovery.py replays a drained log into a replica. */
+int64_t dint_log_drain(dint_engine_t *e, void *records, uint64_t cap, uint64_t *lost);
 int dint_get_stats(dint_engine_t *e, dint_stats *out);
 /* reset tables, locks, log and stats to the freshly-created (unpopulated) state */
 int dint_reset(dint_engine_t *e);

@@ -66,6 +66,26 @@ const void *dint_driver_batch(dint_driver_t *d, uint32_t shard);
 int dint_driver_consume(dint_driver_t *d, const void *const replies[DINT_N_SHARDS]);
 int dint_driver_get_stats(const dint_driver_t *d, dint_driver_stats *out);
 
+/* ---- the same drivers, resident on the GPU -----------------------------------------------
+ * Client state lives in HBM; dint_gdriver_next launches a kernel in which every client runs one phase and emits its
+ * messages into three driver-owned device arrays -- at exactly the positions, hence with exactly the bytes, of the
+ * host driver (tests compare the two streams) -- and writes the three batch sizes to device memory;
+ * the shard servers answer IN PLACE (dint_submit_segments(engine_s, dint_gdriver_batch(d, s), 1, cap, cap * msg,
+ * counts + s, 0, stream): one segment whose live count the engine reads on the device); dint_gdriver_consume
+ * launches the kernel in which every client picks up its replies.  Nothing crosses PCIe.  `cap_per_shard` = slots of
+ * each batch array; messages beyond it are dropped and counted (overflow: size it ~1.3x the expected batch). */
+typedef struct dint_gdriver dint_gdriver_t;
+int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t cap_per_shard, dint_gdriver_t **out);
+void dint_gdriver_destroy(dint_gdriver_t *g);
+int dint_gdriver_next(dint_gdriver_t *g, void *stream);     /* must alternate with dint_gdriver_consume */
+int dint_gdriver_consume(dint_gdriver_t *g, void *stream);
+void *dint_gdriver_batch(dint_gdriver_t *g, uint32_t shard);  /* device pointer: cap_per_shard message slots */
+const void *dint_gdriver_counts(dint_gdriver_t *g);           /* device pointer: uint32_t[3] live messages per shard */
+uint32_t dint_gdriver_cap(const dint_gdriver_t *g);
+/* tests / debugging: synchronise and copy the current batch of `shard` to the host; returns its message count */
+int64_t dint_gdriver_read_batch(dint_gdriver_t *g, uint32_t shard, void *host, uint64_t cap_msgs);
+int dint_gdriver_get_stats(dint_gdriver_t *g, dint_driver_stats *out, uint64_t *overflow);  /* synchronises the device */
+
 /* ---- lock_fasst load generator ---------------------------------------------------------------------------
  * lock_fasst/caladan/client.cc:183-280 (ClientLoop) over transactions shaped like lock_fasst/caladan/trace_init.sh
  * :6-27, W workers in lock step, one outstanding request each.  dint_fasst_client_next returns the epoch's W 9-byte

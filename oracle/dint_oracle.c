@@ -389,6 +389,7 @@ struct orc_tatp {
   orc_kvs *t[5];
   uint32_t hs[5];
   uint8_t *locks[5];
+  uint64_t *owner[5]; /* eBPF lock_kern.c flavour only: key of the last granted lock (struct txn_lock, lock_kern.c:12-15) */
   logring l;
 };
 
@@ -487,12 +488,16 @@ orc_tatp *orc_tatp_create(uint32_t n_sub, uint32_t log_entries, uint32_t populat
 
 void orc_tatp_destroy(orc_tatp *s) {
   if (!s) return;
-  for (int i = 0; i < 5; i++) { orc_kvs_destroy(s->t[i]); free(s->locks[i]); }
+  for (int i = 0; i < 5; i++) { orc_kvs_destroy(s->t[i]); free(s->locks[i]); free(s->owner[i]); }
   free(s->l.ring); free(s);
 }
 orc_kvs *orc_tatp_table(orc_tatp *s, int table) { return s->t[table]; }
 uint32_t orc_tatp_hash_size(orc_tatp *s, int table) { return s->hs[table]; }
 uint8_t *orc_tatp_locks(orc_tatp *s, int table) { return s->locks[table]; }
+void orc_tatp_same_key_mode(orc_tatp *s) {
+  for (int i = 0; i < 5; i++)
+    if (!s->owner[i]) s->owner[i] = (uint64_t *)calloc((size_t)4 * s->hs[i], 8);
+}
 uint8_t *orc_tatp_log_ring(orc_tatp *s) { return s->l.ring; }
 uint32_t orc_tatp_log_tail(orc_tatp *s) { return s->l.tail; }
 
@@ -514,8 +519,14 @@ uint64_t orc_tatp_replay(orc_tatp *s, void *msgs, size_t n) {
         else m[1] = 6;
         break;
       }
-      case 1: /* kAcquireLock  :123-132 */
-        if (*lk == 0) { *lk = 1; m[1] = 7; } else m[1] = 8;
+      case 1: /* kAcquireLock  :123-132;  eBPF ablation build tatp/ebpf/lock_kern.c:289-298: the slot remembers the
+                 key it was granted to, and a rejected request for that same key is told so (REJECT_LOCK_SAME_KEY = 28) */
+        if (*lk == 0) {
+          *lk = 1; m[1] = 7;
+          if (s->owner[tb]) s->owner[tb][lk - s->locks[tb]] = key;
+        } else {
+          m[1] = (s->owner[tb] && s->owner[tb][lk - s->locks[tb]] == key) ? 28 : 8;
+        }
         break;
       case 2: /* kAbort  :134-138 */
         *lk = 0; m[1] = 9;
@@ -644,6 +655,12 @@ uint64_t orc_sb_replay(orc_sb *s, void *msgs, size_t n) {
       case 6: /* kCommitLog  :175-186 */
         logring_append(&s->l, key, val, 8, ld32(m + 19), 0, tb);
         m[1] = 15;
+        break;
+      case 17: /* WARMUP_READ (eBPF flavour only; the udp server has no handler): a plain kvs_get answered
+                  WARMUP_READ_ACK by the user-space store, smallbank/ebpf/shard_user.c:179-186 -- the return value of
+                  kvs_get is ignored there, so a missing key echoes val / ver and still gets the ack */
+        if (orc_kvs_get(t, key, val, &ver) == 0) st32(m + 19, ver);
+        m[1] = 18;
         break;
       default:
         bad++;

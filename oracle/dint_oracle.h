@@ -96,6 +96,8 @@ uint64_t orc_tatp_replay(orc_tatp *s, void *msgs, size_t n);
 orc_kvs *orc_tatp_table(orc_tatp *s, int table);
 uint32_t orc_tatp_hash_size(orc_tatp *s, int table);
 uint8_t *orc_tatp_locks(orc_tatp *s, int table); /* 4*hash_size bytes */
+/* switch to the semantics of the eBPF ablation build tatp/ebpf/lock_kern.c (REJECT_LOCK_SAME_KEY) */
+void orc_tatp_same_key_mode(orc_tatp *s);
 uint8_t *orc_tatp_log_ring(orc_tatp *s);
 uint32_t orc_tatp_log_tail(orc_tatp *s);
 

@@ -60,7 +60,7 @@ def lib() -> C.CDLL:
             "orc_tatp_create": (vp, [u32, u32, u32]), "orc_tatp_destroy": (None, [vp]),
             "orc_tatp_replay": (u64, [vp, vp, sz]),
             "orc_tatp_table": (vp, [vp, C.c_int]), "orc_tatp_hash_size": (u32, [vp, C.c_int]),
-            "orc_tatp_locks": (vp, [vp, C.c_int]),
+            "orc_tatp_locks": (vp, [vp, C.c_int]), "orc_tatp_same_key_mode": (None, [vp]),
             "orc_tatp_log_ring": (vp, [vp]), "orc_tatp_log_tail": (u32, [vp]),
             "orc_sb_create": (vp, [u32, u32, u32]), "orc_sb_destroy": (None, [vp]),
             "orc_sb_replay": (u64, [vp, vp, sz]),
@@ -216,6 +216,8 @@ class TatpOracle(_Base):
         self.h = lib().orc_tatp_create(n_sub, log_entries, n_sub if populate_n is None else populate_n)
 
     def hash_size(self, t: int) -> int: return lib().orc_tatp_hash_size(self.h, t)
+
+    def same_key_mode(self): lib().orc_tatp_same_key_mode(self.h)  # tatp/ebpf/lock_kern.c flavour
 
     def dump(self, t: int): return _dump_kvs(lib().orc_tatp_table(self.h, t), 40)
 
