@@ -34,11 +34,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# HIP gives a process 4 hardware queues by default and lets further streams share them.  N = 1 uses exactly four
-# streams (three engines + torch's); with N > 1 the exchange stream and RCCL's stream come on top, and an engine sharing
-# a queue with them would serialise the exchange behind its kernels.  Must be set before the HIP runtime initialises.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES is left at HIP's default of 4: raising it to 8 / 16 so that the exchange stream and RCCL's stream get
+# queues of their own HALVED the pipelined-exchange rate on MI355X -- tools/gpu_quick.sh, r02: 0.49 -> 1.04 ms per epoch.)
 
 BATCH = 65536
 KV_PASS = 1 << 20  # requests per kernel pass of the store / tatp / smallbank engines (dint_config.max_pass = 0)

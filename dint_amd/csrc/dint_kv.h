@@ -60,7 +60,7 @@ dint_kv_fmt dint_kv_format(uint32_t workload);
 #define DINT_ROUTE_MAXN 1048576u   // requests per dint_route_pack call
 struct dint_route_scratch {
   uint8_t *home;   // [DINT_ROUTE_MAXN] home rank of each request
-  uint32_t *blk;   // [1024][world] requests per destination and 1024-request block, then their exclusive scan
+  uint32_t *blk;   // [4096][world] requests per destination and 256-request block, then their exclusive scan
 };
 // stable partition of n contiguous requests by home rank into `shard.count` slots of `cap` messages, slot w at
 // d_send + w * stride, its live count (u32) at d_cnt + w * cnt_stride; d_slot[i] = home * cap + position (or ~0u)
@@ -69,4 +69,4 @@ void dint_launch_route_pack(uint32_t workload, uint32_t msg, dint_mod slots, con
                             uint64_t cnt_stride, uint32_t *d_slot, dint_route_scratch rs, dint_dev_stats *stats,
                             hipStream_t st);
 void dint_launch_route_unpack(const void *d_back, uint32_t cap, uint64_t stride, const uint32_t *d_slot,
-                              const void *d_req, uint32_t n, uint32_t msg, void *d_rep, hipStream_t st);
+                              const void *d_req, uint32_t n, uint32_t msg, uint32_t world, void *d_rep, hipStream_t st);

@@ -82,6 +82,7 @@ struct dint_engine {
   // first waits for it (dint_submit_device with a caller stream)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_order = nullptr;
+  hipEvent_t ev_wait = nullptr, ev_signal = nullptr;  // dint_stream_wait / dint_stream_signal (re-recorded every call)
 
   // lock tables (fasst / 2pl)
   uint2 *d_lock_tbl = nullptr;
@@ -359,6 +360,8 @@ void dint_engine_destroy(dint_engine_t *e) {
   if (e->h_pinned) hipHostFree(e->h_pinned);
   if (e->h_pool) hipHostFree(e->h_pool);
   if (e->ev_order) hipEventDestroy(e->ev_order);
+  if (e->ev_wait) hipEventDestroy(e->ev_wait);
+  if (e->ev_signal) hipEventDestroy(e->ev_signal);
   if (e->s_h2d && e->s_h2d != e->stream) hipStreamDestroy(e->s_h2d);
   if (e->s_d2h && e->s_d2h != e->stream) hipStreamDestroy(e->s_d2h);
   hipFree(e->d_lock_tbl);
@@ -504,7 +507,7 @@ int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_se
   HIP_TRY(hipSetDevice(e->device));
   if (!e->route.home) {
     if (int rc = dev_alloc((void **)&e->route.home, DINT_ROUTE_MAXN, false)) return rc;
-    if (int rc = dev_alloc((void **)&e->route.blk, (size_t)(DINT_ROUTE_MAXN / 1024) * DINT_ROUTE_MAXW * 4)) return rc;
+    if (int rc = dev_alloc((void **)&e->route.blk, (size_t)(DINT_ROUTE_MAXN / 256) * DINT_ROUTE_MAXW * 4)) return rc;
   }
   hipStream_t st = stream ? (hipStream_t)stream : e->stream;
   if (int rc = order_stream(e, st)) return rc;  // the routing scratch is per engine too
@@ -521,7 +524,7 @@ int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, ui
   if (seg_cap == 0) return fail(DINT_EINVAL, "bad seg_cap");
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-  dint_launch_route_unpack(d_back, seg_cap, seg_stride, d_slot, d_reqs, n, e->msg_size, d_replies, st);
+  dint_launch_route_unpack(d_back, seg_cap, seg_stride, d_slot, d_reqs, n, e->msg_size, e->shard.count, d_replies, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
   return 0;
@@ -534,12 +537,11 @@ int dint_stream_wait(dint_engine_t *e, void *other_stream) {
   if (!e) return fail(DINT_EINVAL, "null engine");
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
-  hipEvent_t ev;
-  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  hipError_t r = hipEventRecord(ev, (hipStream_t)other_stream);
-  if (r == hipSuccess) r = hipStreamWaitEvent(e->stream, ev, 0);
-  hipEventDestroy(ev);  // released by the runtime once the wait has been satisfied
-  if (r != hipSuccess) return fail(DINT_EHIP, "dint_stream_wait: %s", hipGetErrorString(r));
+  // one event per engine and direction: a wait captures the state the event had when the wait was enqueued, so
+  // recording it again for the next call does not disturb waits that are still pending
+  if (!e->ev_wait) HIP_TRY(hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->ev_wait, (hipStream_t)other_stream));
+  HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_wait, 0));
   return 0;
 }
 
@@ -547,12 +549,9 @@ int dint_stream_signal(dint_engine_t *e, void *other_stream) {
   if (!e) return fail(DINT_EINVAL, "null engine");
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
-  hipEvent_t ev;
-  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  hipError_t r = hipEventRecord(ev, e->stream);
-  if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)other_stream, ev, 0);
-  hipEventDestroy(ev);
-  if (r != hipSuccess) return fail(DINT_EHIP, "dint_stream_signal: %s", hipGetErrorString(r));
+  if (!e->ev_signal) HIP_TRY(hipEventCreateWithFlags(&e->ev_signal, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->ev_signal, e->stream));
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)other_stream, e->ev_signal, 0));
   return 0;
 }
 

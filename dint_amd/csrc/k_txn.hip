@@ -35,8 +35,8 @@ void dint_driver_params(const dint_driver_config &c, TxParams *P, ZipfTable *zip
 
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
-k_txn_emit(typename T::Client *cl, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1, uint8_t *out2,
-           uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t *counts, txg_stats *st) {
+k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
+           uint8_t *out2, uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t *counts, txg_stats *st, uint32_t dbg) {
   typedef typename T::Msg Msg;
   __shared__ uint32_t Stile, Sw[3][TXG_TB / 64], Sbase[3], Sred[3][TXG_TB / 64];
   __shared__ unsigned long long Sst[TXG_NSTAT];
@@ -47,18 +47,25 @@ k_txn_emit(typename T::Client *cl, uint32_t n_clients, TxParams P, uint8_t *out0
   const uint32_t tile = Stile, i = tile * TXG_TB + t, ntiles = gridDim.x;
   const bool valid = i < n_clients;
 
+  // the client's header travels through registers: one coalesced 64 / 96-byte load here, one store at the end; the
+  // working messages stay in memory and are touched only where the phase reads or writes them
   typename T::Out o;
   o.clear();
-  if (valid) T::run(cl[i], P, o);
-  uint32_t c[3] = {0, 0, 0};
-  for (uint8_t k = 0; k < o.n; k++) c[o.shard[k]]++;
+  typename T::Client c;
+  if (valid) {
+    c = cl[i];
+    c.m = store + (size_t)i * T::NMSG;
+    if (!(dbg & 2)) T::run(c, P, o);
+  }
+  uint32_t nmsg[3] = {0, 0, 0};
+  for (uint8_t k = 0; k < o.n; k++) nmsg[o.shard[k]]++;
 
   // ---- my messages' positions: workgroup scan per shard ...
   uint32_t x[3], tot[3];
 #pragma unroll
   for (int s = 0; s < 3; s++) {
     uint32_t wt;
-    x[s] = wave_excl_scan_u32(c[s], &wt);
+    x[s] = wave_excl_scan_u32(nmsg[s], &wt);
     if (lane == 0) Sw[s][wave] = wt;
   }
   __syncthreads();
@@ -73,7 +80,7 @@ k_txn_emit(typename T::Client *cl, uint32_t n_clients, TxParams P, uint8_t *out0
   if (t < 3) __hip_atomic_store(&pub[tile * 4 + t], 0x80000000u | tot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- ... + the totals of the workgroups before mine (published long ago: they started earlier)
   uint32_t part[3] = {0, 0, 0};
-  for (uint32_t k = t; k < tile; k += TXG_TB) {
+  for (uint32_t k = t; k < tile && !(dbg & 1); k += TXG_TB) {
 #pragma unroll
     for (int s = 0; s < 3; s++) {
       uint32_t v;
@@ -100,11 +107,12 @@ k_txn_emit(typename T::Client *cl, uint32_t n_clients, TxParams P, uint8_t *out0
   uint8_t *outs[3] = {out0, out1, out2};
   uint32_t lost = 0;
   for (uint8_t k = 0; k < o.n; k++) {
-    const uint32_t s = o.shard[k], pos = Sbase[s] + x[s] + o.msg[k].ord;
-    cl[i].out_pos[k] = pos;
-    if (pos < cap) *(Msg *)(outs[s] + (size_t)pos * sizeof(Msg)) = o.msg[k];
+    const uint32_t s = o.shard[k], pos = Sbase[s] + x[s] + o.ord[k];
+    c.out_pos[k] = pos;
+    if (pos < cap) *(Msg *)(outs[s] + (size_t)pos * sizeof(Msg)) = o.materialize(c, k);
     else lost++;
   }
+  if (valid) cl[i] = c;
   // ---- statistics: LDS first, then one device atomic per counter and workgroup
   if (valid) {
     atomicAdd(&Sst[offsetof(txg_stats, messages) / 8], (unsigned long long)o.n);
@@ -124,8 +132,8 @@ k_txn_emit(typename T::Client *cl, uint32_t n_clients, TxParams P, uint8_t *out0
 
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
-k_txn_consume(typename T::Client *cl, uint32_t n_clients, const uint8_t *rep0, const uint8_t *rep1, const uint8_t *rep2,
-              uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t ntiles) {
+k_txn_consume(const typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, const uint8_t *rep0,
+              const uint8_t *rep1, const uint8_t *rep2, uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t ntiles) {
   typedef typename T::Msg Msg;
   const uint32_t i = blockIdx.x * TXG_TB + threadIdx.x;
   // leave the look-back words clean for the next emit (nothing else runs between consume and the next emit)
@@ -133,12 +141,13 @@ k_txn_consume(typename T::Client *cl, uint32_t n_clients, const uint8_t *rep0, c
   if (i == 0) *ticket = 0;
   if (i >= n_clients) return;
   const uint8_t *reps[3] = {rep0, rep1, rep2};
-  typename T::Client &c = cl[i];
+  const typename T::Client c = cl[i];
+  Msg *m = store + (size_t)i * T::NMSG;
   const uint8_t n = c.n_out;
   for (uint8_t k = 0; k < n; k++) {
     const uint8_t d = c.out_dst[k];
     const uint32_t pos = c.out_pos[k];
-    if (d != TX_NO_DST && pos < cap) c.m[d] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
+    if (d != TX_NO_DST && pos < cap) m[d] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
   }
 }
 
@@ -149,24 +158,27 @@ struct dint_gdriver {
   uint32_t cap = 0, ntiles = 0, msg = 0;
   bool awaiting = false;
   uint64_t epochs = 0;
-  void *d_clients = nullptr;
+  void *d_clients = nullptr, *d_store = nullptr;
   uint8_t *d_batch[DINT_N_SHARDS] = {nullptr, nullptr, nullptr};
   uint32_t *d_counts = nullptr, *d_pub = nullptr, *d_ticket = nullptr, *d_zipf = nullptr;
   txg_stats *d_stats = nullptr;
   TxParams P{};
+  uint32_t dbg = 0;  // DINT_TXN_DBG experiments: 1 = no look-back, 2 = no client logic
 };
 
 namespace {
-template <class Client>
+template <class T>
 int upload_clients(dint_gdriver *g) {
+  typedef typename T::Client Client;
   std::vector<Client> h(g->cfg.n_clients);
   for (uint32_t i = 0; i < g->cfg.n_clients; i++) {
     memset(&h[i], 0, sizeof(Client));
     h[i].rng.s = 0xdeadbeefull + g->cfg.first_client + i;  // ClientLoop :1122
   }
-  const size_t bytes = h.size() * sizeof(Client);
-  if (hipMalloc(&g->d_clients, bytes) != hipSuccess) return DINT_ENOMEM;
+  const size_t bytes = h.size() * sizeof(Client), sbytes = h.size() * T::NMSG * sizeof(typename T::Msg);
+  if (hipMalloc(&g->d_clients, bytes) != hipSuccess || hipMalloc(&g->d_store, sbytes) != hipSuccess) return DINT_ENOMEM;
   if (hipMemcpy(g->d_clients, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;
+  if (hipMemset(g->d_store, 0, sbytes) != hipSuccess) return DINT_EHIP;
   return 0;
 }
 }  // namespace
@@ -188,6 +200,7 @@ int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t 
   g->cap = cap_per_shard;
   g->msg = cfg->workload == DINT_WL_TATP ? 55 : 23;
   g->ntiles = (cfg->n_clients + TXG_TB - 1) / TXG_TB;
+  if (getenv("DINT_TXN_DBG")) g->dbg = (uint32_t)atoi(getenv("DINT_TXN_DBG"));
   int rc = 0;
   try {
     ZipfTable zipf;
@@ -197,7 +210,7 @@ int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t 
       else if (hipMemcpy(g->d_zipf, zipf.cdf.data(), zipf.cdf.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = DINT_EHIP;
       g->P.zipf_cdf = g->d_zipf;
     }
-    if (!rc) rc = cfg->workload == DINT_WL_TATP ? upload_clients<TatpClient>(g) : upload_clients<SbClient>(g);
+    if (!rc) rc = cfg->workload == DINT_WL_TATP ? upload_clients<TatpTraits>(g) : upload_clients<SbTraits>(g);
   } catch (const std::bad_alloc &) {
     rc = DINT_ENOMEM;
   }
@@ -224,6 +237,7 @@ void dint_gdriver_destroy(dint_gdriver_t *g) {
   hipSetDevice(g->device);
   hipDeviceSynchronize();
   hipFree(g->d_clients);
+  hipFree(g->d_store);
   for (auto p : g->d_batch) hipFree(p);
   hipFree(g->d_counts); hipFree(g->d_pub); hipFree(g->d_ticket); hipFree(g->d_zipf); hipFree(g->d_stats);
   delete g;
@@ -236,12 +250,12 @@ int dint_gdriver_next(dint_gdriver_t *g, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (g->cfg.workload == DINT_WL_TATP)
     hipLaunchKernelGGL((k_txn_emit<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (TatpClient *)g->d_clients,
-                       g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
-                       g->d_counts, g->d_stats);
+                       (TatpMsg *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
+                       g->d_counts, g->d_stats, g->dbg);
   else
     hipLaunchKernelGGL((k_txn_emit<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (SbClient *)g->d_clients,
-                       g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
-                       g->d_counts, g->d_stats);
+                       (SbMsg *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
+                       g->d_counts, g->d_stats, g->dbg);
   if (hipGetLastError() != hipSuccess) return DINT_EHIP;
   g->awaiting = true;
   g->epochs++;
@@ -254,11 +268,11 @@ int dint_gdriver_consume(dint_gdriver_t *g, void *stream) {
   if (hipSetDevice(g->device) != hipSuccess) return DINT_EHIP;
   hipStream_t st = (hipStream_t)stream;
   if (g->cfg.workload == DINT_WL_TATP)
-    hipLaunchKernelGGL((k_txn_consume<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (TatpClient *)g->d_clients,
-                       g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
+    hipLaunchKernelGGL((k_txn_consume<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const TatpClient *)g->d_clients,
+                       (TatpMsg *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
   else
-    hipLaunchKernelGGL((k_txn_consume<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (SbClient *)g->d_clients,
-                       g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
+    hipLaunchKernelGGL((k_txn_consume<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const SbClient *)g->d_clients,
+                       (SbMsg *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
   if (hipGetLastError() != hipSuccess) return DINT_EHIP;
   g->awaiting = false;
   return 0;

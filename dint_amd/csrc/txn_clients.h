@@ -72,23 +72,33 @@ struct TxParams {
   uint8_t workgen[100];     // transaction type per percentile (CreateWorkgenArr)
 };
 
-// what one phase emits, and which transactions finished on the way
+// what one phase emits, and which transactions finished on the way.  A message is always one of the client's working
+// messages as it stands when the phase returns, with a type of its own (the reference re-uses one struct for the
+// LOG / BCK / PRIM copies of a row): the queue holds {shard, source message, type, reply destination} and the
+// caller materialises the wire message -- on the GPU that keeps a phase in registers instead of ~0.5 KB of scratch.
 template <class Msg>
 struct TxOut {
   uint8_t n;
-  uint8_t shard[TX_MAXOUT], dst[TX_MAXOUT];
-  Msg msg[TX_MAXOUT];
+  uint8_t shard[TX_MAXOUT], dst[TX_MAXOUT], src[TX_MAXOUT], type[TX_MAXOUT], ord[TX_MAXOUT];
   uint8_t n_fin, fin_txn[2], fin_ok[2];
   TX_HD void clear() { n = 0; n_fin = 0; }
-  // queue `m` for shard s; its reply lands in client message `d`
-  TX_HD void send(uint32_t s, const Msg &m, uint8_t d) {
+  // queue client message `src_msg` (sent with type `ty`) for shard s; its reply lands in client message `d`
+  TX_HD void send(uint32_t s, uint8_t src_msg, uint8_t ty, uint8_t d) {
     uint8_t j = 0;  // msg->ord = position in this phase's queue for shard s (client_udp_shard.cc:376-380)
     for (uint8_t k = 0; k < n; k++) j += shard[k] == s;
     shard[n] = (uint8_t)s;
     dst[n] = d;
-    msg[n] = m;
-    msg[n].ord = j;
+    src[n] = src_msg;
+    type[n] = ty;
+    ord[n] = j;
     n++;
+  }
+  template <class Client>
+  TX_HD Msg materialize(const Client &c, uint8_t k) const {
+    Msg m = c.m[src[k]];
+    m.type = type[k];
+    m.ord = ord[k];
+    return m;
   }
   TX_HD void finish(uint8_t txn, bool committed) {
     if (n_fin < 2) { fin_txn[n_fin] = txn; fin_ok[n_fin] = committed; }
@@ -107,6 +117,8 @@ enum : uint8_t { TT_GET_SUB = 0, TT_GET_NEW_DEST = 1, TT_GET_ACCESS = 2, TT_UPD_
 // the working messages of the running transaction (names as in the reference functions)
 enum : uint8_t { A_READ = 0, A_LOCK = 1, B_READ = 2, B_LOCK = 3, A_VER = 4, B_VER = 5, TMP0 = 6, TMP1 = 7, TMP2 = 8, TATP_NMSG = 9 };
 
+// Client state = a 64-byte header (loaded and stored whole: on the GPU one coalesced access per client and phase)
+// + TATP_NMSG working messages in a separate array, touched only where a phase reads or writes them.
 struct TatpClient {
   TxLcg rng;
   uint8_t txn, step, n_out;  // step 0 = idle
@@ -114,8 +126,9 @@ struct TatpClient {
   uint8_t out_shard[6], out_dst[6];  // a tatp phase emits at most 6 messages
   uint32_t s_id;
   uint32_t out_pos[6];
-  TatpMsg m[TATP_NMSG];
+  TatpMsg *m;  // [TATP_NMSG] -- set by the driver before every use (host vector / device array)
 };
+static_assert(sizeof(TatpClient) == 64, "one 64-byte sector per client header");
 
 TX_HD static inline void tatp_workgen(uint8_t *workgen) {
   // CreateWorkgenArr :63-73 -- note the order: GetSubscriberData, GetAccessData, GetNewDestination, ...
@@ -144,12 +157,15 @@ TX_HD static inline uint64_t tatp_cf_key(const TatpClient &c, uint32_t st) { ret
 
 typedef TxOut<TatpMsg> TatpOut;
 // send client message i to its primary (key % 3, :187); the reply comes back into the same message
-TX_HD static inline void tatp_send_prim(TatpClient &c, TatpOut &o, uint8_t i) { o.send((uint32_t)(c.m[i].key % 3), c.m[i], i); }
-TX_HD static inline void tatp_send_log3(TatpOut &o, const TatpMsg &m) { for (uint32_t s = 0; s < 3; s++) o.send(s, m, TX_NO_DST); }
-// backups of a row whose primary is key % 3: first the "+1" copies of every row, then the "+2" copies
-TX_HD static inline void tatp_send_bck(TatpOut &o, const TatpMsg *rows, int n) {
-  for (int i = 0; i < n; i++) o.send((uint32_t)((rows[i].key % 3 + 1) % 3), rows[i], TX_NO_DST);
-  for (int i = 0; i < n; i++) o.send((uint32_t)((rows[i].key % 3 + 2) % 3), rows[i], TX_NO_DST);
+TX_HD static inline void tatp_send_prim(TatpClient &c, TatpOut &o, uint8_t i) { o.send((uint32_t)(c.m[i].key % 3), i, c.m[i].type, i); }
+// message i as it is now, to its primary, reply discarded
+TX_HD static inline void tatp_send_only(TatpClient &c, TatpOut &o, uint8_t i) { o.send((uint32_t)(c.m[i].key % 3), i, c.m[i].type, TX_NO_DST); }
+TX_HD static inline void tatp_send_log3(TatpClient &c, TatpOut &o, uint8_t i) { for (uint32_t s = 0; s < 3; s++) o.send(s, i, c.m[i].type, TX_NO_DST); }
+// backups of rows whose primary is key % 3: first the "+1" copies of every row, then the "+2" copies
+TX_HD static inline void tatp_send_bck(TatpClient &c, TatpOut &o, uint8_t r0, int n, uint8_t r1 = 0) {
+  const uint8_t rows[2] = {r0, r1};
+  for (int i = 0; i < n; i++) o.send((uint32_t)((c.m[rows[i]].key % 3 + 1) % 3), rows[i], c.m[rows[i]].type, TX_NO_DST);
+  for (int i = 0; i < n; i++) o.send((uint32_t)((c.m[rows[i]].key % 3 + 2) % 3), rows[i], c.m[rows[i]].type, TX_NO_DST);
 }
 TX_HD static inline void tatp_finish(TatpClient &c, TatpOut &o, bool committed) {
   o.finish(c.txn, committed);
@@ -206,19 +222,17 @@ TX_HD static inline void tatp_emit_upd_sub(TatpClient &c, TatpOut &o) {  // TxnU
         if (c.m[A_READ].ver != c.m[A_VER].ver || c.m[B_READ].ver != c.m[B_VER].ver) { c.step = 12; continue; }  // :470
         c.m[A_READ].ver++; c.m[B_READ].ver++;                                                                      // :487-488
         c.m[A_READ].type = c.m[B_READ].type = T_COMMIT_LOG;
-        for (uint32_t s = 0; s < 3; s++) { o.send(s, c.m[A_READ], TX_NO_DST); o.send(s, c.m[B_READ], TX_NO_DST); }  // :493-501
+        for (uint32_t s = 0; s < 3; s++) { o.send(s, A_READ, T_COMMIT_LOG, TX_NO_DST); o.send(s, B_READ, T_COMMIT_LOG, TX_NO_DST); }  // :493-501
         c.step = 4;
         return;
-      case 4: {
+      case 4:
         c.m[A_READ].type = c.m[B_READ].type = T_COMMIT_BCK;  // :521-533
-        const TatpMsg rows[2] = {c.m[A_READ], c.m[B_READ]};
-        tatp_send_bck(o, rows, 2);
+        tatp_send_bck(c, o, A_READ, 2, B_READ);
         c.step = 5;
         return;
-      }
       case 5:
         c.m[A_READ].type = c.m[B_READ].type = T_COMMIT_PRIM;  // :552-556
-        o.send((uint32_t)(c.m[A_READ].key % 3), c.m[A_READ], TX_NO_DST); o.send((uint32_t)(c.m[B_READ].key % 3), c.m[B_READ], TX_NO_DST);
+        tatp_send_only(c, o, A_READ); tatp_send_only(c, o, B_READ);
         c.step = 6;
         return;
       case 6: tatp_finish(c, o, true); return;
@@ -258,11 +272,11 @@ TX_HD static inline void tatp_emit_upd_loc(TatpClient &c, TatpOut &o) {  // TxnU
       if (c.m[A_VER].ver != c.m[A_READ].ver) { c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 8; return; }  // :667-674
       c.m[A_READ].ver++;
       c.m[A_READ].type = T_COMMIT_LOG;
-      tatp_send_log3(o, c.m[A_READ]);  // :677-684
+      tatp_send_log3(c, o, A_READ);  // :677-684
       c.step = 5;
       return;
-    case 5: c.m[A_READ].type = T_COMMIT_BCK; tatp_send_bck(o, &c.m[A_READ], 1); c.step = 6; return;                                  // :702-708
-    case 6: c.m[A_READ].type = T_COMMIT_PRIM; o.send((uint32_t)(c.m[A_READ].key % 3), c.m[A_READ], TX_NO_DST); c.step = 7; return;  // :722-723
+    case 5: c.m[A_READ].type = T_COMMIT_BCK; tatp_send_bck(c, o, A_READ, 1); c.step = 6; return;                                  // :702-708
+    case 6: c.m[A_READ].type = T_COMMIT_PRIM; tatp_send_only(c, o, A_READ); c.step = 7; return;  // :722-723
     case 7: tatp_finish(c, o, true); return;
     default: tatp_finish(c, o, false); return;
   }
@@ -296,11 +310,11 @@ TX_HD static inline void tatp_emit_ins_cf(TatpClient &c, TatpOut &o) {  // TxnIn
       }
       c.m[A_READ].ver = 0;  // :896
       c.m[A_READ].type = T_COMMIT_LOG;
-      tatp_send_log3(o, c.m[A_READ]);
+      tatp_send_log3(c, o, A_READ);
       c.step = 6;
       return;
-    case 6: c.m[A_READ].type = T_INSERT_BCK; tatp_send_bck(o, &c.m[A_READ], 1); c.step = 7; return;                                  // :921-927
-    case 7: c.m[A_READ].type = T_INSERT_PRIM; o.send((uint32_t)(c.m[A_READ].key % 3), c.m[A_READ], TX_NO_DST); c.step = 8; return;  // :944-945
+    case 6: c.m[A_READ].type = T_INSERT_BCK; tatp_send_bck(c, o, A_READ, 1); c.step = 7; return;                                  // :921-927
+    case 7: c.m[A_READ].type = T_INSERT_PRIM; tatp_send_only(c, o, A_READ); c.step = 8; return;  // :944-945
     case 8: tatp_finish(c, o, true); return;
     default: tatp_finish(c, o, false); return;
   }
@@ -329,11 +343,11 @@ TX_HD static inline void tatp_emit_del_cf(TatpClient &c, TatpOut &o) {  // TxnDe
         c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 8; return;
       }
       c.m[A_READ].type = T_DELETE_LOG;  // :1063
-      tatp_send_log3(o, c.m[A_READ]);
+      tatp_send_log3(c, o, A_READ);
       c.step = 5;
       return;
-    case 5: c.m[A_READ].type = T_DELETE_BCK; tatp_send_bck(o, &c.m[A_READ], 1); c.step = 6; return;                                  // :1087-1093
-    case 6: c.m[A_READ].type = T_DELETE_PRIM; o.send((uint32_t)(c.m[A_READ].key % 3), c.m[A_READ], TX_NO_DST); c.step = 7; return;  // :1110-1111
+    case 5: c.m[A_READ].type = T_DELETE_BCK; tatp_send_bck(c, o, A_READ, 1); c.step = 6; return;                                  // :1087-1093
+    case 6: c.m[A_READ].type = T_DELETE_PRIM; tatp_send_only(c, o, A_READ); c.step = 7; return;  // :1110-1111
     case 7: tatp_finish(c, o, true); return;
     default: tatp_finish(c, o, false); return;
   }
@@ -392,6 +406,7 @@ TX_HD static inline void tatp_run(TatpClient &c, const TxParams &P, TatpOut &o) 
 // (:212-246 and siblings) never spin here; a REJECT aborts by releasing whatever was granted, one at a time.
 enum : uint8_t { ST_AMALGAMATE = 0, ST_BALANCE = 1, ST_DEPOSIT_CHECKING = 2, ST_SEND_PAYMENT = 3, ST_TRANSACT_SAVING = 4, ST_WRITE_CHECK = 5 };
 
+#define SB_NMSG 3
 struct SbClient {
   TxLcg rng;
   uint8_t txn, step, n_out;
@@ -399,11 +414,13 @@ struct SbClient {
   uint8_t n_write, wr[3];  // indices into m[] of the rows written back
   uint8_t rel;        // abort: next row to release
   uint8_t out_shard[TX_MAXOUT], out_dst[TX_MAXOUT];
+  uint8_t pad0;
   float amount;
   uint64_t a0, a1;
   uint32_t out_pos[TX_MAXOUT];
-  SbMsg m[3];         // the locked rows, in the reference's order
+  SbMsg *m;           // [SB_NMSG] the locked rows, in the reference's order
 };
+static_assert(sizeof(SbClient) == 104, "client header");
 typedef TxOut<SbMsg> SbOut;
 
 TX_HD static inline void sb_workgen(uint8_t *workgen) {
@@ -513,7 +530,7 @@ TX_HD static inline void sb_emit(SbClient &c, SbOut &o) {
   for (;;) {
     switch (c.step) {
       case 1:  // acquire every lock of the transaction in one phase
-        for (uint8_t i = 0; i < c.n_rows; i++) o.send((uint32_t)(c.m[i].key % 3), c.m[i], i);
+        for (uint8_t i = 0; i < c.n_rows; i++) o.send((uint32_t)(c.m[i].key % 3), i, c.m[i].type, i);
         c.step = 2;
         return;
       case 2: {
@@ -523,34 +540,29 @@ TX_HD static inline void sb_emit(SbClient &c, SbOut &o) {
         if (c.n_write == 0) { c.step = 6; continue; }  // read-only: straight to release
         for (uint8_t k = 0; k < c.n_write; k++) { c.m[c.wr[k]].ver++; }
         for (uint32_t s = 0; s < 3; s++)
-          for (uint8_t k = 0; k < c.n_write; k++) { SbMsg t = c.m[c.wr[k]]; t.type = S_COMMIT_LOG; o.send(s, t, TX_NO_DST); }
+          for (uint8_t k = 0; k < c.n_write; k++) o.send(s, c.wr[k], S_COMMIT_LOG, TX_NO_DST);
         c.step = 3;
         return;
       }
       case 3:  // backups: "+1" copies of every row, then "+2" copies
         for (uint32_t d = 1; d <= 2; d++)
-          for (uint8_t k = 0; k < c.n_write; k++) { SbMsg t = c.m[c.wr[k]]; t.type = S_COMMIT_BCK; o.send((uint32_t)((t.key % 3 + d) % 3), t, TX_NO_DST); }
+          for (uint8_t k = 0; k < c.n_write; k++) o.send((uint32_t)((c.m[c.wr[k]].key % 3 + d) % 3), c.wr[k], S_COMMIT_BCK, TX_NO_DST);
         c.step = 4;
         return;
       case 4:
-        for (uint8_t k = 0; k < c.n_write; k++) { SbMsg t = c.m[c.wr[k]]; t.type = S_COMMIT_PRIM; o.send((uint32_t)(t.key % 3), t, TX_NO_DST); }
+        for (uint8_t k = 0; k < c.n_write; k++) o.send((uint32_t)(c.m[c.wr[k]].key % 3), c.wr[k], S_COMMIT_PRIM, TX_NO_DST);
         c.step = 6;
         return;
       case 6:  // release every lock in one phase
-        for (uint8_t i = 0; i < c.n_rows; i++) {
-          SbMsg t = c.m[i];
-          t.type = (c.m[i].type == S_GRANT_SH) ? S_REL_SH : S_REL_EX;
-          o.send((uint32_t)(t.key % 3), t, TX_NO_DST);
-        }
+        for (uint8_t i = 0; i < c.n_rows; i++)
+          o.send((uint32_t)(c.m[i].key % 3), i, (c.m[i].type == S_GRANT_SH) ? S_REL_SH : S_REL_EX, TX_NO_DST);
         c.step = 7;
         return;
       case 7: o.finish(c.txn, true); c.step = 0; return;
       case 20:  // abort: release the granted locks one round trip at a time (:248-279)
         while (c.rel < c.n_rows && !sb_granted(c.m[c.rel])) c.rel++;
         if (c.rel < c.n_rows) {
-          SbMsg t = c.m[c.rel];
-          t.type = (c.m[c.rel].type == S_GRANT_SH) ? S_REL_SH : S_REL_EX;
-          o.send((uint32_t)(t.key % 3), t, TX_NO_DST);
+          o.send((uint32_t)(c.m[c.rel].key % 3), c.rel, (c.m[c.rel].type == S_GRANT_SH) ? S_REL_SH : S_REL_EX, TX_NO_DST);
           c.rel++;
           return;
         }
@@ -576,9 +588,11 @@ TX_HD static inline void sb_run(SbClient &c, const TxParams &P, SbOut &o) {
 // uniform front for templates
 struct TatpTraits {
   typedef TatpClient Client; typedef TatpMsg Msg; typedef TatpOut Out;
+  static constexpr uint32_t NMSG = TATP_NMSG;
   TX_HD static void run(Client &c, const TxParams &P, Out &o) { tatp_run(c, P, o); }
 };
 struct SbTraits {
   typedef SbClient Client; typedef SbMsg Msg; typedef SbOut Out;
+  static constexpr uint32_t NMSG = SB_NMSG;
   TX_HD static void run(Client &c, const TxParams &P, Out &o) { sb_run(c, P, o); }
 };

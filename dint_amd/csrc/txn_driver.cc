@@ -51,6 +51,7 @@ struct HostDriver final : dint_driver {
   typedef typename T::Client Client;
   typedef typename T::Msg Msg;
   std::vector<Client> cl;
+  std::vector<Msg> store;  // the clients' working messages: T::NMSG per client
   std::vector<Msg> b[DINT_N_SHARDS];
   TxParams P;
   ZipfTable zipf;
@@ -59,9 +60,12 @@ struct HostDriver final : dint_driver {
     cfg = c;
     dint_driver_params(c, &P, &zipf);
     cl.resize(c.n_clients);
+    store.resize((size_t)c.n_clients * T::NMSG);
+    memset(store.data(), 0, store.size() * sizeof(Msg));
     for (uint32_t i = 0; i < c.n_clients; i++) {
       memset(&cl[i], 0, sizeof(Client));
       cl[i].rng.s = 0xdeadbeefull + c.first_client + i;  // ClientLoop :1122
+      cl[i].m = &store[(size_t)i * T::NMSG];
     }
   }
   int msg_size() const override { return (int)sizeof(Msg); }
@@ -75,7 +79,7 @@ struct HostDriver final : dint_driver {
       for (uint8_t k = 0; k < o.n; k++) {
         auto &v = b[o.shard[k]];
         c.out_pos[k] = (uint32_t)v.size();
-        v.push_back(o.msg[k]);
+        v.push_back(o.materialize(c, k));
       }
       st.messages += o.n;
       for (uint8_t k = 0; k < o.n_fin && k < 2; k++) {

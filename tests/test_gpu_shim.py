@@ -101,3 +101,59 @@ def test_shim_tatp_over_loopback_and_cpu_monitor():
         assert len(d) == 16 and 0 <= u < 256 and 0 <= k < 256
     finally:
         srv.stop()
+
+
+def test_shim_sheds_load_with_the_ebpf_refusal_codes():
+    """--shed: a batch that closes while the thread's other batch is still on the GPU is answered REJECT_READ at once
+    (store/ebpf/store_kern.c:57-62); the client sends those requests again, as the reference's eBPF clients do."""
+    S = wire.Store
+    n_sub = 2000
+    srv = Server("--workload", "store", "--rows", str(n_sub), "--populate", "40", "--batch", "256", "--deadline-us", "0",
+                 "--threads", "1", "--shed")
+    try:
+        o = orc.StoreOracle(n_sub * 18 // 4, 40)
+        req = tracegen.store_random(30_000, seed=3, n_sub_touch=40, p_set=0.0, p_missing=0.2)
+        assert (req["type"] == S.READ).all()
+        want = o.replay(req)
+        c = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        c.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 32 << 20)
+        c.settimeout(10)
+        size = req.dtype.itemsize
+        raw = req.tobytes()
+        # `ver` is echoed on NOT_EXIST and overwritten on GRANT_READ: carry the request index in val[8:12] instead
+        idx = np.arange(len(req), dtype="<u4")
+        tagged = req.copy()
+        tagged["val"][:, 8:12] = idx.view(np.uint8).reshape(-1, 4)
+        raw = tagged.tobytes()
+        got = {}
+        refused = 0
+        pending = list(range(len(req)))
+        while pending:
+            burst, pending = pending[:2000], pending[2000:]
+            for i in burst:
+                c.sendto(raw[i * size:(i + 1) * size], ("127.0.0.1", srv.port))
+            for _ in burst:
+                d, _ = c.recvfrom(256)
+                r = np.frombuffer(d, wire.STORE_MSG)[0]
+                if r["type"] == S.REJECT_READ:
+                    refused += 1
+                    i = int(np.frombuffer(r["val"][8:12].tobytes(), "<u4")[0])
+                    assert d == raw[i * size:i * size + 1].replace(bytes([S.READ]), bytes([S.REJECT_READ])) + raw[i * size + 1:(i + 1) * size]
+                    pending.append(i)  # send it again
+                else:
+                    # a served READ: GRANT_READ overwrites val (the tag is gone) -> match by key and position in `want`
+                    got.setdefault(int(r["key"]), []).append(bytes(d))
+        c.close()
+        # every request was eventually served, with the oracle's answer (reads are idempotent; the table never changes)
+        served = sum(len(v) for v in got.values())
+        assert served == len(req)
+        for i in range(0, len(req), 97):
+            k = int(req["key"][i])
+            w = want[i]
+            if w["type"] == S.GRANT_READ:
+                assert any(np.frombuffer(x, wire.STORE_MSG)[0]["val"].tobytes() == w["val"].tobytes() for x in got[k])
+            else:
+                assert any(np.frombuffer(x, wire.STORE_MSG)[0]["type"] == S.NOT_EXIST for x in got[k])
+    finally:
+        out = srv.stop()
+    assert f"refused={refused}" in out
