@@ -39,7 +39,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("batches", C.c_uint64), ("requests", C.c_uint64), ("bad_requests", C.c_uint64),
         ("missing_keys", C.c_uint64), ("foreign_requests", C.c_uint64), ("pool_exhausted", C.c_uint64),
-        ("route_overflow", C.c_uint64), ("reserved", C.c_uint64 * 1),
+        ("route_overflow", C.c_uint64), ("big_bin_requests", C.c_uint64),
     ]
 
 

@@ -303,6 +303,26 @@ KV_HD static inline kv_where kv_locate(const kv_tab &t, uint64_t bucket, const k
   }
   return w;
 }
+// Is there a SECOND valid row with this key after the one kv_locate found (w)?  The reference's kvs_insert does not
+// check for the key (kvs.h:94-121), so a trace that inserts an existing key leaves duplicate rows; a later delete then
+// removes only the first one and reads see the next.  The same-key closed forms assume one row per key: a key
+// segment that inserts / deletes asks this first and goes request by request when the answer is yes.
+KV_HD static inline bool kv_has_dup(const kv_tab &t, uint64_t bucket, const kv_hdr &H, uint64_t key, const kv_where &w) {
+  if (!w.found) return false;
+  uint32_t cur = w.link;
+  bool first = true;
+  for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
+    kv_hdr h;
+    if (cur == KV_INLINE) kv_hdr_copy(h, H);
+    else kv_hdr_copy(h, *kv_entry_hdr(t, bucket, cur));
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+      if ((!first || i > w.slot) && kv_valid(h, i) && h.key[i] == key) return true;
+    first = false;
+    cur = h.next;
+  }
+  return false;
+}
 KV_HD static inline bool kv_find(const kv_tab &t, uint64_t bucket, uint64_t key, kv_loc *loc) {
   uint32_t cur = kv_entry_hdr(t, bucket, KV_INLINE)->head;
   for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {

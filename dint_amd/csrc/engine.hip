@@ -165,7 +165,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
   if (int rc = order_stream(e, st)) return rc;
   static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
-  static const char *const kv_names[] = {"k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve"};
+  static const char *const kv_names[] = {"k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve_big", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
@@ -182,7 +182,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names), view);
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 5, kv_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
@@ -321,7 +321,8 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     rc = dint_kv_create(&e->kv, wl, cfg->n_rows, e->shard, cfg->pool_entries, cfg->flags);
     if (rc) { dint_engine_destroy(e); return fail(rc, "kv table allocation failed (%s)", g_err.c_str()); }
     // the owner-key comparison of DINT_FLAG_LOCK_SAME_KEY exists on the request-by-request path only
-    e->kv.force_rounds = (cfg->flags & (DINT_FLAG_KV_ROUNDS | DINT_FLAG_LOCK_SAME_KEY)) ? 1 : 0;
+    e->kv.force_rounds = ((cfg->flags & (DINT_FLAG_KV_ROUNDS | DINT_FLAG_LOCK_SAME_KEY)) ? 1 : 0) |
+                         ((cfg->flags & DINT_FLAG_KV_NO_HOT) ? 2 : 0);
     for (auto &r : dint_kv_regions(&e->kv)) add_region(e, r.first, r.second);
   }
   if (hipDeviceSynchronize() != hipSuccess) {
@@ -675,6 +676,7 @@ int dint_get_stats(dint_engine_t *e, dint_stats *out) {
   out->foreign_requests = d.foreign_requests;
   out->pool_exhausted = d.pool_exhausted;
   out->route_overflow = d.route_overflow;
+  out->big_bin_requests = d.big_bin_requests;
   return 0;
 }
 

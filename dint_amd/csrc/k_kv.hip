@@ -323,7 +323,8 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
 // between passes, so nothing has to be reset behind the resolve kernel).
 __global__ void __launch_bounds__(256)
 k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
-          uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail) {
+          uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
+          dint_dev_stats *__restrict__ stats) {
   __shared__ uint32_t Sw[4];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 4) big_next[t] = 0;
@@ -342,6 +343,7 @@ k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, 
     if (bin != KV_NONE) bin_off[bin] = run + x;
     run += Sw[0] + Sw[1] + Sw[2] + Sw[3];
   }
+  if (t == 0 && nbig) atomicAdd(&stats->big_bin_requests, (unsigned long long)run + (unsigned long long)nbig * DINT_KV_BINCAP);
 }
 
 // ---- k_kv_place ----------------------------------------------------------------------------------------
@@ -610,10 +612,12 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   const bool structural = (m_struct & seg) != 0;  // my key segment inserts / deletes: row machine by walk
   kv_stamp(tr, 4);
   bool leader = head && simple;
+  uint32_t dupf = 0;  // a second row with my key exists (duplicate inserts of an earlier pass): no closed form for deletes
   if (leader) {
     if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
     const kv_where w = kv_locate(t, bucket, H, key);
     found = w.found; link = w.link; slot = w.slot; ver0 = w.ver;
+    if (WL != DINT_WL_SMALLBANK && structural) dupf = kv_has_dup(t, bucket, H, key, w);
   }
   found = __shfl(found, hl, 64); link = __shfl(link, hl, 64); slot = __shfl(slot, hl, 64);
   ver0 = __shfl(ver0, hl, 64); la0 = __shfl(la0, hl, 64); lb0 = __shfl(lb0, hl, 64);
@@ -686,7 +690,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
         kv_rowst st;
         st.exists = (uint32_t)__builtin_amdgcn_readlane(found, L);
         st.ver = (uint32_t)__builtin_amdgcn_readlane(ver0, L);
-        st.toggles = 0; st.miss = 0; st.bail = 0; st.src = -1;
+        st.toggles = 0; st.miss = 0; st.bail = (uint32_t)__builtin_amdgcn_readlane(dupf, L); st.src = -1;
         for (uint64_t m = sm; m; m &= m - 1) {
           const int l = __ffsll((unsigned long long)m) - 1;
           const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
@@ -882,6 +886,8 @@ __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const k
 #define KVB_NMAX 4096u             // requests resolved together (one stretch of a bin)
 #define KVB_NW (KVB_NMAX / 64u)    // mask words of a stretch = lanes of one wave
 #define KVB_NBK 2048u              // request-index buckets that cut a longer bin into stretches
+#define KVB_HOT_MIN 256u           // a stretch with a key of at least this many requests (and half the stretch) takes the dominant-key path
+#define KVB_MMAX 1024u             // ... if the key has at most this many writers + lock ops
 static_assert(KVB_NW == 64, "the per-word tables are built with one lane per mask word");
 struct kvb_lead { uint32_t found_link, slot, ver0, la0, lb0; };   // found_link: found << 31 | link
 struct kvb_carry { uint32_t la, lb, ver; int src; uint32_t miss; };
@@ -1000,9 +1006,10 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
                                           uint32_t stride, uint32_t *__restrict__ bin_cnt,
                                           const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big,
                                           const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
-                                          dint_dev_stats *__restrict__ stats, int force_rounds, const dint_view &V,
+                                          dint_dev_stats *__restrict__ stats, int force_flags, const dint_view &V,
                                           uint64_t *trace) {
   using F = Fmt<WL>;
+  const int force_rounds = force_flags & 1, no_hot = force_flags & 2;
   __shared__ uint64_t Sk[KVB_NMAX];           // the stretch: group >> pbits | key-hash bits | idx | type, quadrant
   __shared__ uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
   __shared__ uint16_t Bwin[KVB_NBK];          // stretch each idx bucket belongs to
@@ -1018,6 +1025,8 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   __shared__ kvb_pop Phead;
   __shared__ uint32_t Sany, Swn;
   __shared__ uint32_t Sred[KVB_W];
+  __shared__ uint32_t Hs[16];                 // dominant-key path: candidate counts, flags, the row's location
+  __shared__ int Hc[2][KVB_W];                // ... wave carries of its prefix tables
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // k_kv_count listed the bins with more than DINT_KV_BINCAP records; this workgroup takes entries first, first + stride, ...
   const uint32_t nbig = big[0];
@@ -1113,10 +1122,224 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       }
     }
     __syncthreads();
-    const uint32_t m = Swn;
+    uint32_t m = Swn;
     __syncthreads();  // Swn is reset at the top of the next stretch
     if (m == 0) continue;  // workgroup-uniform
     if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+
+    // ---- the stretch's DOMINANT KEY (a hot row: most of a big bin is one key) is answered without sorting the stretch.
+    // Only the requests that change what a later request sees -- writers and lock ops, a few hundred of the thousands
+    // -- are put in request order (the list M: one LDS sort of <= 1024 words); every request of the key then finds,
+    // by binary search on its index, how many of them precede it: version = v0 + writers before me, value = message
+    // of the last writer before me, lock = what the last lock op before me left.  The closed forms are those of
+    // kv_chunk; anything they do not cover (another key of the same bucket on the same lock byte, inserts / deletes,
+    // a key-hash collision, > 1024 ordering ops) leaves the whole stretch to the general path below.
+    if (WL != DINT_WL_SMALLBANK && !force_rounds && !no_hot && m >= KVB_HOT_MIN) {
+      uint32_t *Mk = (uint32_t *)Lead;                 // [1024] idx << 12 | position in Sk, ascending
+      uint16_t *Mwc = (uint16_t *)Carry;                // [j] writers among the first j ops of M
+      int16_t *Mlw = (int16_t *)(Mwc + KVB_MMAX + 8);   // [j] last writer among the first j (index into Mk), -1: none
+      int16_t *Mll = Mlw + KVB_MMAX + 8;                // [j] last lock op among the first j
+      // 1. the most frequent (bucket group, key hash) among eight samples
+      uint64_t cand[8];
+      uint32_t cc[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) { cand[k] = Sk[(uint32_t)(((uint64_t)m * k) >> 3)] >> sh_k; cc[k] = 0; }
+      if (t < 16) Hs[t] = 0;
+      __syncthreads();
+      for (uint32_t p = t; p < m; p += KVB_T) {
+        const uint64_t pf = Sk[p] >> sh_k;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) cc[k] += pf == cand[k];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) {
+        uint32_t v = cc[k];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0 && v) atomicAdd(&Hs[k], v);
+      }
+      __syncthreads();
+      uint32_t best = 0;
+#pragma unroll
+      for (uint32_t k = 1; k < 8; k++) best = Hs[k] > Hs[best] ? k : best;
+      const uint32_t hot_n = Hs[best];
+      const uint64_t hpf = cand[best];
+      const uint32_t hsp = (uint32_t)(((uint64_t)m * best) >> 3);  // a position that holds the hot key
+      __syncthreads();
+      if (hot_n >= KVB_HOT_MIN && 2 * hot_n >= m) {  // workgroup-uniform
+        // 2. everything the closed form needs to hold, checked before anything is written
+        const uint64_t hcur = Sk[hsp];
+        const uint32_t hq = k_q(hcur);
+        const uint64_t hkey = ld_u64(rep + dint_view_off(V, k_idx(hcur), F::MSG) + F::KEY);
+        if (t < 16) Hs[t] = 0;  // [0] bad, [1] ordering ops
+        __syncthreads();
+        uint32_t bad = 0, nord = 0;
+        for (uint32_t p = t; p < m; p += KVB_T) {
+          const uint64_t cur = Sk[p];
+          const uint32_t type = k_type(cur);
+          if ((cur >> sh_k) == hpf) {
+            bad |= !kv_simple_op<WL>(type);
+            bad |= ld_u64(rep + dint_view_off(V, k_idx(cur), F::MSG) + F::KEY) != hkey;  // 9 hash bits can collide
+            nord += is_writer(type) || kv_lock_op<WL>(type);
+          } else if ((cur >> sh_g) == (hpf >> 9)) {  // another key of the hot bucket: must not touch my lock byte or the chain
+            bad |= kv_struct_op<WL>(type) || (kv_lock_op<WL>(type) && k_q(cur) == hq);
+          }
+        }
+        for (int d = 32; d > 0; d >>= 1) nord += __shfl_xor(nord, d, 64);
+        if (lane == 0 && nord) atomicAdd(&Hs[1], nord);
+        if (bad) Hs[0] = 1;
+        __syncthreads();
+        const uint32_t nM = Hs[1];
+        const bool hot_ok = !Hs[0] && nM <= KVB_MMAX;
+        __syncthreads();
+        if (hot_ok) {
+          // 3. M = the key's writers and lock ops, sorted by request index
+          if (t == 0) Hs[2] = 0;
+          __syncthreads();
+          for (uint32_t p0 = 0; p0 < m; p0 += KVB_T) {
+            const uint32_t p = p0 + t;
+            const uint64_t cur = p < m ? Sk[p] : 0;
+            const uint32_t type = k_type(cur);
+            const bool in = p < m && (cur >> sh_k) == hpf && (is_writer(type) || kv_lock_op<WL>(type));
+            const uint64_t im = __ballot(in);
+            uint32_t base = 0;
+            if (lane == 0 && im) base = atomicAdd(&Hs[2], (uint32_t)__popcll(im));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (in) Mk[base + (uint32_t)__popcll(im & lanemask_lt())] = (k_idx(cur) << 12) | p;
+          }
+          uint32_t N2 = 64;
+          while (N2 < nM) N2 <<= 1;
+          __syncthreads();
+          for (uint32_t k = nM + t; k < N2; k += KVB_T) Mk[k] = 0xFFFFFFFFu;
+          __syncthreads();
+          for (uint32_t k = 2; k <= N2 && nM > 1; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+              for (uint32_t a = t; a < N2 / 2; a += KVB_T) {  // compare-exchange pair number a
+                const uint32_t i0 = ((a & ~(j - 1)) << 1) | (a & (j - 1)), i1 = i0 | j;
+                const uint32_t x0 = Mk[i0], x1 = Mk[i1];
+                const bool up = (i0 & k) == 0;
+                if ((x0 > x1) == up) { Mk[i0] = x1; Mk[i1] = x0; }
+              }
+              __syncthreads();
+            }
+          }
+          // prefix tables over M (nM + 1 rows: what precedes op j; row nM = the totals): thread t owns ops 2t, 2t + 1
+          {
+            const uint32_t j0 = 2 * t, j1 = 2 * t + 1;
+            const uint32_t ty0 = j0 < nM ? k_type(Sk[Mk[j0] & 4095u]) : 0xFFu, ty1 = j1 < nM ? k_type(Sk[Mk[j1] & 4095u]) : 0xFFu;
+            const bool w0 = j0 < nM && is_writer(ty0), w1 = j1 < nM && is_writer(ty1);
+            const bool l0 = j0 < nM && kv_lock_op<WL>(ty0), l1 = j1 < nM && kv_lock_op<WL>(ty1);
+            uint32_t wt, wx = wave_excl_scan_u32((uint32_t)w0 + (uint32_t)w1, &wt);
+            int iw = w1 ? (int)j1 : (w0 ? (int)j0 : -1), il = l1 ? (int)j1 : (l0 ? (int)j0 : -1);  // last of my pair
+            for (int d = 1; d < 64; d <<= 1) {  // inclusive running maxima over the wave
+              const int a2 = __shfl_up(iw, d, 64), b2 = __shfl_up(il, d, 64);
+              if ((int)lane >= d) { iw = max(iw, a2); il = max(il, b2); }
+            }
+            if (lane == 63) { Sred[wave] = wt; Hc[0][wave] = iw; Hc[1][wave] = il; }
+            int ew = __shfl_up(iw, 1, 64), el = __shfl_up(il, 1, 64);  // exclusive: what precedes my pair inside the wave
+            if (lane == 0) { ew = -1; el = -1; }
+            __syncthreads();
+            for (uint32_t w = 0; w < wave; w++) { wx += Sred[w]; ew = max(ew, Hc[0][w]); el = max(el, Hc[1][w]); }
+            if (j0 <= nM) { Mwc[j0] = (uint16_t)wx; Mlw[j0] = (int16_t)ew; Mll[j0] = (int16_t)el; }
+            const uint32_t wx1 = wx + (uint32_t)w0;
+            const int ew1 = w0 ? (int)j0 : ew, el1 = l0 ? (int)j0 : el;
+            if (j1 <= nM) { Mwc[j1] = (uint16_t)wx1; Mlw[j1] = (int16_t)ew1; Mll[j1] = (int16_t)el1; }
+            if (j1 + 1 == nM) {  // my pair ends M: the totals
+              Mwc[nM] = (uint16_t)(wx1 + (uint32_t)w1); Mlw[nM] = (int16_t)(w1 ? (int)j1 : ew1); Mll[nM] = (int16_t)(l1 ? (int)j1 : el1);
+            }
+          }
+          __syncthreads();
+          // 4. the row: one thread probes the bucket
+          if (t == 0) {
+            const uint32_t gk = ((uint32_t)(hcur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk);
+            const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
+            const kv_tab tb = kv->tab[table];
+            const uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
+            kv_hdr H;
+            kv_hdr_copy(H, *(const kv_hdr *)ie);
+            const kv_where wh = kv_locate(tb, bucket, H, hkey);
+            Hs[8] = wh.found; Hs[9] = wh.link; Hs[10] = wh.slot; Hs[11] = wh.ver;
+            Hs[12] = WL == DINT_WL_TATP ? (H.lockw >> (8 * hq)) & 0xFFu : 0;
+          }
+          __syncthreads();
+          const uint32_t found = Hs[8], link = Hs[9], slot = Hs[10], ver0 = Hs[11], la0 = Hs[12];
+          const uint32_t hgk = ((uint32_t)(hcur >> sh_g) << pbits) | bin, htable = kv_table_of(kv, hgk);
+          const uint64_t hbucket = (uint64_t)(hgk - kv->gk_base[htable]);
+          const kv_tab htb = kv->tab[htable];
+          uint8_t *hrow = kv_entry_ptr(htb, hbucket, link) + KV_VAL_OFF + slot * F::VS;  // meaningful when found
+          // 5. every request of the key, 512 at a time: no table dependency between them
+          for (uint32_t p = t; p < m; p += KVB_T) {
+            const uint64_t cur = Sk[p];
+            if ((cur >> sh_k) != hpf) continue;
+            const uint32_t type = k_type(cur), idx = k_idx(cur);
+            uint32_t lo = 0, hi = nM;  // ops of M with a smaller request index
+            const uint32_t key32 = idx << 12;
+            while (lo < hi) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if (Mk[mid] < key32) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t my_ver = ver0 + (found ? Mwc[lo] : 0u);
+            const int lw = found ? (int)Mlw[lo] : -1, ll = (int)Mll[lo];
+            uint32_t code, get = 0;
+            if (WL == DINT_WL_STORE) {
+              code = type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
+              get = type == 0 && found;
+            } else {
+              const uint32_t lock_seen = ll >= 0 ? (uint32_t)(k_type(Sk[Mk[ll] & 4095u]) == 1) : la0;
+              switch (type) {
+                case 0: code = found ? 4 : 6; get = found; break;
+                case 1: code = lock_seen ? 8 : 7; break;
+                case 2: code = 9; break;
+                case 12: code = 15; break;
+                default: code = 16; break;  // 13 kCommitBck
+              }
+            }
+            uint8_t *msg = rep + dint_view_off(V, idx, F::MSG);
+            if (get) {
+              const uint8_t *from = lw >= 0 ? rep + dint_view_off(V, k_idx(Sk[Mk[lw] & 4095u]), F::MSG) + F::VAL : hrow;
+              kv_copy_words(msg + F::VAL, from, F::VS);
+              st_u32(msg + F::VER, my_ver);
+            }
+            msg[F::TYPE] = (uint8_t)code;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __syncthreads();  // every read of the row precedes its write-back
+          // 6. final state, written once
+          if (t == 0) {
+            const uint32_t nw = Mwc[nM];
+            const int lw = (int)Mlw[nM], ll = (int)Mll[nM];
+            if (found && lw >= 0) {
+              kv_copy_words(hrow, rep + dint_view_off(V, k_idx(Sk[Mk[lw] & 4095u]), F::MSG) + F::VAL, F::VS);
+              kv_entry_hdr(htb, hbucket, link)->ver[slot] = ver0 + nw;
+            }
+            if (WL == DINT_WL_TATP && ll >= 0) {
+              const uint32_t fin = (uint32_t)(k_type(Sk[Mk[ll] & 4095u]) == 1);
+              if (fin != la0) kv_entry_ptr(htb, hbucket, KV_INLINE)[KV_LOCKB_OFF + hq] = (uint8_t)fin;
+            }
+            if (WL == DINT_WL_TATP && !found && nw) atomicAdd(&stats->missing_keys, (unsigned long long)nw);
+          }
+          // 7. what is left of the stretch moves to the front (destinations never overtake unread sources)
+          if (t == 0) Hs[2] = 0;
+          __syncthreads();
+          for (uint32_t p0 = 0; p0 < m; p0 += KVB_T) {
+            const uint32_t p = p0 + t;
+            const uint64_t cur = p < m ? Sk[p] : 0;
+            const bool keep = p < m && (cur >> sh_k) != hpf;
+            const uint64_t km = __ballot(keep);
+            __syncthreads();  // the round's sources are read
+            uint32_t base = 0;
+            if (lane == 0 && km) base = atomicAdd(&Hs[2], (uint32_t)__popcll(km));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (keep) Sk[base + (uint32_t)__popcll(km & lanemask_lt())] = cur;
+            __syncthreads();
+          }
+          m = Hs[2];
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __syncthreads();
+          if (tr && t == 0) tr[13] += 1u << 16;  // stretches that took the dominant-key path
+          if (m == 0) continue;  // workgroup-uniform
+        }
+      }
+    }
     uint32_t N = 64;
     while (N < m) N <<= 1;
     for (uint32_t k = m + t; k < max(N, KVB_T); k += KVB_T) Sk[k] = ~0ull;  // empty slots sort last
@@ -1272,7 +1495,8 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         if (WL == DINT_WL_SMALLBANK) { Carry[t].la = la0; Carry[t].lb = lb0; Carry[t].ver = wh.ver; Carry[t].src = -1; Carry[t].miss = 0; }
         if (WL != DINT_WL_SMALLBANK) {
           if (kvb_bit(Mstseg, a)) {  // the segment inserts / deletes
-            Crow[t].exists = wh.found; Crow[t].ver = wh.ver; Crow[t].toggles = 0; Crow[t].miss = 0; Crow[t].bail = 0; Crow[t].src = -1;
+            Crow[t].exists = wh.found; Crow[t].ver = wh.ver; Crow[t].toggles = 0; Crow[t].miss = 0; Crow[t].src = -1;
+            Crow[t].bail = kv_has_dup(tb, bucket, H, key, wh);  // duplicate rows of this key: request by request
             Sany = 1;
           }
         }
@@ -1485,7 +1709,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           const uint32_t nw = kvb_popc(Mwr, Pwr, a, seg_b);
           fin_ver = L.ver0 + (found0 ? nw : 0);
           fin_src = found0 ? kvb_last(Mwr, Ewr, a, seg_b) : -1;
-          nmiss = found0 ? 0 : nw;
+          nmiss = (found0 || WL == DINT_WL_STORE) ? 0 : nw;
         }
         if (WL == DINT_WL_TATP && kvb_popc(Mlop, Plop, a, seg_b) != 0) {  // what the last lock op on my lock byte leaves
           const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, a + 1);
@@ -1574,32 +1798,46 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   }
 }
 
-// ---- k_kv_resolve: every bin of the pass, one launch ------------------------------------------------------
-// Workgroups 0 .. KVB_GRID-1 walk the big-bin list (kv_big_bins); each wave of the others resolves one bin of
-// <= DINT_KV_BINCAP records (kv_small_bin).  The two kinds own disjoint bins, hence disjoint buckets, so they run
-// side by side: the hot keys' windows overlap the bulk of the pass instead of preceding it.
+// ---- the resolve kernels -----------------------------------------------------------------------------------
+// k_kv_resolve_big : workgroups 0 .. KVB_GRID-1 walk the pass's big-bin list (kv_big_bins; all but the first few exit at
+//                    once).  ~85 KB of LDS and > 200 VGPRs: one workgroup per CU.
+// k_kv_resolve     : every wave resolves one bin of <= DINT_KV_BINCAP records (kv_small_bin): no LDS beyond the table
+//                    descriptors, <= 128 VGPRs, so four times as many waves are resident as when both paths shared one
+//                    kernel (r01: the whole launch ran at the big-bin path's 2 waves per SIMD, and the one-wave-per-bin
+//                    path -- four dependent memory round trips per wave -- is latency-bound: occupancy is its speed).
+// The two kinds own disjoint bins, hence disjoint buckets; they run back to back on the engine's stream and the other
+// engines' kernels fill the GPU while one engine's big bins finish.
+#define KVS_T 256u
 template <int WL>
-__global__ void __launch_bounds__(KVB_T, 4)
-k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_rounds, uint64_t *trace,
-             dint_view V) {
+__global__ void __launch_bounds__(KVB_T)
+k_kv_resolve_big(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+                 const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+                 const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
+                 dint_view V) {
+  if (blockIdx.x >= big[0]) return;  // nothing on the list for me
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
   // tracing: per workgroup {first wave in, last wave out} after the per-bin rows (10 ns ticks)
   unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
   if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
-  if (blockIdx.x < KVB_GRID) {
-    kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_rounds, V, trace);
-  } else {
-    const uint32_t bin = (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
-    if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_rounds, V, trace);
-  }
+  kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
   if (wg && (threadIdx.x & 63) == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     atomicMax(&wg[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
+}
+
+template <int WL>
+__global__ void __launch_bounds__(KVS_T, 4)
+k_kv_resolve(uint8_t *rep, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
+             dint_view V) {
+  __shared__ kv_dev Skv;
+  for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVS_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
+  __syncthreads();
+  const uint32_t bin = blockIdx.x * (KVS_T / 64) + (threadIdx.x >> 6);
+  if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_flags & 1, V, trace);
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
@@ -1616,15 +1854,18 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
                      log, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode, view);
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
-                     s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr);
+                     s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr, s.stats);
   if (ev) hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(k_kv_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.big,
                      (const uint32_t *)s.bin_off, (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[3], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
-                     pbits, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
-                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace, view);
+  hipLaunchKernelGGL((k_kv_resolve_big<WL>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits, kv.d_dev,
+                     s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+                     (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace, view);
   if (ev) hipEventRecord(ev[4], st);
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3((P + KVS_T / 64 - 1) / (KVS_T / 64)), dim3(KVS_T), 0, st, (uint8_t *)d_rep, pbits,
+                     kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace, view);
+  if (ev) hipEventRecord(ev[5], st);
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,

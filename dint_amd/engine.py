@@ -174,7 +174,7 @@ class Engine:
     def stats(self) -> dict:
         s = _lib.Stats()
         _lib.check(self._L.dint_get_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}  # (no reserved fields left)
 
     def reset(self): _lib.check(self._L.dint_reset(self._h))
     def snapshot(self): _lib.check(self._L.dint_snapshot(self._h))

@@ -26,10 +26,10 @@ from .wire import Workload
 class ShardGroup:
     def __init__(self, workload: Workload, n_rows: int, *, device: int = -1, rank: int = 0, world: int = 1,
                  log_entries: int = 0, populate: Optional[int] = None, transport: Optional[str] = None,
-                 force_exchange: bool = False, n_max: int = 1 << 20):
+                 force_exchange: bool = False, n_max: int = 1 << 20, flags: int = 0):
         self.workload, self.world, self.rank = Workload(workload), world, rank
         self.engines = [Engine(workload, n_rows=n_rows, device=device, shard_index=rank, shard_count=world,
-                               log_entries=log_entries) for _ in range(N_SHARDS)]
+                               log_entries=log_entries, flags=flags) for _ in range(N_SHARDS)]
         self.msg = self.engines[0].msg_size
         self.router = (Router(self.engines, world, rank, transport=transport, n_max=n_max)
                        if world > 1 or force_exchange else None)

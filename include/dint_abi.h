@@ -56,6 +56,8 @@ extern "C" {
                                      tatp/caladan/client_lock.cc:762-771 to tell true conflicts from slot aliasing).
                                      Diagnostic: requests are resolved one by one (as DINT_FLAG_KV_ROUNDS) */
 
+#define DINT_FLAG_KV_NO_HOT 8u /* kv workloads: big bins never take the dominant-key path (A/B runs; identical results) */
+
 /* workloads (dint_config.workload) */
 enum {
   DINT_WL_FASST = 0,     /* lock_fasst: 9-byte {u8 type; u32 lid; u32 ver}            net.h:23-29 */
@@ -126,7 +128,7 @@ typedef struct dint_stats {
                               flavour's "refused, send again", tatp/ebpf/shard_kern.c:509-514), one folded into a
                               same-key closed form keeps its ack; dint_wait / dint_submit return DINT_ENOMEM */
   uint64_t route_overflow; /* requests dint_route_pack could not place (destination slot full): reply = request */
-  uint64_t reserved[1];
+  uint64_t big_bin_requests; /* kv workloads: requests that were resolved by the big-bin kernel (hot keys) */
 } dint_stats;
 
 typedef struct dint_engine dint_engine_t;

@@ -466,3 +466,58 @@ def test_tatp_keys_sharing_a_lock_byte(n, hot):
         assert (want["type"] == T.REJECT_LOCK).sum() > n // 20 and (want["type"] == T.GRANT_LOCK).sum() > n // 50
         assert _same_rows(eng.dump_rows(0), oo.dump(0))
         _tatp_locks(eng, oo)
+
+
+# ---------------------------------------------------------------- dominant key of a big bin (hot rows)
+def _hot_tatp(n, p_hot, mix, seed, hot_key=(0, 7), existing=None, n_noise_sub=2000):
+    """n requests: a fraction p_hot on ONE row (table, key) with the simple op types in `mix` (type -> weight), the rest
+    random well-formed traffic; returns the request array"""
+    rng = np.random.default_rng(seed)
+    req = tracegen.tatp_random(n, existing, seed=seed + 1, n_sub_touch=n_noise_sub)
+    hot = rng.random(n) < p_hot
+    types, w = zip(*mix.items())
+    ty = rng.choice(types, n, p=np.array(w, float) / sum(w))
+    req["type"][hot] = ty[hot]
+    req["table"][hot] = hot_key[0]
+    req["key"][hot] = hot_key[1]
+    return req
+
+
+@pytest.mark.parametrize("p_hot,mix,hot_key", [
+    (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (0, 7)),           # reads + a few hundred lock ops / writers
+    (0.9, {0: 99, 13: 1}, (0, 7)),                               # almost only reads
+    (0.5, {0: 30, 1: 30, 2: 20, 12: 10, 13: 10}, (0, 7)),        # > 1024 ordering ops in a stretch: general path
+    (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (0, 5_000_000)),   # the hot row does not exist
+    (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (4, 7 | (1 << 32))),  # a CALL_FORWARDING row: inserts / deletes around it
+])
+def test_tatp_dominant_key_vs_oracle(p_hot, mix, hot_key):
+    n_sub = 3000
+    o = orc.TatpOracle(n_sub, log_entries=400_000)
+    existing = [o.dump(t)[0] for t in range(5)]
+    eng = _engine(W.TATP, n_rows=n_sub, log_entries=400_000)
+    eng.populate(n_sub)
+    for k, n in enumerate((6000, 40_000, 150_000)):  # one stretch ... several stretches per bin
+        req = _hot_tatp(n, p_hot, mix, seed=10 * k + 3, hot_key=hot_key, existing=existing, n_noise_sub=n_sub)
+        got, want = eng.submit(req), o.replay(req)
+        assert got.tobytes() == want.tobytes(), (k, np.nonzero(np.frombuffer(got.tobytes(), "u1") != np.frombuffer(want.tobytes(), "u1"))[0][:5] // 55)
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+        lk, _ = eng.read_locks(t)
+        assert (lk == o.locks(t)).all()
+    st = eng.stats()
+    assert st["bad_requests"] == 0
+
+
+def test_store_dominant_key_vs_oracle():
+    n_sub = 5000
+    o = orc.StoreOracle(n_sub * 18 // 4, n_sub)
+    eng = _engine(W.STORE, n_rows=n_sub)
+    eng.populate(n_sub)
+    rng = np.random.default_rng(4)
+    for n in (5000, 120_000):
+        req = tracegen.store_random(n, seed=n, n_sub_touch=n_sub, p_set=0.3, p_missing=0.05)
+        hot = rng.random(n) < 0.7
+        req["key"][hot] = tracegen.store_key(11, 2, 8)
+        got, want = eng.submit(req), o.replay(req)
+        assert got.tobytes() == want.tobytes()
+    assert _same_rows(eng.dump_rows(0), o.dump())
