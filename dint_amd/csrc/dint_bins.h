@@ -1,0 +1,222 @@
+// dint_bins.h -- the pass machinery every workload's kernels share (included by k_kv.hip and k_locks.hip; everything
+// here has internal linkage).  One pass = count (each request reserves a position in the bin of its group; the
+// reservations of a workgroup on one bin are merged in an LDS hash) -> k_kv_scan (ranges of the overflow area for the
+// bins of more than DINT_KV_BINCAP records) -> k_kv_place (overflow records into their range) -> resolve.  Also the
+// helpers of the big-bin workgroups: an LDS / register bitonic sort of a stretch of <= KVB_NMAX 64-bit keys, and O(1)
+// range queries (bits set, last / next set bit) over 4096-bit masks of the sorted stretch.
+#pragma once
+#include "dint_kernels.h"
+
+#define KV_TB 1024u           // threads per workgroup of k_kv_count / k_kv_place (= requests per workgroup)
+#define KV_NONE 0xFFFFFFFFu
+
+__device__ static inline uint32_t block_hash_insert(uint32_t *keys, uint32_t k) {  // 2 * KV_TB slots, keys != KV_NONE
+  uint32_t h = (k * 0x9E3779B1u) >> (32 - 11);
+  for (;;) {
+    const uint32_t old = atomicCAS(&keys[h], KV_NONE, k);
+    if (old == KV_NONE || old == k) return h;
+    h = (h + 1) & (2 * KV_TB - 1);
+  }
+}
+static_assert(KV_TB == 1024, "block_hash_insert assumes 2048 slots");
+
+// ---- k_kv_scan: one workgroup ---------------------------------------------------------------------------
+// Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area; make the pass's log tail
+// current; clear the counters the next pass will use (the big-bin lists and the published log counts alternate
+// between passes, so nothing has to be reset behind the resolve kernel).
+static __global__ void __launch_bounds__(256)
+k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
+          uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
+          dint_dev_stats *__restrict__ stats) {
+  __shared__ uint32_t Sw[4];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 4) big_next[t] = 0;
+  for (uint32_t k = t; k < 1024; k += 256) blk_pub_next[k] = 0;
+  if (t == 0 && tail) tail[0] = tail[1];
+  const uint32_t nbig = big[0];
+  uint32_t run = 0;
+  for (uint32_t lo = 0; lo < nbig; lo += 256) {  // workgroup-uniform trip count; one trip unless the pass is very skewed
+    const uint32_t bin = lo + t < nbig ? big[4 + lo + t] : KV_NONE;
+    const uint32_t extra = bin != KV_NONE ? bin_cnt[bin] - DINT_KV_BINCAP : 0;
+    uint32_t tot, x = wave_excl_scan_u32(extra, &tot);
+    __syncthreads();
+    if (lane == 0) Sw[wave] = tot;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; w++) x += Sw[w];
+    if (bin != KV_NONE) bin_off[bin] = run + x;
+    run += Sw[0] + Sw[1] + Sw[2] + Sw[3];
+  }
+  if (t == 0 && nbig) atomicAdd(&stats->big_bin_requests, (unsigned long long)run + (unsigned long long)nbig * DINT_KV_BINCAP);
+}
+
+// ---- k_kv_place ----------------------------------------------------------------------------------------
+// Overflow records (positions DINT_KV_BINCAP.. of a bin): from the pass's list into their bin's range.
+#define KV_PLACE_GRID 64u
+static __global__ void __launch_bounds__(KV_TB)
+k_kv_place(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off, const uint4 *__restrict__ ovl,
+           uint64_t *__restrict__ ovf) {
+  const uint32_t novl = big[1];
+  for (uint32_t i = blockIdx.x * KV_TB + threadIdx.x; i < novl; i += KV_PLACE_GRID * KV_TB) {
+    const uint4 o = ovl[i];
+    ovf[bin_off[o.z] + o.w - DINT_KV_BINCAP] = ((uint64_t)o.y << 32) | o.x;
+  }
+}
+
+// ---- big bins ----------------------------------------------------------------------------------------------
+#define KVB_T 512u
+#define KVB_W (KVB_T / 64u)
+#define KVB_GRID 512u              // workgroups that walk the big-bin list (most exit at once)
+#define KVB_NMAX 4096u             // requests resolved together (one stretch of a bin)
+#define KVB_NW (KVB_NMAX / 64u)    // mask words of a stretch = lanes of one wave
+#define KVB_NBK 2048u              // request-index buckets that cut a longer bin into stretches
+#define KVB_HOT_MIN 256u           // a stretch with a key of at least this many requests (and half the stretch) takes the dominant-key path
+#define KVB_MMAX 1024u             // ... if the key has at most this many writers + lock ops
+static_assert(KVB_NW == 64, "the per-word tables are built with one lane per mask word");
+struct kvb_lead { uint32_t found_link, slot, ver0, la0, lb0; };   // found_link: found << 31 | link
+struct kvb_carry { uint32_t la, lb, ver; int src; uint32_t miss; };
+struct kvb_pop { uint16_t below[KVB_NW + 1]; };                  // bits set in the words before w
+struct kvb_edge { int16_t last[KVB_NW], next[KVB_NW]; };         // highest set bit before word w / lowest after it, -1: none
+
+__device__ static inline void kvb_build_pop(const uint64_t *M, kvb_pop &P) {  // one whole wave
+  const uint32_t lane = lane_id();
+  uint32_t tot;
+  const uint32_t x = wave_excl_scan_u32((uint32_t)__popcll(M[lane]), &tot);
+  P.below[lane] = (uint16_t)x;
+  if (lane == 63) P.below[KVB_NW] = (uint16_t)tot;
+}
+__device__ static inline void kvb_build_edge(const uint64_t *M, kvb_edge &E) {  // one whole wave
+  const int lane = (int)lane_id();
+  const uint64_t m = M[lane];
+  int hi = m ? lane * 64 + 63 - __clzll((long long)m) : -1;
+  int lo = m ? lane * 64 + __ffsll((unsigned long long)m) - 1 : 0x7FFF;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int a = __shfl_up(hi, d, 64), b = __shfl_down(lo, d, 64);
+    if (lane >= d) hi = max(hi, a);
+    if (lane + d < 64) lo = min(lo, b);
+  }
+  const int a = __shfl_up(hi, 1, 64), b = __shfl_down(lo, 1, 64);
+  E.last[lane] = (int16_t)(lane ? a : -1);
+  E.next[lane] = (int16_t)((lane == 63 || b == 0x7FFF) ? -1 : b);
+}
+__device__ static inline bool kvb_bit(const uint64_t *M, uint32_t p) { return (M[p >> 6] >> (p & 63)) & 1ull; }
+__device__ static inline uint32_t kvb_below(const uint64_t *M, const kvb_pop &P, uint32_t x) {  // bits set in [0, x)
+  const uint32_t w = x >> 6, r = x & 63;
+  return P.below[w] + (r ? (uint32_t)__popcll(M[w] & ((1ull << r) - 1ull)) : 0u);
+}
+__device__ static inline uint32_t kvb_popc(const uint64_t *M, const kvb_pop &P, uint32_t a, uint32_t b) {  // in [a, b)
+  return a < b ? kvb_below(M, P, b) - kvb_below(M, P, a) : 0u;
+}
+__device__ static inline int kvb_last(const uint64_t *M, const kvb_edge &E, uint32_t a, uint32_t b) {  // highest in [a, b) or -1
+  if (a >= b) return -1;
+  const uint32_t w = (b - 1) >> 6, r = b & 63;
+  const uint64_t m = M[w] & (r ? (1ull << r) - 1ull : ~0ull);
+  const int res = m ? (int)(w * 64 + 63 - __clzll((long long)m)) : (int)E.last[w];
+  return res >= (int)a ? res : -1;
+}
+__device__ static inline int kvb_first(const uint64_t *M, const kvb_edge &E, uint32_t a) {  // lowest at or above a, or -1
+  if (a >= KVB_NMAX) return -1;
+  const uint32_t w = a >> 6;
+  const uint64_t m = M[w] & (~0ull << (a & 63));
+  return m ? (int)(w * 64 + __ffsll((unsigned long long)m) - 1) : (int)E.next[w];
+}
+__device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, uint32_t b) {  // bits set in [a, b), no table
+  uint32_t cnt = 0;
+  for (uint32_t w = a >> 6; w <= ((b - 1) >> 6) && a < b; w++) {
+    uint64_t m = M[w];
+    if (w == (a >> 6)) m &= ~0ull << (a & 63);
+    if (w == ((b - 1) >> 6) && (b & 63)) m &= (1ull << (b & 63)) - 1ull;
+    cnt += (uint32_t)__popcll(m);
+  }
+  return cnt;
+}
+
+// Bitonic sort of KVB_T * R keys held R per thread (thread t owns positions R*t .. R*t + R - 1): the steps with a
+// partner inside the thread run in registers, those inside the wave by shuffle, and only the few with a partner in
+// another wave go through LDS (the key array itself is the staging area -- every key is in a register by then --
+// laid out [r][t] so the exchange is conflict-free).
+template <int R>
+__device__ __attribute__((noinline)) static void kvb_sort_blocked(uint64_t *Sk) {
+  uint64_t *X = Sk;
+  const uint32_t t = threadIdx.x;
+  uint64_t v[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) v[r] = Sk[R * t + r];
+  auto cmpx = [](uint64_t &a, uint64_t &b, bool up) {  // up: a <= b afterwards
+    const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = up ? lo : hi; b = up ? hi : lo;
+  };
+  for (uint32_t k = 2; k <= KVB_T * R; k <<= 1) {
+    for (uint32_t j = k >> 1; j >= (uint32_t)R; j >>= 1) {  // partner in thread t ^ (j / R), same register
+      const uint32_t tj = j / R;
+      const bool low = (t & tj) == 0;
+      if (tj >= 64) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++) X[r * KVB_T + t] = v[r];
+        __syncthreads();
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        uint64_t o;
+        if (tj < 64) {
+          const uint32_t lo = __shfl_xor((uint32_t)v[r], (int)tj, 64), hi = __shfl_xor((uint32_t)(v[r] >> 32), (int)tj, 64);
+          o = ((uint64_t)hi << 32) | lo;
+        } else {
+          o = X[r * KVB_T + (t ^ tj)];
+        }
+        const bool up = ((R * t + r) & k) == 0;
+        v[r] = (low == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
+      }
+    }
+#pragma unroll
+    for (int jj = R / 2; jj > 0; jj >>= 1) {  // partner in the same thread
+      if ((uint32_t)jj < k) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if ((r & jj) == 0) cmpx(v[r], v[r | jj], ((R * t + r) & k) == 0);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; r++) Sk[R * t + r] = v[r];
+  __syncthreads();
+}
+
+// sort Sk[0, m) ascending (m <= KVB_NMAX; the slots up to the next power of two are filled with ~0 and sort last).
+// <= 512 keys: one per thread, in-wave steps by shuffle, the wide ones through LDS; more: 2 / 4 / 8 keys per thread.
+__device__ static inline void kvb_sort_stretch(uint64_t *Sk, uint32_t m) {
+  const uint32_t t = threadIdx.x;
+  uint32_t N = 64;
+  while (N < m) N <<= 1;
+  for (uint32_t k = m + t; k < max(N, KVB_T); k += KVB_T) Sk[k] = ~0ull;  // empty slots sort last
+  __syncthreads();
+  if (N <= KVB_T) {
+    uint64_t v = Sk[t];
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        uint64_t o;
+        if (j < 64) {
+          const uint32_t lo = __shfl_xor((uint32_t)v, (int)j, 64), hi = __shfl_xor((uint32_t)(v >> 32), (int)j, 64);
+          o = ((uint64_t)hi << 32) | lo;
+        } else {
+          Sk[t] = v;
+          __syncthreads();
+          o = Sk[t ^ j];
+          __syncthreads();
+        }
+        const bool up = (t & k) == 0, low = (t & j) == 0;
+        v = (low == up) ? (v < o ? v : o) : (v < o ? o : v);
+      }
+    }
+    Sk[t] = v;
+    __syncthreads();
+  } else if (N == 2 * KVB_T) {
+    kvb_sort_blocked<2>(Sk);
+  } else if (N == 4 * KVB_T) {
+    kvb_sort_blocked<4>(Sk);
+  } else {
+    kvb_sort_blocked<8>(Sk);
+  }
+}

@@ -9,14 +9,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define DINT_MICRO 65536u          // max requests per kernel pass (idx fits 16 bits)
-#define DINT_PMAX 2048u            // max bins per pass
-#define DINT_KV_PASS 1048576u      // store / tatp / smallbank: max requests per kernel pass (idx fits 20 bits)
+#define DINT_MICRO 65536u          // log append: max requests per kernel pass
+#define DINT_KV_PASS 1048576u      // every other workload: max requests per kernel pass (idx fits 20 bits)
 #define DINT_KV_PMAX 32768u        // ... and max bins per pass
 #define DINT_KV_BINCAP 64u         // records a bin holds in place; the rest goes to the pass's overflow area
-#define DINT_WCAP 512u             // records resolved per window inside one bin
-#define DINT_HSIZE 1024u           // LDS hash slots per window (2 x WCAP)
-#define DINT_EMPTY 0xFFFFFFFFu
 
 // ---- fasthash64 ------------------------------------------------------------------------
 __host__ __device__ static inline uint64_t dint_mix(uint64_t h) {
@@ -109,20 +105,6 @@ __host__ __device__ static inline size_t dint_view_off(const dint_view &v, uint3
   return (size_t)q * v.seg_stride + (size_t)r * msg;
 }
 
-// ---- batch record: one 64-bit word per request --------------------------------------------
-//   bits  0..31  group key (local lock slot, or table_base + local bucket)
-//   bits 32..47  request index inside the micro-batch
-//   bits 48..55  op (workload-specific small integer)
-//   bits 56..63  aux (table id / lock quadrant)
-__device__ static inline uint64_t dint_rec(uint32_t gk, uint32_t idx, uint32_t op, uint32_t aux) {
-  return (uint64_t)gk | ((uint64_t)(idx & 0xFFFF) << 32) | ((uint64_t)(op & 0xFF) << 48) |
-         ((uint64_t)(aux & 0xFF) << 56);
-}
-__device__ static inline uint32_t rec_gk(uint64_t r) { return (uint32_t)r; }
-__device__ static inline uint32_t rec_idx(uint64_t r) { return (uint32_t)(r >> 32) & 0xFFFF; }
-__device__ static inline uint32_t rec_op(uint64_t r) { return (uint32_t)(r >> 48) & 0xFF; }
-__device__ static inline uint32_t rec_aux(uint64_t r) { return (uint32_t)(r >> 56) & 0xFF; }
-
 // ---- wave helpers (wave = 64 lanes) ----------------------------------------------------------
 __device__ static inline uint32_t lane_id() { return threadIdx.x & 63; }
 __device__ static inline uint64_t lanemask_lt() {
@@ -155,60 +137,3 @@ __device__ static inline uint64_t wave_sort_u64(uint64_t w) {
   }
   return w;
 }
-
-// ---- idx ranking: restore request order inside a bin ---------------------------------------------
-// A bin receives its records in arbitrary order (atomic reservation), but every record carries
-// its request index.  The wave marks the indices present in a bitmap over [0, n), prefix-sums the
-// words, and rank(idx) = number of marked indices below idx.  LDS: bm[nwords], wpre[nwords] (u16),
-// lbase[64].  nwords = ceil(n/32) <= 2048.
-struct dint_rank_lds {
-  uint32_t bm[DINT_MICRO / 32];
-  uint16_t wpre[DINT_MICRO / 32];
-  uint32_t lbase[64];
-};
-
-__device__ static inline void rank_build(dint_rank_lds &L, const uint64_t *__restrict__ recs, uint32_t c,
-                                         uint32_t n) {
-  const uint32_t lane = lane_id();
-  const uint32_t nwords = (n + 31) >> 5;
-  const uint32_t wpl = (nwords + 63) >> 6;  // words per lane
-  for (uint32_t w = lane; w < nwords; w += 64) L.bm[w] = 0;
-  __syncthreads();
-  for (uint32_t k = lane; k < c; k += 64) {
-    uint32_t idx = rec_idx(recs[k]);
-    atomicOr(&L.bm[idx >> 5], 1u << (idx & 31));
-  }
-  __syncthreads();
-  uint32_t run = 0;
-  for (uint32_t j = 0; j < wpl; j++) {
-    uint32_t w = lane * wpl + j;
-    if (w < nwords) {
-      L.wpre[w] = (uint16_t)run;
-      run += __popc(L.bm[w]);
-    }
-  }
-  uint32_t tot;
-  uint32_t base = wave_excl_scan_u32(run, &tot);
-  L.lbase[lane] = base;
-  __syncthreads();
-}
-
-__device__ static inline uint32_t rank_of(const dint_rank_lds &L, uint32_t idx, uint32_t n) {
-  const uint32_t nwords = (n + 31) >> 5;
-  const uint32_t wpl = (nwords + 63) >> 6;
-  uint32_t w = idx >> 5;
-  return L.lbase[w / wpl] + L.wpre[w] + __popc(L.bm[w] & ((1u << (idx & 31)) - 1u));
-}
-
-// ---- LDS hash (group key -> dense entry) used for in-window grouping ----------------------------
-__device__ static inline uint32_t lds_hash_insert(uint32_t *keys, uint32_t gk, bool *is_new) {
-  uint32_t h = (gk * 0x9E3779B1u) >> (32 - 10);  // DINT_HSIZE = 1024
-  *is_new = false;
-  for (;;) {
-    uint32_t old = atomicCAS(&keys[h], DINT_EMPTY, gk);
-    if (old == DINT_EMPTY) { *is_new = true; return h; }
-    if (old == gk) return h;
-    h = (h + 1) & (DINT_HSIZE - 1);
-  }
-}
-static_assert(DINT_HSIZE == 1024, "lds_hash_insert assumes 1024 slots");

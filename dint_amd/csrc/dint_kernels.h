@@ -17,11 +17,11 @@ struct dint_dev_stats {
 
 // scratch shared by every workload: bins of batch records
 struct dint_scratch {
-  uint32_t *bin_cnt;   // [DINT_PMAX | DINT_KV_PMAX]   zero between passes (the resolve kernels re-zero their own)
-  uint64_t *bins;      // locks: [DINT_PMAX][DINT_MICRO];  kv: [DINT_KV_PMAX][DINT_KV_BINCAP]
+  uint32_t *bin_cnt;   // [DINT_KV_PMAX]   zero between passes (the resolve kernels re-zero their own)
+  uint64_t *bins;      // [DINT_KV_PMAX][DINT_KV_BINCAP]
   dint_dev_stats *stats;
-  uint32_t *blk_cnt;   // per-block counts of the log scan [256]  (lock_2pl / lock_fasst / log)
-  // ---- store / tatp / smallbank only (k_kv.hip) ----
+  uint32_t *blk_cnt;   // per-block counts of the log scan [256]  (log_server)
+  // ---- every workload but log_server (dint_bins.h) ----
   uint32_t *blk_pub;   // [1024] log requests per 1024-request slice of the pass, bit 31 = published
   uint32_t *blk_pub_next;  // ... of the next pass (two arrays, used alternately)
   uint32_t *big;       // [4 + DINT_KV_PMAX]: big[0] = number of bins with more than DINT_KV_BINCAP records in this
@@ -36,13 +36,8 @@ struct dint_shard {
   uint32_t index, count;  // count >= 1
 };
 
-static inline uint32_t dint_pick_bins(uint32_t n) {
-  // ~32 records per bin on average, so that almost every bin fits one 64-lane chunk (one wave resolves one
-  // bin); power of two, <= DINT_PMAX
-  uint32_t p = 1;
-  while (p < DINT_PMAX && p * 32u < n) p <<= 1;
-  return p;
-}
+// ~32 records per bin on average, so that almost every bin fits one 64-lane chunk (one wave resolves one bin); power
+// of two, <= DINT_KV_PMAX
 static inline uint32_t dint_pick_bins_kv(uint32_t n) {
   uint32_t p = 1;
   while (p < DINT_KV_PMAX && p * 32u < n) p <<= 1;

@@ -163,17 +163,21 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0,
              const dint_view &view = dint_flat_view()) {
   if (int rc = order_stream(e, st)) return rc;
-  static const char *const lock_names[] = {"k_lock_scatter", "k_lock_resolve"};
+  static const char *const lock_names[] = {"k_lock_count", "k_kv_scan+k_kv_place", "k_lock_resolve_big", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
   static const char *const kv_names[] = {"k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve_big", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                        timer_events(e, 2, lock_names), view);
+                        timer_events(e, 4, lock_names), view);
+      std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists alternate between passes
+      std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
     case DINT_WL_2PL:
       dint_launch_2pl(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                      timer_events(e, 2, lock_names), view);
+                      timer_events(e, 4, lock_names), view);
+      std::swap(e->scratch.big, e->scratch.big_next);
+      std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
     case DINT_WL_LOG:
       if (view.seg_cap) return fail(DINT_ESTATE, "the log workload is not sharded by key");
@@ -267,8 +271,8 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   }
   const uint32_t wl = cfg->workload;
   const bool is_kv = wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK;
-  // requests per kernel pass: the request index must fit the batch record (16 bits, kv passes 20 bits)
-  e->pass_max = is_kv ? DINT_KV_PASS : DINT_MICRO;
+  // requests per kernel pass: the request index must fit the batch record (20 bits; the log append 16)
+  e->pass_max = wl == DINT_WL_LOG ? DINT_MICRO : DINT_KV_PASS;
   if (cfg->max_pass) e->pass_max = std::min<uint32_t>(e->pass_max, std::max<uint32_t>(cfg->max_pass, 64u));
   if (wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
     // a pass never laps the log ring, so a DELETE_LOG record keeps the val bytes of the record it overwrites
@@ -278,7 +282,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   }
   TRY(dev_alloc((void **)&e->scratch.stats, sizeof(dint_dev_stats)));
   add_region(e, e->scratch.stats, sizeof(dint_dev_stats));
-  if (is_kv) {
+  if (wl != DINT_WL_LOG) {  // the bins of one pass: 64 records in place per bin + the pass's overflow area
     TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
     TRY(dev_alloc((void **)&e->scratch.blk_pub, 2 * 1024 * sizeof(uint32_t)));
@@ -288,10 +292,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
-  } else {
-    TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_PMAX * sizeof(uint32_t)));
-    if (wl != DINT_WL_LOG)  // the log append has no bins
-      TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_PMAX * DINT_MICRO * sizeof(uint64_t), false));
+  } else {  // the log append has no bins: per-block counts of its scan only
     TRY(dev_alloc((void **)&e->scratch.blk_cnt, 256 * sizeof(uint32_t)));
   }
   TRY(slot_alloc(e, 0));

@@ -1,4 +1,4 @@
-// k_locks.hip -- lock_fasst and lock_2pl on gfx950: one pass = two kernels.
+// k_locks.hip -- lock_fasst and lock_2pl on gfx950, on the pass structure of the kv workloads (dint_bins.h).
 //
 // Reference semantics (serial, one message at a time):
 //   lock_fasst/udp/server.cc:78-119   READ / ACQUIRE_LOCK / ABORT / COMMIT on locks[], ver_table[]
@@ -6,20 +6,26 @@
 // Both index a direct-mapped table with slot = fasthash64(&lid,4,0xdeadbeef) % n_slots; lids that
 // collide modulo n_slots share one lock word -- that aliasing is part of the semantics.
 //
-// GPU formulation.  Ops on different slots commute, ops on one slot must apply in request order.
-//   kernel A  k_lock_scatter : one thread per request: decode, hash, slot, append a 64-bit record
-//             {slot, idx, op} to bin = (slot >> 4) & (P-1) (atomic reservation; order inside a bin is
-//             arbitrary), and copy the request bytes to the reply array.
-//   kernel B  k_lock_resolve : one wave per bin: restore request order with a bitmap rank over idx,
-//             group the window's records by slot in an LDS hash, fetch every distinct slot's 8-byte
-//             {a,b} word from HBM once (all loads in flight together), then walk the records in
-//             request order 64 at a time: lanes whose slot is unique in their chunk apply their op
-//             directly on the LDS copy; slots hit by several lanes of a chunk are resolved in lane
-//             (= request) order -- lock_fasst in closed form with ballots, lock_2pl by a short
-//             wave-uniform loop.  Dirty words are written back once.  No global atomics, no locks.
-// The table is an array of uint2 in HBM: fasst {lock, ver}, 2pl {num_ex, num_sh}; (slot >> 4) keeps the
-// 16 slots of a 128-byte line in one bin, hence in one wave and one XCD's L2.
-#include "dint_kernels.h"
+// GPU formulation.  Ops on different slots commute, ops on one slot must apply in request order.  One pass
+// (n <= 2^20 requests):
+//   k_lock_count       : one thread per request: decode, hash, slot, reserve a position in bin = (slot >> 4) & (P-1)
+//                        (P ~ n / 32; the 16 slots of a 128-byte line share a bin) -- the reservations of a workgroup on
+//                        one bin are merged in an LDS hash, so a hot slot costs one device atomic per workgroup -- and
+//                        store the 64-bit record {slot, idx, op} in place (positions < 64) or on the overflow list;
+//                        copy the request bytes to the reply array.
+//   k_kv_scan / _place : ranges of the overflow area for the bins of more than 64 records (shared with the kv passes)
+//   k_lock_resolve     : one wave per bin of <= 64 records: sort by (slot, idx) in registers -- slots commute, so any
+//                        order that keeps each slot's requests in request order is serial-equivalent -- fetch every
+//                        slot's 8-byte word once, resolve all slots of the chunk at once (lock_fasst: closed form
+//                        with ballots; lock_2pl: the counters are walked per slot with wave-uniform registers), write
+//                        each changed word back once.  No LDS, no global atomics.
+//   k_lock_resolve_big : one 512-thread workgroup per bigger bin (a hot slot): the bin is sorted in LDS a stretch of <=
+//                        4096 records at a time; slots whose requests sit inside one 64-record chunk are resolved as
+//                        above, all chunks in parallel; a slot whose requests cross chunks is walked by one wave with
+//                        the slot's word in registers -- O(requests), where r01 re-ranked the bin once per 512-record
+//                        window (O(c^2 / 512)) and kept 1 GB of worst-case scratch.
+// The table is an array of uint2 in HBM: fasst {lock, ver}, 2pl {num_ex, num_sh}.
+#include "dint_bins.h"
 
 struct __attribute__((packed)) fasst_msg {  // lock_fasst/udp/net.h:23-29
   uint8_t type;
@@ -32,60 +38,118 @@ struct __attribute__((packed)) tpl_msg {  // lock_2pl/udp/net.h:25-31
   uint8_t type;
 };
 
+// batch record: slot (32 bits) << 23 | request index (20 bits) << 3 | op (3 bits).  Sorting the records as integers
+// groups them by slot, request order inside a slot.
+__device__ static inline uint64_t lk_rec(uint32_t slot, uint32_t idx, uint32_t op) { return ((uint64_t)slot << 23) | ((uint64_t)idx << 3) | op; }
+__device__ static inline uint32_t lk_slot(uint64_t r) { return (uint32_t)(r >> 23); }
+__device__ static inline uint32_t lk_idx(uint64_t r) { return (uint32_t)(r >> 3) & 0xFFFFFu; }
+__device__ static inline uint32_t lk_op(uint64_t r) { return (uint32_t)r & 7u; }
+
 // ------------------------------------------------------------------------------------------
 template <int WL>  // 0 = lock_fasst, 1 = lock_2pl
-__global__ void __launch_bounds__(256)
-k_lock_scatter(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod slots, dint_shard shard,
-               uint32_t pmask, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins,
-               dint_dev_stats *__restrict__ stats, dint_view V) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
+__global__ void __launch_bounds__(KV_TB)
+k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod slots, dint_shard shard, uint32_t pbits,
+             uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
+             uint4 *__restrict__ ovl, dint_dev_stats *__restrict__ stats, dint_view V) {
+  constexpr uint32_t MSG = WL == 0 ? sizeof(fasst_msg) : sizeof(tpl_msg);
+  __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
+  __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
+  __shared__ uint32_t Sov[2];
+  const uint32_t t = threadIdx.x, i = blockIdx.x * KV_TB + t;
+  Hb[t] = KV_NONE; Hb[t + KV_TB] = KV_NONE;
+  Hc[t] = 0; Hc[t + KV_TB] = 0;
+  if (t == 0) Sov[0] = 0;
+  __syncthreads();
   bool live;
-  const size_t off = dint_view_off(V, i, WL == 0 ? sizeof(fasst_msg) : sizeof(tpl_msg), &live);
-  if (!live) return;  // padding slot of a segmented pass
-  uint32_t lid, op;
-  bool ok;
-  if (WL == 0) {
-    fasst_msg m = *(const fasst_msg *)(req + off);
-    if (rep != req) *(fasst_msg *)(rep + off) = m;
-    lid = m.lid;
-    op = m.type;  // 0 READ, 1 ACQUIRE_LOCK, 2 ABORT, 3 COMMIT
-    ok = op <= 3;
-  } else {
-    tpl_msg m = *(const tpl_msg *)(req + off);
-    if (rep != req) *(tpl_msg *)(rep + off) = m;
-    lid = m.lid;
-    if (m.action == 0) {  // ACQUIRE: op 0 shared, 1 exclusive; any other lock type panics in the reference
-      ok = m.type <= 1;
-      op = m.type;
-    } else if (m.action == 1) {  // RELEASE: op 2 shared, 3 exclusive, 4 = unknown type (ack, no change)
-      ok = true;
-      op = 2u + (m.type <= 1 ? m.type : 2u);
+  const size_t off = dint_view_off(V, i < n ? i : 0, MSG, &live);
+  live = live && i < n;
+  // replies are the request mutated in place: copy this slice (contiguous passes with separate arrays only)
+  if (rep != req) {
+    const size_t lo = (size_t)blockIdx.x * KV_TB * MSG, hi = min((size_t)n * MSG, lo + (size_t)KV_TB * MSG);
+    if ((((uintptr_t)req | (uintptr_t)rep) & 15) == 0) {
+      const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 576 vectors
+      if (t < nv) ((uint4 *)(rep + lo))[t] = ((const uint4 *)(req + lo))[t];
+      for (size_t k = lo + (size_t)nv * 16 + t; k < hi; k += KV_TB) rep[k] = req[k];
     } else {
-      ok = false;
-      op = 0;
+      for (size_t k = lo + t; k < hi; k += KV_TB) rep[k] = req[k];
     }
   }
-  if (!ok) {
-    atomicAdd(&stats->bad_requests, 1ULL);
-    return;
-  }
-  uint64_t g = dint_fastmod(dint_hash_lid(lid), slots);
-  uint32_t local = (uint32_t)g;
-  if (shard.count > 1) {
-    if ((uint32_t)(g % shard.count) != shard.index) {
-      atomicAdd(&stats->foreign_requests, 1ULL);
-      return;
+  uint32_t lid = 0, op = 0;
+  bool ok = false;
+  if (live) {
+    if (WL == 0) {
+      const fasst_msg m = *(const fasst_msg *)(req + off);
+      lid = m.lid;
+      op = m.type;  // 0 READ, 1 ACQUIRE_LOCK, 2 ABORT, 3 COMMIT
+      ok = op <= 3;
+    } else {
+      const tpl_msg m = *(const tpl_msg *)(req + off);
+      lid = m.lid;
+      if (m.action == 0) {  // ACQUIRE: op 0 shared, 1 exclusive; any other lock type panics in the reference
+        ok = m.type <= 1;
+        op = m.type;
+      } else if (m.action == 1) {  // RELEASE: op 2 shared, 3 exclusive, 4 = unknown type (ack, no change)
+        ok = true;
+        op = 2u + (m.type <= 1 ? m.type : 2u);
+      }
     }
-    local = (uint32_t)(g / shard.count);
+    if (!ok) atomicAdd(&stats->bad_requests, 1ULL);
   }
-  const uint32_t bin = (local >> 4) & pmask;
-  const uint32_t pos = atomicAdd(&bin_cnt[bin], 1u);
-  bins[(size_t)bin * DINT_MICRO + pos] = dint_rec(local, i, op, 0);
+  uint32_t bin = KV_NONE, local = 0;
+  if (ok) {
+    const uint64_t g = dint_fastmod(dint_hash_lid(lid), slots);
+    local = (uint32_t)g;
+    bool mine = true;
+    if (shard.count > 1) {
+      mine = (uint32_t)(g % shard.count) == shard.index;
+      if (!mine) atomicAdd(&stats->foreign_requests, 1ULL);
+      local = (uint32_t)(g / shard.count);
+    }
+    if (mine) bin = (local >> 4) & ((1u << pbits) - 1u);
+  }
+  uint32_t e = 0, mypos = 0;
+  if (bin != KV_NONE) {
+    e = block_hash_insert(Hb, bin);
+    mypos = atomicAdd(&Hc[e], 1u);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < 2; k++) {
+    const uint32_t sl = t + k * KV_TB;
+    if (Hb[sl] != KV_NONE) {
+      const uint32_t cnt = Hc[sl], base = atomicAdd(&bin_cnt[Hb[sl]], cnt);
+      Hc[sl] = base;
+      if (base <= DINT_KV_BINCAP && base + cnt > DINT_KV_BINCAP) big[4 + atomicAdd(&big[0], 1u)] = Hb[sl];
+    }
+  }
+  __syncthreads();
+  if (bin != KV_NONE) mypos += Hc[e];
+  const uint64_t rec = lk_rec(local, i, op);
+  const bool over = bin != KV_NONE && mypos >= DINT_KV_BINCAP;
+  if (bin != KV_NONE && !over) bins[(size_t)bin * DINT_KV_BINCAP + mypos] = rec;
+  uint32_t orank = 0;
+  if (over) orank = atomicAdd(&Sov[0], 1u);
+  __syncthreads();
+  if (Sov[0]) {  // workgroup-uniform
+    if (t == 0) Sov[1] = atomicAdd(&big[1], Sov[0]);
+    __syncthreads();
+    if (over) ovl[Sov[1] + orank] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 struct FasstOps {
+  static constexpr bool CLOSED = true;  // a slot's requests have a closed form: any number of them resolves in parallel
+  // request at sorted position p of a slot segment: `lock_before` = what the last lock-writing op below it left (ACQUIRE
+  // leaves 1 whether granted or not, ABORT / COMMIT leave 0), else the stored lock; ver_before = ver0 + COMMITs below
+  __device__ static void closed(uint32_t op, uint32_t lock_before, uint32_t ver_before, uint32_t &code, uint32_t &rv) {
+    switch (op) {
+      case 0: code = 4; rv = ver_before; break;
+      case 1: code = lock_before ? 6 : 5; break;
+      case 2: code = 7; break;
+      default: code = 8; break;
+    }
+  }
   // one op on one slot word {x = lock, y = ver}: lock_fasst/udp/server.cc:85-114
   __device__ static uint32_t apply(uint32_t op, uint2 &st, uint32_t &rv, bool &wr) {
     switch (op) {
@@ -94,36 +158,6 @@ struct FasstOps {
               return 6;                                            //          else REJECT_LOCK
       case 2: wr = st.x != 0; st.x = 0; return 7;                  // ABORT: CAS 1->0, ABORT_ACK
       default: st.y++; st.x = 0; wr = true; return 8;              // COMMIT: ver++, unlock, COMMIT_ACK
-    }
-  }
-  // all lanes of `same` target one slot; resolve them in lane order in closed form:
-  //   lock before lane l = value written by the last lock-writing op (ACQUIRE sets 1 whether granted
-  //   or not; ABORT/COMMIT set 0) below l, else the initial lock;  ver before l = ver0 + #COMMITs below l.
-  __device__ static void resolve_group(uint64_t same, bool mine, uint32_t op, uint2 *Hst, uint32_t *Hfl,
-                                       uint32_t se, bool is_leader, uint32_t &code, uint32_t &rv) {
-    const uint2 st0 = Hst[se];
-    const uint64_t m_set = __ballot(mine && op != 0);
-    const uint64_t m_acq = __ballot(mine && op == 1);
-    const uint64_t m_com = __ballot(mine && op == 3);
-    (void)same;
-    if (mine) {
-      const uint64_t lt = lanemask_lt();
-      const uint64_t prev = m_set & lt;
-      const uint32_t lock_before = prev ? (uint32_t)((m_acq >> (63 - __clzll(prev))) & 1ULL) : st0.x;
-      const uint32_t ver_before = st0.y + (uint32_t)__popcll(m_com & lt);
-      switch (op) {
-        case 0: code = 4; rv = ver_before; break;
-        case 1: code = lock_before ? 6 : 5; break;
-        case 2: code = 7; break;
-        default: code = 8; break;
-      }
-    }
-    if (is_leader && m_set) {
-      uint2 fin;
-      fin.x = (uint32_t)((m_acq >> (63 - __clzll(m_set))) & 1ULL);
-      fin.y = st0.y + (uint32_t)__popcll(m_com);
-      Hst[se] = fin;
-      atomicOr(&Hfl[se], 0x80000000u);
     }
   }
   // the same closed form over a sorted chunk: `seg` = lane mask of this lane's slot (adjacent lanes, request
@@ -155,6 +189,8 @@ struct FasstOps {
 };
 
 struct TplOps {
+  static constexpr bool CLOSED = false;  // counters: a slot's requests are walked in order
+  __device__ static void closed(uint32_t, uint32_t, uint32_t, uint32_t &, uint32_t &) {}
   // {x = num_ex, y = num_sh}: lock_2pl/udp/server.cc:83-121 (the per-slot spin lock is never
   // contended in a serial replay, so RETRY never occurs)
   __device__ static uint32_t apply(uint32_t op, uint2 &st, uint32_t &rv, bool &wr) {
@@ -165,27 +201,6 @@ struct TplOps {
       case 2: st.y--; wr = true; return 5;  // release shared (unsigned wrap if unmatched, as the reference)
       case 3: st.x--; wr = true; return 5;  // release exclusive
       default: return 5;                    // release with unknown lock type: ack only
-    }
-  }
-  // counters have no closed form: apply the group's ops one by one in lane order (wave-uniform loop)
-  __device__ static void resolve_group(uint64_t same, bool mine, uint32_t op, uint2 *Hst, uint32_t *Hfl,
-                                       uint32_t se, bool is_leader, uint32_t &code, uint32_t &rv) {
-    uint2 st = Hst[se];
-    bool wr = false;
-    const uint32_t lane = lane_id();
-    (void)mine;
-    for (uint64_t m = same; m; m &= m - 1) {
-      const int l = __ffsll((unsigned long long)m) - 1;
-      const uint32_t lop = __builtin_amdgcn_readlane(op, l);
-      uint32_t lrv = 0;
-      bool lwr = false;
-      const uint32_t lcode = apply(lop, st, lrv, lwr);
-      wr |= lwr;
-      if ((int)lane == l) { code = lcode; rv = lrv; }
-    }
-    if (is_leader && wr) {
-      Hst[se] = st;
-      atomicOr(&Hfl[se], 0x80000000u);
     }
   }
   // sorted chunk: single requests apply their op directly; longer segments are walked once each with
@@ -226,122 +241,377 @@ struct TplOps {
   }
 };
 
+// one sorted chunk of <= 64 records (ascending, invalid lanes last): every slot whose requests all sit in the chunk.
+// `take` = this lane's slot segment is handled here (false: its segment crosses into another chunk -- see the big bins)
 template <class Ops>
-__global__ void __launch_bounds__(64)
-k_lock_resolve(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
+__device__ static inline void lk_chunk(uint8_t *rep, const dint_view &V, uint2 *__restrict__ table, uint64_t w, bool valid,
+                                       bool first_is_head, bool last_is_tail) {
+  const uint32_t lane = lane_id();
+  const uint32_t slot = lk_slot(w), idx = lk_idx(w), op = lk_op(w);
+  const uint32_t up = __shfl_up(slot, 1, 64);
+  const bool head = valid && (lane == 0 || up != slot);
+  const uint64_t hm = __ballot(head), vm = __ballot(valid);
+  const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
+  const int hl = valid ? 63 - __clzll(hm & le) : (int)lane;
+  const uint64_t above = hm & ~le;
+  const uint64_t next = above ? (above & (~above + 1ull)) : vm + 1ull;
+  uint64_t seg = valid ? ((next - 1ull) & ~((1ull << hl) - 1ull)) : 0;
+  // a segment that starts before the chunk or goes on after it is not mine
+  const int nvalid = __popcll(vm);
+  bool take = valid;
+  if (!first_is_head && hl == 0) take = false;
+  if (!last_is_tail && valid && ((seg >> (nvalid - 1)) & 1ull)) take = false;
+  if (!take) seg = 0;
+  const bool thead = head && take;
+  uint2 st0 = make_uint2(0, 0);
+  if (thead) st0 = table[slot];
+  st0.x = __shfl(st0.x, hl, 64);
+  st0.y = __shfl(st0.y, hl, 64);
+  uint32_t code = 0, rv = 0;
+  uint2 fin = st0;
+  bool dirty = false;
+  Ops::resolve_sorted(take, seg, op, st0, code, rv, fin, dirty);
+  if (take) Ops::write_reply(rep, V, idx, op, code, rv);
+  if (thead && dirty) table[slot] = fin;
+}
+
+template <class Ops>
+__global__ void __launch_bounds__(256, 4)
+k_lock_resolve(uint8_t *rep, uint32_t pbits, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
                const uint64_t *__restrict__ bins, dint_view V) {
-  __shared__ dint_rank_lds R;
-  __shared__ uint32_t Srec[DINT_WCAP];  // idx | entry << 16 | op << 26, in request order
-  __shared__ uint32_t Hk[DINT_HSIZE];   // slot of each hash entry
-  __shared__ uint2 Hst[DINT_HSIZE];     // its table word
-  __shared__ uint32_t Hfl[DINT_HSIZE];  // low 16 bits: lanes of the current chunk on it; bit 31: dirty
-  const uint32_t bin = blockIdx.x, lane = threadIdx.x;
-  const uint64_t *recs = bins + (size_t)bin * DINT_MICRO;
-  const uint64_t r0 = recs[lane];  // speculative (the bin region always exists): overlaps the counter load
+  const uint32_t lane = threadIdx.x & 63, bin = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bin >= (1u << pbits)) return;
+  const uint64_t r0 = bins[(size_t)bin * DINT_KV_BINCAP + lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
-  if (c == 0) return;
-  if (c <= 64) {
-    // The common case (~32 records per bin): sort the records by (slot, idx) in registers.  Slots commute, so any
-    // order that keeps each slot's requests in idx order is serial-equivalent; after the sort they sit in adjacent
-    // lanes.  Every slot's word is fetched once by its first lane, all slots are resolved at once, and each
-    // changed word is written back once.  No LDS.
-    if (lane == 0) bin_cnt[bin] = 0;
-    uint64_t w = ~0ull;
-    if (lane < c) w = ((uint64_t)rec_gk(r0) << 32) | ((uint64_t)rec_idx(r0) << 16) | rec_op(r0);
-    w = wave_sort_u64(w);
-    const bool valid = lane < c;
-    const uint32_t slot = (uint32_t)(w >> 32), idx = (uint32_t)(w >> 16) & 0xFFFF, op = (uint32_t)w & 0xFF;
-    const uint32_t up = __shfl_up(slot, 1, 64);
-    const bool head = valid && (lane == 0 || up != slot);
-    const uint64_t hm = __ballot(head), vm = __ballot(valid);
-    const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
-    const int hl = valid ? 63 - __clzll(hm & le) : (int)lane;
-    const uint64_t above = hm & ~le;
-    const uint64_t next = above ? (above & (~above + 1ull)) : vm + 1ull;
-    const uint64_t seg = valid ? ((next - 1ull) & ~((1ull << hl) - 1ull)) : 0;
-    uint2 st0 = make_uint2(0, 0);
-    if (head) st0 = table[slot];
-    st0.x = __shfl(st0.x, hl, 64);
-    st0.y = __shfl(st0.y, hl, 64);
-    uint32_t code = 0, rv = 0;
-    uint2 fin = st0;
-    bool dirty = false;
-    Ops::resolve_sorted(valid, seg, op, st0, code, rv, fin, dirty);
-    if (valid) Ops::write_reply(rep, V, idx, op, code, rv);
-    if (head && dirty) table[slot] = fin;
-    return;
-  }
-  rank_build(R, recs, c, n);
-
-  for (uint32_t lo = 0; lo < c; lo += DINT_WCAP) {
-    const uint32_t wn = min(DINT_WCAP, c - lo);
-    for (uint32_t h = lane; h < DINT_HSIZE; h += 64) { Hk[h] = DINT_EMPTY; Hfl[h] = 0; }
-    __syncthreads();
-    // gather this window's records in request order and group them by slot
-    for (uint32_t k = lane; k < c; k += 64) {
-      const uint64_t r = recs[k];
-      const uint32_t rk = rank_of(R, rec_idx(r), n) - lo;
-      if (rk < wn) {
-        bool nw;
-        const uint32_t e = lds_hash_insert(Hk, rec_gk(r), &nw);
-        Srec[rk] = rec_idx(r) | (e << 16) | (rec_op(r) << 26);
-      }
-    }
-    __syncthreads();
-    // one HBM read per distinct slot, all in flight together
-    uint2 v[DINT_HSIZE / 64];
-#pragma unroll
-    for (uint32_t j = 0; j < DINT_HSIZE / 64; j++) {
-      const uint32_t k = Hk[lane + 64 * j];
-      v[j] = make_uint2(0, 0);
-      if (k != DINT_EMPTY) v[j] = table[k];
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < DINT_HSIZE / 64; j++) Hst[lane + 64 * j] = v[j];
-    __syncthreads();
-
-    for (uint32_t ch = 0; ch < wn; ch += 64) {
-      const uint32_t j = ch + lane;
-      const bool valid = j < wn;
-      const uint32_t sr = valid ? Srec[j] : 0;
-      const uint32_t idx = sr & 0xFFFF, e = (sr >> 16) & (DINT_HSIZE - 1), op = sr >> 26;
-      if (valid) atomicAdd(&Hfl[e], 1u);
-      __syncthreads();
-      const uint32_t cnt = valid ? (Hfl[e] & 0xFFFF) : 0;
-      uint32_t code = 0, rv = 0;
-      if (valid && cnt == 1) {  // the only request of this chunk on its slot
-        uint2 st = Hst[e];
-        bool wr = false;
-        code = Ops::apply(op, st, rv, wr);
-        if (wr) { Hst[e] = st; atomicOr(&Hfl[e], 0x80000000u); }
-      }
-      uint64_t conf = __ballot(valid && cnt > 1);
-      while (conf) {  // one iteration per slot shared by several lanes of the chunk
-        const int leader = __ffsll((unsigned long long)conf) - 1;
-        const uint32_t se = __builtin_amdgcn_readlane(e, leader);
-        const bool mine = valid && e == se;
-        const uint64_t same = __ballot(mine);
-        Ops::resolve_group(same, mine, op, Hst, Hfl, se, (int)lane == leader, code, rv);
-        conf &= ~same;
-      }
-      __syncthreads();
-      if (valid) {
-        atomicAnd(&Hfl[e], 0x80000000u);
-        Ops::write_reply(rep, V, idx, op, code, rv);
-      }
-      __syncthreads();
-    }
-    // write back the words that changed
-#pragma unroll
-    for (uint32_t j = 0; j < DINT_HSIZE / 64; j++) {
-      const uint32_t h = lane + 64 * j;
-      const uint32_t k = Hk[h];
-      if (k != DINT_EMPTY && (Hfl[h] >> 31)) table[k] = Hst[h];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // next window may re-read these words
-    __syncthreads();
-  }
+  if (c == 0 || c > DINT_KV_BINCAP) return;  // larger bins are on the big-bin list
   if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
+  const uint64_t w = wave_sort_u64(lane < c ? r0 : ~0ull);
+  lk_chunk<Ops>(rep, V, table, w, lane < c, true, true);
+}
+
+// ---- big bins: one 512-thread workgroup each ---------------------------------------------------------------------
+template <class Ops>
+__global__ void __launch_bounds__(KVB_T)
+k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
+                   const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+                   const uint64_t *__restrict__ ovf, dint_view V) {
+  const uint32_t nbig = big[0];
+  if (blockIdx.x >= nbig) return;
+  __shared__ uint64_t Sk[KVB_NMAX];
+  __shared__ uint32_t Bcnt[KVB_NBK / 2];
+  __shared__ uint16_t Bwin[KVB_NBK];
+  __shared__ uint64_t Mhead[KVB_NW];
+  __shared__ kvb_edge Ehead;
+  __shared__ uint64_t Mset[KVB_NW], Macq[KVB_NW], Mcom[KVB_NW];  // closed form: lock-writing ops, ACQUIREs, COMMITs
+  __shared__ kvb_edge Eset;
+  __shared__ kvb_pop Pcom;
+  __shared__ uint32_t Xs[KVB_NW][2];  // slots whose requests cross 64-record chunks: [a, b) in the sorted stretch
+  __shared__ uint32_t Swn, Snx, Sred[KVB_W];
+  __shared__ uint32_t Hs[16], Mk[KVB_MMAX];   // dominant-slot path: counters; its lock-writing ops, idx << 12 | position
+  __shared__ uint16_t Mcc[KVB_MMAX + 8];       // ... COMMITs among the first j of them
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // request-index buckets that cut a bin of more than KVB_NMAX records into stretches (every request of a stretch
+  // precedes every request of the next one)
+  const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 11 ? nbits - 11 : 0u;
+  const uint32_t wcap = KVB_NMAX - (1u << bs);
+  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const uint32_t bin = big[4 + bi];
+    __syncthreads();
+    const uint32_t c = bin_cnt[bin];
+    const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
+    const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;
+    auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
+    uint32_t nwin = 1;
+    if (c > KVB_NMAX) {
+      for (uint32_t w = t; w < KVB_NBK / 2; w += KVB_T) Bcnt[w] = 0;
+      __syncthreads();
+      for (uint32_t k = t; k < c; k += KVB_T) {
+        const uint32_t b = lk_idx(rec_at(k)) >> bs;
+        atomicAdd(&Bcnt[b >> 1], 1u << (16 * (b & 1)));
+      }
+      __syncthreads();
+      uint32_t cw[2], run = 0;  // thread t owns buckets 4t .. 4t+3
+#pragma unroll
+      for (uint32_t j = 0; j < 2; j++) {
+        cw[j] = Bcnt[2 * t + j];
+        run += (cw[j] & 0xFFFF) + (cw[j] >> 16);
+      }
+      uint32_t tot, base = wave_excl_scan_u32(run, &tot);
+      if (lane == 0) Sred[wave] = tot;
+      __syncthreads();
+      for (uint32_t w = 0; w < wave; w++) base += Sred[w];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        Bwin[4 * t + j] = (uint16_t)(base / wcap);
+        base += (cw[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
+      }
+      nwin = (c - 1) / wcap + 1;
+    }
+    __syncthreads();
+    if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
+    for (uint32_t win = 0; win < nwin; win++) {
+      if (t == 0) { Swn = 0; Snx = 0; }
+      __syncthreads();
+      if (c <= KVB_NMAX) {
+        for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = rec_at(k);
+        if (t == 0) Swn = c;
+      } else {
+        for (uint32_t k0 = 0; k0 < c; k0 += KVB_T) {
+          const uint32_t k = k0 + t;
+          const uint64_t r = k < c ? rec_at(k) : 0;
+          const bool in = k < c && Bwin[lk_idx(r) >> bs] == win;
+          const uint64_t im = __ballot(in);
+          uint32_t base = 0;
+          if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (in) Sk[base + (uint32_t)__popcll(im & lanemask_lt())] = r;
+        }
+      }
+      __syncthreads();
+      uint32_t m = Swn;
+      if (m == 0) continue;  // workgroup-uniform
+      // ---- the stretch's DOMINANT SLOT (lock_fasst; a hot lid: most of a big bin is one slot) without sorting the
+      // stretch: only its lock-writing ops (ACQUIRE / ABORT / COMMIT, a minority) are put in request order -- one LDS sort
+      // of <= 1024 words -- and every request of the slot finds by binary search on its index how many precede it:
+      // lock seen = what the last of them left, version seen = ver0 + the COMMITs among them.
+      if (Ops::CLOSED && m >= KVB_HOT_MIN) {
+        uint64_t cand[8];
+        uint32_t cc[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) { cand[k] = Sk[(uint32_t)(((uint64_t)m * k) >> 3)] >> 23; cc[k] = 0; }
+        if (t < 16) Hs[t] = 0;
+        __syncthreads();
+        for (uint32_t p = t; p < m; p += KVB_T) {
+          const uint64_t pf = Sk[p] >> 23;
+#pragma unroll
+          for (uint32_t k = 0; k < 8; k++) cc[k] += pf == cand[k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+          uint32_t v = cc[k];
+          for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+          if (lane == 0 && v) atomicAdd(&Hs[k], v);
+        }
+        __syncthreads();
+        uint32_t best = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++) best = Hs[k] > Hs[best] ? k : best;
+        const uint32_t hot_n = Hs[best];
+        const uint64_t hslot = cand[best];
+        __syncthreads();
+        if (hot_n >= KVB_HOT_MIN && 2 * hot_n >= m) {  // workgroup-uniform
+          if (t < 16) Hs[t] = 0;  // [1] lock-writing ops of the slot, [2] append cursor
+          __syncthreads();
+          uint32_t nord = 0;
+          for (uint32_t p = t; p < m; p += KVB_T) nord += (Sk[p] >> 23) == hslot && lk_op(Sk[p]) != 0;
+          for (int d = 32; d > 0; d >>= 1) nord += __shfl_xor(nord, d, 64);
+          if (lane == 0 && nord) atomicAdd(&Hs[1], nord);
+          __syncthreads();
+          const uint32_t nM = Hs[1];
+          if (nM <= KVB_MMAX) {  // workgroup-uniform
+            for (uint32_t p0 = 0; p0 < m; p0 += KVB_T) {
+              const uint32_t p = p0 + t;
+              const uint64_t cur = p < m ? Sk[p] : 0;
+              const bool in = p < m && (cur >> 23) == hslot && lk_op(cur) != 0;
+              const uint64_t im = __ballot(in);
+              uint32_t base = 0;
+              if (lane == 0 && im) base = atomicAdd(&Hs[2], (uint32_t)__popcll(im));
+              base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+              if (in) Mk[base + (uint32_t)__popcll(im & lanemask_lt())] = (lk_idx(cur) << 12) | p;
+            }
+            uint32_t N2 = 64;
+            while (N2 < nM) N2 <<= 1;
+            __syncthreads();
+            for (uint32_t k = nM + t; k < N2; k += KVB_T) Mk[k] = 0xFFFFFFFFu;
+            __syncthreads();
+            for (uint32_t k = 2; k <= N2 && nM > 1; k <<= 1) {
+              for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t a = t; a < N2 / 2; a += KVB_T) {
+                  const uint32_t i0 = ((a & ~(j - 1)) << 1) | (a & (j - 1)), i1 = i0 | j;
+                  const uint32_t x0 = Mk[i0], x1 = Mk[i1];
+                  if ((x0 > x1) == ((i0 & k) == 0)) { Mk[i0] = x1; Mk[i1] = x0; }
+                }
+                __syncthreads();
+              }
+            }
+            // COMMITs among the first j ops of M (nM + 1 rows): thread t owns ops 2t, 2t + 1
+            {
+              const uint32_t j0 = 2 * t, j1 = 2 * t + 1;
+              const bool c0 = j0 < nM && lk_op(Sk[Mk[j0] & 4095u]) == 3, c1 = j1 < nM && lk_op(Sk[Mk[j1] & 4095u]) == 3;
+              uint32_t wt, wx = wave_excl_scan_u32((uint32_t)c0 + (uint32_t)c1, &wt);
+              if (lane == 63) Sred[wave] = wt;
+              __syncthreads();
+              for (uint32_t w = 0; w < wave; w++) wx += Sred[w];
+              if (j0 <= nM) Mcc[j0] = (uint16_t)wx;
+              if (j1 <= nM) Mcc[j1] = (uint16_t)(wx + c0);
+              if (j1 + 1 == nM) Mcc[nM] = (uint16_t)(wx + c0 + c1);
+            }
+            const uint2 st0 = table[(uint32_t)hslot];  // one word for the whole slot (workgroup-uniform address)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __syncthreads();  // the tables are built and everyone holds the slot's word
+            for (uint32_t p = t; p < m; p += KVB_T) {
+              const uint64_t cur = Sk[p];
+              if ((cur >> 23) != hslot) continue;
+              const uint32_t op = lk_op(cur), key32 = lk_idx(cur) << 12;
+              uint32_t lo = 0, hi = nM;  // lock-writing ops of the slot with a smaller request index
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (Mk[mid] < key32) lo = mid + 1; else hi = mid;
+              }
+              const uint32_t lock_before = lo ? (uint32_t)(lk_op(Sk[Mk[lo - 1] & 4095u]) == 1) : st0.x;
+              uint32_t code = 0, rv = 0;
+              Ops::closed(op, lock_before, st0.y + Mcc[lo], code, rv);
+              Ops::write_reply(rep, V, lk_idx(cur), op, code, rv);
+            }
+            if (t == 0 && nM) {
+              uint2 fin;
+              fin.x = (uint32_t)(lk_op(Sk[Mk[nM - 1] & 4095u]) == 1);
+              fin.y = st0.y + Mcc[nM];
+              if (fin.x != st0.x || fin.y != st0.y) table[(uint32_t)hslot] = fin;
+            }
+            // what is left of the stretch moves to the front (destinations never overtake unread sources)
+            __syncthreads();
+            if (t == 0) Hs[2] = 0;
+            __syncthreads();
+            for (uint32_t p0 = 0; p0 < m; p0 += KVB_T) {
+              const uint32_t p = p0 + t;
+              const uint64_t cur = p < m ? Sk[p] : 0;
+              const bool keep = p < m && (cur >> 23) != hslot;
+              const uint64_t km = __ballot(keep);
+              __syncthreads();
+              uint32_t base = 0;
+              if (lane == 0 && km) base = atomicAdd(&Hs[2], (uint32_t)__popcll(km));
+              base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+              if (keep) Sk[base + (uint32_t)__popcll(km & lanemask_lt())] = cur;
+              __syncthreads();
+            }
+            m = Hs[2];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __syncthreads();
+            if (m == 0) continue;  // workgroup-uniform
+          }
+        }
+      }
+      kvb_sort_stretch(Sk, m);
+      const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
+      // slot heads of the sorted stretch
+      for (uint32_t j = 0; j < ntile; j++) {
+        const uint32_t p = j * KVB_T + t;
+        const bool valid = p < m;
+        const uint64_t hm = __ballot(valid && (p == 0 || lk_slot(Sk[p]) != lk_slot(Sk[p - 1])));
+        if (lane == 0) Mhead[p >> 6] = hm;
+      }
+      for (uint32_t w = ntile * KVB_W + t; w < KVB_NW; w += KVB_T) Mhead[w] = 0;
+      __syncthreads();
+      if (wave == 0) kvb_build_edge(Mhead, Ehead);
+      __syncthreads();
+      // chunks of 64: the slots inside one chunk, all chunks in parallel; list the slots that cross chunks
+      for (uint32_t j = 0; j < ntile; j++) {
+        const uint32_t p = j * KVB_T + t, p0 = p & ~63u;
+        const bool valid = p < m;
+        if (p0 < m) {  // wave-uniform
+          const uint32_t pl = min(p0 + 63u, m - 1);  // last valid position of my chunk
+          const bool first_is_head = kvb_bit(Mhead, p0), last_is_tail = pl + 1 == m || kvb_bit(Mhead, pl + 1);
+          lk_chunk<Ops>(rep, V, table, valid ? Sk[p] : ~0ull, valid, first_is_head, last_is_tail);
+          if (valid && kvb_bit(Mhead, p)) {
+            const int nx = kvb_first(Mhead, Ehead, p + 1);
+            const uint32_t b = nx >= 0 ? (uint32_t)nx : m;
+            if ((p >> 6) != ((b - 1) >> 6)) {
+              const uint32_t k = atomicAdd(&Snx, 1u);
+              Xs[k][0] = p; Xs[k][1] = b;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (Ops::CLOSED) {
+        // the slots that cross chunks, every request in parallel: masks over the whole sorted stretch + O(1) range tables
+        // answer "last lock-writing op below me in my slot" and "COMMITs below me in my slot"
+        if (Snx) {  // workgroup-uniform
+          for (uint32_t j = 0; j < ntile; j++) {
+            const uint32_t p = j * KVB_T + t;
+            const bool valid = p < m;
+            const uint32_t op = valid ? lk_op(Sk[p]) : 0;
+            const uint64_t m1 = __ballot(valid && op != 0), m2 = __ballot(valid && op == 1), m3 = __ballot(valid && op == 3);
+            if (lane == 0) { Mset[p >> 6] = m1; Macq[p >> 6] = m2; Mcom[p >> 6] = m3; }
+          }
+          for (uint32_t w = ntile * KVB_W + t; w < KVB_NW; w += KVB_T) { Mset[w] = 0; Macq[w] = 0; Mcom[w] = 0; }
+          __syncthreads();
+          if (wave == 0) kvb_build_edge(Mset, Eset);
+          if (wave == 1) kvb_build_pop(Mcom, Pcom);
+          __syncthreads();
+          uint2 st[KVB_NMAX / KVB_T];
+          uint32_t sa[KVB_NMAX / KVB_T], sb[KVB_NMAX / KVB_T];
+#pragma unroll
+          for (uint32_t j = 0; j < KVB_NMAX / KVB_T; j++) {
+            const uint32_t p = j * KVB_T + t;
+            sa[j] = sb[j] = 0;
+            st[j] = make_uint2(0, 0);
+            if (p < m) {
+              const uint32_t a = (uint32_t)kvb_last(Mhead, Ehead, 0, p + 1);
+              const int nx = kvb_first(Mhead, Ehead, p + 1);
+              const uint32_t b = nx >= 0 ? (uint32_t)nx : m;
+              if ((a >> 6) != ((b - 1) >> 6)) {  // my slot crosses chunks
+                sa[j] = a; sb[j] = b;
+                st[j] = table[lk_slot(Sk[p])];
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __syncthreads();  // every request has read its slot's word: the write-backs below cannot be seen by them
+#pragma unroll
+          for (uint32_t j = 0; j < KVB_NMAX / KVB_T; j++) {
+            const uint32_t p = j * KVB_T + t, a = sa[j], b = sb[j];
+            if (b == 0) continue;
+            const uint64_t w = Sk[p];
+            const uint32_t op = lk_op(w);
+            const int prev = kvb_last(Mset, Eset, a, p);
+            const uint32_t lock_before = prev >= 0 ? (uint32_t)kvb_bit(Macq, (uint32_t)prev) : st[j].x;
+            uint32_t code = 0, rv = 0;
+            Ops::closed(op, lock_before, st[j].y + kvb_popc(Mcom, Pcom, a, p), code, rv);
+            Ops::write_reply(rep, V, lk_idx(w), op, code, rv);
+            if (p + 1 == b) {  // the slot's last request writes the word back
+              const int last = kvb_last(Mset, Eset, a, b);
+              uint2 fin;
+              fin.x = last >= 0 ? (uint32_t)kvb_bit(Macq, (uint32_t)last) : st[j].x;
+              fin.y = st[j].y + kvb_popc(Mcom, Pcom, a, b);
+              if (fin.x != st[j].x || fin.y != st[j].y) table[lk_slot(w)] = fin;
+            }
+          }
+        }
+      } else {
+      // the slots that cross chunks: one wave each, the slot's word in registers, 64 requests at a time
+      for (uint32_t k = wave; k < Snx; k += KVB_W) {
+        const uint32_t a = Xs[k][0], b = Xs[k][1];
+        const uint32_t slot = lk_slot(Sk[a]);
+        uint2 st = table[slot];  // wave-uniform address
+        st.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.x);
+        st.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.y);
+        bool wr = false;
+        for (uint32_t base = a; base < b; base += 64) {
+          const uint32_t p = base + lane;
+          const bool valid = p < b;
+          const uint64_t w = valid ? Sk[p] : 0;
+          const uint32_t op = lk_op(w);
+          uint32_t code = 0, rv = 0;
+          const uint32_t cnt = min(64u, b - base);
+          for (uint32_t l = 0; l < cnt; l++) {  // request order = lane order
+            const uint32_t lop = (uint32_t)__builtin_amdgcn_readlane((int)op, (int)l);
+            uint32_t lrv = 0;
+            bool lwr = false;
+            const uint32_t lcode = Ops::apply(lop, st, lrv, lwr);
+            wr |= lwr;
+            if (lane == l) { code = lcode; rv = lrv; }
+          }
+          if (valid) Ops::write_reply(rep, V, lk_idx(w), op, code, rv);
+        }
+        if (lane == 0 && wr) table[slot] = st;
+      }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __syncthreads();  // the next stretch sees this stretch's stores; LDS is free again
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -349,14 +619,25 @@ template <int WL, class Ops>
 static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,
                          dint_scratch s, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
   if (n == 0) return;
-  const uint32_t P = dint_pick_bins(n);
+  const uint32_t P = dint_pick_bins_kv(n);
+  uint32_t pbits = 0;
+  while ((1u << pbits) < P) pbits++;
   if (ev) hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL((k_lock_scatter<WL>), dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t *)d_req,
-                     (uint8_t *)d_rep, n, slots, shard, P - 1, s.bin_cnt, s.bins, s.stats, view);
+  hipLaunchKernelGGL((k_lock_count<WL>), dim3((n + KV_TB - 1) / KV_TB), dim3(KV_TB), 0, st, (const uint8_t *)d_req,
+                     (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3(P), dim3(64), 0, st, (uint8_t *)d_rep, n, table, s.bin_cnt,
-                     (const uint64_t *)s.bins, view);
+  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
+                     s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats);
+  hipLaunchKernelGGL(k_kv_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.big,
+                     (const uint32_t *)s.bin_off, (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL((k_lock_resolve_big<Ops>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, table, s.bin_cnt,
+                     (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+                     (const uint64_t *)s.ovf, view);
+  if (ev) hipEventRecord(ev[3], st);
+  hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3((P + 3) / 4), dim3(256), 0, st, (uint8_t *)d_rep, pbits, table, s.bin_cnt,
+                     (const uint64_t *)s.bins, view);
+  if (ev) hipEventRecord(ev[4], st);
 }
 
 void dint_launch_fasst(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,

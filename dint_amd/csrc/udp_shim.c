@@ -268,7 +268,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(a, "--shed")) { o.shed = 1; }
     else { fprintf(stderr, "unknown option %s\n", a); return 2; }
   }
-  const uint32_t batch_max = o.workload >= DINT_WL_STORE ? DINT_KV_PASS_MAX : DINT_MICRO_BATCH;  /* one kernel pass */
+  const uint32_t batch_max = o.workload == DINT_WL_LOG ? DINT_MICRO_BATCH : DINT_KV_PASS_MAX;  /* one kernel pass */
   if (o.batch == 0 || o.batch > batch_max) o.batch = batch_max;
   if (o.threads == 0 || o.threads > 64) o.threads = 2;
 

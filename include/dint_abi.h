@@ -81,8 +81,8 @@ enum {
 };
 
 /* The largest request count one kernel pass handles: dint_submit splits larger
- * arrays into consecutive passes (correct by the serial-order contract).  FASST / 2PL /
- * LOG engines; STORE / TATP / SMALLBANK engines take DINT_KV_PASS_MAX (see max_pass). */
+ * arrays into consecutive passes (correct by the serial-order contract).  LOG engines take
+ * DINT_MICRO_BATCH, every other workload DINT_KV_PASS_MAX (see max_pass). */
 #define DINT_MICRO_BATCH 65536u
 #define DINT_KV_PASS_MAX 1048576u
 
@@ -107,7 +107,7 @@ typedef struct dint_config {
   uint32_t shard_index;
   uint32_t shard_count;
   /* requests per kernel pass; longer submissions run as several passes.  0 = the engine's maximum
-   * (FASST / 2PL / LOG 65,536; STORE / TATP / SMALLBANK 1,048,576, and never more than log_entries). */
+   * (LOG 65,536; every other workload 1,048,576 -- TATP / SMALLBANK never more than log_entries). */
   uint32_t max_pass;
   /* STORE / TATP / SMALLBANK: overflow entries per table (a bucket whose 4 inline slots are taken chains 4-slot
    * entries from this pool; the reference `new`s them without bound, store/udp/kvs.h:95-102).  0 = local buckets / 4

@@ -151,3 +151,29 @@ def test_log_vs_oracle_with_wrap(n, cap):
     ring, t = eng.read_log(cap)
     assert t == o.tail
     assert (np.frombuffer(ring.tobytes(), "u1").reshape(cap, 64) == o.ring).all()
+
+
+# ---------------------------------------------------------------- passes of up to 2^20 requests, hot slots
+@pytest.mark.parametrize("wl", ["fasst", "tpl"])
+@pytest.mark.parametrize("n,nslots,n_hot,p_hot", [
+    (1 << 20, 36_000_000, 3, 0.02),     # one pass; three slots with ~7,000 requests each: several stretches, chunk-crossing walks
+    (1 << 20, 97, 64, 0.5),             # 97 slots: every bin is big, slots of ~5,000 and ~20,000 requests
+    (300_000, 1 << 20, 2000, 0.9),      # many warm slots (~135 requests each): big bins with dozens of slots per chunk
+    (1_200_000, 1 << 20, 1, 0.5),       # two passes; 600,000 requests on ONE slot
+])
+def test_locks_big_passes_vs_oracle(wl, n, nslots, n_hot, p_hot):
+    if wl == "fasst":
+        req, W_, mk = tracegen.fasst_random(n, seed=n_hot, n_hot=n_hot, p_hot=p_hot), wire.Workload.FASST, orc.FasstOracle
+    else:
+        req, W_, mk = tracegen.tpl_random(n, seed=n_hot, n_hot=n_hot, p_hot=p_hot), wire.Workload.TPL, orc.TplOracle
+    eng, o = _engine(W_, n_slots=nslots), mk(nslots)
+    got, want = eng.submit(req), o.replay(req)
+    assert got.tobytes() == want.tobytes()
+    a, b = eng.read_locks()
+    if wl == "fasst":
+        assert (a == o.locks).all() and (b == o.vers).all()
+    else:
+        assert (a == o.num_ex).all() and (b == o.num_sh).all()
+    # the same trace cut into small passes gives the same replies
+    eng2 = _engine(W_, n_slots=nslots, max_pass=4096)
+    assert eng2.submit(req[:200_000]).tobytes() == want[:200_000].tobytes()
