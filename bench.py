@@ -635,9 +635,8 @@ def bench_txn(args, world, rank, dev, transport, kind):
         avg = {k: float(np.mean([t[k]["avg_us"] for t in tims])) for k in names}
         extra["kernels_us"] = {k: round(v, 3) for k, v in avg.items()}
         # A pass = count / scan / place (every request is classified, hashed and binned; log requests are finished
-        # there), k_kv_resolve_big (the bins of more than 64 records: hot keys) and k_kv_resolve (one wave per bin).
-        # The dominant kernel is the one the most time goes to; its algorithmic bytes are those of the requests it
-        # serves (the engines count the requests that went through big bins).
+        # there) and k_kv_resolve (every bin of the pass, one launch: the table requests).  The dominant kernel is the
+        # one the most time goes to; its algorithmic bytes are those of the requests it serves.
         tab_b, log_b, n_tab, launches = 0.0, 0.0, 0, 0
         for e in range(n_t):
             for s in range(3):
@@ -653,8 +652,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
                         tab_b += b * c
                         n_tab += c
         f_big = big_req / max(1, n_tab)
-        cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b * (1.0 - f_big)),
-                "k_kv_resolve_big": (avg.get("k_kv_resolve_big", 0.0), tab_b * f_big),
+        cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b),
                 "k_kv_count+k_kv_scan+k_kv_place": (avg.get("k_kv_count", 0.0) + avg.get("k_kv_scan", 0.0) + avg.get("k_kv_place", 0.0), tab_b + log_b)}
         dom = max(cand, key=lambda k: cand[k][0])
         dom_us, alg = cand[dom][0], cand[dom][1] / max(1, launches)

@@ -55,6 +55,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # libdint.so is linked against libamdhip64; torch ships its own copy.  Loading torch first makes the two share
+        # ONE HIP runtime (the same SONAME resolves to the copy already mapped) -- with two runtimes in the process the
+        # one initialised second finds no device.  Only the ordering matters; no torch symbol is used here.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise DintError(
             f"{LIB_PATH} is missing: the HIP extension has not been built "

@@ -7,7 +7,7 @@
 // Every request touches exactly one bucket of one table (lock_hash % hash_size == kvs bucket), or only
 // the log ring.  Requests on different buckets commute; requests on one bucket apply in request order.
 //
-// One pass (n <= 2^20 requests) = four kernels:
+// One pass (n <= 2^20 requests) = four kernels (the shared ones live in dint_bins.h):
 //   k_kv_count   : one thread per request -- copy the message to the reply array, classify, hash, reserve a position
 //                  in bin = group & (P-1) (P ~ n / 32) -- merged per workgroup in an LDS hash, so a hot key costs one
 //                  device atomic per workgroup -- and store the {bucket group, idx, type | quadrant | key-hash bits}
@@ -844,8 +844,11 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   __shared__ kvb_edge Ehead, Ebh, Ewr, Elk;
   __shared__ uint64_t Mbail[KVB_W];           // tile-local
   __shared__ kvb_lead Lead[KVB_T];            // by key segment number (a stretch with more segments runs request by request)
-  __shared__ kvb_carry Carry[KVB_T];
-  __shared__ kv_rowst Crow[KVB_T];            // row machine of key segments with an INSERT / DELETE (store / tatp)
+  // smallbank walks its counters through Carry[segment], store / tatp the row machine of segments with an INSERT /
+  // DELETE through Crow[segment]: never both in one instantiation, so they share one buffer
+  __shared__ __attribute__((aligned(8))) uint8_t CarryCrow[KVB_T * (sizeof(kv_rowst) > sizeof(kvb_carry) ? sizeof(kv_rowst) : sizeof(kvb_carry))];
+  kvb_carry *Carry = (kvb_carry *)CarryCrow;
+  kv_rowst *Crow = (kv_rowst *)CarryCrow;
   __shared__ uint16_t HeadPos[KVB_T];         // sorted position of each segment's head
   __shared__ kvb_pop Phead;
   __shared__ uint32_t Sany, Swn;
@@ -1592,46 +1595,36 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   }
 }
 
-// ---- the resolve kernels -----------------------------------------------------------------------------------
-// k_kv_resolve_big : workgroups 0 .. KVB_GRID-1 walk the pass's big-bin list (kv_big_bins; all but the first few exit at
-//                    once).  ~85 KB of LDS and > 200 VGPRs: one workgroup per CU.
-// k_kv_resolve     : every wave resolves one bin of <= DINT_KV_BINCAP records (kv_small_bin): no LDS beyond the table
-//                    descriptors, <= 128 VGPRs, so four times as many waves are resident as when both paths shared one
-//                    kernel (r01: the whole launch ran at the big-bin path's 2 waves per SIMD, and the one-wave-per-bin
-//                    path -- four dependent memory round trips per wave -- is latency-bound: occupancy is its speed).
-// The two kinds own disjoint bins, hence disjoint buckets; they run back to back on the engine's stream and the other
-// engines' kernels fill the GPU while one engine's big bins finish.
-#define KVS_T 256u
+// ---- k_kv_resolve: every bin of the pass, one launch ------------------------------------------------------
+// Workgroups 0 .. KVB_GRID-1 walk the big-bin list (kv_big_bins); each wave of the others resolves one bin of
+// <= DINT_KV_BINCAP records (kv_small_bin).  The two kinds own disjoint bins, hence disjoint buckets, so they run
+// side by side: the hot keys' stretches overlap the bulk of the pass instead of preceding it.  The launch carries
+// the big-bin path's footprint (~75 KB of LDS, 128 VGPRs): two workgroups = 16 waves per CU.  (r02 also measured
+// the split form -- big bins in a kernel of their own, the one-wave-per-bin kernel at 91 VGPRs / 5 waves per SIMD
+// behind it on the same stream: the two then run one after the other, 67 + 55 us instead of 105 us, and putting the
+// big-bin kernel on a second stream cost more in cross-stream event waits than the overlap gave; see DESIGN.md.)
 template <int WL>
-__global__ void __launch_bounds__(KVB_T)
-k_kv_resolve_big(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-                 const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-                 const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
-                 dint_view V) {
-  if (blockIdx.x >= big[0]) return;  // nothing on the list for me
+__global__ void __launch_bounds__(KVB_T, 4)
+k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
+             dint_view V) {
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
   // tracing: per workgroup {first wave in, last wave out} after the per-bin rows (10 ns ticks)
   unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
   if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
-  kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
+  if (blockIdx.x < KVB_GRID) {
+    kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
+  } else {
+    const uint32_t bin = (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
+    if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_flags & 1, V, trace);
+  }
   if (wg && (threadIdx.x & 63) == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     atomicMax(&wg[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
-}
-
-template <int WL>
-__global__ void __launch_bounds__(KVS_T, 4)
-k_kv_resolve(uint8_t *rep, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
-             dint_view V) {
-  __shared__ kv_dev Skv;
-  for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVS_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
-  __syncthreads();
-  const uint32_t bin = blockIdx.x * (KVS_T / 64) + (threadIdx.x >> 6);
-  if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_flags & 1, V, trace);
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
@@ -1653,13 +1646,10 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   hipLaunchKernelGGL(k_kv_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.big,
                      (const uint32_t *)s.bin_off, (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[3], st);
-  hipLaunchKernelGGL((k_kv_resolve_big<WL>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits, kv.d_dev,
-                     s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
-                     (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace, view);
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
+                     pbits, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
+                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace, view);
   if (ev) hipEventRecord(ev[4], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3((P + KVS_T / 64 - 1) / (KVS_T / 64)), dim3(KVS_T), 0, st, (uint8_t *)d_rep, pbits,
-                     kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, s.stats, kv.force_rounds, kv.d_trace, view);
-  if (ev) hipEventRecord(ev[5], st);
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,

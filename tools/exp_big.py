@@ -88,6 +88,9 @@ print("big bins (c, start_us, end_us, stretches, rounds), latest end first:", ro
 names = ["gather", "sort", "A", "B", "C+D", "leaders", "tiles", "wb"]
 big_wg = [i for i in range(512) if wg[i, 2] > 0]
 for i in sorted(big_wg, key=lambda i: -(wg[i, 1] - wg[i, 0]))[:4] + sorted(big_wg, key=lambda i: wg[i, 1] - wg[i, 0])[:2]:
+    if wg[i, 10] > 0:
+        hp = [wg[i, 2]] + [wg[i, k] for k in range(10, 16)]
+        print("    dominant-key path us (detect+verify, build+sort M, tables, probe, answers, write-back+compact):", [round((hp[k + 1] - hp[k]) / 100, 1) for k in range(6)])
     st = [wg[i, 0]] + [wg[i, k] for k in range(2, 10)]
     print("  workgroup %d, %.1f us in all; first stretch of its bin, phases us:" % (i, (wg[i, 1] - wg[i, 0]) / 100),
           {names[k]: round((st[k + 1] - st[k]) / 100, 1) for k in range(8)})

@@ -2,8 +2,12 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
-echo "== lock tests"; timeout 1500 python -m pytest tests/test_gpu_locks.py tests/test_gpu_route.py tests/test_fasst_24m.py tests/test_gpu_shim.py tests/test_gpu_async.py -x -q -m gpu 2>&1 | tail -12
-P='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d.get("kernels_us"), d["latency_us"], d["roofline"]["frac"], d.get("replay_equals_recorded"), (d.get("cpu_baseline") or {}).get("oracle_parity"))'
-echo "== r01 fasst 1M"; (cd gpurun_tmp/r01 && timeout 300 python bench.py --workload fasst --steps 50 --no-cpu-baseline --no-rand64 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d.get("kernels_us"), d["latency_us"])')
-echo "== fasst 1M slots"; timeout 300 python bench.py --workload fasst --steps 50 --no-rand64 2>/dev/null | python -c "$P"
-echo "== fasst 36M slots"; timeout 300 python bench.py --workload fasst --slots 36000000 --steps 50 --no-rand64 2>/dev/null | python -c "$P"
+echo "== tests"; timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+P='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d.get("kernels_us"), d["latency_us"]["p50"], d["latency_us"]["p99"], d["roofline"]["kernel"], d["roofline"]["frac"])'
+for i in 1 2 3; do
+echo "== r01"; (cd gpurun_tmp/r01 && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-rand64 2>/dev/null | python -c "$P")
+echo "== current"; timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-rand64 --no-host-path 2>/dev/null | python -c "$P"
+done
+echo "== current 100"; timeout 300 python bench.py --no-cpu-baseline --no-rand64 --no-host-path 2>/dev/null | python -c "$P"
+echo "== store"; timeout 300 python bench.py --workload store --steps 50 --no-cpu-baseline --no-rand64 2>/dev/null | python -c "$P"
+echo "== fasst"; timeout 300 python bench.py --workload fasst --steps 50 --no-cpu-baseline --no-rand64 2>/dev/null | python -c "$P"
