@@ -60,6 +60,10 @@ def parse():
                     help="closed-loop clients per GPU (one outstanding phase each: a tatp shard server sees ~clients * 0.46 "
                          "requests per epoch, all resolved in one kernel pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-reference", action="store_true",
+                    help="tatp: skip the unmodified reference server leg (7M subscribers on both sides; its populate takes minutes)")
+    ap.add_argument("--ref-timeout", type=float, default=300.0,
+                    help="seconds to wait for the reference server's populate once the GPU legs are done")
     ap.add_argument("--no-rand64", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive dint_submit_async measurement")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the multi-GPU exchange (self all-to-all)")
@@ -226,6 +230,36 @@ def cpu_baseline_fasst(sample: np.ndarray, nslots: int, want: bytes):
     return out
 
 
+def cpu_as_shipped_fasst(sample: np.ndarray):
+    """the reference's as-shipped `lock_fasst/udp/server T` (unmodified; real UDP sockets, on
+    127.0.0.1) driven closed-loop over loopback by oracle/ref_harness/udp_loop_client.c with the bench stream: T = 8
+    (exp/run_lock_fasst.sh:48-49) and T = a quarter of the host's logical cores.  The table has the reference's
+    compile-time size (36M slots) whatever --slots says: this leg prices the reference's per-packet path (syscalls +
+    kernel UDP stack + the lock op), not the table."""
+    from oracle import oracle as orc
+
+    if not orc.loopback_available():
+        return None
+    cores = os.cpu_count() or 8
+    runs = []
+    for t in sorted({8, max(8, cores // 4)}):
+        try:
+            r = orc.ref_loopback_fasst(sample, server_threads=t, client_threads=min(2 * t, max(4, cores // 2)), window=32,
+                                       warmup_s=1.0, measure_s=4.0)
+        except Exception as ex:
+            r = {"server_threads": t, "error": f"{type(ex).__name__}: {ex}"}
+        runs.append(r)
+    ok = [r for r in runs if "ops_per_s" in r]
+    if not ok:
+        return {"runs": runs}
+    best = max(ok, key=lambda r: r["ops_per_s"])
+    return {"value": round(best["ops_per_s"] / 1e6, 4), "unit": "Mtxn/s", "cores": best["server_threads"],
+            "kind": "reference", "path": "as shipped: unmodified lock_fasst/udp/server.cc over loopback UDP",
+            "host_cpu": host_cpu(), "runs": runs,
+            "sample": f"{len(sample)} requests of the bench stream replayed closed-loop for 4 s per run "
+                      f"(client threads x window 32 outstanding requests each)"}
+
+
 def bench_fasst(args, world, rank, dev, transport):
     import torch
 
@@ -330,6 +364,7 @@ def bench_fasst(args, world, rank, dev, transport):
     if not args.no_cpu_baseline and world == 1:
         n_s = min(len(stream), 4_000_000 // BATCH * BATCH)  # from the empty table: checkable as a unit
         cpu = cpu_baseline_fasst(stream[:n_s].copy(), args.slots, got[:n_s * msg])
+        extra["cpu_as_shipped"] = cpu_as_shipped_fasst(stream[:n_s].copy())
     return {
         "metric": "Mtxn/s (lock_fasst: 1 txn = 1 request) + p50/p99 batch latency",
         "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -505,6 +540,63 @@ def cpu_baseline_txn(kind, trace, done, n_rows, lo, hi):
                               "what": "GPU replies of shard server 0 vs the CPU oracle, every byte, on the bench stream"}}
 
 
+REF_TATP_SUBSCRIBERS = 7_000_000  # tatp/udp/tatp.h:28 (constexpr: the unmodified server has no other size)
+
+
+def cpu_reference_tatp(ref, args, dev, C, zipf, n_epochs=12):
+    """BASELINE.md 3(1) for the headline workload: the UNMODIFIED tatp/udp/server_shard.cc (oracle/_ref/ref_tatp,
+    sockets interposed, 1 thread) against the engines on the configuration the reference is compiled for -- 7M
+    subscribers on both sides.  A second shard group is populated at 7M rows, the closed loop runs `n_epochs` epochs
+    through it, shard server 0's request stream is replayed by the reference and every reply byte is compared (bytes
+    the reference's populate leaves unassigned are masked on rows never written: oracle.mask_populate_garbage)."""
+    import torch
+
+    from dint_amd import wire
+    from dint_amd.driver import Driver
+    from dint_amd.replay import Replay, ShardGroup, record
+    from oracle import oracle as orc
+
+    n_rows = REF_TATP_SUBSCRIBERS
+    t_setup = time.perf_counter()
+    grp = ShardGroup(wire.Workload.TATP, n_rows, device=dev, rank=0, world=1, transport="self", n_max=KV_PASS)
+    grp.sync()
+    grp.snapshot()
+    drv = Driver(wire.Workload.TATP, C, n_rows, first_client=0, zipf_theta=zipf)
+    trace, done = record(drv, grp, n_epochs)
+    grp.sync()
+    rp = Replay(trace, grp.msg)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    gpu = []
+    for _ in range(3):
+        grp.restore()
+        grp.sync()
+        t = time.perf_counter()
+        rp.run(grp, 0, n_epochs)
+        grp.sync()
+        gpu.append(sum(done) / (time.perf_counter() - t) / 1e6)
+    rp.check(0, n_epochs)
+    req = np.concatenate([trace[e][0][0] for e in range(n_epochs)])
+    want = np.concatenate([trace[e][1][0] for e in range(n_epochs)])
+    ops_per_txn = sum(sum(len(r) for r in trace[e][0]) for e in range(n_epochs)) / max(1, sum(done))
+    del grp, rp
+    if not ref.wait_populated(args.ref_timeout):
+        return {"error": f"reference server not populated within {args.ref_timeout:.0f} s of the GPU legs ending"}
+    rep, st = ref.replay(req)
+    a = orc.mask_populate_garbage("tatp", rep).tobytes()
+    b = orc.mask_populate_garbage("tatp", want).tobytes()
+    return {"value": round(st["ops_per_s"] / ops_per_txn / 1e6, 4), "unit": "Mtxn/s", "cores": 1, "kind": "reference",
+            "ops_per_s": round(st["ops_per_s"]), "ops_per_txn": round(ops_per_txn, 3), "host_cpu": host_cpu(),
+            "sample": f"{len(req)} requests = shard server 0's stream of the first {n_epochs} closed-loop epochs at "
+                      f"{n_rows} subscribers, unmodified tatp/udp/server_shard.cc (oracle/_ref/ref_tatp, sockets "
+                      f"interposed in-process, 1 thread, populate {ref.populate_s:.0f} s not timed)",
+            "gpu_same_config": {"value": round(max(gpu), 3), "unit": "Mtxn/s", "runs": [round(g, 1) for g in gpu],
+                                "subscribers": n_rows, "epochs": n_epochs, "setup_s": round(t_setup, 1),
+                                "what": "the same epochs replayed from HBM through the three engines at 7M subscribers"},
+            "reference_parity": {"requests": len(req), "ok": a == b,
+                                 "what": "GPU replies of shard server 0 vs the unmodified reference server, every byte"}}
+
+
 def host_path(grp, trace, lo, hi):
     """The boundary the reference's servers sit behind hands over HOST buffers: the same recorded batches through
     dint_submit_async / dint_wait from page-locked memory (H2D + kernels + D2H, three staging slots per engine).
@@ -589,6 +681,11 @@ def bench_txn(args, world, rank, dev, transport, kind):
     dt = max_over_ranks(time.perf_counter() - t0, world, transport)
     rp.check(0, W + K)  # parity with the recorded closed-loop run, every reply byte
     overflow = grp.router.overflow() if grp.router is not None else 0
+    ref = None
+    if kind == "tatp" and world == 1 and not (args.no_cpu_baseline or args.no_cpu_reference):
+        from oracle import oracle as orc  # cpu_baseline leg only: the reference populates (minutes, one host core)
+        if orc.ref_available("tatp"):     # while the remaining GPU legs run; the headline region above is over
+            ref = orc.RefServer("tatp")
 
     txns = sum_over_ranks(sum(done[W:W + K]), world, transport)
     ops = sum_over_ranks(rp.ops(W, W + K), world, transport)
@@ -715,6 +812,28 @@ def bench_txn(args, world, rank, dev, transport, kind):
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline_txn(kind, trace, done, n_rows, W, W + min(K, 60))
+        if ref is not None:
+            try:
+                r = cpu_reference_tatp(ref, args, dev, C, zipf)
+            except Exception as ex:  # the reported baseline falls back to the port, with the reason
+                r = {"error": f"{type(ex).__name__}: {ex}"}
+            finally:
+                ref.close()
+            if "error" in r:
+                cpu["reference"] = r
+            else:
+                r["port_on_bench_config"] = cpu
+                cpu = r
+        if kind == "tatp" and not args.no_cpu_reference:
+            # the reference's as-shipped per-packet path on this host (its lock_fasst server: the one udp/ server
+            # that starts in under a second; tatp's shard server spends minutes populating before it binds)
+            from dint_amd import wire as _w
+            probe = np.zeros(1 << 18, _w.FASST_MSG)
+            probe["type"] = 0
+            probe["lid"] = np.random.default_rng(7).integers(0, 24_000_000, len(probe))
+            extra["cpu_as_shipped"] = cpu_as_shipped_fasst(probe)
+            if extra["cpu_as_shipped"]:
+                extra["cpu_as_shipped"]["workload"] = "lock_fasst READ requests over 24M lids (per-packet path cost; not TATP)"
     if kind == "tatp":
         dist_name = f"Zipf-{theta}" if zipf else "tatp_nurand (reference)"
         what = (f"TATP full txn mix (35/35/10/2/14/2/2) on {world} MI355X: {n_rows} subscribers, 3 replicated "

@@ -12,7 +12,7 @@ struct dint_dev_stats {
   unsigned long long foreign_requests;
   unsigned long long pool_exhausted;
   unsigned long long route_overflow;  // requests dropped by dint_route_pack: a destination slot was full
-  unsigned long long big_bin_requests;  // kv workloads: requests resolved by k_kv_resolve_big (bins of > 64 records)
+  unsigned long long big_bin_requests;  // requests resolved by the big-bin workgroups (bins of > 64 records)
 };
 
 // scratch shared by every workload: bins of batch records

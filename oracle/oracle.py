@@ -11,6 +11,7 @@ import json
 import os
 import subprocess
 import tempfile
+import time
 
 import numpy as np
 
@@ -296,3 +297,115 @@ def ref_replay(workload: str, msgs: np.ndarray, dump: bool = False, timeout: flo
             with open(dp, "rb") as f:
                 return replies, stats, f.read()
         return replies, stats
+
+
+class RefServer:
+    """The unmodified reference server started ahead of its trace (REF_TRACE_WAIT, ref_harness/harness_common.h):
+    tatp / smallbank populate for minutes, so a caller starts the server first, does its own work, and hands the
+    trace over when it has one.  `replay` blocks until the server has populated, replayed and exited."""
+
+    def __init__(self, workload: str):
+        self.workload = workload
+        self.td = tempfile.TemporaryDirectory(prefix="dint_ref_")
+        self.tp, self.rp = (os.path.join(self.td.name, x) for x in ("trace.bin", "replies.bin"))
+        env = dict(os.environ, REF_TRACE_WAIT="1")
+        self.t0 = time.perf_counter()
+        self.proc = subprocess.Popen([os.path.join(REF_DIR, REF_BIN[workload]), self.tp, self.rp],
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+        self.populate_s = None
+
+    def populated(self) -> bool:
+        return os.path.exists(self.rp + ".ready")
+
+    def wait_populated(self, timeout: float) -> bool:
+        end = time.perf_counter() + timeout
+        while not self.populated():
+            if self.proc.poll() is not None or time.perf_counter() > end:
+                return False
+            time.sleep(0.05)
+        if self.populate_s is None:
+            self.populate_s = time.perf_counter() - self.t0
+        return True
+
+    def replay(self, msgs: np.ndarray, timeout: float = 600):
+        msgs = np.ascontiguousarray(msgs)
+        msgs.tofile(self.tp)
+        open(self.tp + ".go", "w").close()
+        out, _ = self.proc.communicate(timeout=timeout)
+        if self.proc.returncode != 0:
+            raise RuntimeError(f"reference {self.workload} server failed rc={self.proc.returncode}")
+        stats = json.loads(out.strip().splitlines()[-1])
+        return np.fromfile(self.rp, dtype=msgs.dtype), stats
+
+    def close(self):
+        if self.proc.poll() is None:
+            self.proc.kill()  # the exact process this object started
+            self.proc.wait()
+        self.td.cleanup()
+
+
+def loopback_available() -> bool:
+    return all(os.path.exists(os.path.join(REF_DIR, b)) for b in ("udp_lock_fasst_server", "udp_loop_client"))
+
+
+def ref_loopback_fasst(msgs: np.ndarray, server_threads: int = 8, client_threads: int = 16, window: int = 32,
+                       warmup_s: float = 1.0, measure_s: float = 5.0) -> dict:
+    """the as-shipped reference `lock_fasst/udp/server <T>` (unmodified, its own main() and thread
+    pinning, kernel UDP sockets on 127.0.0.1) driven by ref_harness/udp_loop_client.c replaying `msgs` closed-loop."""
+    with tempfile.TemporaryDirectory(prefix="dint_ref_") as td:
+        tp = os.path.join(td, "requests.bin")
+        np.ascontiguousarray(msgs).tofile(tp)
+        srv = subprocess.Popen([os.path.join(REF_DIR, "udp_lock_fasst_server"), str(server_threads)],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        try:
+            time.sleep(0.5)
+            if srv.poll() is not None:
+                raise RuntimeError(f"reference udp server exited rc={srv.returncode} (port 20230 busy?)")
+            res = subprocess.run([os.path.join(REF_DIR, "udp_loop_client"), tp, str(msgs.dtype.itemsize), "20230",
+                                  str(client_threads), str(window), str(warmup_s), str(measure_s)],
+                                 capture_output=True, text=True, timeout=warmup_s + measure_s + 60)
+            if res.returncode != 0:
+                raise RuntimeError(f"udp_loop_client failed rc={res.returncode}: {res.stderr[-500:]}")
+            out = json.loads(res.stdout.strip().splitlines()[-1])
+        finally:
+            srv.kill()  # the exact process started above
+            srv.wait()
+    out["server_threads"] = server_threads
+    return out
+
+
+# ---------------------------------------------------------------------------- populate-time garbage
+_STORE_GRANT_READ = 3  # store/udp/net.h:22 kGrantRead
+_TATP_GRANT_READ = 4  # tatp/udp/net.h:23 kGrantRead
+#: value bytes the reference's populate code assigns (everything else is stack
+#: garbage in the reference, zero in the oracle/engine): tatp/udp/tatp.h:283-412
+TATP_ASSIGNED = {
+    0: [i for i in range(40) if not 8 <= i <= 14],
+    1: [0, 1, 2, 3, 4],
+    2: [0],
+    3: [0, 3],
+    4: [0, 1],
+}
+STORE_ASSIGNED = [0, 1]  # store/udp/tatp.h:57-59
+
+
+def mask_populate_garbage(workload: str, rep: np.ndarray) -> np.ndarray:
+    """Zero the unassigned value bytes of GRANT_READ replies with ver == 0 (rows that
+    may still hold the reference's populate-time stack garbage)."""
+    rep = rep.copy()
+    if workload == "store":
+        sel = (rep["type"] == _STORE_GRANT_READ) & (rep["ver"] == 0)
+        keep = np.zeros(40, bool)
+        keep[STORE_ASSIGNED] = True
+        v = rep["val"]
+        v[np.ix_(sel, ~keep)] = 0
+        rep["val"] = v
+    elif workload == "tatp":
+        v = rep["val"]
+        for t, cols in TATP_ASSIGNED.items():
+            sel = (rep["type"] == _TATP_GRANT_READ) & (rep["ver"] == 0) & (rep["table"] == t)
+            keep = np.zeros(40, bool)
+            keep[cols] = True
+            v[np.ix_(sel, ~keep)] = 0
+        rep["val"] = v
+    return rep

@@ -105,3 +105,17 @@ def test_smallbank_golden():
         nz = np.nonzero(ex | sh)[0]
         assert (d[:, 0] == nz).all() and (d[:, 1] == ex[nz]).all() and (d[:, 2] == sh[nz]).all()
     assert set(range(7, 16)) <= set(rep["type"].tolist())
+
+
+@pytest.mark.skipif(not orc.ref_available("lock_fasst"), reason="reference binaries are built only where /root/reference exists")
+def test_ref_server_started_ahead_of_its_trace():
+    """REF_TRACE_WAIT: the reference is started first and given its trace later (bench.py's tatp reference leg)."""
+    req = tracegen.fasst_random(20000, seed=5)
+    want, _ = orc.ref_replay("lock_fasst", req)
+    srv = orc.RefServer("lock_fasst")
+    try:
+        assert srv.wait_populated(60)
+        got, st = srv.replay(req)
+    finally:
+        srv.close()
+    assert got.tobytes() == want.tobytes() and st["n"] == len(req)

@@ -155,35 +155,4 @@ def sb_random(n, seed=0, n_acct_touch=40):
 
 
 # --- masks for the reference's uninitialised populate bytes ------------------ #
-#: value bytes the reference's populate code assigns (everything else is stack
-#: garbage in the reference, zero in the oracle/engine): tatp/udp/tatp.h:283-412
-TATP_ASSIGNED = {
-    0: [i for i in range(40) if not 8 <= i <= 14],
-    1: [0, 1, 2, 3, 4],
-    2: [0],
-    3: [0, 3],
-    4: [0, 1],
-}
-STORE_ASSIGNED = [0, 1]  # store/udp/tatp.h:57-59
-
-
-def mask_populate_garbage(workload: str, rep: np.ndarray) -> np.ndarray:
-    """Zero the unassigned value bytes of GRANT_READ replies with ver == 0 (rows that
-    may still hold the reference's populate-time stack garbage)."""
-    rep = rep.copy()
-    if workload == "store":
-        sel = (rep["type"] == wire.Store.GRANT_READ) & (rep["ver"] == 0)
-        keep = np.zeros(40, bool)
-        keep[STORE_ASSIGNED] = True
-        v = rep["val"]
-        v[np.ix_(sel, ~keep)] = 0
-        rep["val"] = v
-    elif workload == "tatp":
-        v = rep["val"]
-        for t, cols in TATP_ASSIGNED.items():
-            sel = (rep["type"] == wire.Tatp.GRANT_READ) & (rep["ver"] == 0) & (rep["table"] == t)
-            keep = np.zeros(40, bool)
-            keep[cols] = True
-            v[np.ix_(sel, ~keep)] = 0
-        rep["val"] = v
-    return rep
+from oracle.oracle import STORE_ASSIGNED, TATP_ASSIGNED, mask_populate_garbage  # noqa: E402,F401  (shared with bench.py's cpu_baseline leg)
