@@ -64,6 +64,7 @@ def parse():
                     help="tatp: skip the unmodified reference server leg (7M subscribers on both sides; its populate takes minutes)")
     ap.add_argument("--ref-timeout", type=float, default=300.0,
                     help="seconds to wait for the reference server's populate once the GPU legs are done")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the GPU-resident closed-loop leg")
     ap.add_argument("--no-rand64", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive dint_submit_async measurement")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the multi-GPU exchange (self all-to-all)")
@@ -769,7 +770,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
     # ---- the closed loop itself, resident on the GPU: the same clients as device code emit the same
     # stream (tests/test_gpu_gdriver.py), the engines read the batch sizes on the device, nothing crosses PCIe
     closed = None
-    if world == 1 and grp.router is None:
+    if world == 1 and grp.router is None and not args.no_closed_loop:
         from dint_amd.driver import GpuDriver
         from dint_amd.replay import GpuLoop
 

@@ -57,7 +57,7 @@ def main():
     engines = 3 if wl in ("tatp", "smallbank") else 1
     last = engines * min(steps + warm, 200)  # bench.py's event-timed replay = the last launches
     base = [sys.executable, os.path.join(ROOT, "bench.py")] + rest + ["--steps", str(steps), "--warmup", str(warm),
-                                                                       "--no-cpu-baseline", "--no-rand64", "--no-host-path"]
+                                                                       "--no-cpu-baseline", "--no-rand64", "--no-host-path", "--no-closed-loop"]
     env = dict(os.environ, TMPDIR="/tmp")
     passes = [("trace", ["--kernel-trace", "--stats"]), ("FETCH_SIZE", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
               ("WRITE_SIZE", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
