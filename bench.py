@@ -190,8 +190,10 @@ def profile_counters(workload, kernels):
             "command": p.get("command"), "launches": p.get("launches"), "commit": p.get("commit")}
 
 
-def rand64(extra, value_ops_per_s, dev):
-    """Measured random-64B HBM roofline: gathers over an 8 GiB table."""
+def rand64(extra, value_ops_per_s, dev, workload=None, pass_kernels=(), requests_per_launch=None):
+    """Measured random-64B HBM roofline: gathers over an 8 GiB table.  BASELINE.md's fraction of it is
+    ops/s x sectors/op / gathers/s; sectors/op = the counted HBM-side bytes of one whole pass (every kernel of it,
+    profiles/traffic_<workload>.json, only for the sources this run uses) / 64 / the requests of a pass."""
     from dint_amd.engine import bench_rand64
 
     try:
@@ -200,6 +202,11 @@ def rand64(extra, value_ops_per_s, dev):
         extra["rand64_Gaccess_s"] = round(aps / 1e9, 3)
         extra["rand64_rw_Gaccess_s"] = round(aps_w / 1e9, 3)
         extra["ops_frac_of_rand64"] = round(value_ops_per_s / aps, 5)
+        fp = profile_counters(workload, list(pass_kernels)) if workload and requests_per_launch else None
+        if fp and fp.get("traffic_bytes"):
+            spo = fp["traffic_bytes"] / 64.0 / requests_per_launch
+            extra["rand64_roofline"] = {"sectors_per_op": round(spo, 3), "frac": round(value_ops_per_s * spo / aps, 4),
+                                        "what": "ops/s x counted 64-B sectors per op (all kernels of a pass, rocprofv3 PMC) / measured random 64-B gathers/s"}
     except Exception as ex:  # measurement helper only
         extra["rand64_error"] = str(ex)
 
@@ -809,7 +816,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
     if rank != 0:
         return None
     if not args.no_rand64 and world == 1 and grp.router is None:
-        rand64(extra, ops / dt, dev)
+        rand64(extra, ops / dt, dev, kind, ("k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve"), ops / K / 3.0)
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline_txn(kind, trace, done, n_rows, W, W + min(K, 60))

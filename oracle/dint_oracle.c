@@ -15,6 +15,13 @@
  *   - populate: value structs are zero-initialised before the assigned fields are
  *     written (the reference copies partially initialised stack structs,
  *     tatp/udp/tatp.h:291-307).
+ *
+ * PARITY PINNED for the six udp/ servers (tests/golden/*.npz and fasst_24m.json were recorded from the
+ * UNMODIFIED reference servers, oracle/Makefile ref).  PARITY UNPINNED for the eBPF-only codes restated
+ * here from the eBPF sources alone -- STORE INSERT (store/ebpf/store_kern.c:226-297), tatp
+ * REJECT_LOCK_SAME_KEY (orc_tatp_same_key_mode, tatp/ebpf/lock_kern.c:289-298) and smallbank
+ * WARMUP_READ (smallbank/ebpf/shard_user.c:179-186): no XDP program can be loaded in this image, so no
+ * reference run exists to check them against.
  */
 #include "dint_oracle.h"
 
