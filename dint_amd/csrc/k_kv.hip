@@ -1408,8 +1408,16 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           if (lane == 0) Msimple[p >> 6] = sm;
         }
       } else {
-        // smallbank: the counters have no closed form.  Walk every simple segment in sorted order, wave after wave,
-        // with the running state {num_ex, num_sh, version, last writer} carried through Carry[segment].
+        // smallbank: the counters have no closed form.  Every simple segment is walked in sorted order, wave after
+        // wave, with the running state {num_ex, num_sh, version, last writer} carried through Carry[segment] -- but
+        // only what is inherently serial is walked: whether each ACQUIRE is granted (smallbank/udp/server_shard.cc:
+        // 121-147) depends on the counters, one scalar loop over the wave's lock ops with the op kinds as 64-bit
+        // ballot masks and the counters in scalar registers.  Versions and values do not depend on the counters
+        // (a COMMIT writes whatever the locks say, :163-173): version seen = version + #writes below me, value seen =
+        // message of the last write below me, both straight from the write mask.
+        const uint64_t mAS = __ballot(simple && type == 0), mAX = __ballot(simple && type == 1);
+        const uint64_t mRS = __ballot(simple && type == 2), mRX = __ballot(simple && type == 3);
+        const uint64_t mWR = __ballot(simple && type != 0 && type != 1 && type != 2 && type != 3 && type != 17);  // 4 kCommitPrim, 5 kCommitBck
         for (uint32_t wv = 0; wv < KVB_W; wv++) {
           if (wave == wv) {
             uint64_t todo = __ballot(simple);
@@ -1419,28 +1427,42 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
               const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane(si, l0);
               const uint64_t mem = __ballot(simple && seg_a == a);
               todo &= ~mem;
-              kvb_carry st = Carry[sa];
-              const uint32_t fnd = Lead[sa].found_link >> 31;
-              for (uint64_t mm = mem; mm; mm &= mm - 1) {
-                const int l = __ffsll((unsigned long long)mm) - 1;
-                const uint32_t op = (uint32_t)__builtin_amdgcn_readlane(type, l);
-                uint32_t code, get = 0;
-                bool wr = false;
-                const uint32_t ver_seen = st.ver;
-                const int src_seen = st.src;
-                switch (op) {  // la = num_ex, lb = num_sh   smallbank/udp/server_shard.cc:121-173
-                  case 0: if (st.la == 0) { st.lb++; get = fnd; st.miss += !fnd; code = 7; } else code = 8; break;
-                  case 1: if (st.la == 0 && st.lb == 0) { st.la++; get = fnd; st.miss += !fnd; code = 9; } else code = 10; break;
-                  case 2: st.lb--; code = 11; break;
-                  case 3: st.la--; code = 12; break;
-                  case 4: wr = fnd; st.miss += !fnd; code = 13; break;
-                  case 17: get = fnd; code = 18; break;  // WARMUP_READ
-                  default: wr = fnd; st.miss += !fnd; code = 14; break;  // 5 kCommitBck
-                }
-                if (wr) { st.ver++; st.src = (int)(lo + wv * 64 + l); }
-                if ((int)lane == l) { my_code = code; my_ver = ver_seen; my_src = src_seen; my_get = get; }
+              const kvb_carry st = Carry[sa];
+              uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.la), lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.lb);
+              const uint32_t ver = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.ver), miss = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.miss);
+              const int src = __builtin_amdgcn_readfirstlane(st.src);
+              const uint32_t fnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Lead[sa].found_link >> 31));
+              uint64_t G = 0;  // granted ACQUIREs
+              for (uint64_t mm = mem & (mAS | mAX | mRS | mRX); mm; mm &= mm - 1) {
+                const uint64_t bit = mm & (0 - mm);
+                if (bit & mAS) { if (la == 0) { lb++; G |= bit; } }
+                else if (bit & mAX) { if (la == 0 && lb == 0) { la++; G |= bit; } }
+                else if (bit & mRS) lb--;
+                else la--;
               }
-              if ((int)lane == l0) Carry[sa] = st;
+              const uint64_t wmask = fnd ? mem & mWR : 0ull, wlt = wmask & lanemask_lt();
+              if ((mem >> lane) & 1ull) {
+                const bool granted = (G >> lane) & 1ull;
+                my_ver = ver + (uint32_t)__popcll(wlt);
+                my_src = wlt ? (int)(lo + wv * 64 + 63u - (uint32_t)__clzll((long long)wlt)) : src;
+                switch (type) {  // smallbank/udp/server_shard.cc:121-173
+                  case 0: my_code = granted ? 7 : 8; my_get = granted ? fnd : 0; break;
+                  case 1: my_code = granted ? 9 : 10; my_get = granted ? fnd : 0; break;
+                  case 2: my_code = 11; my_get = 0; break;
+                  case 3: my_code = 12; my_get = 0; break;
+                  case 4: my_code = 13; my_get = 0; break;
+                  case 17: my_code = 18; my_get = fnd; break;  // WARMUP_READ
+                  default: my_code = 14; my_get = 0; break;    // 5 kCommitBck
+                }
+              }
+              if ((int)lane == l0) {
+                kvb_carry nx;
+                nx.la = la; nx.lb = lb;
+                nx.ver = ver + (uint32_t)__popcll(wmask);
+                nx.src = wmask ? (int)(lo + wv * 64 + 63u - (uint32_t)__clzll((long long)wmask)) : src;
+                nx.miss = miss + (fnd ? 0u : (uint32_t)__popcll(G) + (uint32_t)__popcll(mem & mWR));
+                Carry[sa] = nx;
+              }
             }
           }
           __syncthreads();
