@@ -5,6 +5,8 @@
 // helpers of the big-bin workgroups: an LDS / register bitonic sort of a stretch of <= KVB_NMAX 64-bit keys, and O(1)
 // range queries (bits set, last / next set bit) over 4096-bit masks of the sorted stretch.
 #pragma once
+#include <cstdlib>
+
 #include "dint_kernels.h"
 
 #define KV_TB 1024u           // threads per workgroup of k_kv_count / k_kv_place (= requests per workgroup)
@@ -70,8 +72,14 @@ k_kv_place(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_of
 #define KVB_NW (KVB_NMAX / 64u)    // mask words of a stretch = lanes of one wave
 #define KVB_NBK 2048u              // request-index buckets that cut a longer bin into stretches
 #define KVB_HOT_MIN 256u           // a stretch with a key of at least this many requests (and half the stretch) takes the dominant-key path
+#define KVB_HOT_MIN_LOCKS 256u     // ... the lock tables' threshold (k_locks.hip)
 #define KVB_MMAX 1024u             // ... if the key has at most this many writers + lock ops
 static_assert(KVB_NW == 64, "the per-word tables are built with one lane per mask word");
+// the thresholds can be overridden from the environment (tuning runs: tools/gpu_r02h.sh); read once per process
+static inline uint32_t dint_hot_min(const char *env, uint32_t dflt) {
+  const char *v = getenv(env);
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
 struct kvb_lead { uint32_t found_link, slot, ver0, la0, lb0; };   // found_link: found << 31 | link
 struct kvb_carry { uint32_t la, lb, ver; int src; uint32_t miss; };
 struct kvb_pop { uint16_t below[KVB_NW + 1]; };                  // bits set in the words before w

@@ -292,6 +292,10 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
+    if ((e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL) && getenv("DINT_KV_TRACE")) {
+      TRY(dev_alloc((void **)&e->kv.d_trace, (size_t)DINT_KV_TRACE_WORDS * 8, true));
+      e->scratch.lock_trace = e->kv.d_trace;
+    }
   } else {  // the log append has no bins: per-block counts of its scan only
     TRY(dev_alloc((void **)&e->scratch.blk_cnt, 256 * sizeof(uint32_t)));
   }
@@ -350,6 +354,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bin_off);
   hipFree(e->scratch.ovl);
   hipFree(e->scratch.ovf);
+  if (e->scratch.lock_trace) { hipFree(e->scratch.lock_trace); e->kv.d_trace = nullptr; }
   for (auto &sl : e->slot) {
     hipFree(sl.d_req);
     hipFree(sl.d_rep);

@@ -12,9 +12,10 @@
 //                  in bin = group & (P-1) (P ~ n / 32) -- merged per workgroup in an LDS hash, so a hot key costs one
 //                  device atomic per workgroup -- and store the {bucket group, idx, type | quadrant | key-hash bits}
 //                  record in place (positions < 64) or on the pass's overflow list; count the log requests.
-//   k_kv_scan    : give every bin with more than 64 records (the big-bin list) a range of the overflow area.
-//   k_kv_place   : move the overflow records there; append the canonical 64-byte log records at ring position
+//                  Log requests are finished here: the canonical 64-byte record goes to ring position
 //                  tail + (#log requests below i)   [deterministic: an exclusive scan, not an atomic].
+//   k_kv_scan    : give every bin with more than 64 records (the big-bin list) a range of the overflow area.
+//   k_kv_place   : move the overflow records there.
 //   k_kv_resolve : every bin, one launch.  A bin of <= 64 records (the common case: ~32 per bin) is one wave: sorted
 //                  by (bucket group, key hash, idx) in registers and handled as one chunk (kv_chunk).  A bigger bin
 //                  (hot keys) is one 512-thread workgroup: sorted in LDS, ballot masks over the whole sorted stretch
@@ -352,7 +353,7 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
     switch (type) {
       case 0: act = KV_ACT_GET; break;   // kRead  store/udp/server.cc:77-82
       case 1: act = KV_ACT_SET; break;   // kSet   :84-89
-      default: act = KV_ACT_INS; code = 8; break;  // kInsert (eBPF store)
+      default: act = KV_ACT_INS; code = 8; break;  // kInsert: engine extension (kvs_insert semantics; no reference parity target, see dint_abi.h)
     }
   } else if (WL == DINT_WL_TATP) {
     const uint32_t lk = (H.lockw >> (8 * q)) & 0xFFu;
@@ -835,6 +836,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
                                           uint64_t *trace) {
   using F = Fmt<WL>;
   const int force_rounds = force_flags & 1, no_hot = force_flags & 2;
+  const uint32_t hot_min = (uint32_t)force_flags >> 8 ? (uint32_t)force_flags >> 8 : KVB_HOT_MIN;
   __shared__ uint64_t Sk[KVB_NMAX];           // the stretch: group >> pbits | key-hash bits | idx | type, quadrant
   __shared__ uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
   __shared__ uint16_t Bwin[KVB_NBK];          // stretch each idx bucket belongs to
@@ -843,7 +845,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   __shared__ kvb_pop Pbad, Plop, Pst, Plkseg[4], Pstseg, Pwr;
   __shared__ kvb_edge Ehead, Ebh, Ewr, Elk;
   __shared__ uint64_t Mbail[KVB_W];           // tile-local
-  __shared__ kvb_lead Lead[KVB_T];            // by key segment number (a stretch with more segments runs request by request)
+  __shared__ __attribute__((aligned(8))) kvb_lead Lead[KVB_T];  // by key segment number (a stretch with more segments runs request by request)
   // smallbank walks its counters through Carry[segment], store / tatp the row machine of segments with an INSERT /
   // DELETE through Crow[segment]: never both in one instantiation, so they share one buffer
   __shared__ __attribute__((aligned(8))) uint8_t CarryCrow[KVB_T * (sizeof(kv_rowst) > sizeof(kvb_carry) ? sizeof(kv_rowst) : sizeof(kvb_carry))];
@@ -962,7 +964,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     // of the last writer before me, lock = what the last lock op before me left.  The closed forms are those of
     // kv_chunk; anything they do not cover (another key of the same bucket on the same lock byte, inserts / deletes,
     // a key-hash collision, > 1024 ordering ops) leaves the whole stretch to the general path below.
-    if (WL != DINT_WL_SMALLBANK && !force_rounds && !no_hot && m >= KVB_HOT_MIN) {
+    if (WL != DINT_WL_SMALLBANK && !force_rounds && !no_hot && m >= hot_min) {
       uint32_t *Mk = (uint32_t *)Lead;                 // [1024] idx << 12 | position in Sk, ascending
       uint16_t *Mwc = (uint16_t *)Carry;                // [j] writers among the first j ops of M
       int16_t *Mlw = (int16_t *)(Mwc + KVB_MMAX + 8);   // [j] last writer among the first j (index into Mk), -1: none
@@ -993,7 +995,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const uint64_t hpf = cand[best];
       const uint32_t hsp = (uint32_t)(((uint64_t)m * best) >> 3);  // a position that holds the hot key
       __syncthreads();
-      if (hot_n >= KVB_HOT_MIN && 2 * hot_n >= m) {  // workgroup-uniform
+      if (hot_n >= hot_min && 2 * hot_n >= m) {  // workgroup-uniform
         // 2. everything the closed form needs to hold, checked before anything is written
         const uint64_t hcur = Sk[hsp];
         const uint32_t hq = k_q(hcur);
@@ -1034,6 +1036,8 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if (in) Mk[base + (uint32_t)__popcll(im & lanemask_lt())] = (k_idx(cur) << 12) | p;
           }
+          // (sorting M with kvb_sort_stretch -- registers / shuffles instead of an LDS step per barrier -- was measured:
+          // the list sort itself is faster, the bench 1.3 % slower on the same box; the kernel is code-size sensitive)
           uint32_t N2 = 64;
           while (N2 < nM) N2 <<= 1;
           __syncthreads();
@@ -1670,7 +1674,8 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   if (ev) hipEventRecord(ev[3], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
                      pbits, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
-                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats, kv.force_rounds, kv.d_trace, view);
+                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats,
+                     kv.force_rounds | (int)(dint_hot_min("DINT_KV_HOT_MIN", 0) << 8), kv.d_trace, view);
   if (ev) hipEventRecord(ev[4], st);
 }
 

@@ -294,9 +294,13 @@ template <class Ops>
 __global__ void __launch_bounds__(KVB_T)
 k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
                    const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-                   const uint64_t *__restrict__ ovf, dint_view V) {
+                   const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, dint_view V) {
+  const uint32_t bin_first = big[4 + blockIdx.x];  // speculative: in flight together with the list length
   const uint32_t nbig = big[0];
   if (blockIdx.x >= nbig) return;
+  // tracing (DINT_KV_TRACE=1): phase stamps of this workgroup's first bin, 10 ns ticks
+  unsigned long long *tw = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
+#define LK_STAMP(k) do { if (tw && threadIdx.x == 0 && bi == blockIdx.x && win == 0) tw[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   __shared__ uint64_t Sk[KVB_NMAX];
   __shared__ uint32_t Bcnt[KVB_NBK / 2];
   __shared__ uint16_t Bwin[KVB_NBK];
@@ -307,7 +311,8 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
   __shared__ kvb_pop Pcom;
   __shared__ uint32_t Xs[KVB_NW][2];  // slots whose requests cross 64-record chunks: [a, b) in the sorted stretch
   __shared__ uint32_t Swn, Snx, Sred[KVB_W];
-  __shared__ uint32_t Hs[16], Mk[KVB_MMAX];   // dominant-slot path: counters; its lock-writing ops, idx << 12 | position
+  __shared__ uint32_t Hs[16];                  // dominant-slot path: counters
+  __shared__ uint64_t Mk[KVB_MMAX];            // ... its lock-writing ops, idx << 12 | position, ascending
   __shared__ uint16_t Mcc[KVB_MMAX + 8];       // ... COMMITs among the first j of them
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // request-index buckets that cut a bin of more than KVB_NMAX records into stretches (every request of a stretch
@@ -315,9 +320,10 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
   const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 11 ? nbits - 11 : 0u;
   const uint32_t wcap = KVB_NMAX - (1u << bs);
   for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-    const uint32_t bin = big[4 + bi];
+    const uint32_t bin = bi == blockIdx.x ? bin_first : big[4 + bi];
     __syncthreads();
     const uint32_t c = bin_cnt[bin];
+    if (tw && threadIdx.x == 0 && bi == blockIdx.x) { tw[0] = __builtin_amdgcn_s_memrealtime(); tw[8] = c; tw[9] = nbig; }
     const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
     const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;
     auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
@@ -370,11 +376,12 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
       __syncthreads();
       uint32_t m = Swn;
       if (m == 0) continue;  // workgroup-uniform
+      LK_STAMP(1);
       // ---- the stretch's DOMINANT SLOT (lock_fasst; a hot lid: most of a big bin is one slot) without sorting the
       // stretch: only its lock-writing ops (ACQUIRE / ABORT / COMMIT, a minority) are put in request order -- one LDS sort
       // of <= 1024 words -- and every request of the slot finds by binary search on its index how many precede it:
       // lock seen = what the last of them left, version seen = ver0 + the COMMITs among them.
-      if (Ops::CLOSED && m >= KVB_HOT_MIN) {
+      if (Ops::CLOSED && m >= hot_min) {
         uint64_t cand[8];
         uint32_t cc[8];
 #pragma unroll
@@ -399,7 +406,7 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
         const uint32_t hot_n = Hs[best];
         const uint64_t hslot = cand[best];
         __syncthreads();
-        if (hot_n >= KVB_HOT_MIN && 2 * hot_n >= m) {  // workgroup-uniform
+        if (hot_n >= hot_min && 2 * hot_n >= m) {  // workgroup-uniform
           if (t < 16) Hs[t] = 0;  // [1] lock-writing ops of the slot, [2] append cursor
           __syncthreads();
           uint32_t nord = 0;
@@ -417,23 +424,10 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
               uint32_t base = 0;
               if (lane == 0 && im) base = atomicAdd(&Hs[2], (uint32_t)__popcll(im));
               base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-              if (in) Mk[base + (uint32_t)__popcll(im & lanemask_lt())] = (lk_idx(cur) << 12) | p;
+              if (in) Mk[base + (uint32_t)__popcll(im & lanemask_lt())] = ((uint64_t)lk_idx(cur) << 12) | p;
             }
-            uint32_t N2 = 64;
-            while (N2 < nM) N2 <<= 1;
             __syncthreads();
-            for (uint32_t k = nM + t; k < N2; k += KVB_T) Mk[k] = 0xFFFFFFFFu;
-            __syncthreads();
-            for (uint32_t k = 2; k <= N2 && nM > 1; k <<= 1) {
-              for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t a = t; a < N2 / 2; a += KVB_T) {
-                  const uint32_t i0 = ((a & ~(j - 1)) << 1) | (a & (j - 1)), i1 = i0 | j;
-                  const uint32_t x0 = Mk[i0], x1 = Mk[i1];
-                  if ((x0 > x1) == ((i0 & k) == 0)) { Mk[i0] = x1; Mk[i1] = x0; }
-                }
-                __syncthreads();
-              }
-            }
+            kvb_sort_stretch(Mk, nM);  // in registers / by shuffle inside a wave, the wide steps through LDS
             // COMMITs among the first j ops of M (nM + 1 rows): thread t owns ops 2t, 2t + 1
             {
               const uint32_t j0 = 2 * t, j1 = 2 * t + 1;
@@ -492,7 +486,9 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
           }
         }
       }
+      LK_STAMP(2);
       kvb_sort_stretch(Sk, m);
+      LK_STAMP(3);
       const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
       // slot heads of the sorted stretch
       for (uint32_t j = 0; j < ntile; j++) {
@@ -524,6 +520,7 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
         }
       }
       __syncthreads();
+      LK_STAMP(4);
       if (Ops::CLOSED) {
         // the slots that cross chunks, every request in parallel: masks over the whole sorted stretch + O(1) range tables
         // answer "last lock-writing op below me in my slot" and "COMMITs below me in my slot"
@@ -610,6 +607,7 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __syncthreads();  // the next stretch sees this stretch's stores; LDS is free again
+      LK_STAMP(5);
     }
   }
 }
@@ -633,7 +631,7 @@ static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *tabl
   if (ev) hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_lock_resolve_big<Ops>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, table, s.bin_cnt,
                      (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
-                     (const uint64_t *)s.ovf, view);
+                     (const uint64_t *)s.ovf, dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS), s.lock_trace, view);
   if (ev) hipEventRecord(ev[3], st);
   hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3((P + 3) / 4), dim3(256), 0, st, (uint8_t *)d_rep, pbits, table, s.bin_cnt,
                      (const uint64_t *)s.bins, view);

@@ -63,7 +63,9 @@ enum {
   DINT_WL_FASST = 0,     /* lock_fasst: 9-byte {u8 type; u32 lid; u32 ver}            net.h:23-29 */
   DINT_WL_2PL = 1,       /* lock_2pl:   6-byte {u8 action; u32 lid; u8 type}          net.h:25-31 */
   DINT_WL_LOG = 2,       /* log_server: 53-byte {u8 type; u64 key; u8 val[40]; u32 ver}           */
-  DINT_WL_STORE = 3,     /* store:      53-byte, same layout                                      */
+  DINT_WL_STORE = 3,     /* store:      53-byte, same layout.  READ / SET are store/udp/server.cc:75-97; INSERT
+                            (type 2 -> 8) is an ENGINE EXTENSION with kvs_insert semantics and no reference parity
+                            target: store/udp panics on it and store/ebpf's type 2 is a cache fill */
   DINT_WL_TATP = 4,      /* tatp:       55-byte {u8 ord,type,table; u64 key; u8 val[40]; u32 ver} */
   DINT_WL_SMALLBANK = 5, /* smallbank:  23-byte {u8 ord,type,table; u64 key; u8 val[8]; u32 ver};
                             the udp server's 7 request types + WARMUP_READ (17 -> 18) of the eBPF flavour */

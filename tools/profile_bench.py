@@ -50,6 +50,8 @@ def last_rows(db, last):
 def main():
     tag = sys.argv[1]
     rest = sys.argv[2:]
+    sq = "--sq" in rest  # also the SQ (instruction mix / wave cycle) counters, two more passes
+    rest = [a for a in rest if a != "--sq"]
     wl = rest[rest.index("--workload") + 1] if "--workload" in rest else "tatp"
     out_dir = os.path.join(ROOT, "gpurun_out", f"{tag}_{wl}")
     os.makedirs(out_dir, exist_ok=True)
@@ -63,6 +65,10 @@ def main():
               ("WRITE_SIZE", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
               ("TCC", ["--pmc", "TCC_HIT_sum", "TCC_MISS_sum", "--kernel-trace"]),
               ("EA", ["--pmc", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "--kernel-trace"])]
+    SQ1 = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"]
+    SQ2 = ["SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_SCA", "GRBM_GUI_ACTIVE"]
+    if sq:
+        passes = passes[:1] + [("SQ1", ["--pmc"] + SQ1 + ["--kernel-trace"]), ("SQ2", ["--pmc"] + SQ2 + ["--kernel-trace"])]
     merged, lines = {}, []
     for name, flags in passes:
         d = os.path.join(out_dir, name)
@@ -96,15 +102,17 @@ def main():
     res = {"workload": wl, "command": "bench.py " + " ".join(rest) + f" --steps {steps} --warmup {warm}", "launches": last,
            "kernel_source_hash": kernel_source_hash(), "commit": commit, "kernels": kernels}
     os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "profiles", f"traffic_{wl}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "profiles", f"{'sq' if sq else 'traffic'}_{wl}.json"), "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     lines.append(f"# kernels over the last {last} dispatches (the event-timed replay of bench.py)")
     cols = ["avg_us", "max_us", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"]
+    if sq:
+        cols = ["avg_us"] + SQ1 + SQ2
     lines.append(f"{'kernel':28s}" + "".join(f"{c:>20s}" for c in cols))
     for k in sorted(kernels, key=lambda x: -kernels[x].get("avg_us", 0)):
         lines.append(f"{k:28s}" + "".join(f"{kernels[k].get(c, float('nan')):20.2f}" for c in cols))
     txt = "\n".join(lines) + "\n"
-    with open(os.path.join(ROOT, "gpurun_out", "profiles", f"{tag}_{wl}_rocprofv3_summary.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "profiles", f"{tag}_{wl}_rocprofv3_{'sq' if sq else 'summary'}.txt"), "w") as f:
         f.write(txt)
     print(txt)
 
