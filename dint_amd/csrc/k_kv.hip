@@ -1436,13 +1436,45 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
               const uint32_t ver = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.ver), miss = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.miss);
               const int src = __builtin_amdgcn_readfirstlane(st.src);
               const uint32_t fnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Lead[sa].found_link >> 31));
-              uint64_t G = 0;  // granted ACQUIREs
-              for (uint64_t mm = mem & (mAS | mAX | mRS | mRX); mm; mm &= mm - 1) {
-                const uint64_t bit = mm & (0 - mm);
-                if (bit & mAS) { if (la == 0) { lb++; G |= bit; } }
-                else if (bit & mAX) { if (la == 0 && lb == 0) { la++; G |= bit; } }
-                else if (bit & mRS) lb--;
-                else la--;
+              // Granted ACQUIREs.  The counters move between two modes.  FREE (num_ex == 0): every ACQUIRE_SHARED is
+              // granted (num_sh++), RELEASE_SHARED decrements, and nothing else happens until an EVENT: an
+              // ACQUIRE_EXCLUSIVE that finds num_sh == 0 (granted: num_ex = 1) or a RELEASE_EXCLUSIVE (num_ex wraps to
+              // 2^32 - 1, as the reference's unsigned counter does).  HELD (num_ex != 0): every ACQUIRE is rejected,
+              // RELEASE_SHARED still decrements, until the num_ex-th RELEASE_EXCLUSIVE.  Between events all lanes are
+              // resolved at once (num_sh before a lane = num_sh + ACQUIRE_SHAREDs - RELEASE_SHAREDs below it), so the
+              // loop runs once per mode change, not once per request: a contended account changes mode rarely.
+              uint64_t G = 0, rem = mem & (mAS | mAX | mRS | mRX);
+              while (rem) {
+                if (la == 0) {
+                  const uint64_t blw = rem & lanemask_lt();
+                  const uint32_t lb_before = lb + (uint32_t)__popcll(blw & mAS) - (uint32_t)__popcll(blw & mRS);
+                  const bool me = (rem >> lane) & 1ull;
+                  const uint64_t ev = __ballot(me && ((type == 1 && lb_before == 0) || type == 3));
+                  const uint64_t upto = ev ? (ev & (0 - ev)) - 1ull : ~0ull;  // the lanes below the first event
+                  const uint64_t seg = rem & upto;
+                  G |= seg & mAS;
+                  lb += (uint32_t)__popcll(seg & mAS) - (uint32_t)__popcll(seg & mRS);
+                  rem &= ~upto;
+                  if (ev) {
+                    const uint64_t bit = ev & (0 - ev);
+                    if (bit & mAX) { G |= bit; la = 1; } else la = 0xFFFFFFFFu;
+                    rem &= ~bit;
+                  }
+                } else {
+                  uint64_t rx = rem & mRX;
+                  const uint32_t nrx = (uint32_t)__popcll(rx);
+                  if (nrx < la) {  // held to the end of these lanes
+                    lb -= (uint32_t)__popcll(rem & mRS);
+                    la -= nrx;
+                    rem = 0;
+                  } else {
+                    for (uint32_t k = 1; k < la; k++) rx &= rx - 1;  // the la-th RELEASE_EXCLUSIVE (la is 1 unless the counter wrapped)
+                    const uint64_t bit = rx & (0 - rx), upto = bit - 1ull;
+                    lb -= (uint32_t)__popcll(rem & upto & mRS);
+                    la = 0;
+                    rem &= ~(upto | bit);
+                  }
+                }
               }
               const uint64_t wmask = fnd ? mem & mWR : 0ull, wlt = wmask & lanemask_lt();
               if ((mem >> lane) & 1ull) {

@@ -16,10 +16,12 @@ from dint_amd.replay import Replay, ShardGroup, record  # noqa: E402
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 theta = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
-n_sub, E = 1_000_000, 16
-grp = ShardGroup(wire.Workload.TATP, n_sub)
+WLN = os.environ.get("EXP_WL", "tatp")  # tatp | smallbank
+WL = wire.Workload.SMALLBANK if WLN == "smallbank" else wire.Workload.TATP
+n_sub, E = (10_000_000 if WLN == "smallbank" else 1_000_000), int(os.environ.get("EXP_EPOCHS", "16"))
+grp = ShardGroup(WL, n_sub)
 grp.sync(); grp.snapshot()
-d = Driver(wire.Workload.TATP, C, n_sub, zipf_theta=theta if theta > 0 else None)
+d = Driver(WL, C, n_sub, zipf_theta=theta if theta > 0 else None)
 trace, done = record(d, grp, E)
 grp.sync(); grp.restore()
 rp = Replay(trace, grp.msg)
