@@ -903,6 +903,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   if (c > KVB_NMAX) {
     for (uint32_t w = t; w < KVB_NBK / 2; w += KVB_T) Bcnt[w] = 0;
     __syncthreads();
+#pragma unroll 4
     for (uint32_t k = t; k < c; k += KVB_T) {
       const uint32_t b = kv_rec_idx(rec_at(k), pbits) >> bs;
       atomicAdd(&Bcnt[b >> 1], 1u << (16 * (b & 1)));
@@ -940,15 +941,24 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = sort_key(rec_at(k));
       if (t == 0) Swn = c;
     } else {
-      for (uint32_t k0 = 0; k0 < c; k0 += KVB_T) {  // one slot reservation per wave and step
-        const uint32_t k = k0 + t;
-        const uint64_t r = k < c ? rec_at(k) : 0;
-        const bool in = k < c && Bwin[kv_rec_idx(r, pbits) >> bs] == win;
-        const uint64_t im = __ballot(in);
-        uint32_t base = 0;
-        if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (in) Sk[base + (uint32_t)__popcll(im & lanemask_lt())] = sort_key(r);
+      for (uint32_t k0 = 0; k0 < c; k0 += 4 * KVB_T) {  // four records per thread in flight; one slot reservation per wave and step
+        uint64_t r4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+          const uint32_t k = k0 + j * KVB_T + t;
+          r4[j] = k < c ? rec_at(k) : 0;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+          const uint32_t k = k0 + j * KVB_T + t;
+          const uint64_t r = r4[j];
+          const bool in = k < c && Bwin[kv_rec_idx(r, pbits) >> bs] == win;
+          const uint64_t im = __ballot(in);
+          uint32_t base = 0;
+          if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (in) Sk[base + (uint32_t)__popcll(im & lanemask_lt())] = sort_key(r);
+        }
       }
     }
     __syncthreads();
