@@ -22,8 +22,14 @@ SYMBOLS = [
     "dint_home_shard", "dint_bench_rand64", "dint_timing_enable", "dint_timing_read", "dint_kv_trace_read",
     "dint_submit_async", "dint_wait", "dint_alloc_pinned", "dint_free_pinned", "dint_engine_stream", "dint_max_pass",
     "dint_stream_wait", "dint_stream_signal", "dint_route_pack", "dint_route_unpack", "dint_submit_segments",
-    "dint_log_drain", "dint_refuse",
+    "dint_log_drain", "dint_refuse", "dint_route_pack_multi", "dint_route_unpack_multi",
 ]
+
+
+class RouteItem(C.Structure):
+    """dint_route_item (include/dint_abi.h)"""
+    _fields_ = [("engine", C.c_void_p), ("d_reqs", C.c_void_p), ("n", C.c_uint32), ("seg_cap", C.c_uint32),
+                ("d_slots", C.c_void_p), ("d_cnt", C.c_void_p), ("d_slot", C.c_void_p), ("d_replies", C.c_void_p)]
 
 
 class Config(C.Structure):
@@ -102,6 +108,8 @@ def load() -> C.CDLL:
         "dint_stream_signal": (C.c_int, [vp, vp]),
         "dint_route_pack": (C.c_int, [vp, vp, u32, vp, u32, u64, vp, u64, vp, vp]),
         "dint_route_unpack": (C.c_int, [vp, vp, u32, u64, vp, vp, u32, vp, vp]),
+        "dint_route_pack_multi": (C.c_int, [C.POINTER(RouteItem), u32, u64, u64, vp]),
+        "dint_route_unpack_multi": (C.c_int, [C.POINTER(RouteItem), u32, u64, vp]),
         "dint_submit_segments": (C.c_int, [vp, vp, u32, u32, u64, vp, u64, vp]),
         "dint_log_drain": (i64, [vp, vp, u64, C.POINTER(u64)]),
         "dint_refuse": (C.c_int, [u32, vp, u32, vp]),

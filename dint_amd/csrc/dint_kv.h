@@ -64,9 +64,20 @@ struct dint_route_scratch {
 };
 // stable partition of n contiguous requests by home rank into `shard.count` slots of `cap` messages, slot w at
 // d_send + w * stride, its live count (u32) at d_cnt + w * cnt_stride; d_slot[i] = home * cap + position (or ~0u)
-void dint_launch_route_pack(uint32_t workload, uint32_t msg, dint_mod slots, const dint_kv *kv, dint_shard shard,
-                            const void *d_req, uint32_t n, void *d_send, uint32_t cap, uint64_t stride, void *d_cnt,
-                            uint64_t cnt_stride, uint32_t *d_slot, dint_route_scratch rs, dint_dev_stats *stats,
-                            hipStream_t st);
-void dint_launch_route_unpack(const void *d_back, uint32_t cap, uint64_t stride, const uint32_t *d_slot,
-                              const void *d_req, uint32_t n, uint32_t msg, uint32_t world, void *d_rep, hipStream_t st);
+#define DINT_ROUTE_MAXS 4u         // batches (logical servers of one rank) routed by one launch set
+struct dint_route_job {            // one batch and the engine whose hash / modulus routes it
+  uint32_t workload, msg;
+  dint_mod slots;
+  const dint_kv *kv;
+  dint_shard shard;
+  const void *d_req;
+  void *d_rep;                     // unpack only
+  uint32_t n, cap;
+  void *d_send, *d_cnt;            // this batch's slot / live-count word of peer 0
+  uint64_t cnt_stride;
+  uint32_t *d_slot;
+  dint_route_scratch rs;
+  dint_dev_stats *stats;
+};
+void dint_launch_route_pack(const dint_route_job *jobs, uint32_t n_jobs, uint64_t stride, hipStream_t st);
+void dint_launch_route_unpack(const dint_route_job *jobs, uint32_t n_jobs, uint64_t stride, hipStream_t st);

@@ -82,6 +82,10 @@ struct dint_engine {
   // first waits for it (dint_submit_device with a caller stream)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_order = nullptr;
+  // ... the routing kernels have scratch of their own (route.home / route.blk) and touch neither tables nor pass
+  // scratch: they are ordered among themselves only, so a pack for the next step overlaps the pass of this one
+  hipStream_t route_last_stream = nullptr;
+  hipEvent_t ev_route_order = nullptr;
   hipEvent_t ev_wait = nullptr, ev_signal = nullptr;  // dint_stream_wait / dint_stream_signal (re-recorded every call)
 
   // lock tables (fasst / 2pl)
@@ -127,6 +131,16 @@ int order_stream(dint_engine *e, hipStream_t st) {
     HIP_TRY(hipStreamWaitEvent(st, e->ev_order, 0));
   }
   e->last_stream = st;
+  return 0;
+}
+
+int order_route_stream(dint_engine *e, hipStream_t st) {
+  if (e->route_last_stream && e->route_last_stream != st) {
+    if (!e->ev_route_order) HIP_TRY(hipEventCreateWithFlags(&e->ev_route_order, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->ev_route_order, e->route_last_stream));
+    HIP_TRY(hipStreamWaitEvent(st, e->ev_route_order, 0));
+  }
+  e->route_last_stream = st;
   return 0;
 }
 
@@ -367,6 +381,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   if (e->h_pinned) hipHostFree(e->h_pinned);
   if (e->h_pool) hipHostFree(e->h_pool);
   if (e->ev_order) hipEventDestroy(e->ev_order);
+  if (e->ev_route_order) hipEventDestroy(e->ev_route_order);
   if (e->ev_wait) hipEventDestroy(e->ev_wait);
   if (e->ev_signal) hipEventDestroy(e->ev_signal);
   if (e->s_h2d && e->s_h2d != e->stream) hipStreamDestroy(e->s_h2d);
@@ -503,38 +518,85 @@ void dint_free_pinned(void *p) {
 }
 
 // ---- multi-GPU routing ---------------------------------------------------------------------------------------
-int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_send, uint32_t seg_cap,
-                    uint64_t seg_stride, void *d_cnt, uint64_t cnt_stride, uint32_t *d_slot, void *stream) {
-  if (!e || !d_send || !d_cnt || (n && (!d_reqs || !d_slot))) return fail(DINT_EINVAL, "null argument");
+namespace {
+// validate one batch of a routing call, make sure the engine's routing scratch exists, order the stream, fill the job
+int route_job(const dint_route_item &it, bool pack, uint64_t cnt_stride, hipStream_t &st, void *stream, dint_route_job *job) {
+  dint_engine *e = it.engine;
+  if (!e) return fail(DINT_EINVAL, "null engine");
+  if (pack && (!it.d_slots || !it.d_cnt || (it.n && (!it.d_reqs || !it.d_slot)))) return fail(DINT_EINVAL, "null argument");
+  if (!pack && it.n && (!it.d_slots || !it.d_slot || !it.d_reqs || !it.d_replies)) return fail(DINT_EINVAL, "null argument");
   if (e->cfg.workload == DINT_WL_LOG) return fail(DINT_ESTATE, "workload is not sharded by key");
-  if (n > DINT_ROUTE_MAXN) return fail(DINT_EINVAL, "at most %u requests per dint_route_pack", DINT_ROUTE_MAXN);
+  if (it.n > DINT_ROUTE_MAXN) return fail(DINT_EINVAL, "at most %u requests per routed batch", DINT_ROUTE_MAXN);
   if (e->shard.count > DINT_ROUTE_MAXW) return fail(DINT_EINVAL, "at most %u shards can be routed to", DINT_ROUTE_MAXW);
-  if (seg_cap == 0 || (uint64_t)seg_cap * e->shard.count > 0xFFFFFFF0ull) return fail(DINT_EINVAL, "bad seg_cap");
-  std::lock_guard<std::mutex> lk(e->mu);
+  if (it.seg_cap == 0 || (uint64_t)it.seg_cap * e->shard.count > 0xFFFFFFF0ull) return fail(DINT_EINVAL, "bad seg_cap");
   HIP_TRY(hipSetDevice(e->device));
-  if (!e->route.home) {
-    if (int rc = dev_alloc((void **)&e->route.home, DINT_ROUTE_MAXN, false)) return rc;
-    if (int rc = dev_alloc((void **)&e->route.blk, (size_t)(DINT_ROUTE_MAXN / 256) * DINT_ROUTE_MAXW * 4)) return rc;
+  if (!st) st = stream ? (hipStream_t)stream : e->stream;
+  if (pack) {
+    if (!e->route.home) {
+      if (int rc = dev_alloc((void **)&e->route.home, DINT_ROUTE_MAXN, false)) return rc;
+      if (int rc = dev_alloc((void **)&e->route.blk, (size_t)(DINT_ROUTE_MAXN / 256) * DINT_ROUTE_MAXW * 4)) return rc;
+      HIP_TRY(hipDeviceSynchronize());  // the zero-fill ran on the null stream, which a caller's non-blocking stream does not wait for
+    }
+    if (int rc = order_route_stream(e, st)) return rc;  // the routing scratch is per engine, and only the routing kernels use it
   }
-  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-  if (int rc = order_stream(e, st)) return rc;  // the routing scratch is per engine too
-  dint_launch_route_pack(e->cfg.workload, e->msg_size, e->slots_mod, &e->kv, e->shard, d_reqs, n, d_send, seg_cap,
-                         seg_stride, d_cnt, cnt_stride, d_slot, e->route, e->scratch.stats, st);
+  job->workload = e->cfg.workload;
+  job->msg = e->msg_size;
+  job->slots = e->slots_mod;
+  job->kv = &e->kv;
+  job->shard = e->shard;
+  job->d_req = it.d_reqs;
+  job->d_rep = it.d_replies;
+  job->n = it.n;
+  job->cap = it.seg_cap;
+  job->d_send = it.d_slots;
+  job->d_cnt = it.d_cnt;
+  job->cnt_stride = cnt_stride;
+  job->d_slot = it.d_slot;
+  job->rs = e->route;
+  job->stats = e->scratch.stats;
+  return 0;
+}
+}  // namespace
+
+int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64_t seg_stride, uint64_t cnt_stride,
+                          void *stream) {
+  if (!items || n_items == 0 || n_items > DINT_ROUTE_MAXS) return fail(DINT_EINVAL, "1 .. %u batches per call", DINT_ROUTE_MAXS);
+  dint_route_job jobs[DINT_ROUTE_MAXS];
+  hipStream_t st = nullptr;
+  for (uint32_t k = 0; k < n_items; k++) {  // engines are locked one at a time: the launch below needs no lock
+    if (!items[k].engine) return fail(DINT_EINVAL, "null engine");
+    if (items[k].engine->device != items[0].engine->device) return fail(DINT_EINVAL, "the batches of one call share a device");
+    std::lock_guard<std::mutex> lk(items[k].engine->mu);
+    if (int rc = route_job(items[k], true, cnt_stride, st, stream, &jobs[k])) return rc;
+  }
+  dint_launch_route_pack(jobs, n_items, seg_stride, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
   return 0;
 }
 
-int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, uint64_t seg_stride,
-                      const uint32_t *d_slot, const void *d_reqs, uint32_t n, void *d_replies, void *stream) {
-  if (!e || (n && (!d_back || !d_slot || !d_reqs || !d_replies))) return fail(DINT_EINVAL, "null argument");
-  if (seg_cap == 0) return fail(DINT_EINVAL, "bad seg_cap");
-  HIP_TRY(hipSetDevice(e->device));
-  hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-  dint_launch_route_unpack(d_back, seg_cap, seg_stride, d_slot, d_reqs, n, e->msg_size, e->shard.count, d_replies, st);
+int dint_route_unpack_multi(const dint_route_item *items, uint32_t n_items, uint64_t seg_stride, void *stream) {
+  if (!items || n_items == 0 || n_items > DINT_ROUTE_MAXS) return fail(DINT_EINVAL, "1 .. %u batches per call", DINT_ROUTE_MAXS);
+  dint_route_job jobs[DINT_ROUTE_MAXS];
+  hipStream_t st = nullptr;
+  for (uint32_t k = 0; k < n_items; k++)
+    if (int rc = route_job(items[k], false, 0, st, stream, &jobs[k])) return rc;
+  dint_launch_route_unpack(jobs, n_items, seg_stride, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
   return 0;
+}
+
+int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_send, uint32_t seg_cap,
+                    uint64_t seg_stride, void *d_cnt, uint64_t cnt_stride, uint32_t *d_slot, void *stream) {
+  dint_route_item it = {e, d_reqs, n, seg_cap, d_send, d_cnt, d_slot, nullptr};
+  return dint_route_pack_multi(&it, 1, seg_stride, cnt_stride, stream);
+}
+
+int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, uint64_t seg_stride,
+                      const uint32_t *d_slot, const void *d_reqs, uint32_t n, void *d_replies, void *stream) {
+  dint_route_item it = {e, d_reqs, n, seg_cap, const_cast<void *>(d_back), nullptr, const_cast<uint32_t *>(d_slot), d_replies};
+  return dint_route_unpack_multi(&it, 1, seg_stride, stream);
 }
 
 void *dint_engine_stream(dint_engine_t *e) { return e ? (void *)e->stream : nullptr; }

@@ -17,6 +17,8 @@
 //
 // A slot is `cap` messages; a destination that would receive more drops the excess (reply = request, counted in
 // dint_stats.route_overflow): callers size `cap` from the recorded or expected maximum and check the counter.
+#include <algorithm>
+
 #include "../../include/dint_abi.h"
 #include "dint_kv.h"
 
@@ -32,6 +34,27 @@ struct rt_params {
   dint_mod slots;      // lid workloads: % n_slots
   const kv_dev *kv;    // kv workloads
   uint32_t world, self;
+};
+
+// one batch to route (or to bring back): grid.y of every kernel below selects the item, so the S logical servers of a
+// rank (S = 3 for tatp / smallbank) share ONE launch of each kernel -- a step costs 3 + 1 launches on the exchange
+// stream, not 3 S + S (at ~10 us per dependent launch the stream, not the engines, was the limit of a step)
+struct rt_item {
+  const uint8_t *req;
+  uint8_t *rep;          // unpack: replies in request order
+  uint32_t n, cap;       // requests; slot capacity (messages)
+  uint8_t *send;         // this item's slot of peer 0 (peer w at + w * stride); unpack: the returned slots
+  uint8_t *cnt;          // its u32 live count of peer 0 (peer w at + w * cnt_stride)
+  uint64_t cnt_stride;
+  uint32_t *slot;        // [n] where each request went
+  uint8_t *home;         // [n] scratch: home rank
+  uint32_t *blk;         // [blocks][world] scratch: counts, then exclusive prefixes
+  dint_dev_stats *stats;
+  rt_params p;
+};
+struct rt_items {
+  uint64_t stride;
+  rt_item it[DINT_ROUTE_MAXS];
 };
 
 __device__ static inline uint32_t rt_home(const uint8_t *m, const rt_params &p) {
@@ -66,8 +89,14 @@ __device__ static inline void rt_copy_msg(uint8_t *dst, const uint8_t *src, uint
 }
 
 __global__ void __launch_bounds__(RT_TB)
-k_route_count(const uint8_t *__restrict__ req, uint32_t n, rt_params p, uint8_t *__restrict__ home,
-              uint32_t *__restrict__ blk) {
+k_route_count(rt_items I) {
+  const rt_item &it = I.it[blockIdx.y];
+  const uint32_t n = it.n;
+  if (blockIdx.x * RT_TB >= n) return;  // the grid is as wide as the largest item
+  const uint8_t *__restrict__ req = it.req;
+  uint8_t *__restrict__ home = it.home;
+  uint32_t *__restrict__ blk = it.blk;
+  const rt_params &p = it.p;
   __shared__ uint32_t H[DINT_ROUTE_MAXW];
   const uint32_t t = threadIdx.x, i = blockIdx.x * RT_TB + t;
   if (t < p.world) H[t] = 0;
@@ -90,8 +119,13 @@ k_route_count(const uint8_t *__restrict__ req, uint32_t n, rt_params p, uint8_t 
 }
 
 __global__ void __launch_bounds__(RS_TB)
-k_route_scan(uint32_t nb, uint32_t world, uint32_t cap, uint32_t *__restrict__ blk, uint8_t *cnt, uint64_t cnt_stride,
-             dint_dev_stats *__restrict__ stats) {
+k_route_scan(rt_items I) {  // one workgroup per item
+  const rt_item &it = I.it[blockIdx.x];
+  const uint32_t nb = (it.n + RT_TB - 1) / RT_TB, world = it.p.world, cap = it.cap;
+  uint32_t *__restrict__ blk = it.blk;
+  uint8_t *cnt = it.cnt;
+  const uint64_t cnt_stride = it.cnt_stride;
+  dint_dev_stats *__restrict__ stats = it.stats;
   __shared__ uint32_t Sw[RS_TB / 64];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   for (uint32_t w = 0; w < world; w++) {
@@ -125,9 +159,16 @@ k_route_scan(uint32_t nb, uint32_t world, uint32_t cap, uint32_t *__restrict__ b
 }
 
 __global__ void __launch_bounds__(RT_TB)
-k_route_scatter_simple(const uint8_t *__restrict__ req, uint32_t n, uint32_t msg, uint32_t world, uint32_t cap,
-                const uint8_t *__restrict__ home, const uint32_t *__restrict__ blk, uint8_t *send, uint64_t stride,
-                uint32_t *__restrict__ slot) {
+k_route_scatter_simple(rt_items I) {
+  const rt_item &it = I.it[blockIdx.y];
+  const uint32_t n = it.n, msg = it.p.msg, world = it.p.world, cap = it.cap;
+  if (blockIdx.x * RT_TB >= n) return;
+  const uint8_t *__restrict__ req = it.req;
+  const uint8_t *__restrict__ home = it.home;
+  const uint32_t *__restrict__ blk = it.blk;
+  uint8_t *send = it.send;
+  const uint64_t stride = I.stride;
+  uint32_t *__restrict__ slot = it.slot;
   __shared__ uint32_t Wc[RT_TB / 64][DINT_ROUTE_MAXW];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, i = blockIdx.x * RT_TB + t;
   for (uint32_t k = t; k < (RT_TB / 64) * DINT_ROUTE_MAXW; k += RT_TB) (&Wc[0][0])[k] = 0;
@@ -156,8 +197,14 @@ k_route_scatter_simple(const uint8_t *__restrict__ req, uint32_t n, uint32_t msg
 }
 
 __global__ void __launch_bounds__(256)
-k_route_unpack_simple(const uint8_t *__restrict__ back, uint32_t cap, uint64_t stride, const uint32_t *__restrict__ slot,
-               const uint8_t *req, uint32_t n, uint32_t msg, uint8_t *rep) {
+k_route_unpack_simple(rt_items I) {
+  const rt_item &it = I.it[blockIdx.y];
+  const uint8_t *__restrict__ back = it.send;
+  const uint32_t cap = it.cap, n = it.n, msg = it.p.msg;
+  const uint64_t stride = I.stride;
+  const uint32_t *__restrict__ slot = it.slot;
+  const uint8_t *req = it.req;
+  uint8_t *rep = it.rep;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const uint32_t s = slot[i];
@@ -205,9 +252,16 @@ __device__ static inline void rt_lds_put(uint8_t *L, const rt_regs &r, uint32_t 
 }
 
 __global__ void __launch_bounds__(RT_TB)
-k_route_scatter(const uint8_t *__restrict__ req, uint32_t n, uint32_t msg, uint32_t world, uint32_t cap,
-                const uint8_t *__restrict__ home, const uint32_t *__restrict__ blk, uint8_t *send, uint64_t stride,
-                uint32_t *__restrict__ slot) {
+k_route_scatter(rt_items I) {
+  const rt_item &it = I.it[blockIdx.y];
+  const uint32_t n = it.n, msg = it.p.msg, world = it.p.world, cap = it.cap;
+  if (blockIdx.x * RT_TB >= n) return;
+  const uint8_t *__restrict__ req = it.req;
+  const uint8_t *__restrict__ home = it.home;
+  const uint32_t *__restrict__ blk = it.blk;
+  uint8_t *send = it.send;
+  const uint64_t stride = I.stride;
+  uint32_t *__restrict__ slot = it.slot;
   __shared__ __attribute__((aligned(16))) uint8_t Lb[RT_LDS_BYTES];
   __shared__ uint32_t Wc[RT_TB / 64][DINT_ROUTE_MAXW];
   __shared__ uint32_t Cnt[DINT_ROUTE_MAXW], Loff[DINT_ROUTE_MAXW];  // messages of the tile per destination; LDS byte offset of its run
@@ -265,8 +319,15 @@ k_route_scatter(const uint8_t *__restrict__ req, uint32_t n, uint32_t msg, uint3
 }
 
 __global__ void __launch_bounds__(RT_TB)
-k_route_unpack(const uint8_t *__restrict__ back, uint32_t cap, uint64_t stride, const uint32_t *__restrict__ slot,
-               const uint8_t *req, uint32_t n, uint32_t msg, uint32_t world, uint8_t *rep) {
+k_route_unpack(rt_items I) {
+  const rt_item &it = I.it[blockIdx.y];
+  const uint8_t *__restrict__ back = it.send;
+  const uint32_t cap = it.cap, n = it.n, msg = it.p.msg, world = it.p.world;
+  if (blockIdx.x * RT_TB >= n) return;
+  const uint64_t stride = I.stride;
+  const uint32_t *__restrict__ slot = it.slot;
+  const uint8_t *req = it.req;
+  uint8_t *rep = it.rep;
   __shared__ __attribute__((aligned(16))) uint8_t Lb[RT_LDS_BYTES];
   __shared__ uint32_t Cnt[DINT_ROUTE_MAXW], Min[DINT_ROUTE_MAXW], Loff[DINT_ROUTE_MAXW];
   const uint32_t t = threadIdx.x, lane = t & 63, i = blockIdx.x * RT_TB + t;
@@ -341,33 +402,63 @@ static rt_params make_params(uint32_t workload, uint32_t msg, dint_mod slots, co
   return p;
 }
 
-void dint_launch_route_pack(uint32_t workload, uint32_t msg, dint_mod slots, const dint_kv *kv, dint_shard shard,
-                            const void *d_req, uint32_t n, void *d_send, uint32_t cap, uint64_t stride, void *d_cnt,
-                            uint64_t cnt_stride, uint32_t *d_slot, dint_route_scratch rs, dint_dev_stats *stats,
-                            hipStream_t st) {
-  const rt_params p = make_params(workload, msg, slots, kv, shard);
-  const uint32_t nb = (n + RT_TB - 1) / RT_TB;  // <= DINT_ROUTE_MAXN / RT_TB = 4096; 0 blocks still writes the headers
-  if (nb)
-    hipLaunchKernelGGL(k_route_count, dim3(nb), dim3(RT_TB), 0, st, (const uint8_t *)d_req, n, p, rs.home, rs.blk);
-  hipLaunchKernelGGL(k_route_scan, dim3(1), dim3(RS_TB), 0, st, nb, shard.count, cap, rs.blk, (uint8_t *)d_cnt,
-                     cnt_stride, stats);
-  if (nb && ((uintptr_t)d_req & 15) == 0)
-    hipLaunchKernelGGL(k_route_scatter, dim3(nb), dim3(RT_TB), 0, st, (const uint8_t *)d_req, n, msg, shard.count, cap,
-                       (const uint8_t *)rs.home, (const uint32_t *)rs.blk, (uint8_t *)d_send, stride, d_slot);
-  else if (nb)
-    hipLaunchKernelGGL(k_route_scatter_simple, dim3(nb), dim3(RT_TB), 0, st, (const uint8_t *)d_req, n, msg, shard.count, cap,
-                       (const uint8_t *)rs.home, (const uint32_t *)rs.blk, (uint8_t *)d_send, stride, d_slot);
+// items[k] routed with engine k's parameters; every kernel once, grid.y = item
+void dint_launch_route_pack(const dint_route_job *jobs, uint32_t n_jobs, uint64_t stride, hipStream_t st) {
+  rt_items I;
+  I.stride = stride;
+  uint32_t nb_max = 0;
+  bool aligned = true;
+  for (uint32_t k = 0; k < n_jobs; k++) {
+    const dint_route_job &j = jobs[k];
+    rt_item &it = I.it[k];
+    it.req = (const uint8_t *)j.d_req;
+    it.rep = nullptr;
+    it.n = j.n;
+    it.cap = j.cap;
+    it.send = (uint8_t *)j.d_send;
+    it.cnt = (uint8_t *)j.d_cnt;
+    it.cnt_stride = j.cnt_stride;
+    it.slot = j.d_slot;
+    it.home = j.rs.home;
+    it.blk = j.rs.blk;
+    it.stats = j.stats;
+    it.p = make_params(j.workload, j.msg, j.slots, j.kv, j.shard);
+    nb_max = std::max(nb_max, (j.n + RT_TB - 1) / RT_TB);  // <= DINT_ROUTE_MAXN / RT_TB = 4096
+    aligned = aligned && ((uintptr_t)j.d_req & 15) == 0;
+  }
+  if (nb_max) hipLaunchKernelGGL(k_route_count, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
+  hipLaunchKernelGGL(k_route_scan, dim3(n_jobs), dim3(RS_TB), 0, st, I);  // 0 blocks still writes the headers
+  if (nb_max && aligned)
+    hipLaunchKernelGGL(k_route_scatter, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
+  else if (nb_max)
+    hipLaunchKernelGGL(k_route_scatter_simple, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
 }
 
-void dint_launch_route_unpack(const void *d_back, uint32_t cap, uint64_t stride, const uint32_t *d_slot,
-                              const void *d_req, uint32_t n, uint32_t msg, uint32_t world, void *d_rep, hipStream_t st) {
-  if (n == 0) return;
-  if (((uintptr_t)d_rep & 15) == 0)
-    hipLaunchKernelGGL(k_route_unpack, dim3((n + RT_TB - 1) / RT_TB), dim3(RT_TB), 0, st, (const uint8_t *)d_back, cap, stride,
-                       d_slot, (const uint8_t *)d_req, n, msg, world, (uint8_t *)d_rep);
+void dint_launch_route_unpack(const dint_route_job *jobs, uint32_t n_jobs, uint64_t stride, hipStream_t st) {
+  rt_items I;
+  I.stride = stride;
+  uint32_t n_max = 0;
+  bool aligned = true;
+  for (uint32_t k = 0; k < n_jobs; k++) {
+    const dint_route_job &j = jobs[k];
+    rt_item &it = I.it[k];
+    it = rt_item();
+    it.req = (const uint8_t *)j.d_req;
+    it.rep = (uint8_t *)j.d_rep;
+    it.n = j.n;
+    it.cap = j.cap;
+    it.send = (uint8_t *)j.d_send;  // the slots as they came back
+    it.slot = j.d_slot;
+    it.p.msg = j.msg;
+    it.p.world = j.shard.count;
+    n_max = std::max(n_max, j.n);
+    aligned = aligned && ((uintptr_t)j.d_rep & 15) == 0;
+  }
+  if (n_max == 0) return;
+  if (aligned)
+    hipLaunchKernelGGL(k_route_unpack, dim3((n_max + RT_TB - 1) / RT_TB, n_jobs), dim3(RT_TB), 0, st, I);
   else
-    hipLaunchKernelGGL(k_route_unpack_simple, dim3((n + 255) / 256), dim3(256), 0, st, (const uint8_t *)d_back, cap, stride,
-                       d_slot, (const uint8_t *)d_req, n, msg, (uint8_t *)d_rep);
+    hipLaunchKernelGGL(k_route_unpack_simple, dim3((n_max + 255) / 256, n_jobs), dim3(256), 0, st, I);
 }
 
 static_assert(RS_TB * RS_PER * RT_TB == DINT_ROUTE_MAXN, "the scan workgroup covers every block of the largest batch");

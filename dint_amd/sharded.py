@@ -84,6 +84,10 @@ class Router:
         self.stream = torch.cuda.Stream() if device == "cuda" else None  # routing kernels and collectives
         # the engines' own streams, as torch streams (event waits / records only; kernels are launched by the ABI)
         self.estream = [torch.cuda.ExternalStream(e.stream) for e in self.engines] if device == "cuda" else None
+        self.multi = None  # (pack, unpack) of several batches per launch set: the real engines on a GPU
+        if device == "cuda" and self.S <= 4:
+            from .engine import route_pack_multi, route_unpack_multi
+            self.multi = (route_pack_multi, route_unpack_multi)
         self.NBUF = 2  # exchange buffer sets: step k uses set k % 2 (see run())
         self.d_slot = [[torch.empty(n_max, dtype=torch.int32, device=device) for _ in range(self.S)] for _ in range(self.NBUF)]
         self.send = self.recv = None
@@ -125,10 +129,14 @@ class Router:
         b = k % self.NBUF
         xs = self.stream.cuda_stream if self.stream is not None else 0
         sp = self.send[b].data_ptr()
-        for s, e in enumerate(self.engines):
-            assert counts[s] <= self.n_max
-            e.route_pack(d_reqs[s], counts[s], sp + self.off[s], self.caps[s], self.chunk, sp + 4 * s, self.chunk,
-                         self.d_slot[b][s], xs)
+        assert all(counts[s] <= self.n_max for s in range(self.S))
+        if self.multi:  # the S servers' batches in one set of launches (grid.y = server)
+            self.multi[0](self.engines, d_reqs, counts, [sp + self.off[s] for s in range(self.S)], self.caps, self.chunk,
+                          [sp + 4 * s for s in range(self.S)], self.chunk, self.d_slot[b], xs)
+        else:
+            for s, e in enumerate(self.engines):
+                e.route_pack(d_reqs[s], counts[s], sp + self.off[s], self.caps[s], self.chunk, sp + 4 * s, self.chunk,
+                             self.d_slot[b][s], xs)
         if track:  # slot occupancy (host sync; recording runs only)
             hdr = self.send[b].view(self.world, self.chunk)[:, :4 * self.S].cpu().numpy().view("<u4")
             for s in range(self.S):
@@ -162,9 +170,13 @@ class Router:
             self.stream.wait_event(ev)
         self.ex.all_to_all(self.send[b], self.recv[b])
         sp = self.send[b].data_ptr()
-        for s, e in enumerate(self.engines):
-            e.route_unpack(sp + self.off[s], self.caps[s], self.chunk, self.d_slot[b][s], d_reqs[s], counts[s],
-                           d_reps[s], xs)
+        if self.multi:
+            self.multi[1](self.engines, [sp + self.off[s] for s in range(self.S)], self.caps, self.chunk, self.d_slot[b],
+                          d_reqs, counts, d_reps, xs)
+        else:
+            for s, e in enumerate(self.engines):
+                e.route_unpack(sp + self.off[s], self.caps[s], self.chunk, self.d_slot[b][s], d_reqs[s], counts[s],
+                               d_reps[s], xs)
 
     def run(self, steps, track: bool = False) -> None:
         """steps: [(d_reqs[S], counts[S], d_reps[S])] -- independent batches (a recorded trace).  Asynchronous.

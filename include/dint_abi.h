@@ -239,6 +239,24 @@ int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_se
                     uint64_t seg_stride, void *d_cnt, uint64_t cnt_stride, uint32_t *d_slot, void *stream);
 int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, uint64_t seg_stride,
                       const uint32_t *d_slot, const void *d_reqs, uint32_t n, void *d_replies, void *stream);
+/* The same for several batches at once -- the S logical servers of a rank (3 for tatp / smallbank), each routed with
+ * its own engine's hash and modulus -- in ONE set of kernel launches (grid.y = batch): a step then costs 3 + 1 launches
+ * on the exchange stream whatever S is.  d_slots = this batch's slot of peer 0 (peer w at + w * seg_stride) in the send
+ * buffer (pack) or in the returned buffer (unpack); d_cnt = its live-count word of peer 0 (peer w at + w *
+ * cnt_stride).  At most 4 batches per call, all on one device; callers pass the engines in the same order. */
+typedef struct dint_route_item {
+  dint_engine_t *engine;
+  const void *d_reqs;
+  uint32_t n;
+  uint32_t seg_cap;
+  void *d_slots;
+  void *d_cnt;      /* pack only */
+  uint32_t *d_slot; /* [n]: written by pack, read by unpack */
+  void *d_replies;  /* unpack only */
+} dint_route_item;
+int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64_t seg_stride, uint64_t cnt_stride,
+                          void *stream);
+int dint_route_unpack_multi(const dint_route_item *items, uint32_t n_items, uint64_t seg_stride, void *stream);
 /* n_seg segments of seg_cap message slots, segment k at d_base + k * seg_stride holding *(u32 *)(d_cnt + k *
  * cnt_stride) requests: processed in place as ONE serial history, segment by segment (kernel passes take whole
  * segments: seg_cap <= max_pass). */

@@ -65,6 +65,59 @@ def test_route_pack_unpack_vs_numpy(n, world, cap):
     assert d_rep.cpu().numpy()[:n * msg].tobytes() == req.tobytes()
 
 
+@pytest.mark.parametrize("sizes,world", [((5000, 0, 777), 2), ((70_000, 65_000, 1), 8), ((300, 300, 300), 3)])
+def test_route_multi_equals_per_engine_calls(sizes, world):
+    """dint_route_pack_multi / _unpack_multi (the S servers of a rank in one set of launches, grid.y = server) against
+    the same batches routed one engine at a time: identical exchange buffers, slot maps, overflow counts, replies."""
+    from dint_amd.engine import route_pack_multi, route_unpack_multi
+
+    rank, msg, HDRB = 1, 55, 64
+    o = orc.TatpOracle(300, log_entries=1000)
+    existing = [o.dump(t)[0] for t in range(5)]
+    reqs = [tracegen.tatp_random(max(n, 1), existing, seed=11 + k, n_sub_touch=200)[:n] for k, n in enumerate(sizes)]
+    caps = [max(64, (3 * n) // (2 * world) // 64 * 64 + 64) for n in sizes]
+    caps[1] = max(64, sizes[1] // world // 2 // 64 * 64)  # the second server's slots overflow
+    offs, o_ = [], HDRB
+    for c in caps:
+        offs.append(o_)
+        o_ += (c * msg + 15) // 16 * 16
+    stride = (o_ + 63) // 64 * 64
+
+    def run(multi):
+        engs = [_engine(W.TATP, n_rows=300 * world, log_entries=1000, shard_index=rank, shard_count=world) for _ in sizes]
+        d_req = [_dev(r) if len(r) else torch.zeros(16, dtype=torch.uint8, device="cuda") for r in reqs]
+        d_send = torch.zeros(world * stride, dtype=torch.uint8, device="cuda")
+        d_slot = [torch.full((max(n, 1),), 12345, dtype=torch.int32, device="cuda") for n in sizes]
+        d_rep = [torch.zeros_like(d) for d in d_req]
+        sp = d_send.data_ptr()
+        if multi:
+            route_pack_multi(engs, d_req, list(sizes), [sp + offs[k] for k in range(3)], caps, stride,
+                             [sp + 4 * k for k in range(3)], stride, d_slot)
+            route_unpack_multi(engs, [sp + offs[k] for k in range(3)], caps, stride, d_slot, d_req, list(sizes), d_rep)
+        else:
+            for k, e in enumerate(engs):
+                e.route_pack(d_req[k], sizes[k], sp + offs[k], caps[k], stride, sp + 4 * k, stride, d_slot[k])
+            for k, e in enumerate(engs):
+                e.route_unpack(sp + offs[k], caps[k], stride, d_slot[k], d_req[k], sizes[k], d_rep[k])
+        torch.cuda.synchronize()
+        for e in engs:
+            e.sync()
+        return (d_send.cpu().numpy(), [d.cpu().numpy()[:n] for d, n in zip(d_slot, sizes)],
+                [d.cpu().numpy()[:n * msg].tobytes() for d, n in zip(d_rep, sizes)], [e.stats()["route_overflow"] for e in engs])
+
+    a, b = run(False), run(True)
+    sa, sb = a[0].reshape(world, stride), b[0].reshape(world, stride)
+    cnt = sa[:, :12].copy().view("<u4")
+    assert (cnt == sb[:, :12].copy().view("<u4")).all()
+    for w in range(world):
+        for k in range(3):
+            lo = offs[k]
+            assert (sa[w, lo:lo + cnt[w, k] * msg] == sb[w, lo:lo + cnt[w, k] * msg]).all(), (w, k)
+    assert all((x == y).all() for x, y in zip(a[1], b[1]))
+    assert a[2] == b[2] and a[2] == [r.tobytes() for r in reqs]  # straight back from the send buffer: reply = request
+    assert a[3] == b[3] and a[3][0] == 0 and (a[3][1] > 0) == (sizes[1] > 0)  # only the second server's slots are too small
+
+
 def _segmented(req: np.ndarray, cuts, cap, hdr=64):
     """lay `req` out as len(cuts)-1 segments of capacity `cap` with a header in front of each"""
     msg = req.dtype.itemsize
