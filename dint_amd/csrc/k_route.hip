@@ -222,7 +222,7 @@ k_route_unpack_simple(rt_items I) {
 // across a dozen cache lines, and a wave issues ~28 partially used transactions (measured: 22 us to move 13 MB, 0.6
 // TB/s).  Here the workgroup's 1024-message tile is read with 16-byte vectors into LDS, permuted there
 // (request order <-> destination-major order), and every destination's run leaves as one contiguous stream.
-#define RT_LDS_BYTES (RT_TB * 55u + 4u * DINT_ROUTE_MAXW)
+#define RT_LDS_BYTES (RT_TB * 55u + 32u * DINT_ROUTE_MAXW)  // + up to 31 bytes per run: each run keeps its 16-byte phase
 
 __device__ static inline void rt_lds_load_tile(uint8_t *L, const uint8_t *g, uint32_t nbytes) {  // g 16-byte aligned
   const uint32_t t = threadIdx.x, nv = nbytes >> 4;
@@ -233,6 +233,22 @@ __device__ static inline void rt_lds_store_tile(uint8_t *g, const uint8_t *L, ui
   const uint32_t t = threadIdx.x, nv = nbytes >> 4;
   for (uint32_t k = t; k < nv; k += RT_TB) ((uint4 *)g)[k] = ((const uint4 *)L)[k];
   for (uint32_t k = (nv << 4) + t; k < nbytes; k += RT_TB) g[k] = L[k];
+}
+// A run of nb bytes between global memory g and LDS L, where L was placed with g's 16-byte phase ((L - Lb) & 15 ==
+// g & 15, Lb 16-byte aligned): head bytes up to the first 16-byte boundary, 16-byte vectors, tail bytes.
+__device__ static inline void rt_run_store(uint8_t *g, const uint8_t *L, uint32_t nb) {
+  const uint32_t t = threadIdx.x, hb = min(nb, (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u), nv = (nb - hb) >> 4;
+  if (t < hb) g[t] = L[t];
+  for (uint32_t k = t; k < nv; k += RT_TB) ((uint4 *)(g + hb))[k] = ((const uint4 *)(L + hb))[k];
+  const uint32_t done = hb + (nv << 4);
+  if (t < nb - done) g[done + t] = L[done + t];
+}
+__device__ static inline void rt_run_load(uint8_t *L, const uint8_t *g, uint32_t nb) {
+  const uint32_t t = threadIdx.x, hb = min(nb, (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u), nv = (nb - hb) >> 4;
+  if (t < hb) L[t] = g[t];
+  for (uint32_t k = t; k < nv; k += RT_TB) ((uint4 *)(L + hb))[k] = ((const uint4 *)(g + hb))[k];
+  const uint32_t done = hb + (nv << 4);
+  if (t < nb - done) L[done + t] = g[done + t];
 }
 // one message between LDS and registers (w[14] + 3 tail bytes)
 struct rt_regs { uint32_t w[14]; uint8_t tail[3]; };
@@ -290,9 +306,14 @@ k_route_scatter(rt_items I) {
     Cnt[t] = c;
   }
   __syncthreads();
-  if (t == 0) {
+  if (t == 0) {  // every destination's run gets the 16-byte phase of where it goes in memory
     uint32_t o = 0;
-    for (uint32_t w = 0; w < world; w++) { Loff[w] = o; o += (Cnt[w] * msg + 3u) & ~3u; }
+    for (uint32_t w = 0; w < world; w++) {
+      const uint8_t *g = send + (size_t)w * stride + (size_t)blk[(size_t)blockIdx.x * world + w] * msg;
+      o = ((o + 15u) & ~15u) + (uint32_t)((uintptr_t)g & 15u);
+      Loff[w] = o;
+      o += Cnt[w] * msg;
+    }
   }
   __syncthreads();
   uint32_t lrank = rank;
@@ -307,14 +328,7 @@ k_route_scatter(rt_items I) {
     const uint32_t base = blk[(size_t)blockIdx.x * world + w];
     const uint32_t cnt = base < cap ? min(Cnt[w], cap - base) : 0;
     const uint32_t nb = cnt * msg;
-    uint8_t *g = send + (size_t)w * stride + (size_t)base * msg;
-    const uint8_t *L = Lb + Loff[w];
-    for (uint32_t o = t * 4; o + 4 <= nb; o += RT_TB * 4) {
-      uint32_t v;
-      __builtin_memcpy(&v, L + o, 4);  // the run starts 4-byte aligned in LDS
-      __builtin_memcpy(g + o, &v, 4);  // ... and anywhere in memory
-    }
-    if (t < (nb & 3u)) g[(nb & ~3u) + t] = L[(nb & ~3u) + t];
+    rt_run_store(send + (size_t)w * stride + (size_t)base * msg, Lb + Loff[w], cnt * msg);
   }
 }
 
@@ -350,20 +364,18 @@ k_route_unpack(rt_items I) {
   __syncthreads();
   if (t == 0) {
     uint32_t o = 0;
-    for (uint32_t w = 0; w < world; w++) { Loff[w] = o; o += (Cnt[w] * msg + 3u) & ~3u; }
+    for (uint32_t w = 0; w < world; w++) {
+      const uint8_t *g = back + (size_t)w * stride + (size_t)(Cnt[w] ? Min[w] : 0u) * msg;
+      o = ((o + 15u) & ~15u) + (uint32_t)((uintptr_t)g & 15u);
+      Loff[w] = o;
+      o += Cnt[w] * msg;
+    }
   }
   __syncthreads();
   for (uint32_t w = 0; w < world; w++) {  // every home's run: one contiguous stream into LDS
     const uint32_t nb = Cnt[w] * msg;
     if (!nb) continue;
-    const uint8_t *g = back + (size_t)w * stride + (size_t)Min[w] * msg;
-    uint8_t *L = Lb + Loff[w];
-    for (uint32_t o = t * 4; o + 4 <= nb; o += RT_TB * 4) {
-      uint32_t v;
-      __builtin_memcpy(&v, g + o, 4);
-      __builtin_memcpy(L + o, &v, 4);
-    }
-    if (t < (nb & 3u)) L[(nb & ~3u) + t] = g[(nb & ~3u) + t];
+    rt_run_load(Lb + Loff[w], back + (size_t)w * stride + (size_t)Min[w] * msg, nb);
   }
   __syncthreads();
   rt_regs r;
