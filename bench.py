@@ -153,14 +153,20 @@ def host_cpu():
     return {"model": model, "logical_cores": os.cpu_count()}
 
 
-def kernel_source_hash():
-    """sha256 over the kernel sources: profiles/ counters are only quoted for the build they were taken from"""
+KERNEL_SOURCES = {  # the files the device code of a workload's pass is compiled from (dint_amd/csrc/)
+    "fasst": ("k_locks.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h"),
+    None: ("k_kv.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h", "dint_kv.h", "dint_kv_core.h"),
+}
+
+
+def kernel_source_hash(workload=None):
+    """sha256 over the sources of the workload's pass kernels: profiles/ counters are only quoted for the build they
+    were taken from (host code, the routing kernels and the client kernels do not enter)"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "dint_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in KERNEL_SOURCES.get(workload, KERNEL_SOURCES[None]):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -174,7 +180,7 @@ def profile_counters(workload, kernels):
         p = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if p.get("kernel_source_hash") != kernel_source_hash():
+    if p.get("kernel_source_hash") != kernel_source_hash(workload):
         return {"stale": True, "file": os.path.relpath(path, ROOT), "profiled_sources": p.get("kernel_source_hash")}
     tot_b, tot_us, seen = 0.0, 0.0, 0
     for k in kernels:

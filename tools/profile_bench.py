@@ -100,7 +100,7 @@ def main():
     except Exception:
         commit = None
     res = {"workload": wl, "command": "bench.py " + " ".join(rest) + f" --steps {steps} --warmup {warm}", "launches": last,
-           "kernel_source_hash": kernel_source_hash(), "commit": commit, "kernels": kernels}
+           "kernel_source_hash": kernel_source_hash(wl), "commit": commit, "kernels": kernels}
     os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "profiles", f"{'sq' if sq else 'traffic'}_{wl}.json"), "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
