@@ -250,27 +250,29 @@ __device__ static inline void rt_run_load(uint8_t *L, const uint8_t *g, uint32_t
   const uint32_t done = hb + (nv << 4);
   if (t < nb - done) L[done + t] = g[done + t];
 }
-// one message between LDS and registers (w[14] + 3 tail bytes)
-struct rt_regs { uint32_t w[14]; uint8_t tail[3]; };
-__device__ static inline void rt_lds_get(rt_regs &r, const uint8_t *L, uint32_t msg) {
-  const uint32_t nd = msg >> 2;
+// one message between LDS / memory and registers.  MSG is a compile-time constant (the kernels are instantiated per
+// wire format): with a run-time size the array was indexed dynamically and lived in scratch memory -- 64 bytes per
+// lane written and read back through HBM in both staged kernels.
+template <uint32_t MSG> struct rt_regs { uint32_t w[MSG / 4]; uint8_t tail[MSG % 4 ? MSG % 4 : 1]; };
+template <uint32_t MSG> __device__ static inline void rt_get(rt_regs<MSG> &r, const uint8_t *L) {
 #pragma unroll
-  for (uint32_t k = 0; k < 14; k++)
-    if (k < nd) __builtin_memcpy(&r.w[k], L + 4 * k, 4);
-  for (uint32_t k = nd * 4; k < msg; k++) r.tail[k - nd * 4] = L[k];
+  for (uint32_t k = 0; k < MSG / 4; k++) __builtin_memcpy(&r.w[k], L + 4 * k, 4);
+#pragma unroll
+  for (uint32_t k = 0; k < MSG % 4; k++) r.tail[k] = L[(MSG / 4) * 4 + k];
 }
-__device__ static inline void rt_lds_put(uint8_t *L, const rt_regs &r, uint32_t msg) {
-  const uint32_t nd = msg >> 2;
+template <uint32_t MSG> __device__ static inline void rt_put(uint8_t *L, const rt_regs<MSG> &r) {
 #pragma unroll
-  for (uint32_t k = 0; k < 14; k++)
-    if (k < nd) __builtin_memcpy(L + 4 * k, &r.w[k], 4);
-  for (uint32_t k = nd * 4; k < msg; k++) L[k] = r.tail[k - nd * 4];
+  for (uint32_t k = 0; k < MSG / 4; k++) __builtin_memcpy(L + 4 * k, &r.w[k], 4);
+#pragma unroll
+  for (uint32_t k = 0; k < MSG % 4; k++) L[(MSG / 4) * 4 + k] = r.tail[k];
 }
 
+template <uint32_t MSG>
 __global__ void __launch_bounds__(RT_TB)
 k_route_scatter(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
-  const uint32_t n = it.n, msg = it.p.msg, world = it.p.world, cap = it.cap;
+  constexpr uint32_t msg = MSG;
+  const uint32_t n = it.n, world = it.p.world, cap = it.cap;
   if (blockIdx.x * RT_TB >= n) return;
   const uint8_t *__restrict__ req = it.req;
   const uint8_t *__restrict__ home = it.home;
@@ -297,8 +299,8 @@ k_route_scatter(rt_items I) {
     if ((int)lane == l) Wc[wave][hh] = (uint32_t)__popcll(m);
     todo &= ~m;
   }
-  rt_regs r;
-  if (valid) rt_lds_get(r, Lb + t * msg, msg);
+  rt_regs<MSG> r;
+  if (valid) rt_get<MSG>(r, Lb + t * msg);
   __syncthreads();  // every message is in registers: the buffer can be rewritten destination-major
   if (t < world) {
     uint32_t c = 0;
@@ -319,7 +321,7 @@ k_route_scatter(rt_items I) {
   uint32_t lrank = rank;
   for (uint32_t k = 0; k < wave; k++) lrank += Wc[k][h];
   if (valid) {
-    rt_lds_put(Lb + Loff[h] + lrank * msg, r, msg);
+    rt_put<MSG>(Lb + Loff[h] + lrank * msg, r);
     const uint32_t pos = blk[(size_t)blockIdx.x * world + h] + lrank;
     slot[i] = pos < cap ? h * cap + pos : RT_NONE;
   }
@@ -332,11 +334,13 @@ k_route_scatter(rt_items I) {
   }
 }
 
+template <uint32_t MSG>
 __global__ void __launch_bounds__(RT_TB)
 k_route_unpack(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
   const uint8_t *__restrict__ back = it.send;
-  const uint32_t cap = it.cap, n = it.n, msg = it.p.msg, world = it.p.world;
+  constexpr uint32_t msg = MSG;
+  const uint32_t cap = it.cap, n = it.n, world = it.p.world;
   if (blockIdx.x * RT_TB >= n) return;
   const uint64_t stride = I.stride;
   const uint32_t *__restrict__ slot = it.slot;
@@ -378,18 +382,11 @@ k_route_unpack(rt_items I) {
     rt_run_load(Lb + Loff[w], back + (size_t)w * stride + (size_t)Min[w] * msg, nb);
   }
   __syncthreads();
-  rt_regs r;
-  if (routed) rt_lds_get(r, Lb + Loff[h] + (pos - Min[h]) * msg, msg);
-  else if (valid) {  // not sent (slot overflow): reply = request
-    const uint8_t *q = req + (size_t)i * msg;
-    const uint32_t nd = msg >> 2;
-#pragma unroll
-    for (uint32_t k = 0; k < 14; k++)
-      if (k < nd) __builtin_memcpy(&r.w[k], q + 4 * k, 4);
-    for (uint32_t k = nd * 4; k < msg; k++) r.tail[k - nd * 4] = q[k];
-  }
+  rt_regs<MSG> r;
+  if (routed) rt_get<MSG>(r, Lb + Loff[h] + (pos - Min[h]) * msg);
+  else if (valid) rt_get<MSG>(r, req + (size_t)i * msg);  // not sent (slot overflow): reply = request
   __syncthreads();
-  if (valid) rt_lds_put(Lb + t * msg, r, msg);  // request order
+  if (valid) rt_put<MSG>(Lb + t * msg, r);  // request order
   __syncthreads();
   rt_lds_store_tile(rep + (size_t)blockIdx.x * RT_TB * msg, Lb, tile_n * msg);
 }
@@ -440,9 +437,21 @@ void dint_launch_route_pack(const dint_route_job *jobs, uint32_t n_jobs, uint64_
   }
   if (nb_max) hipLaunchKernelGGL(k_route_count, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
   hipLaunchKernelGGL(k_route_scan, dim3(n_jobs), dim3(RS_TB), 0, st, I);  // 0 blocks still writes the headers
-  if (nb_max && aligned)
-    hipLaunchKernelGGL(k_route_scatter, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
-  else if (nb_max)
+  bool staged = nb_max && aligned;
+  for (uint32_t k = 1; k < n_jobs; k++) staged = staged && jobs[k].msg == jobs[0].msg;  // one instantiation per launch
+  if (staged) {
+    const dim3 g(nb_max, n_jobs), b(RT_TB);
+    switch (jobs[0].msg) {
+      case 6: hipLaunchKernelGGL(k_route_scatter<6>, g, b, 0, st, I); break;
+      case 9: hipLaunchKernelGGL(k_route_scatter<9>, g, b, 0, st, I); break;
+      case 23: hipLaunchKernelGGL(k_route_scatter<23>, g, b, 0, st, I); break;
+      case 53: hipLaunchKernelGGL(k_route_scatter<53>, g, b, 0, st, I); break;
+      case 55: hipLaunchKernelGGL(k_route_scatter<55>, g, b, 0, st, I); break;
+      default: staged = false;
+    }
+  }
+  if (staged) return;
+  if (nb_max)
     hipLaunchKernelGGL(k_route_scatter_simple, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
 }
 
@@ -467,9 +476,20 @@ void dint_launch_route_unpack(const dint_route_job *jobs, uint32_t n_jobs, uint6
     aligned = aligned && ((uintptr_t)j.d_rep & 15) == 0;
   }
   if (n_max == 0) return;
-  if (aligned)
-    hipLaunchKernelGGL(k_route_unpack, dim3((n_max + RT_TB - 1) / RT_TB, n_jobs), dim3(RT_TB), 0, st, I);
-  else
+  bool staged = aligned;
+  for (uint32_t k = 1; k < n_jobs; k++) staged = staged && jobs[k].msg == jobs[0].msg;
+  if (staged) {
+    const dim3 g((n_max + RT_TB - 1) / RT_TB, n_jobs), b(RT_TB);
+    switch (jobs[0].msg) {
+      case 6: hipLaunchKernelGGL(k_route_unpack<6>, g, b, 0, st, I); break;
+      case 9: hipLaunchKernelGGL(k_route_unpack<9>, g, b, 0, st, I); break;
+      case 23: hipLaunchKernelGGL(k_route_unpack<23>, g, b, 0, st, I); break;
+      case 53: hipLaunchKernelGGL(k_route_unpack<53>, g, b, 0, st, I); break;
+      case 55: hipLaunchKernelGGL(k_route_unpack<55>, g, b, 0, st, I); break;
+      default: staged = false;
+    }
+  }
+  if (!staged)
     hipLaunchKernelGGL(k_route_unpack_simple, dim3((n_max + 255) / 256, n_jobs), dim3(256), 0, st, I);
 }
 
