@@ -23,6 +23,7 @@ run.  `Exchange` is the only class that touches torch.distributed.
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -84,6 +85,10 @@ class Router:
         self.stream = torch.cuda.Stream() if device == "cuda" else None  # routing kernels and collectives
         # the engines' own streams, as torch streams (event waits / records only; kernels are launched by the ABI)
         self.estream = [torch.cuda.ExternalStream(e.stream) for e in self.engines] if device == "cuda" else None
+        # the backward half of a step (inverse all-to-all + unpack) on a stream of its own: the exchange stream then
+        # carries only pack + forward all-to-all, and the two halves of consecutive steps run side by side
+        self.bstream = (torch.cuda.Stream() if device == "cuda" and os.environ.get("DINT_BWD_STREAM", "1") != "0" else None)
+        self.ev_unpacked = [None] * 2  # per buffer set: its last unpack has read the send buffer
         self.multi = None  # (pack, unpack) of several batches per launch set: the real engines on a GPU
         if device == "cuda" and self.S <= 4:
             from .engine import route_pack_multi, route_unpack_multi
@@ -111,6 +116,7 @@ class Router:
         self.chunk = _align(o, 64)
         if self.device == "cuda":
             torch.cuda.synchronize()
+        self.ev_unpacked = [None] * 2
         self.send = [torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device) for _ in range(self.NBUF)]
         self.recv = [torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device) for _ in range(self.NBUF)]
 
@@ -130,6 +136,8 @@ class Router:
         xs = self.stream.cuda_stream if self.stream is not None else 0
         sp = self.send[b].data_ptr()
         assert all(counts[s] <= self.n_max for s in range(self.S))
+        if self.bstream is not None and self.ev_unpacked[b] is not None:
+            self.stream.wait_event(self.ev_unpacked[b])  # step k - 2 is done with this buffer set
         if self.multi:  # the S servers' batches in one set of launches (grid.y = server)
             self.multi[0](self.engines, d_reqs, counts, [sp + self.off[s] for s in range(self.S)], self.caps, self.chunk,
                           [sp + 4 * s for s in range(self.S)], self.chunk, self.d_slot[b], xs)
@@ -165,10 +173,12 @@ class Router:
 
     def _backward(self, k: int, ev_done, d_reqs, counts, d_reps):
         b = k % self.NBUF
-        xs = self.stream.cuda_stream if self.stream is not None else 0
+        st = self.bstream if self.bstream is not None else self.stream
+        xs = st.cuda_stream if st is not None else 0
         for ev in ev_done:
-            self.stream.wait_event(ev)
-        self.ex.all_to_all(self.send[b], self.recv[b])
+            st.wait_event(ev)
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            self.ex.all_to_all(self.send[b], self.recv[b])
         sp = self.send[b].data_ptr()
         if self.multi:
             self.multi[1](self.engines, [sp + self.off[s] for s in range(self.S)], self.caps, self.chunk, self.d_slot[b],
@@ -177,6 +187,10 @@ class Router:
             for s, e in enumerate(self.engines):
                 e.route_unpack(sp + self.off[s], self.caps[s], self.chunk, self.d_slot[b][s], d_reqs[s], counts[s],
                                d_reps[s], xs)
+        if self.bstream is not None:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.ev_unpacked[b] = ev
 
     def run(self, steps, track: bool = False) -> None:
         """steps: [(d_reqs[S], counts[S], d_reps[S])] -- independent batches (a recorded trace).  Asynchronous.
@@ -189,6 +203,8 @@ class Router:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())  # the caller's uploads of the request tensors
+            if self.bstream is not None:
+                self.bstream.wait_stream(torch.cuda.current_stream())
         with self._on_stream():
             ev = self._forward(0, steps[0][0], steps[0][1], track)
             done = self._engines(0, ev)
@@ -209,6 +225,8 @@ class Router:
     def sync(self) -> None:
         if self.stream is not None:
             self.stream.synchronize()
+        if self.bstream is not None:
+            self.bstream.synchronize()
         for e in self.engines:
             e.sync()
 
