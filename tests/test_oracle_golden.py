@@ -119,3 +119,12 @@ def test_ref_server_started_ahead_of_its_trace():
     finally:
         srv.close()
     assert got.tobytes() == want.tobytes() and st["n"] == len(req)
+
+
+@pytest.mark.skipif(not orc.loopback_available(), reason="reference binaries are built only where /root/reference exists")
+def test_as_shipped_reference_server_over_loopback():
+    """BASELINE.md 3(2) plumbing: the unmodified lock_fasst/udp/server (real UDP sockets, bind redirected to 127.0.0.1)
+    answers the closed-loop client; a short run, only the mechanics are checked here."""
+    req = tracegen.fasst_random(50_000, seed=9)
+    r = orc.ref_loopback_fasst(req, server_threads=2, client_threads=2, window=8, warmup_s=0.2, measure_s=0.6)
+    assert r["replies"] > 1000 and r["server_threads"] == 2 and r["ops_per_s"] > 0
