@@ -47,14 +47,15 @@ k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, T
   const uint32_t tile = Stile, i = tile * TXG_TB + t, ntiles = gridDim.x;
   const bool valid = i < n_clients;
 
-  // the client's header travels through registers: one coalesced 64 / 96-byte load here, one store at the end; the
+  // the client's header travels through registers: one coalesced 72 / 112-byte load here, one store at the end; the
   // working messages stay in memory and are touched only where the phase reads or writes them
   typename T::Out o;
   o.clear();
   typename T::Client c;
   if (valid) {
     c = cl[i];
-    c.m = store + (size_t)i * T::NMSG;
+    c.m.base = store + i;  // message k of every client is one array (TxMsgs)
+    c.m.stride = n_clients;
     if (!(dbg & 2)) T::run(c, P, o);
   }
   uint32_t nmsg[3] = {0, 0, 0};
@@ -142,12 +143,12 @@ k_txn_consume(const typename T::Client *cl, typename T::Msg *store, uint32_t n_c
   if (i >= n_clients) return;
   const uint8_t *reps[3] = {rep0, rep1, rep2};
   const typename T::Client c = cl[i];
-  Msg *m = store + (size_t)i * T::NMSG;
+  Msg *m = store + i;  // message d of this client at m[d * n_clients]
   const uint8_t n = c.n_out;
   for (uint8_t k = 0; k < n; k++) {
     const uint8_t d = c.out_dst[k];
     const uint32_t pos = c.out_pos[k];
-    if (d != TX_NO_DST && pos < cap) m[d] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
+    if (d != TX_NO_DST && pos < cap) m[(size_t)d * n_clients] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
   }
 }
 

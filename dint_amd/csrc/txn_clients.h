@@ -117,7 +117,18 @@ enum : uint8_t { TT_GET_SUB = 0, TT_GET_NEW_DEST = 1, TT_GET_ACCESS = 2, TT_UPD_
 // the working messages of the running transaction (names as in the reference functions)
 enum : uint8_t { A_READ = 0, A_LOCK = 1, B_READ = 2, B_LOCK = 3, A_VER = 4, B_VER = 5, TMP0 = 6, TMP1 = 7, TMP2 = 8, TATP_NMSG = 9 };
 
-// Client state = a 64-byte header (loaded and stored whole: on the GPU one coalesced access per client and phase)
+// A client's working messages: message k at base[k * stride].  The host driver keeps a client's messages together
+// (stride 1).  The device driver keeps message k of ALL clients together (base = store + client, stride = number of
+// clients): the lanes of a wave are consecutive clients, so one access of the wave is one run of consecutive 55-byte
+// messages -- with a client's messages contiguous every lane touched sectors of its own (k_txn_emit + k_txn_consume
+// 348 -> 317 us for 524,288 clients, tools/exp_emit.py; the divergent client logic itself is the larger part).
+template <class M> struct TxMsgs {
+  M *base;
+  uint32_t stride;
+  TX_HD M &operator[](uint32_t k) const { return base[(size_t)k * stride]; }
+};
+
+// Client state = a 72-byte header (loaded and stored whole: on the GPU one coalesced access per client and phase)
 // + TATP_NMSG working messages in a separate array, touched only where a phase reads or writes them.
 struct TatpClient {
   TxLcg rng;
@@ -126,9 +137,9 @@ struct TatpClient {
   uint8_t out_shard[6], out_dst[6];  // a tatp phase emits at most 6 messages
   uint32_t s_id;
   uint32_t out_pos[6];
-  TatpMsg *m;  // [TATP_NMSG] -- set by the driver before every use (host vector / device array)
+  TxMsgs<TatpMsg> m;  // [TATP_NMSG] -- set by the driver before every use (host vector / device array)
 };
-static_assert(sizeof(TatpClient) == 64, "one 64-byte sector per client header");
+static_assert(sizeof(TatpClient) == 72, "client header");
 
 TX_HD static inline void tatp_workgen(uint8_t *workgen) {
   // CreateWorkgenArr :63-73 -- note the order: GetSubscriberData, GetAccessData, GetNewDestination, ...
@@ -418,9 +429,9 @@ struct SbClient {
   float amount;
   uint64_t a0, a1;
   uint32_t out_pos[TX_MAXOUT];
-  SbMsg *m;           // [SB_NMSG] the locked rows, in the reference's order
+  TxMsgs<SbMsg> m;    // [SB_NMSG] the locked rows, in the reference's order
 };
-static_assert(sizeof(SbClient) == 104, "client header");
+static_assert(sizeof(SbClient) == 112, "client header");
 typedef TxOut<SbMsg> SbOut;
 
 TX_HD static inline void sb_workgen(uint8_t *workgen) {
