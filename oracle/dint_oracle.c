@@ -16,7 +16,7 @@
  *     written (the reference copies partially initialised stack structs,
  *     tatp/udp/tatp.h:291-307).
  *
- * PARITY PINNED for the six udp/ servers (tests/golden/*.npz and fasst_24m.json were recorded from the
+ * PARITY PINNED for the six udp/ servers (the .npz fixtures and fasst_24m.json under tests/golden were recorded from the
  * UNMODIFIED reference servers, oracle/Makefile ref).  PARITY UNPINNED for the eBPF-only codes restated
  * here from the eBPF sources alone -- STORE INSERT (store/ebpf/store_kern.c:226-297), tatp
  * REJECT_LOCK_SAME_KEY (orc_tatp_same_key_mode, tatp/ebpf/lock_kern.c:289-298) and smallbank
