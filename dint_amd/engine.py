@@ -226,6 +226,19 @@ def bench_rand64(bytes_: int, n_access: int, write_back: bool = False, device: i
     return aps.value, sec.value
 
 
+BENCH_MODES = {"gather": 0, "rmw": 1, "scatter": 2, "atomic": 3, "atomic_ret": 4, "stream_rd": 5, "stream_wr": 6}
+
+
+def bench_access(bytes_: int, n_access: int, mode: str, width: int = 64, blocks_per_cu: int = 8, device: int = -1):
+    """One access pattern of csrc/k_bench.hip over `bytes_` of HBM; returns (accesses/s, seconds) -- for the two
+    streaming modes 16-byte vectors/s."""
+    L = _lib.load()
+    aps = C.c_double(); sec = C.c_double()
+    _lib.check(L.dint_bench_access(device, bytes_, n_access, BENCH_MODES[mode], width, blocks_per_cu,
+                                   C.byref(aps), C.byref(sec)))
+    return aps.value, sec.value
+
+
 def refuse(workload, reqs: np.ndarray) -> np.ndarray:
     """the back-pressure replies of the eBPF-flavour servers (REJECT_* / RETRY) for a batch that is not taken"""
     L = _lib.load()

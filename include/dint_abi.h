@@ -271,6 +271,13 @@ int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d
  * SURVEY.md 8d): returns accesses per second via *out_aps, elapsed seconds via *out_s. */
 int dint_bench_rand64(int32_t device, uint64_t bytes, uint64_t n_access, int write_back,
                       double *out_aps, double *out_s);
+/* The general form: one access pattern over `bytes` of HBM, `blocks_per_cu` 256-thread workgroups per CU (0 = 8).
+ * mode 0 = random gather of `width` (8 / 16 / 64) bytes from a 64-byte-aligned sector; 1 = the same + an 8-byte store
+ * into the sector (read-modify-write); 2 = blind scatter of `width` (1 / 8 / 16 / 64) bytes; 3 = device-scope 64-bit
+ * atomic add without / 4 = with a returned value; 5 / 6 = streaming read / write of the whole table in 16-byte
+ * vectors (*out_aps = vectors per second).  Indices come from the engines' own hash + magic-multiply modulo. */
+int dint_bench_access(int32_t device, uint64_t bytes, uint64_t n_access, uint32_t mode, uint32_t width,
+                      uint32_t blocks_per_cu, double *out_aps, double *out_s);
 /* Per-kernel launch time of the most recent dint_submit_device micro-batch sequence, measured
  * with HIP events on the stream the kernels ran on.  Call dint_timing_enable(e,1) first. */
 int dint_timing_enable(dint_engine_t *e, int on);
