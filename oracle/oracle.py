@@ -27,7 +27,7 @@ def build(force: bool = False) -> None:
     ):
         subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     if os.path.isdir("/root/reference/lock_fasst/udp"):
-        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref", "ref_ebpf"])
 
 
 _lib = None
@@ -297,6 +297,33 @@ def ref_replay(workload: str, msgs: np.ndarray, dump: bool = False, timeout: flo
             with open(dp, "rb") as f:
                 return replies, stats, f.read()
         return replies, stats
+
+
+#: the eBPF flavour (DINT proper): unmodified <wl>/ebpf/*_kern.c + *_user.c under ref_harness/ebpf's emulator
+EBPF_BIN = {
+    "lock_fasst": "ref_ebpf_lock_fasst", "lock_2pl": "ref_ebpf_lock_2pl", "log_server": "ref_ebpf_log_server",
+    "tatp_lock": "ref_ebpf_tatp_lock", "tatp": "ref_ebpf_tatp", "smallbank": "ref_ebpf_smallbank",
+    "store": "ref_ebpf_store",
+}
+
+
+def ebpf_available(workload: str) -> bool:
+    return os.access(os.path.join(REF_DIR, EBPF_BIN[workload]), os.X_OK)
+
+
+def ebpf_replay(workload: str, msgs: np.ndarray, timeout: float = 3600):
+    """Run the unmodified reference eBPF server of `workload` (XDP program -> user-space fallback -> TC program,
+    oracle/ref_harness/ebpf) over `msgs`, one request at a time.  Returns (replies, stats); a request the server
+    never answers comes back unchanged and is counted in stats["unanswered"]."""
+    exe = os.path.join(REF_DIR, EBPF_BIN[workload])
+    msgs = np.ascontiguousarray(msgs)
+    with tempfile.TemporaryDirectory(prefix="dint_ebpf_") as td:
+        tp, rp = os.path.join(td, "trace.bin"), os.path.join(td, "replies.bin")
+        msgs.tofile(tp)
+        res = subprocess.run([exe, tp, rp], capture_output=True, text=True, timeout=timeout)
+        if res.returncode != 0:
+            raise RuntimeError(f"{exe} failed rc={res.returncode}: {res.stderr[-2000:]}")
+        return np.fromfile(rp, dtype=msgs.dtype), json.loads(res.stdout.strip().splitlines()[-1])
 
 
 class RefServer:
