@@ -45,10 +45,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("DINT_BENCH_WORKLOAD", "tatp"),
-                    choices=["tatp", "smallbank", "store", "fasst"])
+                    choices=["tatp", "smallbank", "store", "fasst", "2pl", "log"])
+    ap.add_argument("--per-step", type=int, default=16,
+                    help="batches (tatp / smallbank: epochs) per step: a step is a fixed bundle, so that K steps are "
+                         "tens of milliseconds of GPU work, not a few launches")
     ap.add_argument("--slots", type=int, default=1 << 20, help="lock_fasst table slots (BASELINE configs[1]: 1M; reference 36000000)")
     ap.add_argument("--theta", type=float, default=None,
                     help="Zipf skew of the key stream (default 0.8; smallbank 0.99); 0 = the reference's own distribution")
@@ -68,6 +71,11 @@ def parse():
     ap.add_argument("--no-rand64", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive dint_submit_async measurement")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the multi-GPU exchange (self all-to-all)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="tatp: skip the compact legs of the other BASELINE configs (lock_fasst, lock_2pl, log, store, smallbank)")
+    ap.add_argument("--no-shim", action="store_true", help="skip the UDP shim loopback leg")
+    ap.add_argument("--sweep-clients", action="store_true",
+                    help="tatp / smallbank: abort rate and Mtxn/s at 4096 / 32768 / 131072 / 524288 closed-loop clients")
     return ap.parse_args()
 
 
@@ -155,6 +163,8 @@ def host_cpu():
 
 KERNEL_SOURCES = {  # the files the device code of a workload's pass is compiled from (dint_amd/csrc/)
     "fasst": ("k_locks.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h"),
+    "2pl": ("k_locks.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h"),
+    "log": ("k_log.hip", "dint_device.h", "dint_kernels.h"),
     None: ("k_kv.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h", "dint_kv.h", "dint_kv_core.h"),
 }
 
@@ -196,49 +206,63 @@ def profile_counters(workload, kernels):
             "command": p.get("command"), "launches": p.get("launches"), "commit": p.get("commit")}
 
 
-def rand64(extra, value_ops_per_s, dev, workload=None, pass_kernels=(), requests_per_launch=None):
-    """Measured random-64B HBM roofline: gathers over an 8 GiB table.  BASELINE.md's fraction of it is
-    ops/s x sectors/op / gathers/s; sectors/op = the counted HBM-side bytes of one whole pass (every kernel of it,
-    profiles/traffic_<workload>.json, only for the sources this run uses) / 64 / the requests of a pass."""
-    from dint_amd.engine import bench_rand64
+L2_PEAK_GBS = 34500.0  # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+_RAND_CACHE = {}
+
+
+def rand_roofline(extra, ops_per_s, dev, U, u_what, table_gb):
+    """The north star's fraction of the random-64-B HBM roofline: ops/s x U / (random sector gathers/s), U = the 64-byte
+    table sectors a request touches at random by the layout (stated per workload; request / reply streams and the pass
+    scratch are not in it).  The denominator is measured here (csrc/k_bench.hip): one 8-byte load from a random
+    64-byte-aligned sector -- a sector costs the same whatever part of it is used -- over a table of the engines'
+    own footprint and over 8 GB (past ~4 GB the 4 x 16-byte form of r02 was TLB-bound: 21 G/s), 8 workgroups per CU;
+    the best rate is the roofline."""
+    from dint_amd.engine import bench_access
 
     try:
-        aps, _ = bench_rand64(8 << 30, 1 << 28, False, dev)
-        aps_w, _ = bench_rand64(8 << 30, 1 << 28, True, dev)
-        extra["rand64_Gaccess_s"] = round(aps / 1e9, 3)
-        extra["rand64_rw_Gaccess_s"] = round(aps_w / 1e9, 3)
-        extra["ops_frac_of_rand64"] = round(value_ops_per_s / aps, 5)
-        fp = profile_counters(workload, list(pass_kernels)) if workload and requests_per_launch else None
-        if fp and fp.get("traffic_bytes"):
-            spo = fp["traffic_bytes"] / 64.0 / requests_per_launch
-            extra["rand64_roofline"] = {"sectors_per_op": round(spo, 3), "frac": round(value_ops_per_s * spo / aps, 4),
-                                        "what": "ops/s x counted 64-B sectors per op (all kernels of a pass, rocprofv3 PMC) / measured random 64-B gathers/s"}
+        den = {}
+        for gb in sorted({max(1, min(int(round(table_gb)), 16)), 8}):
+            key = (dev, gb)
+            if key not in _RAND_CACHE:
+                _RAND_CACHE[key] = {"gather8": bench_access(gb << 30, 1 << 28, "gather", 8, 8, dev)[0],
+                                    "gather64": bench_access(gb << 30, 1 << 28, "gather", 64, 8, dev)[0],
+                                    "rmw64": bench_access(gb << 30, 1 << 28, "rmw", 64, 8, dev)[0],
+                                    "scatter8": bench_access(gb << 30, 1 << 28, "scatter", 8, 8, dev)[0]}
+            den[f"{gb}GB"] = {k: round(v / 1e9, 2) for k, v in _RAND_CACHE[key].items()}
+        best = max(max(v["gather8"], v["gather64"]) for v in den.values()) * 1e9
+        extra["roofline_rand64"] = {"frac": round(ops_per_s * U / best, 4), "U": round(U, 3), "U_what": u_what,
+                                    "ops_per_s": round(ops_per_s), "gathers_per_s": round(best),
+                                    "G_per_s_by_table_size": den,
+                                    "what": "ops/s x U / measured random 64-B sector gathers/s (best of the table sizes)"}
     except Exception as ex:  # measurement helper only
-        extra["rand64_error"] = str(ex)
+        extra["roofline_rand64_error"] = str(ex)
 
 
 def pct(a, q):
     return round(float(np.percentile(a, q)), 2)
 
 
-# ------------------------------------------------------------------------------------------- lock_fasst
-def cpu_baseline_fasst(sample: np.ndarray, nslots: int, want: bytes):
-    """The CPU baseline on rank 0's host cores over a bounded sample of the same stream: the unmodified
-    reference server when its replay binary is present and the table has the reference's size (kind "reference"),
-    else the C restatement.  Its replies must equal the GPU's on the same requests (`want`)."""
+# ----------------------------------------------------------------------------- lock_fasst / lock_2pl / log
+def cpu_baseline_micro(kind, sample: np.ndarray, size: int, want: bytes):
+    """The CPU baseline on rank 0's host cores over a bounded sample of the same stream: the unmodified reference
+    server when its replay binary is present and the table has the reference's size (kind "reference"), else the C
+    restatement.  Its replies must equal the GPU's on the same requests (`want`)."""
     from oracle import oracle as orc
 
-    if nslots == 36_000_000 and orc.ref_available("lock_fasst"):
-        rep, st = orc.ref_replay("lock_fasst", sample)
+    ref_name = {"fasst": "lock_fasst", "2pl": "lock_2pl", "log": "log_server"}[kind]
+    ref_size = 1_000_000 if kind == "log" else 36_000_000
+    if size == ref_size and orc.ref_available(ref_name):
+        rep, st = orc.ref_replay(ref_name, sample)
         out = {"value": st["ops_per_s"] / 1e6, "unit": "Mtxn/s", "cores": 1, "kind": "reference",
-               "sample": f"{len(sample)} requests of the bench stream, unmodified lock_fasst/udp/server.cc, sockets interposed"}
+               "sample": f"{len(sample)} requests of the bench stream, unmodified {ref_name}/udp/server.cc, sockets interposed"}
     else:
-        o = orc.FasstOracle(nslots)
+        o = {"fasst": orc.FasstOracle, "2pl": orc.TplOracle, "log": orc.LogOracle}[kind](size)
         t = time.perf_counter()
         rep = o.replay(sample)
         dt = time.perf_counter() - t
         out = {"value": len(sample) / dt / 1e6, "unit": "Mtxn/s", "cores": 1, "kind": "port",
-               "sample": f"{len(sample)} requests of the bench stream, oracle/dint_oracle.c ({nslots} slots)"}
+               "sample": f"{len(sample)} requests of the bench stream, oracle/dint_oracle.c ({size} {'ring entries' if kind == 'log' else 'slots'})"}
+    out["value"] = round(out["value"], 4)
     out["host_cpu"] = host_cpu()
     out["oracle_parity"] = {"requests": len(sample), "ok": rep.tobytes() == want}
     return out
@@ -246,7 +270,7 @@ def cpu_baseline_fasst(sample: np.ndarray, nslots: int, want: bytes):
 
 def cpu_as_shipped_fasst(sample: np.ndarray):
     """the reference's as-shipped `lock_fasst/udp/server T` (unmodified; real UDP sockets, on
-    127.0.0.1) driven closed-loop over loopback by oracle/ref_harness/udp_loop_client.c with the bench stream: T = 8
+    127.0.0.1) driven closed-loop over loopback by dint_amd/csrc/udp_loop_client.c with the bench stream: T = 8
     (exp/run_lock_fasst.sh:48-49) and T = a quarter of the host's logical cores.  The table has the reference's
     compile-time size (36M slots) whatever --slots says: this leg prices the reference's per-packet path (syscalls +
     kernel UDP stack + the lock op), not the table."""
@@ -274,23 +298,76 @@ def cpu_as_shipped_fasst(sample: np.ndarray):
                       f"(client threads x window 32 outstanding requests each)"}
 
 
-def bench_fasst(args, world, rank, dev, transport):
+def shim_loopback(sample: np.ndarray, dev: int, threads=(2, 8, 16)):
+    """SURVEY.md 8 f1, measured: the UDP host shim (dint_amd/dint_udp_server: recvmmsg -> dint_submit_async -> sendmmsg,
+    the GPU engine behind it) over loopback, driven by the same closed-loop client as `cpu_as_shipped` with the same
+    lock_fasst stream, for 2 / 8 / 16 socket threads.  Kernel UDP stack on both sides of every datagram: this is what
+    a socket-fed deployment of the engine delivers on this host, next to the reference's own server."""
+    import socket as _s
+    import subprocess as sp
+    import tempfile
+
+    here = os.path.join(ROOT, "dint_amd")
+    server, client = os.path.join(here, "dint_udp_server"), os.path.join(here, "dint_udp_client")
+    if not (os.access(server, os.X_OK) and os.access(client, os.X_OK)):
+        return None
+    cores = os.cpu_count() or 8
+    runs = []
+    with tempfile.TemporaryDirectory(prefix="dint_shim_") as td:
+        tp = os.path.join(td, "requests.bin")
+        np.ascontiguousarray(sample).tofile(tp)
+        for t in threads:
+            so = _s.socket(_s.AF_INET, _s.SOCK_DGRAM)
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1] & ~1
+            so.close()
+            srv = sp.Popen([server, "--workload", "fasst", "--bind", "127.0.0.1", "--port", str(port), "--threads", str(t),
+                            "--batch", "4096", "--deadline-us", "50", "--device", str(dev)], stdout=sp.PIPE, stderr=sp.DEVNULL, text=True)
+            try:
+                line = srv.stdout.readline()
+                if "ready" not in line:
+                    raise RuntimeError(f"shim did not start: {line!r}")
+                res = sp.run([client, tp, str(sample.dtype.itemsize), str(port), str(min(4 * t, max(4, cores // 2))), "64", "1.0", "3.0"],
+                             capture_output=True, text=True, timeout=60)
+                r = json.loads(res.stdout.strip().splitlines()[-1])
+                r["server_threads"] = t
+            except Exception as ex:
+                r = {"server_threads": t, "error": f"{type(ex).__name__}: {ex}"}
+            finally:
+                srv.terminate()  # the exact process started above
+                try:
+                    srv.wait(timeout=20)
+                except sp.TimeoutExpired:
+                    srv.kill()
+            runs.append(r)
+    ok = [r for r in runs if "ops_per_s" in r]
+    if not ok:
+        return {"runs": runs}
+    best = max(ok, key=lambda r: r["ops_per_s"])
+    return {"value": round(best["ops_per_s"] / 1e6, 4), "unit": "M requests/s", "socket_threads": best["server_threads"],
+            "runs": runs, "path": "dint_udp_server (recvmmsg / dint_submit_async / sendmmsg) over loopback UDP, lock_fasst, 36M slots",
+            "what": "closed-loop loopback clients, 64 outstanding requests per client thread, 3 s per run"}
+
+
+def bench_lock(args, world, rank, dev, transport, kind):
+    """lock_fasst (BASELINE configs[1]) and lock_2pl: the reference's load generators restated -- lock_fasst/caladan/
+    client.cc:183-280 (csrc/fasst_client.cc) and lock_2pl/caladan/client.cc:167-240 (dint_amd.driver.TplClient) -- 4096
+    closed-loop workers over 24M lids; the trace is generated once through the engine itself (the clients need the
+    replies) and cut into 64k-request batches, which the timed region replays from HBM.  One step = `--per-step`
+    batches."""
     import torch
 
     from dint_amd import wire
     from dint_amd.engine import Engine
     from dint_amd.sharded import Router
 
-    K, W = args.steps, args.warmup
+    K, W, B = args.steps, args.warmup, args.per_step
     theta = 0.8 if args.theta is None else args.theta
-    # the lock_fasst trace -- the reference's load generator (lock_fasst/caladan/client.cc:183-280
-    # restated, csrc/fasst_client.cc: 4096 closed-loop workers, 5..10 keys per transaction over 24M lids, read
-    # proportion 0.8, REJECT -> abort + restart, validation, commit; the same generator as the 24M-op parity trace of
-    # tests/test_fasst_24m.py) -- cut into 64k-request batches.  The trace is generated once through the engine itself
-    # (the clients need the replies), then replayed from HBM in the timed region.
-    from dint_amd.driver import fasst_trace
+    fasst = kind == "fasst"
+    from dint_amd.driver import fasst_trace, tpl_trace
 
-    eng = Engine(wire.Workload.FASST, n_slots=args.slots, device=dev, shard_index=rank, shard_count=world)
+    wl, dtype = (wire.Workload.FASST, wire.FASST_MSG) if fasst else (wire.Workload.TPL, wire.TPL_MSG)
+    eng = Engine(wl, n_slots=args.slots, device=dev, shard_index=rank, shard_count=world)
     rt = Router([eng], world, rank, transport=None if world > 1 else "self", n_max=BATCH) if (world > 1 or args.force_exchange) else None
 
     class _Server:  # 4096-request epochs through the host path (through the exchange when there are several ranks)
@@ -298,9 +375,13 @@ def bench_fasst(args, world, rank, dev, transport):
             return eng.submit(r) if rt is None else rt.submit([r])[0]
 
     eng.snapshot()
-    stream, recorded, cst = fasst_trace(_Server(), (W + K) * BATCH, n_workers=4096, key_space=24_000_000,
-                                        zipf_theta=theta if theta > 0 else None, first_worker=rank * 4096)
-    reps = [recorded]
+    n_batches = (W + K) * B
+    if fasst:
+        stream, recorded, cst = fasst_trace(_Server(), n_batches * BATCH, n_workers=4096, key_space=24_000_000,
+                                            zipf_theta=theta if theta > 0 else None, first_worker=rank * 4096)
+    else:
+        stream, recorded, cst = tpl_trace(_Server(), n_batches * BATCH, n_workers=4096, key_space=24_000_000,
+                                          zipf_theta=theta if theta > 0 else None, seed=0xDEADBEEF + rank)
     if rt is not None:
         rt.tighten_caps()
         rt.set_caps([rt.default_cap(BATCH)])  # the timed batches are 16 epochs long
@@ -308,10 +389,10 @@ def bench_fasst(args, world, rank, dev, transport):
     eng.restore()
     d_req = torch.from_numpy(np.frombuffer(stream.tobytes(), np.uint8).copy()).cuda()
     d_rep = torch.empty_like(d_req)
-    msg = wire.FASST_MSG.itemsize
+    msg = dtype.itemsize
     torch.cuda.synchronize()
 
-    def run(lo, hi):
+    def run(lo, hi):  # batches [lo, hi)
         if rt is None:
             for b in range(lo, hi):
                 o = b * BATCH * msg
@@ -325,22 +406,22 @@ def bench_fasst(args, world, rank, dev, transport):
         eng.sync()
         torch.cuda.synchronize()
 
-    run(0, W)
+    run(0, W * B)
     sync()
     barrier(world)
     t0 = time.perf_counter()
-    run(W, W + K)
+    run(W * B, n_batches)
     sync()
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, transport)
     got = d_rep.cpu().numpy().tobytes()
     # every reply byte of the recorded closed loop (one GPU: the replay applies the same requests in the same order;
     # several: a 64k batch takes 16 epochs of rank 0 before rank 1's, the recording interleaved them epoch by epoch)
-    replay_ok = (got == np.concatenate(reps).tobytes()) if world == 1 else None
+    replay_ok = (got == recorded.tobytes()) if world == 1 else None
     overflow = rt.overflow() if rt is not None else 0
 
     lat = []
-    for b in range(W, W + min(K, 100)):
+    for b in range(W * B, min(n_batches, W * B + 100)):
         sync()
         t = time.perf_counter()
         run(b, b + 1)
@@ -351,46 +432,144 @@ def bench_fasst(args, world, rank, dev, transport):
     roof, extra = None, {}
     if rt is None:
         eng.timing_enable(True)
-        run(W, W + min(K, 200))
+        run(W * B, min(n_batches, W * B + 200))
         sync()
         tim = eng.timing_read()
         eng.timing_enable(False)
         extra["kernels_us"] = {k: round(v["avg_us"], 3) for k, v in tim.items()}
-        mut = float((stream[W * BATCH:(W + K) * BATCH]["type"] != 0).mean())
-        # 9 (req) + 9 (reply) + 8 (lock+ver read) + 8 if the op mutates the slot
-        alg_bytes = BATCH * (26.0 + 8.0 * mut)
+        timed = stream[W * B * BATCH:]
+        if fasst:  # 9 (req) + 9 (reply) + 8 (lock + ver read) + 8 if the op mutates the slot
+            mut = float((timed["type"] != 0).mean())
+            alg_bytes = BATCH * (26.0 + 8.0 * mut)
+        else:      # 6 + 6 + 8 (counters read) + 8 when they are written back (a grant or a release)
+            ra = recorded[W * B * BATCH:]["action"]
+            mut = float(((ra == 2) | (ra == 5)).mean())
+            alg_bytes = BATCH * (20.0 + 8.0 * mut)
         dom = max(tim.items(), key=lambda kv: kv[1]["avg_us"])
         achieved = alg_bytes / (dom[1]["avg_us"] * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        # a table of a few MB lives in L2 / Infinity Cache: priced against the L2, not against HBM
+        in_cache = args.slots * 8 <= 64 << 20
+        peak = L2_PEAK_GBS if in_cache else HBM_PEAK_GBS
+        roof = {"bound": "l2" if in_cache else "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
+                "unit": "GB/s", "frac": round(achieved / peak, 5), "traffic": None,
                 "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(dom[1]["avg_us"], 3),
-                "from_profile": profile_counters("fasst", [dom[0]])}
+                "from_profile": profile_counters(kind, [dom[0]])}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
 
-    value = world * K * BATCH / dt / 1e6
+    value = world * K * B * BATCH / dt / 1e6
     if rank != 0:
         return None
     if not args.no_rand64 and rt is None:
-        rand64(extra, value * 1e6, dev)
+        rand_roofline(extra, value * 1e6, dev, 1.0, "one 8-byte slot {lock, ver} / {num_ex, num_sh} of the table per request",
+                      args.slots * 8 / 2**30)
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         n_s = min(len(stream), 4_000_000 // BATCH * BATCH)  # from the empty table: checkable as a unit
-        cpu = cpu_baseline_fasst(stream[:n_s].copy(), args.slots, got[:n_s * msg])
-        extra["cpu_as_shipped"] = cpu_as_shipped_fasst(stream[:n_s].copy())
+        cpu = cpu_baseline_micro(kind, stream[:n_s].copy(), args.slots, got[:n_s * msg])
+        if fasst and not getattr(args, "compact", False):
+            extra["cpu_as_shipped"] = cpu_as_shipped_fasst(stream[:n_s].copy())
+            if not args.no_shim:
+                extra["shim_loopback"] = shim_loopback(stream[:n_s].copy(), dev)
+    name = "lock_fasst" if fasst else "lock_2pl"
+    shape = ("read / lock / validate / commit, retries on REJECT; 5-10 keys per txn" if fasst else
+             "5-10 locks per txn in ascending order, exclusive with p = 0.2, REJECT releases and restarts, release in reverse")
     return {
-        "metric": "Mtxn/s (lock_fasst: 1 txn = 1 request) + p50/p99 batch latency",
+        "metric": f"Mtxn/s ({name}: 1 txn = 1 request) + p50/p99 batch latency",
         "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"lock_fasst on {world} MI355X: {args.slots}-slot lock table, 64k-request batches of the FaSST client "
-                               f"trace (4096 closed-loop workers per GPU: read / lock / validate / commit, retries on REJECT; "
-                               f"5-10 keys per txn, {'Zipf-%g' % theta if theta > 0 else 'uniform'} over 24M lids, read proportion 0.8)",
-                   "batch": BATCH, "slots": args.slots, "parallelism": f"hash-shard x{world}", "transport": transport},
-        "client": {k: cst[k] for k in ("committed", "rejects", "rollbacks", "protocol_errors")},
+        "config": {"workload": f"{name} on {world} MI355X: {args.slots}-slot lock table, 64k-request batches of the {name} client "
+                               f"trace (4096 closed-loop workers per GPU: {shape}, "
+                               f"{'Zipf-%g' % theta if theta > 0 else 'uniform'} over 24M lids); 1 step = {B} batches",
+                   "batch": BATCH, "batches_per_step": B, "slots": args.slots, "parallelism": f"hash-shard x{world}", "transport": transport},
+        "client": {k: cst[k] for k in ("committed", "rejects", "protocol_errors") if k in cst},
         "replay_equals_recorded": replay_ok,
-        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99)}, "route_overflow": overflow,
+        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "one 64k-request batch, submit -> replies in HBM"},
+        "route_overflow": overflow, "roofline": roof, "cpu_baseline": cpu, **extra,
+    }
+
+
+def bench_log(args, world, rank, dev, transport):
+    """log_server (log_server/udp/server.cc:73-88): 53-byte COMMIT records appended to the ring, 64k-request batches
+    (the reference's client resends one record forever, log_server/caladan/client.cc:153-166; here every record is
+    different).  Replicas only: the log is not sharded by key, every rank appends its own stream to its own ring."""
+    import torch
+
+    from dint_amd import wire
+    from dint_amd.engine import Engine
+
+    K, W, B = args.steps, args.warmup, args.per_step
+    ring = 1_000_000  # log_server/udp/utils.h:16
+    eng = Engine(wire.Workload.LOG, log_entries=ring, device=dev)
+    n_batches = (W + K) * B
+    rng = np.random.default_rng(0x5EED + rank)
+    n = n_batches * BATCH
+    stream = np.zeros(n, wire.LOG_MSG)
+    stream["key"] = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+    stream["val"][:, :8] = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+    stream["ver"] = rng.integers(0, 1 << 31, n)
+    d_req = torch.from_numpy(np.frombuffer(stream.tobytes(), np.uint8).copy()).cuda()
+    d_rep = torch.empty_like(d_req)
+    msg = wire.LOG_MSG.itemsize
+    torch.cuda.synchronize()
+
+    def run(lo, hi):
+        for b in range(lo, hi):
+            o = b * BATCH * msg
+            eng.submit_device(d_req.data_ptr() + o, BATCH, d_rep.data_ptr() + o, 0)
+
+    def sync():
+        eng.sync()
+        torch.cuda.synchronize()
+
+    run(0, W * B)
+    sync()
+    barrier(world)
+    t0 = time.perf_counter()
+    run(W * B, n_batches)
+    sync()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, transport)
+    got = d_rep.cpu().numpy().tobytes()
+    lat = []
+    for b in range(W * B, min(n_batches, W * B + 100)):
+        sync()
+        t = time.perf_counter()
+        run(b, b + 1)
+        sync()
+        lat.append((time.perf_counter() - t) * 1e6)
+    lat = np.array(lat)
+    eng.timing_enable(True)
+    run(W * B, min(n_batches, W * B + 200))
+    sync()
+    tim = eng.timing_read()
+    eng.timing_enable(False)
+    extra = {"kernels_us": {k: round(v["avg_us"], 3) for k, v in tim.items()}}
+    alg_bytes = BATCH * 162.0  # SURVEY.md 8(d): 53 (req) + 53 (reply) + 56 (ring entry)
+    us = sum(v["avg_us"] for v in tim.values())
+    achieved = alg_bytes / (us * 1e-6) / 1e9
+    roof = {"bound": "hbm", "kernel": "+".join(tim.keys()), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(us, 3), "from_profile": profile_counters("log", list(tim.keys()))}
+    value = world * K * B * BATCH / dt / 1e6
+    if rank != 0:
+        return None
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the whole stream from the empty ring: replies and the ring's final contents must equal the oracle's
+        n_s = min(n, 4_000_000 // BATCH * BATCH)
+        cpu = cpu_baseline_micro("log", stream[:n_s].copy(), ring, got[:n_s * msg])
+    return {
+        "metric": "Mtxn/s (log_server: 1 txn = 1 appended record) + p50/p99 batch latency",
+        "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"log_server on {world} MI355X: 53-byte COMMIT records into a {ring}-entry ring, 64k-request "
+                               f"batches; 1 step = {B} batches", "batch": BATCH, "batches_per_step": B,
+                   "parallelism": f"replicas only x{world} (the log is not sharded by key)", "transport": transport},
+        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "one 64k-request batch, submit -> replies in HBM"},
         "roofline": roof, "cpu_baseline": cpu, **extra,
     }
 
@@ -423,28 +602,30 @@ def bench_store(args, world, rank, dev, transport):
     from dint_amd.engine import Engine
     from dint_amd.sharded import Router
 
-    K, W = args.steps, args.warmup
+    K, W, B = args.steps, args.warmup, args.per_step
     theta = 0.8 if args.theta is None else args.theta
     n_sub = args.keys // 12  # 12 rows per subscriber (store/udp/tatp.h:44-66)
-    NB = 262144            # requests per step
+    NB = 262144            # requests per batch
     eng = Engine(wire.Workload.STORE, n_rows=n_sub, device=dev, shard_index=rank, shard_count=world)
     t_setup = time.perf_counter()
     eng.populate(n_sub)
     eng.sync()
     t_setup = time.perf_counter() - t_setup
-    stream = store_stream(NB * (K + W), n_sub, theta, 77 + rank)
+    n_batches = (K + W) * B
+    stream = store_stream(NB * n_batches, n_sub, theta, 77 + rank)
     d_req = torch.from_numpy(np.frombuffer(stream.tobytes(), np.uint8).copy()).cuda()
     d_rep = torch.empty_like(d_req)
     msg = wire.STORE_MSG.itemsize
     rt = Router([eng], world, rank, n_max=NB) if world > 1 else None
     torch.cuda.synchronize()
 
-    def step(b):
-        lo = b * NB * msg
-        if rt is None:
-            eng.submit_device(d_req.data_ptr() + lo, NB, d_rep.data_ptr() + lo, 0)
-        else:
-            rt.step([d_req.data_ptr() + lo], [NB], [d_rep.data_ptr() + lo])
+    def run(lo, hi):
+        for b in range(lo, hi):
+            o = b * NB * msg
+            if rt is None:
+                eng.submit_device(d_req.data_ptr() + o, NB, d_rep.data_ptr() + o, 0)
+            else:
+                rt.step([d_req.data_ptr() + o], [NB], [d_rep.data_ptr() + o])
 
     def sync():
         if rt is not None:
@@ -452,46 +633,47 @@ def bench_store(args, world, rank, dev, transport):
         eng.sync()
         torch.cuda.synchronize()
 
-    for b in range(W):
-        step(b)
+    run(0, W * B)
     sync()
     barrier(world)
     t0 = time.perf_counter()
-    for b in range(W, W + K):
-        step(b)
+    run(W * B, n_batches)
     sync()
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, transport)
-    got = d_rep.cpu().numpy().tobytes()
+    got = d_rep.cpu().numpy()
     lat = []
-    for b in range(W, W + min(K, 100)):
+    for b in range(W * B, min(n_batches, W * B + 100)):
         sync()
         t = time.perf_counter()
-        step(b)
+        run(b, b + 1)
         sync()
         lat.append((time.perf_counter() - t) * 1e6)
     lat = np.array(lat)
     roof, extra, cpu = None, {}, None
+    ty = stream[W * B * NB:]["type"]
     if rt is None:
         eng.timing_enable(True)
-        for b in range(W, W + min(K, 200)):
-            step(b)
+        run(W * B, min(n_batches, W * B + 200))
         sync()
         tim = eng.timing_read()
         eng.timing_enable(False)
         extra["kernels_us"] = {k: round(v["avg_us"], 3) for k, v in tim.items()}
-        ty = stream[W * NB:(W + K) * NB]["type"]
         alg = NB * (STORE_ALG[0] * float((ty == 0).mean()) + STORE_ALG[1] * float((ty == 1).mean()))
         us = tim["k_kv_resolve"]["avg_us"]
         ach = alg / (us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": "k_kv_resolve", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(alg),
                 "kernel_avg_us": round(us, 3), "from_profile": profile_counters("store", ["k_kv_resolve"])}
-    value = world * K * NB / dt / 1e6
+    value = world * K * B * NB / dt / 1e6
     if rank != 0:
         return None
     if not args.no_rand64 and rt is None:
-        rand64(extra, value * 1e6, dev)
+        rt_ = np.frombuffer(got.tobytes(), wire.STORE_MSG)[W * B * NB:]["type"]
+        hit = float(((rt_ == 3) | (rt_ == 5)).mean())  # GRANT_READ / SET_ACK: the row's value sector(s) are touched
+        rand_roofline(extra, value * 1e6, dev, 1.0 + 1.5 * hit,
+                      "bucket header sector + 1.5 value sectors for a request that finds its row (40-byte values at 64 + 40 k "
+                      "straddle a sector boundary for two of the four slots)", eng_table_gb(eng))
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as orc
 
@@ -502,18 +684,25 @@ def bench_store(args, world, rank, dev, transport):
         dtc = time.perf_counter() - t
         cpu = {"value": round(n_s / dtc / 1e6, 4), "unit": "Mtxn/s", "cores": 1, "kind": "port", "host_cpu": host_cpu(),
                "sample": f"the first {n_s} requests of the bench stream, oracle/dint_oracle.c ({n_sub * 12} keys), 1 thread",
-               "oracle_parity": {"requests": n_s, "ok": rep.tobytes() == got[:n_s * msg]}}
+               "oracle_parity": {"requests": n_s, "ok": rep.tobytes() == got.tobytes()[:n_s * msg]}}
     return {
         "metric": "Mtxn/s (store: 1 txn = 1 request) + p50/p99 batch latency",
         "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"store KV on {world} MI355X: {n_sub * 12} keys x 40-B values (64-B slots), 95/5 read/write, "
-                               f"s_id ~ Zipf-{theta}, {NB}-request batches", "keys": n_sub * 12, "batch": NB,
-                   "parallelism": f"hash-shard x{world}", "transport": transport},
-        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99)},
+        "config": {"workload": f"store KV on {world} MI355X: {n_sub * 12} keys x 40-B values, 95/5 read/write, "
+                               f"s_id ~ Zipf-{theta}, {NB}-request batches; 1 step = {B} batches", "keys": n_sub * 12, "batch": NB,
+                   "batches_per_step": B, "parallelism": f"hash-shard x{world}", "transport": transport},
+        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "one batch, submit -> replies in HBM"},
         "roofline": roof, "cpu_baseline": cpu, "setup_s": round(t_setup, 2), **extra,
     }
+
+
+def eng_table_gb(eng, n_engines=1):
+    """HBM footprint of the kv tables of `n_engines` engines like `eng`, in GB (for the roofline's table size)"""
+    per = 256 if eng.msg_size != 23 else 128
+    buckets = sum(eng.hash_size(t) for t in range({53: 1, 55: 5, 23: 2}[eng.msg_size]))
+    return n_engines * buckets * 1.25 * per / 2**30
 
 
 # ----------------------------------------------------------------------------------- tatp / smallbank
@@ -524,7 +713,17 @@ SB_ALG = {0: 78, 1: 78, 2: 58, 3: 58, 4: 66, 5: 66, 6: 78}  # 23 + 23 + {20 row 
 SB_LOG_TYPES = (6,)
 
 
-def cpu_baseline_txn(kind, trace, done, n_rows, lo, hi):
+def epoch_host(rp, e, shards=(0, 1, 2)):
+    """host copies (requests, recorded replies) of epoch e's batches, pulled from HBM on demand"""
+    from dint_amd import wire
+
+    dt = {55: wire.TATP_MSG, 23: wire.SB_MSG}[rp.msg]
+    req = [np.frombuffer(rp.d_req[e][s].cpu().numpy().tobytes(), dt) if s in shards else None for s in range(3)]
+    rep = [np.frombuffer(rp.d_want[e][s].cpu().numpy().tobytes(), dt) if s in shards else None for s in range(3)]
+    return req, rep
+
+
+def cpu_baseline_txn(kind, rp, done, n_rows, lo, hi):
     """Shard server 0's recorded request stream of epochs [0, hi) replayed on one host core by the CPU port
     (oracle/dint_oracle.c); epochs [lo, hi) are timed.  Every reply must equal what the GPU engine answered when the
     stream was recorded (oracle parity on the exact bench stream).  A transaction costs `ops_per_txn` requests over
@@ -536,15 +735,16 @@ def cpu_baseline_txn(kind, trace, done, n_rows, lo, hi):
     ok, checked = True, 0
     n, dt = 0, 0.0
     for e in range(hi):
-        req = trace[e][0][0]
+        rq, want = epoch_host(rp, e, (0,))
+        req = rq[0]
         t = time.perf_counter()
         rep = o.replay(req)
         if e >= lo:
             dt += time.perf_counter() - t
             n += len(req)
-        ok = ok and rep.tobytes() == trace[e][1][0].tobytes()
+        ok = ok and rep.tobytes() == want[0].tobytes()
         checked += len(req)
-    ops_all = sum(sum(len(r) for r in trace[e][0]) for e in range(lo, hi))
+    ops_all = rp.ops(lo, hi)
     ops_per_txn = ops_all / max(1, sum(done[lo:hi]))
     return {"value": round(n / dt / ops_per_txn / 1e6, 4), "unit": "Mtxn/s", "cores": 1, "kind": "port",
             "ops_per_s": round(n / dt), "ops_per_txn": round(ops_per_txn, 3), "host_cpu": host_cpu(),
@@ -611,22 +811,24 @@ def cpu_reference_tatp(ref, args, dev, C, zipf, n_epochs=12):
                                  "what": "GPU replies of shard server 0 vs the unmodified reference server, every byte"}}
 
 
-def host_path(grp, trace, lo, hi):
+def host_path(grp, rp, lo, hi):
     """The boundary the reference's servers sit behind hands over HOST buffers: the same recorded batches through
     dint_submit_async / dint_wait from page-locked memory (H2D + kernels + D2H, three staging slots per engine).
     Returns per-epoch latency (submit of the three batches -> all replies in host memory) and the pipelined rate."""
     from dint_amd.engine import Pinned
 
     msg = grp.msg
-    bufs = []
+    bufs, want = [], []
     for e in range(lo, hi):
+        rq, rw = epoch_host(rp, e)
         row = []
         for s in range(3):
-            b = trace[e][0][s].tobytes()
+            b = rq[s].tobytes()
             pin, pout = Pinned(max(len(b), 1)), Pinned(max(len(b), 1))
             pin.array[:len(b)] = np.frombuffer(b, np.uint8)
             row.append((pin, pout, len(b) // msg))
         bufs.append(row)
+        want.append([rw[s].tobytes() for s in range(3)])
     grp.sync()
     lat = []
     for row in bufs:  # one epoch at a time: latency
@@ -635,8 +837,7 @@ def host_path(grp, trace, lo, hi):
         for s in range(3):
             grp.engines[s].wait(tk[s])
         lat.append((time.perf_counter() - t) * 1e6)
-    ok = all(row[s][1].array[:row[s][2] * msg].tobytes() == trace[lo + i][1][s].tobytes()
-             for i, row in enumerate(bufs) for s in range(3))
+    ok = all(row[s][1].array[:row[s][2] * msg].tobytes() == want[i][s] for i, row in enumerate(bufs) for s in range(3))
     return np.array(lat), bufs, ok
 
 
@@ -653,14 +854,54 @@ def host_path_rate(grp, bufs):
     return time.perf_counter() - t
 
 
+def type_histogram(rp, lo, hi, type_off):
+    """request types of epochs [lo, hi) (all three servers), counted on the device"""
+    import torch
+
+    h = torch.zeros(256, dtype=torch.long, device="cuda")
+    launches = 0
+    for e in range(lo, hi):
+        for s in range(3):
+            if rp.counts[e][s]:
+                h += torch.bincount(rp.d_req[e][s][type_off::rp.msg].long(), minlength=256)
+                launches += -(-rp.counts[e][s] // KV_PASS)
+    return h.cpu().numpy(), launches
+
+
+def txn_U(kind, rp, lo, hi):
+    """random 64-byte table sectors a request touches, by the layout (dint_kv_core.h), averaged over the requests of
+    epochs [lo, hi): tatp -- the bucket's header sector for every table request, + 1.5 value sectors when a row is read or
+    written (READ that finds it, COMMIT_*, INSERT_*; 40-byte values straddle a sector for two slots of four), log
+    appends are sequential (0); smallbank -- header sector + the sector holding the four 8-byte values and the
+    counters for every table request."""
+    import torch
+
+    tot, units = 0, 0.0
+    for e in range(lo, hi):
+        for s in range(3):
+            n = rp.counts[e][s]
+            if not n:
+                continue
+            rq = rp.d_req[e][s][1::rp.msg].long()
+            rep = rp.d_want[e][s][1::rp.msg].long()
+            tot += n
+            if kind == "tatp":
+                is_log = (rq == 14) | (rq == 24)
+                row = (rep == 4) | (rq == 12) | (rq == 13) | (rq == 18) | (rq == 19)
+                units += float((~is_log).sum() + 1.5 * row.sum())
+            else:
+                units += 2.0 * float((rq != 6).sum())
+    return units / max(1, tot)
+
+
 def bench_txn(args, world, rank, dev, transport, kind):
     import torch
 
     from dint_amd import wire
     from dint_amd.driver import Driver
-    from dint_amd.replay import Replay, ShardGroup, record
+    from dint_amd.replay import Replay, ShardGroup
 
-    K, W = args.steps, args.warmup
+    K, W, B = args.steps, args.warmup, args.per_step
     C = args.clients
     if kind == "tatp":
         wl, n_rows, theta = wire.Workload.TATP, args.subscribers, (0.8 if args.theta is None else args.theta)
@@ -670,51 +911,52 @@ def bench_txn(args, world, rank, dev, transport, kind):
         n_rows = args.accounts if args.accounts else 10_000_000 * world
         alg_tab, log_types, dtype = SB_ALG, SB_LOG_TYPES, "u64"
     zipf = theta if theta > 0 else None
+    E0, E1 = W * B, (W + K) * B  # timed epochs
     t_setup = time.perf_counter()
     grp = ShardGroup(wl, n_rows, device=dev, rank=rank, world=world, transport=None if world > 1 else "self",
                      force_exchange=args.force_exchange, n_max=KV_PASS, flags=int(os.environ.get("DINT_BENCH_FLAGS", "0")))
     grp.sync()
     grp.snapshot()
     drv = Driver(wl, C, n_rows, first_client=rank * C, zipf_theta=zipf)
-    trace, done = record(drv, grp, W + K)  # the closed loop, once, through the real engines
+    rp, done, _ = Replay.recording(drv, grp, E1)  # the closed loop, once, through the real engines; every epoch stays in HBM
     stats = drv.stats()
     grp.sync()
     caps = grp.router.tighten_caps() if grp.router is not None else None  # slot capacities from the recorded maxima
     grp.restore()
-    rp = Replay(trace, grp.msg)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
-    rp.run(grp, 0, W)
+    rp.run(grp, 0, E0)
     grp.sync()
     barrier(world)
     t0 = time.perf_counter()
-    rp.run(grp, W, W + K)
+    rp.run(grp, E0, E1)
     t_issue = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind it)
     grp.sync()
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, transport)
-    rp.check(0, W + K)  # parity with the recorded closed-loop run, every reply byte
+    rp.check(0, E1)  # parity with the recorded closed-loop run, every reply byte
     overflow = grp.router.overflow() if grp.router is not None else 0
     ref = None
-    if kind == "tatp" and world == 1 and not (args.no_cpu_baseline or args.no_cpu_reference):
+    compact = getattr(args, "compact", False)
+    if kind == "tatp" and world == 1 and not (args.no_cpu_baseline or args.no_cpu_reference or compact):
         from oracle import oracle as orc  # cpu_baseline leg only: the reference populates (minutes, one host core)
         if orc.ref_available("tatp"):     # while the remaining GPU legs run; the headline region above is over
             ref = orc.RefServer("tatp")
 
-    txns = sum_over_ranks(sum(done[W:W + K]), world, transport)
-    ops = sum_over_ranks(rp.ops(W, W + K), world, transport)
+    txns = sum_over_ranks(sum(done[E0:E1]), world, transport)
+    ops = sum_over_ranks(rp.ops(E0, E1), world, transport)
     value = txns / dt / 1e6
 
-    # run-to-run spread of the same K steps (state restored before each): the driver's 20-step run is a few ms
+    # run-to-run spread of the same K steps (state restored before each)
     repeats = []
-    for _ in range(4):
+    for _ in range(0 if compact else 4):
         grp.restore()
-        rp.run(grp, 0, W)
+        rp.run(grp, 0, E0)
         grp.sync()
         barrier(world)
         t1 = time.perf_counter()
-        rp.run(grp, W, W + K)
+        rp.run(grp, E0, E1)
         grp.sync()
         barrier(world)
         repeats.append(txns / max_over_ranks(time.perf_counter() - t1, world, transport) / 1e6)
@@ -722,20 +964,20 @@ def bench_txn(args, world, rank, dev, transport, kind):
     # per-epoch latency, device side: submit of the three batches -> all replies visible in HBM
     grp.restore()
     lat = []
-    for e in range(min(W + K, 120)):
+    for e in range(min(E1, 120)):
         grp.sync()
         t = time.perf_counter()
         rp.run(grp, e, e + 1)
         grp.sync()
         lat.append((time.perf_counter() - t) * 1e6)
-    lat = np.array(lat[min(W, len(lat) // 2):])
+    lat = np.array(lat[min(E0, len(lat) // 2):])
 
     roof, extra = None, {}
     if world == 1 and grp.router is None:
         grp.restore()
         for e in grp.engines:
             e.timing_enable(True)
-        n_t = min(W + K, 200)
+        n_t = min(E1, 200)
         big0 = sum(e.stats()["big_bin_requests"] for e in grp.engines)
         rp.run(grp, 0, n_t)
         grp.sync()
@@ -749,20 +991,10 @@ def bench_txn(args, world, rank, dev, transport, kind):
         # A pass = count / scan / place (every request is classified, hashed and binned; log requests are finished
         # there) and k_kv_resolve (every bin of the pass, one launch: the table requests).  The dominant kernel is the
         # one the most time goes to; its algorithmic bytes are those of the requests it serves.
-        tab_b, log_b, n_tab, launches = 0.0, 0.0, 0, 0
-        for e in range(n_t):
-            for s in range(3):
-                ty = trace[e][0][s]["type"]
-                if len(ty) == 0:
-                    continue
-                launches += -(-len(ty) // KV_PASS)
-                for code, b in alg_tab.items():
-                    c = int((ty == code).sum())
-                    if code in log_types:
-                        log_b += b * c
-                    else:
-                        tab_b += b * c
-                        n_tab += c
+        hist, launches = type_histogram(rp, 0, n_t, 1)
+        tab_b = sum(b * int(hist[c]) for c, b in alg_tab.items() if c not in log_types)
+        log_b = sum(b * int(hist[c]) for c, b in alg_tab.items() if c in log_types)
+        n_tab = sum(int(hist[c]) for c in alg_tab if c not in log_types)
         f_big = big_req / max(1, n_tab)
         cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b),
                 "k_kv_count+k_kv_scan+k_kv_place": (avg.get("k_kv_count", 0.0) + avg.get("k_kv_scan", 0.0) + avg.get("k_kv_place", 0.0), tab_b + log_b)}
@@ -784,7 +1016,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
     # ---- the closed loop itself, resident on the GPU: the same clients as device code emit the same
     # stream (tests/test_gpu_gdriver.py), the engines read the batch sizes on the device, nothing crosses PCIe
     closed = None
-    if world == 1 and grp.router is None and not args.no_closed_loop:
+    if world == 1 and grp.router is None and not args.no_closed_loop and not compact:
         from dint_amd.driver import GpuDriver
         from dint_amd.replay import GpuLoop
 
@@ -792,41 +1024,44 @@ def bench_txn(args, world, rank, dev, transport, kind):
         cap = min(min(e.pass_max for e in grp.engines), int(1.25 * max(max(c) for c in rp.counts)) + 4096)
         gd = GpuDriver(wl, C, n_rows, cap, first_client=rank * C, zipf_theta=zipf)
         loop = GpuLoop(grp, gd)
-        loop.epochs(W)
+        loop.epochs(E0)
         loop.sync()
         tx0 = gd.stats()["txns"]
         t1 = time.perf_counter()
-        loop.epochs(K)
+        loop.epochs(E1 - E0)
         loop.sync()
         dtc = time.perf_counter() - t1
         gs = gd.stats()
         # same seeds, same servers => the device clients must have finished exactly the transactions the host
         # driver finished while the trace was recorded
         same = all(gs[k] == stats[k] for k in ("txns", "committed", "by_type", "committed_by_type"))
-        closed = {"value": round((gs["txns"] - tx0) / dtc / 1e6, 3), "unit": "Mtxn/s", "ms_per_epoch": round(dtc / K * 1e3, 5),
-                  "epochs": K, "equals_host_driver_run": bool(same), "overflow": gs["overflow"],
+        closed = {"value": round((gs["txns"] - tx0) / dtc / 1e6, 3), "unit": "Mtxn/s", "ms_per_epoch": round(dtc / (E1 - E0) * 1e3, 5),
+                  "epochs": E1 - E0, "equals_host_driver_run": bool(same), "overflow": gs["overflow"],
                   "what": "GPU-resident clients (k_txn_emit / k_txn_consume) + the three shard servers, closed loop, no host round trip"}
         del loop, gd
 
     host = {}
-    if world == 1 and grp.router is None and not args.no_host_path:
+    if world == 1 and grp.router is None and not args.no_host_path and not compact:
         grp.restore()
-        n_h = min(W + K, 24)
-        hl, bufs, ok = host_path(grp, trace, 0, n_h)
+        n_h = min(E1, 24)
+        hl, bufs, ok = host_path(grp, rp, 0, n_h)
         grp.restore()
         dth = host_path_rate(grp, bufs)
-        tx_h, ops_h = sum(done[:n_h]), sum(sum(len(r) for r in trace[e][0]) for e in range(n_h))
+        tx_h, ops_h = sum(done[:n_h]), rp.ops(0, n_h)
         host = {"latency_host_us": {"p50": pct(hl[n_h // 4:], 50), "p99": pct(hl[n_h // 4:], 99),
                                     "what": "dint_submit_async x3 + dint_wait from page-locked host buffers: H2D + kernels + D2H"},
                 "value_pcie": round(tx_h / dth / 1e6, 3), "Mops_s_pcie": round(ops_h / dth / 1e6, 3),
                 "pcie_parity_ok": bool(ok)}
+        del bufs
     if rank != 0:
         return None
     if not args.no_rand64 and world == 1 and grp.router is None:
-        rand64(extra, ops / dt, dev, kind, ("k_kv_count", "k_kv_scan", "k_kv_place", "k_kv_resolve"), ops / K / 3.0)
+        u_what = ("bucket header sector per table request + 1.5 value sectors when a row is read or written; log appends are sequential"
+                  if kind == "tatp" else "bucket header sector + the sector of the four values and the counters, per table request")
+        rand_roofline(extra, ops / dt, dev, txn_U(kind, rp, E0, min(E1, E0 + 32)), u_what, eng_table_gb(grp.engines[0], 3))
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline_txn(kind, trace, done, n_rows, W, W + min(K, 60))
+        cpu = cpu_baseline_txn(kind, rp, done, n_rows, E0, min(E1, E0 + (12 if compact else 60)))
         if ref is not None:
             try:
                 r = cpu_reference_tatp(ref, args, dev, C, zipf)
@@ -839,9 +1074,10 @@ def bench_txn(args, world, rank, dev, transport, kind):
             else:
                 r["port_on_bench_config"] = cpu
                 cpu = r
-        if kind == "tatp" and not args.no_cpu_reference:
+        if kind == "tatp" and not args.no_cpu_reference and not compact:
             # the reference's as-shipped per-packet path on this host (its lock_fasst server: the one udp/ server
-            # that starts in under a second; tatp's shard server spends minutes populating before it binds)
+            # that starts in under a second; tatp's shard server spends minutes populating before it binds) -- and
+            # the engine's own socket path (the UDP shim) on the same stream
             from dint_amd import wire as _w
             probe = np.zeros(1 << 18, _w.FASST_MSG)
             probe["type"] = 0
@@ -849,58 +1085,158 @@ def bench_txn(args, world, rank, dev, transport, kind):
             extra["cpu_as_shipped"] = cpu_as_shipped_fasst(probe)
             if extra["cpu_as_shipped"]:
                 extra["cpu_as_shipped"]["workload"] = "lock_fasst READ requests over 24M lids (per-packet path cost; not TATP)"
+            if not args.no_shim:
+                extra["shim_loopback"] = shim_loopback(probe, dev)
     if kind == "tatp":
         dist_name = f"Zipf-{theta}" if zipf else "tatp_nurand (reference)"
         what = (f"TATP full txn mix (35/35/10/2/14/2/2) on {world} MI355X: {n_rows} subscribers, 3 replicated "
                 f"shard servers per GPU group, {C} closed-loop clients per GPU, s_id ~ {dist_name}; "
-                f"1 step = 1 epoch = 3 request batches")
+                f"1 step = {B} epochs = {3 * B} request batches")
         metric = "Mtxn/s + p50/p99 batch latency, TATP"
         rows_key = "subscribers"
     else:
         dist_name = f"Zipf-{theta}" if zipf else "90% of txns on the 4% hot accounts (reference)"
         what = (f"SmallBank (6 txns, 15/15/15/25/15/15, 2PL) on {world} MI355X: {n_rows} accounts hash-sharded, 3 replicated "
                 f"shard servers per GPU group, {C} closed-loop clients per GPU, accounts ~ {dist_name}; "
-                f"1 step = 1 epoch = 3 request batches")
+                f"1 step = {B} epochs = {3 * B} request batches")
         metric = "Mtxn/s + p50/p99 batch latency, SmallBank"
         rows_key = "accounts"
     nt = 7 if kind == "tatp" else 6
-    return {
+    commit_rate = stats["committed"] / max(1, stats["txns"])
+    out = {
         "metric": metric,
         "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 5), "host_issue_ms_per_step": round(t_issue / K * 1e3, 5),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": what, rows_key: n_rows, "clients_per_gpu": C, "requests_per_step": round(ops / K / world),
-                   "parallelism": f"3 shard servers x hash-shard x{world}", "transport": transport,
-                   "exchange_slot_caps": caps},
-        "Mops_s": round(ops / dt / 1e6, 3), "ops_per_txn": round(ops / max(1.0, txns), 3),
-        "abort_rate": round(1.0 - stats["committed"] / max(1, stats["txns"]), 5),
+        "config": {"workload": what, rows_key: n_rows, "clients_per_gpu": C, "epochs_per_step": B,
+                   "requests_per_step": round(ops / K / world), "parallelism": f"3 shard servers x hash-shard x{world}",
+                   "transport": transport, "exchange_slot_caps": caps},
+        "Mops_s": round(ops / dt / 1e6, 3), "ops_per_txn": round(ops / max(1.0, txns), 3), "ms_per_epoch": round(dt / (E1 - E0) * 1e3, 5),
+        # the reference client's two rates (tatp/caladan/client_udp_shard.cc:102-103): throughput = finished
+        # transactions, goodput = committed ones (a NOT_EXIST read of a row the population never made counts as not
+        # committed there too)
+        "goodput_Mtxn_s": round(value * commit_rate, 3), "abort_rate": round(1.0 - commit_rate, 5),
         "txns_by_type": stats["by_type"][:nt], "committed_by_type": stats["committed_by_type"][:nt],
+        "commit_rate_by_type": [round(c / max(1, t), 4) for c, t in zip(stats["committed_by_type"][:nt], stats["by_type"][:nt])],
         "value_repeats": [round(v, 1) for v in repeats], "closed_loop": closed,
-        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "device side: 3 batches submitted -> replies in HBM"},
+        "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "device side: the 3 batches of one epoch submitted -> replies in HBM"},
         **host, "route_overflow": overflow,
         "roofline": roof, "cpu_baseline": cpu, "setup_s": round(t_setup, 2), **extra,
     }
+    del rp, grp
+    return out
+
+
+def client_sweep(args, world, rank, dev, transport, kind):
+    """abort rate and Mtxn/s against the number of closed-loop clients (the reference runs 13 machines x <= 300 uthreads,
+    exp/run_tatp_wrapper.sh:3-7; 524,288 lock-step clients on 1M Zipf-0.8 subscribers conflict far more often)"""
+    import copy
+    import gc
+
+    rows = []
+    for c in (4096, 32768, 131072, 524288):
+        a = copy.copy(args)
+        a.clients, a.compact, a.steps, a.warmup, a.per_step = c, True, 6, 2, 8
+        a.no_cpu_baseline = a.no_rand64 = a.no_closed_loop = a.no_host_path = True
+        r = bench_txn(a, world, rank, dev, transport, kind)
+        gc.collect()
+        if r:
+            rows.append({"clients": c, "Mtxn_s": r["value"], "goodput_Mtxn_s": r["goodput_Mtxn_s"], "abort_rate": r["abort_rate"],
+                         "commit_rate_by_type": r["commit_rate_by_type"], "ms_per_epoch": r["ms_per_epoch"],
+                         "latency_us": r["latency_us"]})
+    return rows
+
+
+def other_workloads(args, world, rank, dev, transport):
+    """Compact legs of the other BASELINE configs appended to the default (tatp) line, after its timed region: lock_fasst
+    configs[1], lock_2pl, log_server, store configs[2], smallbank (one GPU's 10M-account slice of configs[4]) -- each with
+    its own value, roofline and oracle parity on its own bench stream."""
+    import copy
+    import gc
+
+    out = {}
+    for wl in ("fasst", "2pl", "log", "store", "smallbank"):
+        a = copy.copy(args)
+        a.workload, a.compact, a.steps, a.warmup, a.per_step, a.theta = wl, True, 8, 2, (4 if wl in ("store", "smallbank") else 16), None
+        a.no_rand64 = a.no_closed_loop = a.no_host_path = True
+        try:
+            r = run_workload(a, world, rank, dev, transport)
+        except Exception as ex:  # one leg failing must not take the headline down; it fails the run at the end
+            out[wl] = {"error": f"{type(ex).__name__}: {ex}"}
+            continue
+        gc.collect()
+        if r is None:
+            continue
+        cb = r.get("cpu_baseline") or {}
+        par = cb.get("oracle_parity") or (cb.get("port_on_bench_config") or {}).get("oracle_parity")
+        out[wl] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                   "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "frac")} if r.get("roofline") else None,
+                   "kernels_us": r.get("kernels_us"), "latency_us": r.get("latency_us"),
+                   "replay_equals_recorded": r.get("replay_equals_recorded"), "abort_rate": r.get("abort_rate"),
+                   "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None, "oracle_parity": par}
+    return out
+
+
+def run_workload(args, world, rank, dev, transport):
+    if args.workload in ("fasst", "2pl"):
+        return bench_lock(args, world, rank, dev, transport, args.workload)
+    if args.workload == "log":
+        return bench_log(args, world, rank, dev, transport)
+    if args.workload == "store":
+        return bench_store(args, world, rank, dev, transport)
+    return bench_txn(args, world, rank, dev, transport, args.workload)
+
+
+def parity_failures(out, path=""):
+    """every parity flag of the line that is false: a run whose replies differ from the recorded run, the oracle or the
+    reference must not pass as a result"""
+    bad = []
+    if isinstance(out, dict):
+        for k, v in out.items():
+            p = f"{path}.{k}" if path else k
+            if k in ("oracle_parity", "reference_parity") and isinstance(v, dict) and v.get("ok") is False:
+                bad.append(p)
+            elif k in ("pcie_parity_ok", "replay_equals_recorded", "equals_host_driver_run") and v is False:
+                bad.append(p)
+            elif k == "error" and path.startswith("other_workloads"):
+                bad.append(p)
+            else:
+                bad += parity_failures(v, p)
+    return bad
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
+    import gc
+
     import torch.distributed as dist
 
     world, rank, dev, transport = init_dist(args)
-    if args.workload == "fasst":
-        out = bench_fasst(args, world, rank, dev, transport)
-    elif args.workload == "store":
-        out = bench_store(args, world, rank, dev, transport)
-    else:
-        out = bench_txn(args, world, rank, dev, transport, args.workload)
+    out = run_workload(args, world, rank, dev, transport)
+    gc.collect()
+    if args.workload in ("tatp", "smallbank") and args.sweep_clients and world == 1:
+        sweep = client_sweep(args, world, rank, dev, transport, args.workload)
+        if out is not None:
+            out["client_sweep"] = sweep
+    if args.workload == "tatp" and world == 1 and not args.no_other_workloads and not args.force_exchange:
+        ow = other_workloads(args, world, rank, dev, transport)
+        if out is not None:
+            out["other_workloads"] = ow
+    bad = []
     if rank == 0:
+        bad = parity_failures(out)
+        if bad:
+            out["parity_failures"] = bad
+            out["value_unchecked"], out["value"] = out["value"], None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -14,11 +14,12 @@ LIB = os.path.join(HERE, "libdint.so")
 SOURCES = ["engine.hip", "k_locks.hip", "k_log.hip", "k_kv.hip", "k_route.hip", "k_bench.hip", "k_txn.hip", "txn_driver.cc", "fasst_client.cc"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SHIM = os.path.join(HERE, "dint_udp_server")
+CLIENT = os.path.join(HERE, "dint_udp_client")  # closed-loop loopback load generator (csrc/udp_loop_client.c)
 ROCM_LIB = os.environ.get("ROCM_LIB", "/opt/rocm/lib")
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(SHIM):
+    if not os.path.exists(LIB) or not os.path.exists(SHIM) or not os.path.exists(CLIENT):
         return True
     t = os.path.getmtime(LIB)
     inc = os.path.join(HERE, "..", "include")
@@ -40,6 +41,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(shim))
     subprocess.check_call(shim)
+    subprocess.check_call([os.environ.get("CC", "gcc"), "-std=gnu11", "-O2", "-Wall", "-pthread", "-o", CLIENT,
+                           os.path.join(CSRC, "udp_loop_client.c")])
     return LIB
 
 

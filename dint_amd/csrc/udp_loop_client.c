@@ -1,7 +1,8 @@
-/* udp_loop_client.c -- TEST / BASELINE INFRASTRUCTURE ONLY.
+/* udp_loop_client.c -- MEASUREMENT TOOL (dint_amd/dint_udp_client; also built as oracle/_ref/udp_loop_client).
  *
- * A closed-loop UDP load generator for the reference's as-shipped udp/ servers on loopback: the
- * Caladan clients (lock_fasst/caladan/client.cc) cannot be built offline, so this stands in for them on the wire.
+ * A closed-loop UDP load generator on loopback, for the host shim (dint_udp_server) and for the reference's as-shipped
+ * udp/ servers alike: the Caladan clients (lock_fasst/caladan/client.cc) cannot be built offline,
+ * so this stands in for them on the wire.
  * Each thread owns one UDP socket and keeps `window` requests of a recorded request stream outstanding: every
  * reply releases the next request (the closed loop of client.cc:183-280, minus the transaction logic -- the stream
  * was recorded from that logic, and any request is legal for the server in any state).  A request whose reply does

@@ -23,9 +23,15 @@
  * (16 bytes {double ucores, kcores}, tatp/caladan/client_udp_shard.cc:75-92) so unmodified clients do not hang in
  * CollectStat.
  *
+ * `--caladan`: the port handshake of the reference's Caladan servers, which the client_caladan* binaries expect
+ * (lock_fasst/caladan/server.cc:93-132, proto.h:38-45): the well-known port takes `net_req {int nports}` and answers
+ * `net_resp {int nports; u16 ports[nports]}` after opening one data socket per requested port (the reference starts a
+ * ServerLoop uthread per port; here the new sockets join the socket threads' epoll sets round robin).  Requests then
+ * arrive on the data ports and every reply leaves from the port its request came to.
+ *
  *   dint_udp_server --workload {fasst|2pl|log|store|tatp|smallbank} [--rows N] [--slots N] [--populate N]
  *                   [--bind 10.10.1.1] [--port 20230] [--batch 4096] [--deadline-us 100] [--threads 2] [--shed]
- *                   [--device 0]
+ *                   [--caladan] [--device 0]
  */
 #define _GNU_SOURCE
 #include <arpa/inet.h>
@@ -38,6 +44,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/epoll.h>
 #include <sys/resource.h>
 #include <sys/socket.h>
 #include <sys/time.h>
@@ -65,7 +72,7 @@ struct options {
   const char *bind_ip;
   int port, device;
   uint32_t batch, deadline_us, threads;
-  int shed;
+  int shed, caladan;
 };
 
 static int parse_workload(const char *s, uint32_t *out) {
@@ -118,6 +125,7 @@ static void *monitor_thread(void *p) {
 struct batch_slot {
   uint8_t *reqs, *reps;          /* page-locked (dint_alloc_pinned) */
   struct sockaddr_in *peers;
+  int *fds;                      /* --caladan: the data socket each request arrived on (its reply leaves from it) */
   uint32_t n;
   dint_ticket ticket;
   int busy;
@@ -125,6 +133,7 @@ struct batch_slot {
 struct worker {
   pthread_t th;
   int id, fd, msg_size;
+  int efd;                       /* --caladan: epoll set of this thread's data sockets (fd is unused then) */
   const struct options *o;
   dint_engine_t *eng;
   struct batch_slot slot[2];
@@ -132,10 +141,16 @@ struct worker {
 };
 
 /* replies [0, n) to their peers; would-block -> wait for the socket, a dead destination -> skip that one reply */
-static void send_replies(struct worker *w, const uint8_t *reps, const struct sockaddr_in *peers, uint32_t n,
+static void send_replies(struct worker *w, const uint8_t *reps, const struct sockaddr_in *peers, const int *fds, uint32_t n,
                          struct mmsghdr *mm, struct iovec *iov) {
   for (uint32_t off = 0; off < n && !g_stop;) {
-    const uint32_t cnt = (n - off) < VLEN ? (n - off) : VLEN;
+    uint32_t cnt = (n - off) < VLEN ? (n - off) : VLEN;
+    const int fd = fds ? fds[off] : w->fd;
+    if (fds) {  /* one sendmmsg per run of replies that leave from the same data socket */
+      uint32_t run = 1;
+      while (run < cnt && fds[off + run] == fd) run++;
+      cnt = run;
+    }
     for (uint32_t k = 0; k < cnt; k++) {
       iov[k].iov_base = (void *)(reps + (size_t)(off + k) * w->msg_size);
       iov[k].iov_len = (size_t)w->msg_size;
@@ -145,11 +160,11 @@ static void send_replies(struct worker *w, const uint8_t *reps, const struct soc
       mm[k].msg_hdr.msg_name = (void *)&peers[off + k];
       mm[k].msg_hdr.msg_namelen = sizeof peers[off + k];
     }
-    const int sent = sendmmsg(w->fd, mm, cnt, 0);
+    const int sent = sendmmsg(fd, mm, cnt, 0);
     if (sent > 0) { off += (uint32_t)sent; continue; }
     if (sent < 0 && errno == EINTR) continue;
     if (sent == 0 || errno == EAGAIN || errno == EWOULDBLOCK || errno == ENOBUFS) {
-      struct pollfd pf = {w->fd, POLLOUT, 0};
+      struct pollfd pf = {fd, POLLOUT, 0};
       poll(&pf, 1, 100);
       continue;
     }
@@ -160,7 +175,7 @@ static void send_replies(struct worker *w, const uint8_t *reps, const struct soc
 
 static void complete(struct worker *w, struct batch_slot *b, struct mmsghdr *mm, struct iovec *iov) {
   if (dint_wait(w->eng, b->ticket)) fprintf(stderr, "dint_wait: %s\n", dint_last_error());  /* replies are valid */
-  send_replies(w, b->reps, b->peers, b->n, mm, iov);
+  send_replies(w, b->reps, b->peers, w->o->caladan ? b->fds : NULL, b->n, mm, iov);
   w->requests += b->n;
   w->batches++;
   b->busy = 0;
@@ -176,7 +191,8 @@ static void *socket_thread(void *arg) {
   struct sockaddr_in *from = (struct sockaddr_in *)calloc(VLEN, sizeof *from);
   uint8_t *shed_tmp = (uint8_t *)malloc((size_t)o->batch * MAX_MSG);
   struct sockaddr_in *shed_peers = (struct sockaddr_in *)malloc((size_t)o->batch * sizeof *shed_peers);
-  if (!rx || !mm || !iov || !from || !shed_tmp || !shed_peers) { fprintf(stderr, "out of memory\n"); g_stop = 1; return NULL; }
+  int *shed_fds = (int *)malloc((size_t)o->batch * sizeof *shed_fds);
+  if (!rx || !mm || !iov || !from || !shed_tmp || !shed_peers || !shed_fds) { fprintf(stderr, "out of memory\n"); g_stop = 1; return NULL; }
   int cur = 0;
   while (!g_stop) {
     struct batch_slot *b = &w->slot[cur], *other = &w->slot[cur ^ 1];
@@ -197,7 +213,15 @@ static void *socket_thread(void *arg) {
       /* first datagram of a batch: block -- unless the other batch is on the GPU, whose replies must not wait for
        * new traffic; afterwards only take what is already queued */
       const int flags = (n == 0 && !other->busy) ? MSG_WAITFORONE : MSG_DONTWAIT;
-      const int got = recvmmsg(w->fd, mm, want, flags, NULL);
+      int got, rfd = w->fd;
+      if (o->caladan) {  /* any of this thread's data sockets: take what one ready socket holds */
+        struct epoll_event ev;
+        const int nr = epoll_wait(w->efd, &ev, 1, (flags & MSG_DONTWAIT) ? 0 : 100);
+        rfd = nr > 0 ? ev.data.fd : -1;
+        got = nr > 0 ? recvmmsg(rfd, mm, want, MSG_DONTWAIT, NULL) : -1;
+      } else {
+        got = recvmmsg(w->fd, mm, want, flags, NULL);
+      }
       if (got <= 0) {
         if (n == 0) {
           if (other->busy) complete(w, other, mm, iov);       /* idle socket: finish what is in flight */
@@ -211,6 +235,7 @@ static void *socket_thread(void *arg) {
         if ((int)mm[k].msg_len != msg_size) { w->dropped++; continue; }
         memcpy(b->reqs + (size_t)n * msg_size, rx[k], (size_t)msg_size);
         b->peers[n] = from[k];
+        b->fds[n] = rfd;
         n++;
       }
       if (now_us() - t_first >= o->deadline_us) break;
@@ -224,13 +249,15 @@ static void *socket_thread(void *arg) {
       for (uint32_t k = 0; k < n; k++) {
         if (memcmp(shed_tmp + (size_t)k * msg_size, b->reqs + (size_t)k * msg_size, (size_t)msg_size) != 0) {
           memmove(shed_tmp + (size_t)ref * msg_size, shed_tmp + (size_t)k * msg_size, (size_t)msg_size);
+          shed_fds[ref] = b->fds[k];
           shed_peers[ref++] = b->peers[k];
         } else {
           memmove(b->reqs + (size_t)keep * msg_size, b->reqs + (size_t)k * msg_size, (size_t)msg_size);
+          b->fds[keep] = b->fds[k];
           b->peers[keep++] = b->peers[k];
         }
       }
-      send_replies(w, shed_tmp, shed_peers, ref, mm, iov);
+      send_replies(w, shed_tmp, shed_peers, o->caladan ? shed_fds : NULL, ref, mm, iov);
       w->refused += ref;
       n = keep;
       if (n == 0) continue;
@@ -246,12 +273,59 @@ static void *socket_thread(void *arg) {
   }
   for (int k = 0; k < 2; k++)
     if (w->slot[k].busy) complete(w, &w->slot[k], mm, iov);
-  free(rx); free(mm); free(iov); free(from); free(shed_tmp); free(shed_peers);
+  free(rx); free(mm); free(iov); free(from); free(shed_tmp); free(shed_peers); free(shed_fds);
+  return NULL;
+}
+
+/* ---- --caladan: the control port (lock_fasst/caladan/server.cc:93-132) ------------------------------------------- */
+struct control_arg { const struct options *o; struct worker *ws; };
+static void *control_thread(void *p) {
+  struct control_arg *c = (struct control_arg *)p;
+  const struct options *o = c->o;
+  int fd = socket(AF_INET, SOCK_DGRAM, 0);
+  struct sockaddr_in addr;
+  memset(&addr, 0, sizeof addr);
+  addr.sin_family = AF_INET;
+  addr.sin_port = htons((uint16_t)o->port);
+  inet_pton(AF_INET, o->bind_ip, &addr.sin_addr);
+  if (fd < 0 || bind(fd, (struct sockaddr *)&addr, sizeof addr) < 0) { perror("control port"); g_stop = 1; return NULL; }
+  struct timeval tv = {0, 100000};
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+  uint32_t next = 0;
+  while (!g_stop) {
+    int32_t nports = 0;  /* net_req {int nports}, proto.h:38-40 */
+    struct sockaddr_in cli;
+    socklen_t len = sizeof cli;
+    if (recvfrom(fd, &nports, sizeof nports, 0, (struct sockaddr *)&cli, &len) != (ssize_t)sizeof nports) continue;
+    if (nports <= 0 || nports > 730) continue;  /* the answer must fit one datagram (server.cc:121-123: rt::UdpConn::kMaxPayloadSize) */
+    uint8_t resp[4 + 2 * 730];
+    memcpy(resp, &nports, 4);  /* net_resp {int nports; uint16_t ports[]}, proto.h:42-45 */
+    int ok = 1;
+    for (int32_t i = 0; i < nports && ok; i++) {
+      int dfd = socket(AF_INET, SOCK_DGRAM | SOCK_NONBLOCK, 0);
+      struct sockaddr_in da = addr;
+      da.sin_port = 0;  /* any free port, as rt::UdpConn::Listen({0, 0}) */
+      socklen_t dl = sizeof da;
+      int buf = 4 << 20;
+      if (dfd < 0 || bind(dfd, (struct sockaddr *)&da, sizeof da) < 0 || getsockname(dfd, (struct sockaddr *)&da, &dl) < 0) { ok = 0; break; }
+      setsockopt(dfd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
+      setsockopt(dfd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
+      const uint16_t port = ntohs(da.sin_port);  /* host order: Caladan's netaddr.port is host order (client_caladan.cc:305-308) */
+      memcpy(resp + 4 + 2 * i, &port, 2);
+      struct epoll_event ev;
+      memset(&ev, 0, sizeof ev);
+      ev.events = EPOLLIN;
+      ev.data.fd = dfd;
+      if (epoll_ctl(c->ws[next++ % o->threads].efd, EPOLL_CTL_ADD, dfd, &ev) < 0) ok = 0;
+    }
+    if (ok) sendto(fd, resp, (size_t)(4 + 2 * nports), 0, (struct sockaddr *)&cli, len);
+  }
+  close(fd);
   return NULL;
 }
 
 int main(int argc, char **argv) {
-  struct options o = {DINT_WL_FASST, 0, 0, 0, 0, "10.10.1.1", 20230, 0, 4096, 100, 2, 0};
+  struct options o = {DINT_WL_FASST, 0, 0, 0, 0, "10.10.1.1", 20230, 0, 4096, 100, 2, 0, 0};
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i], *v = (i + 1 < argc) ? argv[i + 1] : NULL;
 #define NEED_V if (!v) { fprintf(stderr, "%s needs a value\n", a); return 2; } i++
@@ -266,6 +340,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(a, "--deadline-us")) { NEED_V; o.deadline_us = (uint32_t)strtoul(v, NULL, 10); }
     else if (!strcmp(a, "--threads")) { NEED_V; o.threads = (uint32_t)strtoul(v, NULL, 10); }
     else if (!strcmp(a, "--shed")) { o.shed = 1; }
+    else if (!strcmp(a, "--caladan")) { o.caladan = 1; }
     else { fprintf(stderr, "unknown option %s\n", a); return 2; }
   }
   const uint32_t batch_max = o.workload == DINT_WL_LOG ? DINT_MICRO_BATCH : DINT_KV_PASS_MAX;  /* one kernel pass */
@@ -301,15 +376,22 @@ int main(int argc, char **argv) {
   for (uint32_t t = 0; t < o.threads; t++) {
     struct worker *w = &ws[t];
     w->id = (int)t; w->o = &o; w->eng = eng; w->msg_size = msg_size;
-    w->fd = socket(AF_INET, SOCK_DGRAM, 0);
-    if (w->fd < 0) { perror("socket"); return 1; }
-    int one = 1, buf = 64 << 20;
-    setsockopt(w->fd, SOL_SOCKET, SO_REUSEPORT, &one, sizeof one);  /* as the reference: lock_fasst/udp/server.cc:57-58 */
-    setsockopt(w->fd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
-    setsockopt(w->fd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
-    if (bind(w->fd, (struct sockaddr *)&addr, sizeof addr) < 0) { perror("bind"); return 1; }
-    struct timeval tv = {0, 100000};  /* wake up to notice signals */
-    setsockopt(w->fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    w->fd = -1;
+    w->efd = -1;
+    if (o.caladan) {  /* data sockets appear with the clients' handshakes (control_thread) */
+      w->efd = epoll_create1(0);
+      if (w->efd < 0) { perror("epoll_create1"); return 1; }
+    } else {
+      w->fd = socket(AF_INET, SOCK_DGRAM, 0);
+      if (w->fd < 0) { perror("socket"); return 1; }
+      int one = 1, buf = 64 << 20;
+      setsockopt(w->fd, SOL_SOCKET, SO_REUSEPORT, &one, sizeof one);  /* as the reference: lock_fasst/udp/server.cc:57-58 */
+      setsockopt(w->fd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
+      setsockopt(w->fd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
+      if (bind(w->fd, (struct sockaddr *)&addr, sizeof addr) < 0) { perror("bind"); return 1; }
+      struct timeval tv = {0, 100000};  /* wake up to notice signals */
+      setsockopt(w->fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    }
     for (int k = 0; k < 2; k++) {
       void *a = NULL, *b = NULL;
       if (dint_alloc_pinned((size_t)o.batch * MAX_MSG, &a) || dint_alloc_pinned((size_t)o.batch * MAX_MSG, &b)) {
@@ -319,16 +401,20 @@ int main(int argc, char **argv) {
       w->slot[k].reqs = (uint8_t *)a;
       w->slot[k].reps = (uint8_t *)b;
       w->slot[k].peers = (struct sockaddr_in *)malloc((size_t)o.batch * sizeof(struct sockaddr_in));
-      if (!w->slot[k].peers) { fprintf(stderr, "out of memory\n"); return 1; }
+      w->slot[k].fds = (int *)malloc((size_t)o.batch * sizeof(int));
+      if (!w->slot[k].peers || !w->slot[k].fds) { fprintf(stderr, "out of memory\n"); return 1; }
     }
   }
   pthread_t mon;
   struct mon_arg ma = {o.bind_ip, o.port + 1};
   pthread_create(&mon, NULL, monitor_thread, &ma);
+  pthread_t ctl;
+  struct control_arg ca = {&o, ws};
+  if (o.caladan) pthread_create(&ctl, NULL, control_thread, &ca);
   for (uint32_t t = 0; t < o.threads; t++) pthread_create(&ws[t].th, NULL, socket_thread, &ws[t]);
 
-  fprintf(stdout, "dint_udp_server ready workload=%u msg=%d %s:%d batch=%u deadline_us=%u threads=%u shed=%d\n", o.workload,
-          msg_size, o.bind_ip, o.port, o.batch, o.deadline_us, o.threads, o.shed);
+  fprintf(stdout, "dint_udp_server ready workload=%u msg=%d %s:%d batch=%u deadline_us=%u threads=%u shed=%d caladan=%d\n", o.workload,
+          msg_size, o.bind_ip, o.port, o.batch, o.deadline_us, o.threads, o.shed, o.caladan);
   fflush(stdout);
 
   uint64_t total = 0, batches = 0, dropped = 0, refused = 0, send_dropped = 0;
@@ -342,9 +428,11 @@ int main(int argc, char **argv) {
           (unsigned long long)total, (unsigned long long)batches, (unsigned long long)dropped, (unsigned long long)refused,
           (unsigned long long)send_dropped);
   pthread_join(mon, NULL);
+  if (o.caladan) pthread_join(ctl, NULL);
   for (uint32_t t = 0; t < o.threads; t++) {
-    close(ws[t].fd);
-    for (int k = 0; k < 2; k++) { dint_free_pinned(ws[t].slot[k].reqs); dint_free_pinned(ws[t].slot[k].reps); free(ws[t].slot[k].peers); }
+    if (ws[t].fd >= 0) close(ws[t].fd);
+    if (ws[t].efd >= 0) close(ws[t].efd);  /* (the data sockets die with the process) */
+    for (int k = 0; k < 2; k++) { dint_free_pinned(ws[t].slot[k].reqs); dint_free_pinned(ws[t].slot[k].reps); free(ws[t].slot[k].peers); free(ws[t].slot[k].fds); }
   }
   dint_engine_destroy(eng);
   free(ws);

@@ -236,6 +236,104 @@ def fasst_trace(server, n_requests: int = 24_000_000, **kw):
     return np.concatenate(reqs), np.concatenate(reps), st
 
 
+class TplClient:
+    """The lock_2pl load generator, W workers in lock step (numpy over the workers): lock_2pl/caladan/client.cc:167-240
+    over transactions shaped by lock_2pl/caladan/trace_init.sh:6-27 -- 5..10 distinct locks in ascending order, each
+    exclusive with probability 1 - read_prop -- acquire them one by one; a REJECT releases what the transaction holds
+    (in acquisition order) and starts it again; once all are held, release them in reverse order.  ``next()`` = one
+    6-byte request per worker, ``consume(replies)`` advances them.  Only granted locks are ever released, as in the
+    reference."""
+
+    ACQ, ROLL, REL = 0, 1, 2
+
+    def __init__(self, n_workers: int = 4096, key_space: int = 24_000_000, *, read_prop: float = 0.8,
+                 zipf_theta: float | None = 0.8, seed: int = 0xDEADBEEF):
+        from .wire import TPL_MSG
+        from .workloads import Zipf
+
+        self.dtype, self.n, self.key_space, self.read_prop = TPL_MSG, n_workers, key_space, read_prop
+        self.rng = np.random.default_rng(seed)
+        self.z = Zipf(key_space, zipf_theta or 0.0, seed + 1)
+        W = n_workers
+        self.lid = np.zeros((W, 10), np.uint32)
+        self.typ = np.zeros((W, 10), np.uint8)
+        self.nlock = np.zeros(W, np.int64)
+        self.mode = np.zeros(W, np.int64)
+        self.pos = np.zeros(W, np.int64)   # ACQ: lock being acquired; ROLL: lock being released; REL: lock being released
+        self.held = np.zeros(W, np.int64)  # locks the transaction holds (ROLL releases 0 .. held-1)
+        self.stats_ = {"requests": 0, "committed": 0, "rejects": 0, "protocol_errors": 0}
+        self._new_txn(np.arange(W))
+        self._out = False
+
+    def _new_txn(self, w):
+        if len(w) == 0:
+            return
+        n = self.rng.integers(5, 11, len(w))
+        k = self.z.sample((len(w), 10)).astype(np.uint32)
+        k[np.arange(10)[None, :] >= n[:, None]] = 0xFFFFFFFF  # unused tail sorts last
+        for _ in range(64):  # distinct lids per transaction (random.sample in trace_init.sh)
+            k.sort(axis=1)
+            dup = (k[:, 1:] == k[:, :-1]) & (k[:, 1:] != 0xFFFFFFFF)
+            if not dup.any():
+                break
+            r, c = np.nonzero(dup)
+            k[r, c + 1] = self.rng.integers(0, self.key_space, len(r))
+        self.lid[w] = k
+        self.typ[w] = (self.rng.random((len(w), 10)) >= self.read_prop).astype(np.uint8)
+        self.nlock[w], self.mode[w], self.pos[w], self.held[w] = n, self.ACQ, 0, 0
+
+    def next(self) -> np.ndarray:
+        assert not self._out, "replies of the previous epoch are still outstanding"
+        m = np.zeros(self.n, self.dtype)
+        r = np.arange(self.n)
+        m["action"] = (self.mode != self.ACQ).astype(np.uint8)  # 0 ACQUIRE, 1 RELEASE (lock_2pl/udp/net.h:11-16)
+        m["lid"] = self.lid[r, self.pos]
+        m["type"] = self.typ[r, self.pos]
+        self._out = True
+        self.stats_["requests"] += self.n
+        return m
+
+    def consume(self, rep: np.ndarray):
+        a = rep["action"]
+        acq, roll, rel = self.mode == self.ACQ, self.mode == self.ROLL, self.mode == self.REL
+        self.stats_["protocol_errors"] += int((acq & ~np.isin(a, (2, 3))).sum() + ((roll | rel) & (a != 5)).sum())
+        grant, rej = acq & (a == 2), acq & (a == 3)
+        self.stats_["rejects"] += int(rej.sum())
+        self.pos[grant] += 1
+        self.held[grant] += 1
+        full = grant & (self.pos == self.nlock)
+        self.mode[full], self.pos[full] = self.REL, self.nlock[full] - 1
+        rb = rej & (self.held > 0)          # release what is held, then start the transaction again
+        self.mode[rb], self.pos[rb] = self.ROLL, 0
+        # (a reject with nothing held: the same ACQUIRE goes out again)
+        self.pos[roll] += 1
+        done_roll = roll & (self.pos == self.held)
+        self.mode[done_roll], self.pos[done_roll], self.held[done_roll] = self.ACQ, 0, 0
+        self.pos[rel] -= 1
+        fin = rel & (self.pos < 0)
+        self.stats_["committed"] += int(fin.sum())
+        self._new_txn(np.nonzero(fin)[0])
+        self._out = False
+
+    def stats(self) -> dict:
+        return dict(self.stats_)
+
+
+def tpl_trace(server, n_requests: int, **kw):
+    """closed loop of a TplClient against `server` (submit(ndarray) -> ndarray) for n_requests requests"""
+    c = TplClient(**kw)
+    reqs, reps, n = [], [], 0
+    while n < n_requests:
+        r = c.next()[:n_requests - n]
+        p = server.submit(r)
+        if len(r) == c.n:
+            c.consume(p)
+        reqs.append(r)
+        reps.append(p)
+        n += len(r)
+    return np.concatenate(reqs), np.concatenate(reps), c.stats()
+
+
 def run_epochs(driver: Driver, servers, n_epochs: int, record: bool = False):
     """Closed loop: `servers` = 3 objects with submit(ndarray) -> ndarray (one per shard).
     Returns the recorded [(requests[3], replies[3])] per epoch when record=True."""

@@ -87,18 +87,39 @@ def record(driver: Driver, group, n_epochs: int):
 
 
 class Replay:
-    """A recorded trace resident in HBM."""
+    """A recorded trace resident in HBM: per epoch and shard server the request batch, a reply buffer, and the replies
+    of the recorded run (also in HBM: `check` compares on the device)."""
 
-    def __init__(self, trace, msg_size: int):
+    def __init__(self, trace=(), msg_size: int = 0):
         self.msg = msg_size
-        self.counts = [[len(t[0][s]) for s in range(N_SHARDS)] for t in trace]
-        self.d_req, self.d_rep, self.want = [], [], []
+        self.counts, self.d_req, self.d_rep, self.d_want = [], [], [], []
         for req, rep in ((t[0], t[1]) for t in trace):
-            self.d_req.append([torch.from_numpy(np.frombuffer(req[s].tobytes(), np.uint8).copy()).cuda()
-                               for s in range(N_SHARDS)])
-            self.d_rep.append([torch.empty(len(req[s]) * msg_size, dtype=torch.uint8, device="cuda")
-                               for s in range(N_SHARDS)])
-            self.want.append([rep[s].tobytes() for s in range(N_SHARDS)])
+            self.append(req, rep)
+
+    def append(self, req, rep) -> None:
+        up = lambda a: torch.from_numpy(np.frombuffer(a.tobytes(), np.uint8).copy()).cuda()  # noqa: E731
+        self.counts.append([len(req[s]) for s in range(N_SHARDS)])
+        self.d_req.append([up(req[s]) for s in range(N_SHARDS)])
+        self.d_want.append([up(rep[s]) for s in range(N_SHARDS)])
+        self.d_rep.append([torch.empty(len(req[s]) * self.msg, dtype=torch.uint8, device="cuda") for s in range(N_SHARDS)])
+
+    @classmethod
+    def recording(cls, driver: Driver, group, n_epochs: int, keep_host: int = 0):
+        """Run the closed loop for n_epochs and keep every epoch in HBM; host copies only of the first `keep_host`
+        epochs (what the CPU legs replay).  Returns (replay, finished txns per epoch, host trace)."""
+        rp, done, host = cls(msg_size=group.msg), [], []
+        last = driver.stats()["txns"]
+        for e in range(n_epochs):
+            req = driver.next()
+            rep = group.submit(req)
+            driver.consume(rep)
+            rp.append(req, rep)
+            if e < keep_host:
+                host.append((req, rep))
+            now = driver.stats()["txns"]
+            done.append(now - last)
+            last = now
+        return rp, done, host
 
     def __len__(self):
         return len(self.counts)
@@ -114,8 +135,7 @@ class Replay:
         """The replayed replies must equal the recorded ones byte for byte."""
         for e in range(lo, hi):
             for s in range(N_SHARDS):
-                got = self.d_rep[e][s].cpu().numpy().tobytes()
-                if got != self.want[e][s]:
+                if not torch.equal(self.d_rep[e][s], self.d_want[e][s]):
                     raise AssertionError(f"replay diverged from the recorded run at epoch {e}, shard {s}")
 
     def ops(self, lo: int, hi: int) -> int:

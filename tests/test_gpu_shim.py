@@ -157,3 +157,53 @@ def test_shim_sheds_load_with_the_ebpf_refusal_codes():
     finally:
         out = srv.stop()
     assert f"refused={refused}" in out
+
+
+def test_shim_caladan_port_handshake():
+    """--caladan: the control port answers net_req {int nports} with net_resp {int nports; u16 ports[]} and serves
+    every data port (lock_fasst/caladan/server.cc:93-132, proto.h:38-45; the client side is
+    lock_fasst/caladan/client_caladan.cc:285-310: one ClientLoop per returned port).  Replies leave from the port their
+    request was sent to, and the three ports see one serial lock table."""
+    srv = Server("--workload", "fasst", "--slots", str(1 << 20), "--batch", "256", "--deadline-us", "200", "--threads", "2",
+                 "--caladan")
+    try:
+        ctl = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        ctl.settimeout(5)
+        ctl.sendto(struct.pack("<i", 3), ("127.0.0.1", srv.port))
+        d, frm = ctl.recvfrom(2048)
+        assert frm[1] == srv.port and len(d) == 4 + 2 * 3
+        nports, *ports = struct.unpack("<i3H", d)
+        assert nports == 3 and len(set(ports)) == 3 and all(p not in (0, srv.port) for p in ports)
+        ctl.sendto(struct.pack("<i", 2), ("127.0.0.1", srv.port))  # a second client machine gets ports of its own
+        d2, _ = ctl.recvfrom(2048)
+        more = struct.unpack("<i2H", d2)[1:]
+        assert not set(more) & set(ports)
+        ctl.close()
+        # one closed-loop client per data port, as the reference's client threads: each sees its own replies, from its port
+        req = tracegen.fasst_random(6_000, seed=44, n_hot=8, p_hot=0.8)
+        o = orc.FasstOracle(1 << 20)
+        socks = []
+        for p in ports:
+            c = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+            c.settimeout(10)
+            socks.append((c, p))
+        size = req.dtype.itemsize
+        raw = req.tobytes()
+        for i in range(len(req)):  # one outstanding request in all: the serial order is the send order
+            c, p = socks[i % 3]
+            c.sendto(raw[i * size:(i + 1) * size], ("127.0.0.1", p))
+            d, frm = c.recvfrom(64)
+            assert frm[1] == p
+            assert d == o.replay(req[i:i + 1]).tobytes(), i
+        # and a burst: 200 in flight per port
+        burst = tracegen.fasst_random(600, seed=45, n_hot=4, p_hot=0.0)  # distinct cold lids: order between ports is irrelevant
+        braw = burst.tobytes()
+        for i in range(len(burst)):
+            socks[i % 3][0].sendto(braw[i * size:(i + 1) * size], ("127.0.0.1", socks[i % 3][1]))
+        got = sum(1 for k in range(len(burst)) if len(socks[k % 3][0].recvfrom(64)[0]) == size)
+        assert got == len(burst)
+        for c, _ in socks:
+            c.close()
+    finally:
+        out = srv.stop()
+    assert "requests=6600" in out
