@@ -181,6 +181,8 @@ struct FasstOps {
     fin.y = st0.y + (uint32_t)__popcll(m_com);
     dirty = fin.x != st0.x || fin.y != st0.y;
   }
+  __device__ static void walk64(bool, uint32_t, uint2 &, uint32_t &) {}  // (never called: CLOSED)
+  __device__ static uint64_t walk64_mask(bool, uint32_t, uint2 &) { return 0; }
   __device__ static void write_reply(uint8_t *rep, const dint_view &V, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
     fasst_msg *m = (fasst_msg *)(rep + dint_view_off(V, idx, sizeof(fasst_msg)));
     m->type = (uint8_t)code;
@@ -234,6 +236,60 @@ struct TplOps {
       }
       if ((int)lane == L) { fin = st; dirty = wr; }
     }
+  }
+  // <= 64 consecutive requests of ONE slot, one per lane in request order (a whole wave calls this), the slot's counters
+  // in wave-uniform registers.  Which ACQUIREs are granted is the only thing that depends on the counters, and they move
+  // between two modes: FREE (num_ex == 0: every shared ACQUIRE is granted, until an exclusive ACQUIRE finds num_sh == 0
+  // -- granted, num_ex = 1 -- or a RELEASE of an exclusive lock nobody holds wraps num_ex) and HELD (num_ex != 0: every
+  // ACQUIRE is rejected until the num_ex-th exclusive RELEASE).  Between two mode changes all lanes are resolved at once
+  // from ballot masks (num_sh before a lane = num_sh + shared acquires - shared releases below it), so the loop runs
+  // once per mode change, not once per request: a lock that hundreds of workers hammer changes mode rarely.
+  // (the same walk as smallbank's counters in k_kv.hip; lock_2pl/udp/server.cc:83-121)
+  __device__ static void walk64(bool valid, uint32_t op, uint2 &st, uint32_t &code) {
+    const uint64_t G = walk64_mask(valid, op, st);
+    code = op <= 1 ? (((G >> lane_id()) & 1ull) ? 2u : 3u) : 5u;
+  }
+  // ... returning the lanes whose ACQUIRE is granted
+  __device__ static uint64_t walk64_mask(bool valid, uint32_t op, uint2 &st) {
+    const uint32_t lane = lane_id();
+    const uint64_t mAS = __ballot(valid && op == 0), mAX = __ballot(valid && op == 1);
+    const uint64_t mRS = __ballot(valid && op == 2), mRX = __ballot(valid && op == 3);
+    uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.x), lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.y);
+    uint64_t G = 0, rem = mAS | mAX | mRS | mRX;
+    while (rem) {
+      if (la == 0) {
+        const uint64_t blw = rem & lanemask_lt();
+        const uint32_t lb_before = lb + (uint32_t)__popcll(blw & mAS) - (uint32_t)__popcll(blw & mRS);
+        const bool me = (rem >> lane) & 1ull;
+        const uint64_t ev = __ballot(me && ((op == 1 && lb_before == 0) || op == 3));
+        const uint64_t upto = ev ? (ev & (0 - ev)) - 1ull : ~0ull;  // the lanes below the first event
+        const uint64_t seg = rem & upto;
+        G |= seg & mAS;
+        lb += (uint32_t)__popcll(seg & mAS) - (uint32_t)__popcll(seg & mRS);
+        rem &= ~upto;
+        if (ev) {
+          const uint64_t bit = ev & (0 - ev);
+          if (bit & mAX) { G |= bit; la = 1; } else la = 0xFFFFFFFFu;
+          rem &= ~bit;
+        }
+      } else {
+        uint64_t rx = rem & mRX;
+        const uint32_t nrx = (uint32_t)__popcll(rx);
+        if (nrx < la) {  // held to the end of these lanes
+          lb -= (uint32_t)__popcll(rem & mRS);
+          la -= nrx;
+          rem = 0;
+        } else {
+          for (uint32_t k = 1; k < la; k++) rx &= rx - 1;  // the la-th exclusive RELEASE (la is 1 unless the counter wrapped)
+          const uint64_t bit = rx & (0 - rx), upto = bit - 1ull;
+          lb -= (uint32_t)__popcll(rem & upto & mRS);
+          la = 0;
+          rem &= ~(upto | bit);
+        }
+      }
+    }
+    st.x = la; st.y = lb;
+    return G;
   }
   __device__ static void write_reply(uint8_t *rep, const dint_view &V, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
     (void)op; (void)rv;
@@ -289,6 +345,9 @@ k_lock_resolve(uint8_t *rep, uint32_t pbits, uint2 *__restrict__ table, uint32_t
   lk_chunk<Ops>(rep, V, table, w, lane < c, true, true);
 }
 
+#define TPL_HOT_NMAX 65536u   // lock_2pl dominant-slot path: passes of at most this many requests (an 8 KB index bitmap)
+#define TPL_HOT_WIN 8192u     // ... ranks walked per window (the ordered list lives where the stretch would)
+
 // ---- big bins: one 512-thread workgroup each ---------------------------------------------------------------------
 template <class Ops>
 __global__ void __launch_bounds__(KVB_T)
@@ -314,6 +373,10 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
   __shared__ uint32_t Hs[16];                  // dominant-slot path: counters
   __shared__ uint64_t Mk[KVB_MMAX];            // ... its lock-writing ops, idx << 12 | position, ascending
   __shared__ uint16_t Mcc[KVB_MMAX + 8];       // ... COMMITs among the first j of them
+  __shared__ uint16_t Pw[TPL_HOT_NMAX / 32 + 1];  // dominant slot: bits set in the index words below w
+  __shared__ uint64_t Gm[TPL_HOT_WIN / 64];    // lock_2pl dominant slot: grant mask per group of 64 requests
+  __shared__ uint32_t Gsum[TPL_HOT_WIN / 64];  // ... {shared ACQUIREs : 8 | shared RELEASEs : 8 | has exclusive ACQUIRE | RELEASE}
+  __shared__ uint8_t Gk[TPL_HOT_WIN / 64];     // ... 0 walked, 1 inert while HELD, 2 inert while FREE
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // request-index buckets that cut a bin of more than KVB_NMAX records into stretches (every request of a stretch
   // precedes every request of the next one)
@@ -327,14 +390,213 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
     const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
     const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;
     auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
+    // ---- the bin's DOMINANT SLOT in a pass of <= 65,536 requests (a lid that hundreds of closed-loop workers keep
+    // retrying: most of a big bin is one slot, up to a sixth of a 64k batch) is resolved WITHOUT a sort: every request
+    // owns one bit of an index bitmap, so "in request order" is "in bit order".
+    //   lock_2pl  : rank = bits below mine (a prefix count per word) puts the slot's requests in order; one wave walks
+    //               them 64 at a time (TplOps::walk64: once per mode change of the counters, not once per request).
+    //   lock_fasst: three bitmaps -- lock-writing ops, ACQUIREs, COMMITs -- answer every request in O(1): lock seen =
+    //               was the last lock-writing op below me an ACQUIRE, version seen = ver0 + COMMITs below me; no limit
+    //               on the number of ordering ops (the stretch-level path below sorts at most 1024 of them).
+    // The rest of the bin takes the general path below.  All passes over the bin's records keep 8 loads per thread
+    // in flight (one memory round trip per 4096 records instead of one per 512).
+    uint32_t hslot_done = KV_NONE, c_rest = c;
+#define LK_FOR_RECORDS(...)                                                       \
+    for (uint32_t k0_ = 0; k0_ < c; k0_ += 8 * KVB_T) {                           \
+      uint64_t r8_[8];                                                            \
+      _Pragma("unroll") for (uint32_t j_ = 0; j_ < 8; j_++) {                     \
+        const uint32_t k_ = k0_ + j_ * KVB_T + t;                                 \
+        r8_[j_] = k_ < c ? rec_at(k_) : ~0ull;                                    \
+      }                                                                           \
+      _Pragma("unroll") for (uint32_t j_ = 0; j_ < 8; j_++) {                     \
+        const uint64_t r = r8_[j_];                                               \
+        if (k0_ + j_ * KVB_T + t < c) { __VA_ARGS__ }                                 \
+      }                                                                           \
+    }
+    if (c >= hot_min && n <= TPL_HOT_NMAX) {
+      uint32_t *Bm = (uint32_t *)Mk;              // [n / 32] lock_2pl: the slot's requests; lock_fasst: its lock-writing ops
+      uint32_t *R = (uint32_t *)Sk;               // lock_2pl: [TPL_HOT_WIN] idx << 3 | op, by rank
+      uint32_t *Bacq = (uint32_t *)Sk, *Bcom = Bacq + TPL_HOT_NMAX / 32, *Lw = Bcom + TPL_HOT_NMAX / 32;  // lock_fasst
+      uint32_t cand[8], cc[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) { cand[k] = lk_slot(rec_at((uint32_t)(((uint64_t)c * k) >> 3))); cc[k] = 0; }
+      if (t < 16) Hs[t] = 0;
+      for (uint32_t w = t; w < TPL_HOT_NMAX / 32; w += KVB_T) {
+        Bm[w] = 0;
+        if (Ops::CLOSED) { Bacq[w] = 0; Bcom[w] = 0; }
+      }
+      __syncthreads();
+      LK_FOR_RECORDS({
+        const uint32_t sl = lk_slot(r);
+        _Pragma("unroll") for (uint32_t j = 0; j < 8; j++) cc[j] += sl == cand[j];
+      })
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) {
+        uint32_t v = cc[j];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0 && v) atomicAdd(&Hs[j], v);
+      }
+      __syncthreads();
+      uint32_t best = 0;
+#pragma unroll
+      for (uint32_t j = 1; j < 8; j++) best = Hs[j] > Hs[best] ? j : best;
+      const uint32_t hot_n = Hs[best], hslot = cand[best];
+      __syncthreads();
+      if (tw && t == 0 && bi == blockIdx.x) { tw[10] = __builtin_amdgcn_s_memrealtime(); tw[13] = hot_n; }
+      if (hot_n >= hot_min && 2 * hot_n >= c) {  // workgroup-uniform
+        LK_FOR_RECORDS({
+          if (lk_slot(r) == hslot) {
+            const uint32_t idx = lk_idx(r), op = lk_op(r), w = idx >> 5, bit = 1u << (idx & 31u);
+            if (!Ops::CLOSED) atomicOr(&Bm[w], bit);
+            else if (op != 0) {
+              atomicOr(&Bm[w], bit);
+              if (op == 1) atomicOr(&Bacq[w], bit);
+              if (op == 3) atomicOr(&Bcom[w], bit);
+            }
+          }
+        })
+        __syncthreads();
+        {  // Pw[w] = bits set in the words before w (lock_2pl: of Bm; lock_fasst: of Bcom); thread t owns words 4t .. 4t + 3.
+           // lock_fasst also: Lw[w] = index of the last lock-writing op in the words before w, ~0u = none
+          const uint32_t *src = Ops::CLOSED ? Bcom : Bm;
+          uint32_t pc[4], run = 0, last = ~0u;
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++) {
+            pc[j] = (uint32_t)__popc(src[4 * t + j]);
+            run += pc[j];
+            if (Ops::CLOSED && Bm[4 * t + j]) last = (4 * t + j) * 32 + 31 - (uint32_t)__clz(Bm[4 * t + j]);
+          }
+          uint32_t tot, base = wave_excl_scan_u32(run, &tot);
+          int lm = (int)last;  // running maximum of "last" over the threads below me (~0u = -1 sorts lowest)
+          for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(lm, d, 64);
+            if ((int)lane >= d) lm = max(lm, o);
+          }
+          if (lane == 63) { Sred[wave] = tot; Hs[8 + wave] = (uint32_t)lm; }
+          int ex = __shfl_up(lm, 1, 64);  // exclusive: the threads strictly below me in my wave
+          if (lane == 0) ex = -1;
+          __syncthreads();
+          for (uint32_t w = 0; w < wave; w++) { base += Sred[w]; ex = max(ex, (int)Hs[8 + w]); }
+#pragma unroll
+          for (uint32_t j = 0; j < 4; j++) {
+            Pw[4 * t + j] = (uint16_t)base;
+            base += pc[j];
+            if (Ops::CLOSED) {
+              Lw[4 * t + j] = (uint32_t)ex;
+              if (Bm[4 * t + j]) ex = (int)((4 * t + j) * 32 + 31 - (uint32_t)__clz(Bm[4 * t + j]));
+            }
+          }
+          if (t == KVB_T - 1) { Pw[TPL_HOT_NMAX / 32] = (uint16_t)base; Hs[7] = (uint32_t)ex; }  // totals: COMMITs / last op of all
+        }
+        __syncthreads();
+        uint2 st = table[hslot];  // workgroup-uniform address
+        const uint2 st_in = st;
+        if (tw && t == 0 && bi == blockIdx.x) tw[11] = __builtin_amdgcn_s_memrealtime();
+        if (Ops::CLOSED) {
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __syncthreads();  // everyone holds the slot's word before anyone can write it
+          LK_FOR_RECORDS({
+            if (lk_slot(r) == hslot) {
+              const uint32_t idx = lk_idx(r), op = lk_op(r), w = idx >> 5, below = (1u << (idx & 31u)) - 1u;
+              const uint32_t mw = Bm[w] & below;
+              const uint32_t prev = mw ? w * 32 + 31 - (uint32_t)__clz(mw) : Lw[w];  // last lock-writing op below me
+              const uint32_t lock_before = prev != ~0u ? (Bacq[prev >> 5] >> (prev & 31u)) & 1u : st.x;
+              uint32_t code = 0, rv = 0;
+              Ops::closed(op, lock_before, st.y + Pw[w] + (uint32_t)__popc(Bcom[w] & below), code, rv);
+              Ops::write_reply(rep, V, idx, op, code, rv);
+            }
+          })
+          if (t == 0) {
+            const uint32_t lastop = Hs[7];
+            if (lastop != ~0u) st.x = (Bacq[lastop >> 5] >> (lastop & 31u)) & 1u;
+            st.y += Pw[TPL_HOT_NMAX / 32];
+          }
+        } else {
+          for (uint32_t r0 = 0; r0 < hot_n; r0 += TPL_HOT_WIN) {
+            const uint32_t wn = min(TPL_HOT_WIN, hot_n - r0);
+            LK_FOR_RECORDS({
+              if (lk_slot(r) == hslot) {
+                const uint32_t idx = lk_idx(r);
+                const uint32_t rk = Pw[idx >> 5] + (uint32_t)__popc(Bm[idx >> 5] & ((1u << (idx & 31u)) - 1u));
+                if (rk - r0 < wn) R[rk - r0] = (idx << 3) | lk_op(r);
+              }
+            })
+            __syncthreads();
+            // Most groups of 64 requests cannot change the counters' mode, whatever order their requests come in:
+            //   HELD (num_ex != 0), no exclusive RELEASE in the group: every ACQUIRE is rejected, num_sh -= shared RELEASEs;
+            //   FREE (num_ex == 0), no exclusive RELEASE, and no exclusive ACQUIRE that could find num_sh == 0 (num_sh
+            //   stays above 0 even if all the group's shared RELEASEs came first): every shared ACQUIRE is granted,
+            //   every exclusive one rejected, num_sh += shared ACQUIREs - shared RELEASEs.
+            // So: (1) all waves summarise the groups {shared ACQUIREs, shared RELEASEs, has exclusive ACQUIRE / RELEASE};
+            // (2) one wave goes through the summaries -- a few scalar operations per inert group -- and walks only the
+            // others (walk64_mask); (3) all waves write the replies from the groups' grant masks.
+            const uint32_t ng = (wn + 63) / 64;  // <= TPL_HOT_WIN / 64 = 128
+            for (uint32_t g = wave; g < ng; g += KVB_W) {
+              const bool valid = g * 64 + lane < wn;
+              const uint32_t op = valid ? R[g * 64 + lane] & 7u : 7u;
+              const uint64_t mAS = __ballot(op == 0), mAX = __ballot(op == 1), mRS = __ballot(op == 2), mRX = __ballot(op == 3);
+              if (lane == 0) Gsum[g] = (uint32_t)__popcll(mAS) | ((uint32_t)__popcll(mRS) << 8) | (mAX ? 1u << 16 : 0u) | (mRX ? 1u << 17 : 0u);
+            }
+            __syncthreads();
+            if (wave == 0) {
+              const uint32_t s0 = lane < ng ? Gsum[lane] : 0, s1 = 64 + lane < ng ? Gsum[64 + lane] : 0;  // lane l: groups l, 64 + l
+              uint64_t g0 = 0, g1 = 0;  // ... their grant masks (walked groups)
+              uint32_t k0 = 0, k1 = 0;  // ... and kinds: 0 walked, 1 inert while HELD, 2 inert while FREE
+              st.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.x);
+              st.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.y);
+              for (uint32_t g = 0; g < ng; g++) {  // wave-uniform
+                const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)(g < 64 ? s0 : s1), (int)(g & 63));
+                const uint32_t nas = sm & 0xFFu, nrs = (sm >> 8) & 0xFFu;
+                const bool has_ax = (sm >> 16) & 1u, has_rx = (sm >> 17) & 1u;
+                uint64_t G = 0;
+                uint32_t kind = 0;
+                if (st.x != 0 && !has_rx) {
+                  st.y -= nrs;
+                  kind = 1;
+                } else if (st.x == 0 && !has_rx && (!has_ax || (st.y > nrs && st.y <= 0xFFFFFFFFu - nas))) {
+                  st.y += nas - nrs;
+                  kind = 2;
+                } else {
+                  const bool valid = g * 64 + lane < wn;
+                  const uint32_t e = valid ? R[g * 64 + lane] : 0;
+                  G = Ops::walk64_mask(valid, e & 7u, st);
+                }
+                if (lane == (g & 63)) {
+                  if (g < 64) { g0 = G; k0 = kind; } else { g1 = G; k1 = kind; }
+                }
+              }
+              if (lane < ng) { Gm[lane] = g0; Gk[lane] = (uint8_t)k0; }
+              if (64 + lane < ng) { Gm[64 + lane] = g1; Gk[64 + lane] = (uint8_t)k1; }
+            }
+            __syncthreads();
+            for (uint32_t k = t; k < wn; k += KVB_T) {
+              const uint32_t e = R[k], op = e & 7u;
+              const uint32_t kind = Gk[k >> 6];
+              const bool granted = kind == 0 ? (Gm[k >> 6] >> (k & 63)) & 1ull : (kind == 2 && op == 0);
+              const uint32_t code = op <= 1 ? (granted ? 2u : 3u) : 5u;
+              Ops::write_reply(rep, V, e >> 3, op, code, 0);
+            }
+            __syncthreads();
+          }
+        }
+        if (t == 0 && (st.x != st_in.x || st.y != st_in.y)) table[hslot] = st;
+        if (tw && t == 0 && bi == blockIdx.x) tw[12] = __builtin_amdgcn_s_memrealtime();
+        hslot_done = hslot;
+        c_rest = c - hot_n;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+      }
+    }
     uint32_t nwin = 1;
-    if (c > KVB_NMAX) {
+    if (c_rest > KVB_NMAX) {
       for (uint32_t w = t; w < KVB_NBK / 2; w += KVB_T) Bcnt[w] = 0;
       __syncthreads();
-      for (uint32_t k = t; k < c; k += KVB_T) {
-        const uint32_t b = lk_idx(rec_at(k)) >> bs;
-        atomicAdd(&Bcnt[b >> 1], 1u << (16 * (b & 1)));
-      }
+      LK_FOR_RECORDS({
+        if (lk_slot(r) != hslot_done) {
+          const uint32_t b = lk_idx(r) >> bs;
+          atomicAdd(&Bcnt[b >> 1], 1u << (16 * (b & 1)));
+        }
+      })
       __syncthreads();
       uint32_t cw[2], run = 0;  // thread t owns buckets 4t .. 4t+3
 #pragma unroll
@@ -351,21 +613,21 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
         Bwin[4 * t + j] = (uint16_t)(base / wcap);
         base += (cw[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
       }
-      nwin = (c - 1) / wcap + 1;
+      nwin = (c_rest - 1) / wcap + 1;
     }
     __syncthreads();
     if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
     for (uint32_t win = 0; win < nwin; win++) {
       if (t == 0) { Swn = 0; Snx = 0; }
       __syncthreads();
-      if (c <= KVB_NMAX) {
+      if (c_rest <= KVB_NMAX && hslot_done == KV_NONE) {
         for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = rec_at(k);
         if (t == 0) Swn = c;
       } else {
         for (uint32_t k0 = 0; k0 < c; k0 += KVB_T) {
           const uint32_t k = k0 + t;
           const uint64_t r = k < c ? rec_at(k) : 0;
-          const bool in = k < c && Bwin[lk_idx(r) >> bs] == win;
+          const bool in = k < c && lk_slot(r) != hslot_done && (c_rest <= KVB_NMAX || Bwin[lk_idx(r) >> bs] == win);
           const uint64_t im = __ballot(in);
           uint32_t base = 0;
           if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
@@ -584,25 +846,17 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
         uint2 st = table[slot];  // wave-uniform address
         st.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.x);
         st.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.y);
-        bool wr = false;
-        for (uint32_t base = a; base < b; base += 64) {
+        const uint2 st_in = st;
+        for (uint32_t base = a; base < b; base += 64) {  // request order = lane order; 64 requests per step (Ops::walk64)
           const uint32_t p = base + lane;
           const bool valid = p < b;
           const uint64_t w = valid ? Sk[p] : 0;
           const uint32_t op = lk_op(w);
-          uint32_t code = 0, rv = 0;
-          const uint32_t cnt = min(64u, b - base);
-          for (uint32_t l = 0; l < cnt; l++) {  // request order = lane order
-            const uint32_t lop = (uint32_t)__builtin_amdgcn_readlane((int)op, (int)l);
-            uint32_t lrv = 0;
-            bool lwr = false;
-            const uint32_t lcode = Ops::apply(lop, st, lrv, lwr);
-            wr |= lwr;
-            if (lane == l) { code = lcode; rv = lrv; }
-          }
-          if (valid) Ops::write_reply(rep, V, lk_idx(w), op, code, rv);
+          uint32_t code = 0;
+          Ops::walk64(valid, op, st, code);
+          if (valid) Ops::write_reply(rep, V, lk_idx(w), op, code, 0);
         }
-        if (lane == 0 && wr) table[slot] = st;
+        if (lane == 0 && (st.x != st_in.x || st.y != st_in.y)) table[slot] = st;
       }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

@@ -177,3 +177,44 @@ def test_locks_big_passes_vs_oracle(wl, n, nslots, n_hot, p_hot):
     # the same trace cut into small passes gives the same replies
     eng2 = _engine(W_, n_slots=nslots, max_pass=4096)
     assert eng2.submit(req[:200_000]).tobytes() == want[:200_000].tobytes()
+
+
+@pytest.mark.parametrize("n,max_pass,p_hot,p_acq", [
+    (65536, 0, 0.9, 0.5),      # one hot slot holds 90 % of a 64k pass: the dominant-slot path (index bitmap + mode walk)
+    (65536, 0, 0.6, 0.8),      # ... mostly ACQUIREs (the lock is held most of the time)
+    (65536, 0, 1.0, 0.5),      # nothing but the hot slot
+    (200_000, 65536, 0.85, 0.55),   # several passes, the counters carry over
+    (200_000, 0, 0.85, 0.55),  # one pass of more than 65,536 requests: the general big-bin path (sorted stretches + walk)
+    (20_000, 0, 0.3, 0.5),     # a dominant slot of a few thousand among other traffic
+])
+def test_2pl_dominant_slot_vs_oracle(n, max_pass, p_hot, p_acq):
+    """the closed-loop shape that makes a lock hot (hundreds of workers retrying it), plus releases nobody holds (the
+    reference's unsigned counters wrap: lock_2pl/udp/server.cc:108-111)"""
+    rng = np.random.default_rng(n + int(100 * p_hot))
+    m = np.zeros(n, wire.TPL_MSG)
+    m["action"] = (rng.random(n) >= p_acq).astype(np.uint8)
+    m["type"] = (rng.random(n) < 0.3).astype(np.uint8)
+    hot = rng.random(n) < p_hot
+    m["lid"] = np.where(hot, 777, rng.integers(0, 24_000_000, n)).astype("<u4")
+    m["lid"][rng.random(n) < 0.02] = 778  # a second, smaller hot slot
+    eng = _engine(wire.Workload.TPL, n_slots=1 << 20, max_pass=max_pass)
+    o = orc.TplOracle(1 << 20)
+    assert eng.submit(m).tobytes() == o.replay(m).tobytes()
+    ex, sh = eng.read_locks()
+    assert (ex == o.num_ex).all() and (sh == o.num_sh).all()
+
+
+def test_2pl_client_trace_vs_oracle():
+    """the lock_2pl client loop (dint_amd.driver.TplClient) against the engine, 64k-request passes; the oracle replays it"""
+    from dint_amd.driver import tpl_trace
+
+    eng = _engine(wire.Workload.TPL, n_slots=1 << 20, max_pass=65536)
+    req, rep, st = tpl_trace(eng, 65536 * 12, n_workers=4096, zipf_theta=0.8)
+    assert st["protocol_errors"] == 0 and st["committed"] > 1000 and st["rejects"] > 1000
+    o = orc.TplOracle(1 << 20)
+    assert rep.tobytes() == o.replay(req).tobytes()
+    # the replay in 64k passes from the empty table meets the dominant-slot path with a slot of thousands of requests
+    eng2 = _engine(wire.Workload.TPL, n_slots=1 << 20, max_pass=65536)
+    assert eng2.submit(req).tobytes() == rep.tobytes()
+    ex, sh = eng2.read_locks()
+    assert (ex == o.num_ex).all() and (sh == o.num_sh).all()
