@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdint.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MICRO_BATCH = 65536
 
 #: every symbol include/dint_abi.h declares (checked by tests/test_abi.py)
@@ -29,7 +29,8 @@ SYMBOLS = [
 class RouteItem(C.Structure):
     """dint_route_item (include/dint_abi.h)"""
     _fields_ = [("engine", C.c_void_p), ("d_reqs", C.c_void_p), ("n", C.c_uint32), ("seg_cap", C.c_uint32),
-                ("d_slots", C.c_void_p), ("d_cnt", C.c_void_p), ("d_slot", C.c_void_p), ("d_replies", C.c_void_p)]
+                ("d_slots", C.c_void_p), ("d_cnt", C.c_void_p), ("d_slot", C.c_void_p), ("d_replies", C.c_void_p),
+                ("d_n", C.c_void_p)]
 
 
 class Config(C.Structure):

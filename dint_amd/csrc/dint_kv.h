@@ -73,6 +73,7 @@ struct dint_route_job {            // one batch and the engine whose hash / modu
   const void *d_req;
   void *d_rep;                     // unpack only
   uint32_t n, cap;
+  const uint32_t *d_n;             // live request count on the device (n is then its upper bound), or nullptr
   void *d_send, *d_cnt;            // this batch's slot / live-count word of peer 0
   uint64_t cnt_stride;
   uint32_t *d_slot;

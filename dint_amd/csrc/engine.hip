@@ -96,6 +96,7 @@ struct dint_engine {
   // log
   dint_log log{};
   uint64_t log_drained = 0;  // records handed out (or given up as lost) by dint_log_drain
+  uint64_t snap_log_drained = 0;  // ... when the snapshot was taken (dint_restore puts it back)
 
   // kv workloads (store / tatp / smallbank)
   dint_kv kv{};
@@ -127,10 +128,17 @@ void add_region(dint_engine *e, void *p, size_t bytes) { e->regions.push_back({p
 // enqueued last on another stream.
 int order_stream(dint_engine *e, hipStream_t st) {
   if (e->last_stream && e->last_stream != st) {
-    HIP_TRY(hipEventRecord(e->ev_order, e->last_stream));
+    // the engine's own stream outlives every call: its position is recorded now.  A CALLER's stream is never touched
+    // after the call that used it (the caller may have destroyed it by now -- ADVICE r02): mark_stream recorded
+    // ev_order on it at the end of that call.
+    if (e->last_stream == e->stream) HIP_TRY(hipEventRecord(e->ev_order, e->stream));
     HIP_TRY(hipStreamWaitEvent(st, e->ev_order, 0));
   }
   e->last_stream = st;
+  return 0;
+}
+int mark_stream(dint_engine *e, hipStream_t st) {  // end of a call that enqueued the engine's work on `st`
+  if (st != e->stream) HIP_TRY(hipEventRecord(e->ev_order, st));
   return 0;
 }
 
@@ -209,6 +217,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  if (int rc = mark_stream(e, st)) return rc;
   e->batches++;
   e->requests += n;
   return 0;
@@ -547,6 +556,7 @@ int route_job(const dint_route_item &it, bool pack, uint64_t cnt_stride, hipStre
   job->d_req = it.d_reqs;
   job->d_rep = it.d_replies;
   job->n = it.n;
+  job->d_n = it.d_n;
   job->cap = it.seg_cap;
   job->d_send = it.d_slots;
   job->d_cnt = it.d_cnt;
@@ -556,6 +566,19 @@ int route_job(const dint_route_item &it, bool pack, uint64_t cnt_stride, hipStre
   job->stats = e->scratch.stats;
   return 0;
 }
+// every engine of a routing call, each once, locked in address order (two calls that share engines cannot deadlock)
+int lock_engines(const dint_route_item *items, uint32_t n_items, std::vector<std::unique_lock<std::mutex>> &locks) {
+  std::vector<dint_engine *> es;
+  for (uint32_t k = 0; k < n_items; k++) {
+    if (!items[k].engine) return fail(DINT_EINVAL, "null engine");
+    if (items[k].engine->device != items[0].engine->device) return fail(DINT_EINVAL, "the batches of one call share a device");
+    es.push_back(items[k].engine);
+  }
+  std::sort(es.begin(), es.end());
+  es.erase(std::unique(es.begin(), es.end()), es.end());
+  for (dint_engine *e : es) locks.emplace_back(e->mu);
+  return 0;
+}
 }  // namespace
 
 int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64_t seg_stride, uint64_t cnt_stride,
@@ -563,12 +586,10 @@ int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64
   if (!items || n_items == 0 || n_items > DINT_ROUTE_MAXS) return fail(DINT_EINVAL, "1 .. %u batches per call", DINT_ROUTE_MAXS);
   dint_route_job jobs[DINT_ROUTE_MAXS];
   hipStream_t st = nullptr;
-  for (uint32_t k = 0; k < n_items; k++) {  // engines are locked one at a time: the launch below needs no lock
-    if (!items[k].engine) return fail(DINT_EINVAL, "null engine");
-    if (items[k].engine->device != items[0].engine->device) return fail(DINT_EINVAL, "the batches of one call share a device");
-    std::lock_guard<std::mutex> lk(items[k].engine->mu);
+  std::vector<std::unique_lock<std::mutex>> locks;
+  if (int rc = lock_engines(items, n_items, locks)) return rc;  // held across the launch: two threads packing with
+  for (uint32_t k = 0; k < n_items; k++)                        // one engine launch in the order order_route_stream recorded
     if (int rc = route_job(items[k], true, cnt_stride, st, stream, &jobs[k])) return rc;
-  }
   dint_launch_route_pack(jobs, n_items, seg_stride, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
@@ -579,6 +600,8 @@ int dint_route_unpack_multi(const dint_route_item *items, uint32_t n_items, uint
   if (!items || n_items == 0 || n_items > DINT_ROUTE_MAXS) return fail(DINT_EINVAL, "1 .. %u batches per call", DINT_ROUTE_MAXS);
   dint_route_job jobs[DINT_ROUTE_MAXS];
   hipStream_t st = nullptr;
+  std::vector<std::unique_lock<std::mutex>> locks;
+  if (int rc = lock_engines(items, n_items, locks)) return rc;
   for (uint32_t k = 0; k < n_items; k++)
     if (int rc = route_job(items[k], false, 0, st, stream, &jobs[k])) return rc;
   dint_launch_route_unpack(jobs, n_items, seg_stride, st);
@@ -589,13 +612,13 @@ int dint_route_unpack_multi(const dint_route_item *items, uint32_t n_items, uint
 
 int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_send, uint32_t seg_cap,
                     uint64_t seg_stride, void *d_cnt, uint64_t cnt_stride, uint32_t *d_slot, void *stream) {
-  dint_route_item it = {e, d_reqs, n, seg_cap, d_send, d_cnt, d_slot, nullptr};
+  dint_route_item it = {e, d_reqs, n, seg_cap, d_send, d_cnt, d_slot, nullptr, nullptr};
   return dint_route_pack_multi(&it, 1, seg_stride, cnt_stride, stream);
 }
 
 int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, uint64_t seg_stride,
                       const uint32_t *d_slot, const void *d_reqs, uint32_t n, void *d_replies, void *stream) {
-  dint_route_item it = {e, d_reqs, n, seg_cap, const_cast<void *>(d_back), nullptr, const_cast<uint32_t *>(d_slot), d_replies};
+  dint_route_item it = {e, d_reqs, n, seg_cap, const_cast<void *>(d_back), nullptr, const_cast<uint32_t *>(d_slot), d_replies, nullptr};
   return dint_route_unpack_multi(&it, 1, seg_stride, stream);
 }
 
@@ -626,9 +649,15 @@ int dint_stream_signal(dint_engine_t *e, void *other_stream) {
 
 int dint_sync(dint_engine_t *e) {
   if (!e) return fail(DINT_EINVAL, "null engine");
+  hipStream_t s0, s1, s2;
+  {
+    std::lock_guard<std::mutex> lk(e->mu);  // the copy streams are created lazily by the first host submission
+    s0 = e->stream; s1 = e->s_h2d; s2 = e->s_d2h;
+  }
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (e->s_d2h) HIP_TRY(hipStreamSynchronize(e->s_d2h));
+  HIP_TRY(hipStreamSynchronize(s0));
+  if (s1 && s1 != s0) HIP_TRY(hipStreamSynchronize(s1));
+  if (s2 && s2 != s0) HIP_TRY(hipStreamSynchronize(s2));
   return 0;
 }
 
@@ -778,6 +807,7 @@ int dint_snapshot(dint_engine_t *e) {
   for (size_t i = 0; i < e->regions.size(); i++)
     HIP_TRY(hipMemcpy(e->snap[i], e->regions[i].first, e->regions[i].second, hipMemcpyDeviceToDevice));
   HIP_TRY(hipDeviceSynchronize());
+  e->snap_log_drained = e->log_drained;
   return 0;
 }
 
@@ -792,6 +822,7 @@ int dint_restore(dint_engine_t *e) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(e->h_pool, &e->scratch.stats->pool_exhausted, sizeof(unsigned long long), hipMemcpyDeviceToHost));
   e->pool_seen = *e->h_pool;
+  e->log_drained = e->snap_log_drained;  // the drain cursor belongs to the log's history
   return 0;
 }
 
@@ -833,6 +864,7 @@ int64_t dint_dump_rows(dint_engine_t *e, uint32_t table, uint64_t *keys, uint32_
 
 int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d_home, void *stream) {
   if (!e || (n && (!d_reqs || !d_home))) return fail(DINT_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = stream ? (hipStream_t)stream : e->stream;
   switch (e->cfg.workload) {

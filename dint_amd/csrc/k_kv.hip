@@ -320,6 +320,15 @@ __device__ static inline void kv_stamp_real(uint64_t *tr, uint32_t k) {
   if (tr && lane_id() == 0) tr[k] = __builtin_amdgcn_s_memrealtime();
 }
 
+// The overflow-entry pool is nearly used up: a bucket run that inserts goes request by request (kv_do_request answers
+// an INSERT that finds the pool full with the reject code and leaves its lock byte alone; a closed form has written
+// its replies before the one physical insert at the write-back can fail -- ADVICE r02).  The margin covers the
+// inserts other waves have in flight; recycled entries are ignored, which only makes the answer more careful.
+#define KV_POOL_MARGIN 4096u
+__device__ static inline uint32_t kv_pool_low(const kv_tab &t) {
+  return __hip_atomic_load(t.pool_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + KV_POOL_MARGIN >= t.pool_cap;
+}
+
 // ---- one request against the table ---------------------------------------------------------------------
 // Written so that the lanes of a wave, which run different request types, share their memory round trips:
 //   load phase   : the bucket's inline header sector (probe keys, versions, valid bits, chain head AND the tatp lock
@@ -564,7 +573,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
     if (WL == DINT_WL_TATP) la0 = (H.lockw >> (8 * q)) & 0xFFu;
     const kv_where w = kv_locate(t, bucket, H, key);
     found = w.found; link = w.link; slot = w.slot; ver0 = w.ver;
-    if (WL != DINT_WL_SMALLBANK && structural) dupf = kv_has_dup(t, bucket, H, key, w);
+    if (WL != DINT_WL_SMALLBANK && structural) dupf = kv_has_dup(t, bucket, H, key, w) | kv_pool_low(t);
   }
   found = __shfl(found, hl, 64); link = __shfl(link, hl, 64); slot = __shfl(slot, hl, 64);
   ver0 = __shfl(ver0, hl, 64); la0 = __shfl(la0, hl, 64); lb0 = __shfl(lb0, hl, 64);
@@ -1307,7 +1316,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         if (WL != DINT_WL_SMALLBANK) {
           if (kvb_bit(Mstseg, a)) {  // the segment inserts / deletes
             Crow[t].exists = wh.found; Crow[t].ver = wh.ver; Crow[t].toggles = 0; Crow[t].miss = 0; Crow[t].src = -1;
-            Crow[t].bail = kv_has_dup(tb, bucket, H, key, wh);  // duplicate rows of this key: request by request
+            Crow[t].bail = kv_has_dup(tb, bucket, H, key, wh) | kv_pool_low(tb);  // duplicate rows of this key, or hardly an overflow entry left: request by request
             Sany = 1;
           }
         }

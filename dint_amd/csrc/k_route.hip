@@ -42,7 +42,8 @@ struct rt_params {
 struct rt_item {
   const uint8_t *req;
   uint8_t *rep;          // unpack: replies in request order
-  uint32_t n, cap;       // requests; slot capacity (messages)
+  uint32_t n, cap;       // requests (with n_dev: their upper bound, which sizes the grid); slot capacity (messages)
+  const uint32_t *n_dev; // the live request count in device memory (a batch a kernel produced), or nullptr
   uint8_t *send;         // this item's slot of peer 0 (peer w at + w * stride); unpack: the returned slots
   uint8_t *cnt;          // its u32 live count of peer 0 (peer w at + w * cnt_stride)
   uint64_t cnt_stride;
@@ -56,6 +57,8 @@ struct rt_items {
   uint64_t stride;
   rt_item it[DINT_ROUTE_MAXS];
 };
+
+__device__ static inline uint32_t rt_n(const rt_item &it) { return it.n_dev ? min(*it.n_dev, it.n) : it.n; }
 
 __device__ static inline uint32_t rt_home(const uint8_t *m, const rt_params &p) {
   uint64_t g;
@@ -91,7 +94,7 @@ __device__ static inline void rt_copy_msg(uint8_t *dst, const uint8_t *src, uint
 __global__ void __launch_bounds__(RT_TB)
 k_route_count(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
-  const uint32_t n = it.n;
+  const uint32_t n = rt_n(it);
   if (blockIdx.x * RT_TB >= n) return;  // the grid is as wide as the largest item
   const uint8_t *__restrict__ req = it.req;
   uint8_t *__restrict__ home = it.home;
@@ -121,7 +124,7 @@ k_route_count(rt_items I) {
 __global__ void __launch_bounds__(RS_TB)
 k_route_scan(rt_items I) {  // one workgroup per item
   const rt_item &it = I.it[blockIdx.x];
-  const uint32_t nb = (it.n + RT_TB - 1) / RT_TB, world = it.p.world, cap = it.cap;
+  const uint32_t nb = (rt_n(it) + RT_TB - 1) / RT_TB, world = it.p.world, cap = it.cap;
   uint32_t *__restrict__ blk = it.blk;
   uint8_t *cnt = it.cnt;
   const uint64_t cnt_stride = it.cnt_stride;
@@ -161,7 +164,7 @@ k_route_scan(rt_items I) {  // one workgroup per item
 __global__ void __launch_bounds__(RT_TB)
 k_route_scatter_simple(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
-  const uint32_t n = it.n, msg = it.p.msg, world = it.p.world, cap = it.cap;
+  const uint32_t n = rt_n(it), msg = it.p.msg, world = it.p.world, cap = it.cap;
   if (blockIdx.x * RT_TB >= n) return;
   const uint8_t *__restrict__ req = it.req;
   const uint8_t *__restrict__ home = it.home;
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(256)
 k_route_unpack_simple(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
   const uint8_t *__restrict__ back = it.send;
-  const uint32_t cap = it.cap, n = it.n, msg = it.p.msg;
+  const uint32_t cap = it.cap, n = rt_n(it), msg = it.p.msg;
   const uint64_t stride = I.stride;
   const uint32_t *__restrict__ slot = it.slot;
   const uint8_t *req = it.req;
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(RT_TB)
 k_route_scatter(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
   constexpr uint32_t msg = MSG;
-  const uint32_t n = it.n, world = it.p.world, cap = it.cap;
+  const uint32_t n = rt_n(it), world = it.p.world, cap = it.cap;
   if (blockIdx.x * RT_TB >= n) return;
   const uint8_t *__restrict__ req = it.req;
   const uint8_t *__restrict__ home = it.home;
@@ -340,7 +343,7 @@ k_route_unpack(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
   const uint8_t *__restrict__ back = it.send;
   constexpr uint32_t msg = MSG;
-  const uint32_t cap = it.cap, n = it.n, world = it.p.world;
+  const uint32_t cap = it.cap, n = rt_n(it), world = it.p.world;
   if (blockIdx.x * RT_TB >= n) return;
   const uint64_t stride = I.stride;
   const uint32_t *__restrict__ slot = it.slot;
@@ -423,6 +426,7 @@ void dint_launch_route_pack(const dint_route_job *jobs, uint32_t n_jobs, uint64_
     it.req = (const uint8_t *)j.d_req;
     it.rep = nullptr;
     it.n = j.n;
+    it.n_dev = j.d_n;
     it.cap = j.cap;
     it.send = (uint8_t *)j.d_send;
     it.cnt = (uint8_t *)j.d_cnt;
@@ -467,6 +471,7 @@ void dint_launch_route_unpack(const dint_route_job *jobs, uint32_t n_jobs, uint6
     it.req = (const uint8_t *)j.d_req;
     it.rep = (uint8_t *)j.d_rep;
     it.n = j.n;
+    it.n_dev = j.d_n;
     it.cap = j.cap;
     it.send = (uint8_t *)j.d_send;  // the slots as they came back
     it.slot = j.d_slot;

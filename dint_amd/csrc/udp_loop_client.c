@@ -1,4 +1,4 @@
-/* udp_loop_client.c -- MEASUREMENT TOOL (dint_amd/dint_udp_client; also built as oracle/_ref/udp_loop_client).
+/* udp_loop_client.c -- MEASUREMENT TOOL (built as dint_amd/dint_udp_client; the baseline harness builds the same source).
  *
  * A closed-loop UDP load generator on loopback, for the host shim (dint_udp_server) and for the reference's as-shipped
  * udp/ servers alike: the Caladan clients (lock_fasst/caladan/client.cc) cannot be built offline,

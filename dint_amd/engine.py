@@ -200,21 +200,23 @@ class Engine:
 
 
 def route_pack_multi(engines, d_reqs, counts, d_slots, seg_caps, seg_stride: int, d_cnts, cnt_stride: int, d_slot,
-                     stream: int = 0) -> None:
+                     stream: int = 0, d_n=None) -> None:
     """dint_route_pack_multi: batch k (engine k's hash / modulus) into its slot d_slots[k] of every peer chunk, one set
-    of kernel launches for all of them."""
+    of kernel launches for all of them.  d_n[k]: device pointer to batch k's live request count (counts[k] is then
+    its upper bound)."""
     items = (_lib.RouteItem * len(engines))()
     for k, e in enumerate(engines):
         items[k] = _lib.RouteItem(e._h, _ptr(d_reqs[k]), counts[k], seg_caps[k], _ptr(d_slots[k]), _ptr(d_cnts[k]),
-                                  _ptr(d_slot[k]), None)
+                                  _ptr(d_slot[k]), None, d_n[k] if d_n else None)
     _lib.check(engines[0]._L.dint_route_pack_multi(items, len(engines), seg_stride, cnt_stride, stream))
 
 
-def route_unpack_multi(engines, d_backs, seg_caps, seg_stride: int, d_slot, d_reqs, counts, d_replies, stream: int = 0) -> None:
+def route_unpack_multi(engines, d_backs, seg_caps, seg_stride: int, d_slot, d_reqs, counts, d_replies, stream: int = 0,
+                       d_n=None) -> None:
     items = (_lib.RouteItem * len(engines))()
     for k, e in enumerate(engines):
         items[k] = _lib.RouteItem(e._h, _ptr(d_reqs[k]), counts[k], seg_caps[k], _ptr(d_backs[k]), None, _ptr(d_slot[k]),
-                                  _ptr(d_replies[k]))
+                                  _ptr(d_replies[k]), d_n[k] if d_n else None)
     _lib.check(engines[0]._L.dint_route_unpack_multi(items, len(engines), seg_stride, stream))
 
 

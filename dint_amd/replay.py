@@ -144,12 +144,15 @@ class Replay:
 
 class GpuLoop:
     """The closed loop that never leaves the GPU: a :class:`dint_amd.driver.GpuDriver` and the three shard servers of a
-    single-GPU :class:`ShardGroup`.  One epoch = emit kernel -> the three engines on their own streams, each answering
-    its batch in place (the batch size is read on the device) -> consume kernel; no host round trip, no PCIe."""
+    :class:`ShardGroup`.  One epoch = emit kernel -> the three engines on their own streams, each answering its batch in
+    place (the batch size is read on the device) -> consume kernel; no host round trip, no PCIe.  With a router (several
+    GPUs, or the exchange forced on) the epoch's batches cross the exchange on the way: pack / unpack read the batch
+    sizes on the device as well (dint_route_item.d_n), and the home engines read theirs from the slot headers."""
 
     def __init__(self, group: ShardGroup, gdriver):
-        assert group.router is None, "single GPU (the exchange needs host-known batch sizes)"
         assert gdriver.cap <= min(e.pass_max for e in group.engines)
+        if group.router is not None:
+            assert gdriver.cap <= group.router.n_max and group.router.multi is not None
         self.g, self.d = group, gdriver
         self.stream = torch.cuda.Stream()
         self.msg = group.msg
@@ -157,12 +160,18 @@ class GpuLoop:
     def epochs(self, n: int) -> None:
         xs = self.stream.cuda_stream
         cap, msg, d = self.d.cap, self.msg, self.d
+        rt = self.g.router
         for _ in range(n):
             d.next(xs)
-            for s, e in enumerate(self.g.engines):
-                e.stream_wait(xs)
-                e.submit_segments(d.batch_ptr[s], 1, cap, cap * msg, d.counts_ptr + 4 * s, 0)
-                e.stream_signal(xs)
+            if rt is None:
+                for s, e in enumerate(self.g.engines):
+                    e.stream_wait(xs)
+                    e.submit_segments(d.batch_ptr[s], 1, cap, cap * msg, d.counts_ptr + 4 * s, 0)
+                    e.stream_signal(xs)
+            else:
+                with torch.cuda.stream(self.stream):  # Router.run waits for the current stream: the emit kernel
+                    rt.step(d.batch_ptr, [cap] * N_SHARDS, d.batch_ptr, d_n=[d.counts_ptr + 4 * s for s in range(N_SHARDS)])
+                rt.join(self.stream)
             d.consume(xs)
 
     def sync(self):

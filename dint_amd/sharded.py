@@ -130,8 +130,9 @@ class Router:
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
-    def _forward(self, k: int, d_reqs, counts, track: bool):
-        """pack + all-to-all of step k into buffer set k % 2; returns the event the engines wait for"""
+    def _forward(self, k: int, d_reqs, counts, track: bool, d_n=None):
+        """pack + all-to-all of step k into buffer set k % 2; returns the event the engines wait for.  d_n: per server a
+        device pointer to the batch's live request count (counts[s] is then only its upper bound)"""
         b = k % self.NBUF
         xs = self.stream.cuda_stream if self.stream is not None else 0
         sp = self.send[b].data_ptr()
@@ -140,8 +141,9 @@ class Router:
             self.stream.wait_event(self.ev_unpacked[b])  # step k - 2 is done with this buffer set
         if self.multi:  # the S servers' batches in one set of launches (grid.y = server)
             self.multi[0](self.engines, d_reqs, counts, [sp + self.off[s] for s in range(self.S)], self.caps, self.chunk,
-                          [sp + 4 * s for s in range(self.S)], self.chunk, self.d_slot[b], xs)
+                          [sp + 4 * s for s in range(self.S)], self.chunk, self.d_slot[b], xs, d_n)
         else:
+            assert d_n is None, "device-side batch sizes need the multi-batch routing calls"
             for s, e in enumerate(self.engines):
                 e.route_pack(d_reqs[s], counts[s], sp + self.off[s], self.caps[s], self.chunk, sp + 4 * s, self.chunk,
                              self.d_slot[b][s], xs)
@@ -171,7 +173,7 @@ class Router:
                 done.append(ev)
         return done
 
-    def _backward(self, k: int, ev_done, d_reqs, counts, d_reps):
+    def _backward(self, k: int, ev_done, d_reqs, counts, d_reps, d_n=None):
         b = k % self.NBUF
         st = self.bstream if self.bstream is not None else self.stream
         xs = st.cuda_stream if st is not None else 0
@@ -182,7 +184,7 @@ class Router:
         sp = self.send[b].data_ptr()
         if self.multi:
             self.multi[1](self.engines, [sp + self.off[s] for s in range(self.S)], self.caps, self.chunk, self.d_slot[b],
-                          d_reqs, counts, d_reps, xs)
+                          d_reqs, counts, d_reps, xs, d_n)
         else:
             for s, e in enumerate(self.engines):
                 e.route_unpack(sp + self.off[s], self.caps[s], self.chunk, self.d_slot[b][s], d_reqs[s], counts[s],
@@ -193,7 +195,7 @@ class Router:
             self.ev_unpacked[b] = ev
 
     def run(self, steps, track: bool = False) -> None:
-        """steps: [(d_reqs[S], counts[S], d_reps[S])] -- independent batches (a recorded trace).  Asynchronous.
+        """steps: [(d_reqs[S], counts[S], d_reps[S][, d_n[S]])] -- independent batches (a recorded trace).  Asynchronous.
 
         Software pipeline over two buffer sets: the forward exchange of step k+1 is issued BEFORE the backward
         exchange of step k, so on the exchange stream (and on RCCL's, which runs collectives in issue order) step
@@ -206,21 +208,30 @@ class Router:
             if self.bstream is not None:
                 self.bstream.wait_stream(torch.cuda.current_stream())
         with self._on_stream():
-            ev = self._forward(0, steps[0][0], steps[0][1], track)
+            dn = lambda k: steps[k][3] if len(steps[k]) > 3 else None  # noqa: E731
+            ev = self._forward(0, steps[0][0], steps[0][1], track, dn(0))
             done = self._engines(0, ev)
             for k in range(len(steps)):
                 nxt = None
                 if k + 1 < len(steps):
-                    ev = self._forward(k + 1, steps[k + 1][0], steps[k + 1][1], track)
+                    ev = self._forward(k + 1, steps[k + 1][0], steps[k + 1][1], track, dn(k + 1))
                     nxt = ev
-                self._backward(k, done, *steps[k])
+                self._backward(k, done, *steps[k][:3], dn(k))
                 if k + 1 < len(steps):
                     done = self._engines(k + 1, nxt)
 
-    def step(self, d_reqs, counts, d_reps, track: bool = False) -> None:
+    def step(self, d_reqs, counts, d_reps, track: bool = False, d_n=None) -> None:
         """one batch per server: d_reqs / d_reps are per server uint8 device tensors (or raw device pointers) of
-        counts[s] messages"""
-        self.run([(d_reqs, counts, d_reps)], track)
+        counts[s] messages -- or, with d_n (device pointers to the live counts), of at most counts[s]"""
+        self.run([(d_reqs, counts, d_reps) if d_n is None else (d_reqs, counts, d_reps, d_n)], track)
+
+    def join(self, stream) -> None:
+        """`stream` (a torch stream) waits for everything this router has enqueued: the replies of the last step are
+        in place"""
+        if self.stream is not None:
+            stream.wait_stream(self.stream)
+        if self.bstream is not None:
+            stream.wait_stream(self.bstream)
 
     def sync(self) -> None:
         if self.stream is not None:

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 2
+#define DINT_ABI_VERSION 3
 
 /* dint_config.flags */
 #define DINT_FLAG_KV_ROUNDS 1u /* kv workloads: resolve same-key conflicts request by request instead of in
@@ -253,6 +253,9 @@ typedef struct dint_route_item {
   void *d_cnt;      /* pack only */
   uint32_t *d_slot; /* [n]: written by pack, read by unpack */
   void *d_replies;  /* unpack only */
+  const uint32_t *d_n; /* ABI v3: the batch's live request count in DEVICE memory (a batch a kernel produced -- the
+                          GPU-resident clients -- whose size the host never sees), n is then its upper bound; NULL: n
+                          is the count */
 } dint_route_item;
 int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64_t seg_stride, uint64_t cnt_stride,
                           void *stream);

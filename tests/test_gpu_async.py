@@ -61,11 +61,13 @@ def test_submit_device_on_alternating_caller_streams_is_serial():
         assert d[k].cpu().numpy().tobytes() == o.replay(reqs[k]).tobytes(), k
 
 
-def test_pool_exhaustion_is_reported_not_silent():
-    """a full overflow pool refuses INSERTs: reject code on the request-by-request path, DINT_ENOMEM from the host
-    submit, nothing stored"""
+@pytest.mark.parametrize("flags", [1, 0])  # 1 = DINT_FLAG_KV_ROUNDS; 0 = the default path (closed forms)
+def test_pool_exhaustion_is_reported_not_silent(flags):
+    """a full overflow pool refuses INSERTs: every INSERT that stores nothing carries the reject code -- also on the
+    default path, where a bucket run that inserts goes request by request once the pool runs low --, DINT_ENOMEM from
+    the host submit, nothing stored"""
     S = wire.Store
-    e = Engine(W.STORE, n_rows=8, pool_entries=2, flags=1)  # 36 buckets, 2 overflow entries; flag 1 = rounds
+    e = Engine(W.STORE, n_rows=8, pool_entries=2, flags=flags)  # 36 buckets, 2 overflow entries
     n = 2000
     m = np.zeros(n, wire.STORE_MSG)
     m["type"], m["key"] = S.INSERT, np.arange(1, n + 1, dtype=np.uint64) << np.uint64(32)

@@ -76,3 +76,29 @@ def test_gpu_loop_free_running_matches_oracle_state():
         assert tail == ora[s].tail and (np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64) == ora[s].ring).all()
         st = g.engines[s].stats()
         assert st["bad_requests"] == 0 and st["missing_keys"] == 0
+
+
+@pytest.mark.parametrize("wl,n_rows,clients,zipf", [(W.TATP, 20_000, 6000, 0.8), (W.SMALLBANK, 50_000, 4000, 0.99 - 1e-9)])
+def test_gpu_loop_through_the_exchange(wl, n_rows, clients, zipf):
+    """the GPU-resident clients drive the SHARDED path: pack / all-to-all / in-place passes / all-to-all / unpack with
+    every batch size read on the device (dint_route_item.d_n); same statistics and tables as the host driver's run
+    through a plain group (tatp/caladan/client_udp_shard.cc:1120-1185 is the loop both restate)"""
+    from dint_amd.replay import GpuLoop, ShardGroup
+
+    epochs, cap = 60, 4 * clients + 64
+    plain = ShardGroup(wl, n_rows, log_entries=400_000)
+    routed = ShardGroup(wl, n_rows, log_entries=400_000, force_exchange=True, n_max=1 << 16)
+    host = Driver(wl, clients, n_rows, first_client=3, zipf_theta=zipf)
+    for _ in range(epochs):
+        host.consume(plain.submit(host.next()))
+    gpu = GpuDriver(wl, clients, n_rows, cap, first_client=3, zipf_theta=zipf)
+    loop = GpuLoop(routed, gpu)
+    loop.epochs(epochs)
+    loop.sync()
+    hs, gs = host.stats(), gpu.stats()
+    assert gs["overflow"] == 0 and routed.router.overflow() == 0
+    for k in ("txns", "committed", "by_type", "committed_by_type"):
+        assert gs[k] == hs[k], k
+    for s in range(3):
+        for t in range(5 if wl == W.TATP else 2):
+            assert all((x == y).all() for x, y in zip(plain.engines[s].dump_rows(t), routed.engines[s].dump_rows(t)))

@@ -296,3 +296,60 @@ def test_two_sharded_ranks_on_one_gpu_equal_unsharded_oracle(wl, n_rows, clients
             assert st["foreign_requests"] == 0 and st["route_overflow"] == 0 and st["bad_requests"] == 0
         assert res[r][4]["committed"] > 0
     assert res[0][3] == res[1][3]  # the tightened capacities are agreed by all ranks
+
+
+# ------------------------------------------------------------------------- RCCL itself, on the one GPU a box has
+def _nccl_main(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from dint_amd.driver import Driver
+    from dint_amd.replay import Replay, ShardGroup
+
+    n_sub, clients, epochs = 20_000, 6000, 24
+    plain = ShardGroup(W.TATP, n_sub, log_entries=200_000)
+    routed = ShardGroup(W.TATP, n_sub, log_entries=200_000, transport="nccl", force_exchange=True, n_max=1 << 16)
+    assert routed.router.ex.transport == "nccl"
+    routed.snapshot()
+    d = Driver(W.TATP, clients, n_sub, zipf_theta=0.8)
+    ok, trace = True, []
+    for _ in range(epochs):  # host path: Router.submit -> pack, dist.all_to_all_single (RCCL), segments, back, unpack
+        req = d.next()
+        a, b = plain.submit(req), routed.submit(req)
+        ok = ok and all(a[s].tobytes() == b[s].tobytes() for s in range(3))
+        d.consume(a)
+        trace.append((req, a))
+    # device path, pipelined over the two buffer sets (what bench.py times): Router.run with the backward half on its
+    # own stream next to torch's NCCL stream
+    routed.router.tighten_caps()
+    routed.restore()
+    rp = Replay(trace, routed.msg)
+    rp.run(routed, 0, epochs)
+    routed.sync()
+    rp.check(0, epochs)
+    q.put((ok, routed.router.overflow(), d.stats()["committed"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_router_over_rccl_world_size_one():
+    """transport "nccl" with one rank: every collective of a step is a real RCCL all_to_all_single on device buffers
+    (a self-copy as far as the data goes), on torch's NCCL stream, ordered against the exchange streams and the
+    engines' streams by the same events the multi-GPU run uses.  The boxes have one GPU, so this is the branch's only
+    execution before the driver's 8-GPU run."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_main, args=(_free_port(), q))
+    p.start()
+    ok, overflow, committed = q.get(timeout=500)
+    p.join(120)
+    assert p.exitcode == 0
+    assert ok and overflow == 0 and committed > 0
