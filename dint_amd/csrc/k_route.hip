@@ -15,8 +15,9 @@
 //                     concatenation of all ingest batches, whatever the number of GPUs
 //   k_route_unpack  : replies[i] = the slot message request i was sent in, after the inverse all-to-all
 //
-// A slot is `cap` messages; a destination that would receive more drops the excess (reply = request, counted in
-// dint_stats.route_overflow): callers size `cap` from the recorded or expected maximum and check the counter.
+// A slot is `cap` messages; what a destination cannot take is answered "not now, send again" by the sender's own
+// unpack (rt_refuse: the eBPF servers' REJECT_* / RETRY replies) and counted in dint_stats.route_overflow: callers size
+// `cap` from the recorded or expected maximum, and Router grows it when the counter moves.
 #include <algorithm>
 
 #include "../../include/dint_abi.h"
@@ -57,6 +58,25 @@ struct rt_items {
   uint64_t stride;
   rt_item it[DINT_ROUTE_MAXS];
 };
+
+// A request that found its destination slot full is not sent; its sender gets the reply the reference's eBPF servers give
+// when they cannot take a request right now -- REJECT_READ / REJECT_LOCK / REJECT_COMMIT (tatp), RETRY (smallbank,
+// lock_2pl), kReject* (store): every client answers these by sending the request again (dint_refuse in the ABI; e.g.
+// tatp/ebpf/shard_kern.c:173-178,289-293,371-376).  Request types those servers never refuse (ABORT, log appends,
+// lock_fasst's READ / ABORT / COMMIT) come back unchanged: not answered.  Either way it is counted (route_overflow).
+__device__ static inline void rt_refuse(uint8_t *m, uint32_t msg) {
+  switch (msg) {
+    case 6: m[0] = 4; break;                                                 // lock_2pl RETRY
+    case 9: if (m[0] == 1) m[0] = 6; break;                                  // lock_fasst REJECT_LOCK
+    case 53: if (m[0] <= 2) m[0] = (uint8_t)(4 + 2 * m[0] + (m[0] == 2)); break;  // store 0 -> 4, 1 -> 6, 2 -> 9
+    case 55:
+      if (m[1] == 0) m[1] = 5;
+      else if (m[1] == 1) m[1] = 8;
+      else if (m[1] == 12 || m[1] == 13 || m[1] == 18 || m[1] == 19 || m[1] == 22 || m[1] == 23) m[1] = 11;
+      break;
+    default: if (m[1] <= 5 || m[1] == 17) m[1] = 16; break;                  // smallbank RETRY
+  }
+}
 
 __device__ static inline uint32_t rt_n(const rt_item &it) { return it.n_dev ? min(*it.n_dev, it.n) : it.n; }
 
@@ -214,8 +234,9 @@ k_route_unpack_simple(rt_items I) {
   if (s != RT_NONE) {
     const uint32_t h = s / cap, pos = s - h * cap;
     rt_copy_msg(rep + (size_t)i * msg, back + (size_t)h * stride + (size_t)pos * msg, msg);
-  } else if (rep != req) {
-    rt_copy_msg(rep + (size_t)i * msg, req + (size_t)i * msg, msg);
+  } else {  // not sent (slot overflow): the "not now, send again" reply
+    if (rep != req) rt_copy_msg(rep + (size_t)i * msg, req + (size_t)i * msg, msg);
+    rt_refuse(rep + (size_t)i * msg, msg);
   }
 }
 
@@ -387,9 +408,10 @@ k_route_unpack(rt_items I) {
   __syncthreads();
   rt_regs<MSG> r;
   if (routed) rt_get<MSG>(r, Lb + Loff[h] + (pos - Min[h]) * msg);
-  else if (valid) rt_get<MSG>(r, req + (size_t)i * msg);  // not sent (slot overflow): reply = request
+  else if (valid) rt_get<MSG>(r, req + (size_t)i * msg);  // not sent (slot overflow): the request, refused below
   __syncthreads();
   if (valid) rt_put<MSG>(Lb + t * msg, r);  // request order
+  if (valid && !routed) rt_refuse(Lb + t * msg, msg);
   __syncthreads();
   rt_lds_store_tile(rep + (size_t)blockIdx.x * RT_TB * msg, Lb, tile_n * msg);
 }

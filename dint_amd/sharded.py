@@ -245,12 +245,32 @@ class Router:
         return sum(e.stats()["route_overflow"] for e in self.engines)
 
     # ---- host convenience (recording, tests) ---------------------------------------------------------------------
-    def submit(self, reqs: List[np.ndarray]) -> List[np.ndarray]:
+    def grow_caps(self) -> bool:
+        """After a step whose slots overflowed (the refused requests were answered "send again"): a slot that was
+        full -- its header count is clamped to the capacity, so the true demand is unknown -- doubles, agreed by all
+        ranks.  Returns whether anything changed.  (max_seen is tracked by `submit`; a free-running caller reads
+        `overflow()` at its sync points and calls this.)"""
+        full = self.ex.max_int([int(m >= c) for m, c in zip(self.max_seen, self.caps)])
+        lim = self.engines[0].pass_max // 64 * 64
+        new = [min(max(self.n_max, c), lim, 2 * c) if f else c for c, f in zip(self.caps, full)]
+        if new == self.caps:
+            return False
+        self.set_caps(new)
+        return True
+
+    def submit(self, reqs: List[np.ndarray], on_overflow: str = "raise") -> List[np.ndarray]:
+        """one step from host arrays.  A full slot: "raise" (recording runs must be lossless) or "refuse" -- the
+        requests that did not fit come back with the back-pressure reply (their senders send them again) and the
+        capacities grow for the next step."""
         d_req = [torch.from_numpy(np.frombuffer(r.tobytes(), np.uint8).copy()).to(self.device) for r in reqs]
         d_rep = [torch.empty_like(d) for d in d_req]
         before = self.overflow()
         self.step(d_req, [len(r) for r in reqs], d_rep, track=True)
         self.sync()
-        if self.overflow() != before:
+        over = self.overflow() != before
+        if over and on_overflow == "raise":
             raise RuntimeError("exchange slot overflow: raise the slot capacities (Router.set_caps)")
-        return [np.frombuffer(d.cpu().numpy().tobytes(), r.dtype) for d, r in zip(d_rep, reqs)]
+        out = [np.frombuffer(d.cpu().numpy().tobytes(), r.dtype) for d, r in zip(d_rep, reqs)]
+        if self.ex.max_int([int(over)])[0]:  # every rank rebuilds its buffers together
+            self.grow_caps()
+        return out

@@ -129,7 +129,8 @@ typedef struct dint_stats {
                               its own is answered REJECT_INSERT (store, 9) / REJECT_COMMIT (tatp, 11 -- the eBPF
                               flavour's "refused, send again", tatp/ebpf/shard_kern.c:509-514), one folded into a
                               same-key closed form keeps its ack; dint_wait / dint_submit return DINT_ENOMEM */
-  uint64_t route_overflow; /* requests dint_route_pack could not place (destination slot full): reply = request */
+  uint64_t route_overflow; /* requests dint_route_pack could not place (destination slot full): answered by
+                              dint_route_unpack with the back-pressure reply of dint_refuse ("not now, send again") */
   uint64_t big_bin_requests; /* kv workloads: requests that were resolved by the big-bin kernel (hot keys) */
 } dint_stats;
 
@@ -233,8 +234,9 @@ int dint_restore(dint_engine_t *e);
  *   dint_route_unpack    replies to their original positions
  * A slot = seg_cap messages at d_send + w * seg_stride, with its live count (u32) at d_cnt + w * cnt_stride (the
  * caller decides where the header lives, e.g. in front of the slot so that it travels with it).  d_slot[n] (u32)
- * remembers where each request went.  Requests beyond a slot's capacity are not sent (reply = request,
- * dint_stats.route_overflow); n <= 1,048,576 and G <= 64 per call. */
+ * remembers where each request went.  Requests beyond a slot's capacity are not sent: dint_route_unpack answers them
+ * with the back-pressure reply of dint_refuse, which every client answers by sending the request again
+ * (dint_stats.route_overflow counts them); n <= 1,048,576 and G <= 64 per call. */
 int dint_route_pack(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_send, uint32_t seg_cap,
                     uint64_t seg_stride, void *d_cnt, uint64_t cnt_stride, uint32_t *d_slot, void *stream);
 int dint_route_unpack(dint_engine_t *e, const void *d_back, uint32_t seg_cap, uint64_t seg_stride,

@@ -46,7 +46,8 @@ class ServerDouble:
     home rank per message."""
 
     def __init__(self, workload, oracle, world: int, rank: int, home_of, pass_max: int = 1 << 20):
-        self.dtype = wire.MSG_DTYPE[wire.Workload(workload)]
+        self.workload = wire.Workload(workload)
+        self.dtype = wire.MSG_DTYPE[self.workload]
         self.msg_size = self.dtype.itemsize
         self.oracle, self.world, self.rank, self.home_of = oracle, world, rank, home_of
         self.pass_max = pass_max
@@ -89,10 +90,16 @@ class ServerDouble:
         slot = np.frombuffer((C.c_uint32 * n).from_address(_p(d_slot)), np.uint32)
         req = _buf(_p(d_reqs), n * msg).reshape(n, msg)
         rep = _buf(_p(d_replies), n * msg).reshape(n, msg)
+        over = np.nonzero(slot == 0xFFFFFFFF)[0]
+        if len(over):  # not sent (slot full): the back-pressure reply, as k_route.hip rt_refuse (= dint_refuse, host code)
+            from dint_amd.engine import refuse
+
+            r = refuse(self.workload, np.frombuffer(req[over].tobytes(), self.dtype))
+            rep[over] = np.frombuffer(r.tobytes(), np.uint8).reshape(-1, msg)
         for i in range(n):
             s = int(slot[i])
             if s == 0xFFFFFFFF:
-                rep[i] = req[i]
+                continue
             else:
                 h, pos = divmod(s, seg_cap)
                 rep[i] = _buf(_p(d_back) + h * seg_stride + pos * msg, msg)

@@ -58,11 +58,19 @@ def test_route_pack_unpack_vs_numpy(n, world, cap):
         assert (got[w, HDRB:HDRB + cnt[w] * msg] == want[w, HDRB:HDRB + cnt[w] * msg]).all(), w
     assert (d_slot.cpu().numpy()[:n] == h_slot.numpy()[:n]).all()
     assert eng.stats()["route_overflow"] == dbl.route_overflow
-    # unpack straight from the send buffer: every request comes back unchanged (overflowed ones via reply = request)
+    # unpack straight from the send buffer: every request that was sent comes back unchanged; one that found its slot
+    # full comes back with the back-pressure reply (dint_refuse: lock_fasst refuses ACQUIRE_LOCK only)
     d_rep = torch.zeros_like(d_req)
     eng.route_unpack(d_send.data_ptr() + HDRB, cap, stride, d_slot, d_req, n, d_rep)
     eng.sync()
-    assert d_rep.cpu().numpy()[:n * msg].tobytes() == req.tobytes()
+    want_rep = req.copy()
+    over = h_slot.numpy()[:n].view(np.uint32) == 0xFFFFFFFF
+    if n:
+        from dint_amd.engine import refuse
+
+        want_rep[over] = refuse(W.FASST, req[over])
+        assert over.sum() == dbl.route_overflow
+    assert d_rep.cpu().numpy()[:n * msg].tobytes() == want_rep.tobytes()
 
 
 @pytest.mark.parametrize("sizes,world", [((5000, 0, 777), 2), ((70_000, 65_000, 1), 8), ((300, 300, 300), 3)])
@@ -114,7 +122,16 @@ def test_route_multi_equals_per_engine_calls(sizes, world):
             lo = offs[k]
             assert (sa[w, lo:lo + cnt[w, k] * msg] == sb[w, lo:lo + cnt[w, k] * msg]).all(), (w, k)
     assert all((x == y).all() for x, y in zip(a[1], b[1]))
-    assert a[2] == b[2] and a[2] == [r.tobytes() for r in reqs]  # straight back from the send buffer: reply = request
+    # straight back from the send buffer: reply = request, except what found its slot full: the back-pressure reply
+    from dint_amd.engine import refuse
+
+    want = []
+    for k, r in enumerate(reqs):
+        w = r.copy()
+        over = a[1][k].view(np.uint32) == 0xFFFFFFFF
+        w[over] = refuse(W.TATP, r[over])
+        want.append(w.tobytes())
+    assert a[2] == b[2] and a[2] == want
     assert a[3] == b[3] and a[3][0] == 0 and (a[3][1] > 0) == (sizes[1] > 0)  # only the second server's slots are too small
 
 

@@ -121,3 +121,99 @@ def test_router_world2_gloo():
                 n = len(per_rank[r][s])
                 assert res[r]["tatp"][step][s] == want[lo:lo + n].tobytes(), (step, s, r)
                 lo += n
+
+
+# ---------------------------------------------------------------------------------------- 8 ranks, a hot account
+N_ACCT, N_SB, HOT = 2000, 3000, 77
+
+
+def _sb_batch(step, rank):
+    """SmallBank lock traffic where 40 % of the requests go for one account: its home rank is offered more than any
+    1.5x-mean slot holds (BASELINE configs[4]: hot-account Zipf-0.99)"""
+    from dint_amd import wire
+
+    rng = np.random.default_rng(7000 + 100 * step + rank)
+    m = np.zeros(N_SB, wire.SB_MSG)
+    m["ord"] = rng.integers(0, 256, N_SB)
+    m["type"] = rng.choice([0, 1, 2, 3, 4, 5], N_SB, p=[.4, .2, .15, .05, .1, .1])
+    m["table"] = rng.integers(0, 2, N_SB)
+    m["key"] = np.where(rng.random(N_SB) < 0.4, HOT, rng.integers(0, N_ACCT, N_SB))
+    m["val"], m["ver"] = rng.integers(0, 256, (N_SB, 8)), rng.integers(0, 100, N_SB)
+    return m
+
+
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import shard_double as sd
+    from dint_amd import wire
+    from dint_amd.sharded import Router
+    from oracle import oracle as orc
+
+    o = orc.SmallbankOracle(N_ACCT, log_entries=1000)
+    hs = [o.hash_size(t) for t in range(2)]
+    dbl = sd.ServerDouble(wire.Workload.SMALLBANK, o, world, rank, sd.kv_home(hs, world, rank))
+    rt = Router([dbl], world, rank, n_max=N_SB, device="cpu")
+    cap0 = rt.caps[0]
+    out = []
+    pending = _sb_batch(0, rank)
+    for step in range(4):  # every client sends what was refused again, with the next step's new requests behind it
+        rep = rt.submit([pending], on_overflow="refuse")[0]
+        out.append((pending.tobytes(), rep.tobytes(), rt.caps[0]))
+        refused = pending[rep["type"] == wire.Sb.RETRY]
+        pending = np.concatenate([refused, _sb_batch(step + 1, rank)])[:N_SB]
+    q.put((rank, cap0, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_router_world8_hot_account_overflow_is_refused_not_dropped():
+    """SURVEY.md 8e / VERDICT r02: a destination slot that is full must not lose requests.  The sender's unpack answers
+    what did not fit with the eBPF servers' "not now" reply (RETRY for smallbank, smallbank/ebpf/shard_kern.c:96-110),
+    the capacities double for the next step, the clients resend -- and everything that WAS sent is answered exactly as
+    the unsharded server answers the rank-major concatenation of the sent requests."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dint_amd import wire
+    from oracle import oracle as orc
+
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, cap0, out = q.get(timeout=500)
+        res[r] = (cap0, out)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    o = orc.SmallbankOracle(N_ACCT, log_entries=1000)
+    n_refused = []
+    for step in range(4):
+        reqs = [np.frombuffer(res[r][1][step][0], wire.SB_MSG) for r in range(world)]
+        reps = [np.frombuffer(res[r][1][step][1], wire.SB_MSG) for r in range(world)]
+        sent = [rp["type"] != wire.Sb.RETRY for rp in reps]  # (a serial replay never answers RETRY)
+        want = o.replay(np.concatenate([rq[m] for rq, m in zip(reqs, sent)]))
+        lo = 0
+        for r in range(world):
+            n = int(sent[r].sum())
+            assert reps[r][sent[r]].tobytes() == want[lo:lo + n].tobytes(), (step, r)
+            lo += n
+            # what was refused is the request with nothing but the type changed -- and only refusable types
+            a, b = reqs[r][~sent[r]].copy(), reps[r][~sent[r]].copy()
+            assert (a["type"] <= 5).all()
+            a["type"] = b["type"] = 0
+            assert a.tobytes() == b.tobytes()
+        n_refused.append(sum(int((~m).sum()) for m in sent))
+    cap0 = res[0][0]
+    assert n_refused[0] > 100, n_refused                      # the hot account's home was over-subscribed ...
+    assert res[0][1][0][2] == min(2 * cap0, N_SB // 64 * 64) or res[0][1][0][2] > cap0  # ... the slots grew ...
+    assert n_refused[-1] == 0, n_refused                      # ... and everything was served in the end
+    assert len({res[r][1][-1][2] for r in range(world)}) == 1  # capacities agreed by all ranks
