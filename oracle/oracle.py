@@ -27,7 +27,7 @@ def build(force: bool = False) -> None:
     ):
         subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     if os.path.isdir("/root/reference/lock_fasst/udp"):
-        subprocess.check_call(["make", "-s", "-C", HERE, "ref", "ref_ebpf"])
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref", "ref_ebpf", "ref_client"])
 
 
 _lib = None
