@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Long reference-made traces for the four workloads whose committed .npz fixtures are short: lock_2pl,
+log_server, store, smallbank.  Each trace -- 3,000,000 requests -- is generated from seeds by code in this repository
+(tests/long_traces.py: the restated lock_2pl / smallbank clients in closed loop against CPU oracle servers, seeded
+streams for the other two), replayed through the UNMODIFIED reference udp/ server (oracle/_ref/ref_*, compile-time
+sizes) and only hashes are committed: of the request stream, of the reference's reply stream (whole and a 1M prefix)
+and of its state dump where the harness writes one.  tests/test_long_traces.py regenerates the traces -- through the CPU
+oracle, and on the GPU through the engines -- and compares.  Needs /root/reference (`make -C oracle ref`).
+
+    python tests/golden/make_long.py [workload ...]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import long_traces as lt  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def sha(a) -> str:
+    return hashlib.sha256(a.tobytes() if hasattr(a, "tobytes") else a).hexdigest()
+
+
+def main():
+    path = os.path.join(HERE, "long_traces.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    for wl in sys.argv[1:] or list(lt.TRACES):
+        t = time.time()
+        req, rep = lt.TRACES[wl](lt.oracle_servers(wl))  # closed loop / stream against the CPU oracle
+        ref = orc.ref_replay(lt.REF_NAME[wl], req, dump=wl in ("lock_2pl", "log_server"))
+        ref_rep = ref[0]
+        if wl in ("store", "smallbank"):  # rows the trace never wrote still hold the reference's populate-time stack bytes
+            a, b = orc.mask_populate_garbage(wl, ref_rep.copy()), orc.mask_populate_garbage(wl, rep.copy())
+        else:
+            a, b = ref_rep, rep
+        assert a.tobytes() == b.tobytes(), f"{wl}: the restatement and the unmodified reference disagree"
+        out[wl] = {"n_requests": len(req), "req_sha256": sha(req), "rep_sha256": sha(b), "rep_prefix_1m_sha256": sha(b[:1 << 20]),
+                   "dump_sha256": sha(ref[2]) if len(ref) > 2 else None, "reference_ops_per_s": ref[1].get("ops_per_s"),
+                   "reply_types": lt.reply_types(wl, b), "params": lt.PARAMS[wl]}
+        print(wl, f"{time.time() - t:.0f}s", json.dumps(out[wl])[:300])
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

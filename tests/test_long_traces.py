@@ -1,0 +1,111 @@
+"""Long reference-made traces (tests/golden/long_traces.json, made by tests/golden/make_long.py): 3,000,000 requests each
+for lock_2pl, log_server, store and smallbank, replayed through the UNMODIFIED reference udp/ servers at their
+compile-time sizes; hashes of the reply streams are committed.  The traces are regenerated here (tests/long_traces.py)
+-- the closed-loop ones through the servers under test, so a single wrong grant would send the clients down another
+path and change the request hash -- and compared: the CPU oracle (not gpu), the engines at two pass sizes (gpu)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import long_traces as lt
+from dint_amd import wire
+from oracle import oracle as orc
+
+FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "long_traces.json")))
+W = wire.Workload
+
+
+def sha(a) -> str:
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def _check(wl, req, rep):
+    f = FIX[wl]
+    assert len(req) == f["n_requests"] and sha(req) == f["req_sha256"], "the trace itself differs (a reply sent a client down another path, or a generator drifted)"
+    rep = orc.mask_populate_garbage(wl, rep) if wl in ("store", "smallbank") else rep
+    assert sha(rep[:1 << 20]) == f["rep_prefix_1m_sha256"]
+    assert sha(rep) == f["rep_sha256"]
+    assert lt.reply_types(wl, rep) == f["reply_types"]
+
+
+@pytest.mark.parametrize("wl", ["lock_2pl", "log_server", "store"])
+def test_oracle_long_trace(wl):
+    req, rep = lt.TRACES[wl](lt.oracle_servers(wl))
+    _check(wl, req, rep)
+
+
+@pytest.mark.slow
+def test_oracle_long_trace_smallbank():
+    req, rep = lt.TRACES["smallbank"](lt.oracle_servers("smallbank"))
+    _check("smallbank", req, rep)
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _replay(eng, req, batch):
+    return np.concatenate([eng.submit(req[i:i + batch]) for i in range(0, len(req), batch)])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_long_trace_lock_2pl():
+    from dint_amd.engine import Engine
+
+    p = lt.PARAMS["lock_2pl"]
+    eng = Engine(W.TPL, n_slots=p["slots"])
+    req, rep = lt.lock_2pl([eng])  # closed loop, 4096-request passes
+    _check("lock_2pl", req, rep)
+    for batch in (65_536, 1 << 20):  # 65,536: the dominant-slot path of the lock tables; 2^20: one pass per million
+        e2 = Engine(W.TPL, n_slots=p["slots"])
+        _check("lock_2pl", req, _replay(e2, req, batch))
+
+
+@pytest.mark.gpu
+def test_gpu_long_trace_log_server():
+    from dint_amd.engine import Engine
+
+    eng = Engine(W.LOG, log_entries=lt.PARAMS["log_server"]["ring"])
+    req, rep = lt.log_server([eng])  # 65,536-request passes
+    _check("log_server", req, rep)
+    e2 = Engine(W.LOG, log_entries=lt.PARAMS["log_server"]["ring"])
+    _check("log_server", req, _replay(e2, req, 4096))
+    ring_a, tail_a = eng.read_log(1_000_000)
+    ring_b, tail_b = e2.read_log(1_000_000)
+    assert tail_a == tail_b == len(req) % 1_000_000 and ring_a.tobytes() == ring_b.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_long_trace_store():
+    from dint_amd.engine import Engine
+
+    n = lt.PARAMS["store"]["subscribers"]
+    for batch in (262_144, 1 << 20):
+        eng = Engine(W.STORE, n_rows=n)
+        eng.populate(n)
+        if batch == 262_144:
+            req, rep = lt.store([eng])
+        else:
+            rep = _replay(eng, req, batch)
+        _check("store", req, rep)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_long_trace_smallbank():
+    from dint_amd.engine import Engine
+
+    n = lt.PARAMS["smallbank"]["accounts"]
+    engs = []
+    for _ in range(3):
+        e = Engine(W.SMALLBANK, n_rows=n)
+        e.populate(n)
+        engs.append(e)
+    req, rep = lt.smallbank(engs)  # closed loop: 4096 clients, three servers
+    _check("smallbank", req, rep)
+    del engs
+    e2 = Engine(W.SMALLBANK, n_rows=n)
+    e2.populate(n)
+    _check("smallbank", req, _replay(e2, req, 1 << 20))
