@@ -449,6 +449,10 @@ __device__ static inline bool kv_struct_op(uint32_t type) {  // inserts / delete
   if (WL == DINT_WL_TATP) return type == 18 || type == 19 || type == 22 || type == 23;
   return false;
 }
+// requests that change nothing (store / tatp READ, smallbank WARMUP_READ): in the request-by-request fallback the reads
+// between two other requests of a bucket run share one round -- they only have to see what came before them
+template <int WL>
+__device__ static inline bool kv_pure_read(uint32_t type) { return WL == DINT_WL_SMALLBANK ? type == 17 : type == 0; }
 template <int WL>
 __device__ static inline bool kv_lock_op(uint32_t type) {  // touches the bucket's lock word
   if (WL == DINT_WL_STORE) return false;
@@ -756,24 +760,27 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   }
   kv_stamp(tr, 7);
 
-  // ---- every other bucket run: request by request.  Position of a request inside its run = number of the run's
-  // requests with a smaller idx (the run is sorted by key first); the k-th request executes in round k.
+  // ---- every other bucket run: request by request, in request order (the run is sorted by key first).  The w-th
+  // request of the run that is not a pure read executes alone in round 2w + 1; the reads that follow it (and precede
+  // the next such request) share round 2w + 2: they change nothing and only have to see what came before them.
   const bool rounds = valid && !simple;
   uint64_t rheads = __ballot(rounds && bhead);
   if (rheads) {
+    const uint64_t m_rd = __ballot(valid && kv_pure_read<WL>(type));
     uint32_t pos = 0, maxlen = 0;
     while (rheads) {
       const int L = __ffsll((unsigned long long)rheads) - 1;
       rheads &= rheads - 1;
       const uint64_t rmask = readlane_u64(run, L);
-      maxlen = max(maxlen, (uint32_t)__popcll(rmask));
+      maxlen = max(maxlen, 2u * (uint32_t)__popcll(rmask & ~m_rd) + 1u);
       const bool mine = (rmask >> lane) & 1ull;
-      for (uint64_t m = rmask; m; m &= m - 1) {
+      for (uint64_t m = rmask & ~m_rd; m; m &= m - 1) {
         const int l = __ffsll((unsigned long long)m) - 1;
         const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane(idx, l);
         if (mine && oi < idx) pos++;
       }
     }
+    pos = 2u * pos + (kv_pure_read<WL>(type) ? 0u : 1u);
     for (uint32_t r = 0; r < maxlen; r++) {
       if (rounds && pos == r) kv_do_request<WL>(msg, type, table, q, bucket, kv, stats);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the next round must see this round's stores
@@ -1625,25 +1632,120 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
 
-    // ---- every other bucket run: request by request.  Position inside the run = number of its requests that come
-    // earlier in request order (the run is sorted by key first); the k-th request executes in round k.
-    uint16_t *Rpos = (uint16_t *)Lead;  // by sorted position; Lead is free now
+    // ---- every other bucket run: request by request.  What has to stay in request order inside a run is less than
+    // everything:
+    //   W  a request that changes rows (SET / INSERT / DELETE, smallbank's lock ops): after everything before it;
+    //   R  a pure read: after the W requests before it -- the reads between two W requests share one round;
+    //   A  tatp ACQUIRE_LOCK, B tatp ABORT: they touch the lock byte only, reads and they do not see each other.  The
+    //      first ACQUIRE after a W or an ABORT (per lock byte) finds out whether the byte is free; the ACQUIREs that
+    //      follow it find the byte taken whatever it answered, so they share the next round.
+    // With w = W requests before a request, j = ABORTs before it behind its last W, nB = ABORTs of the run, the round
+    // of a request is  w * (3 nB + 3) + {R: 0, first A: 3j, other A: 3j + 1, B: 3j + 2, W: 3 nB + 2};  empty rounds are
+    // skipped through a bitmap.  A run of ONE key segment lies in request order, so a wave numbers it 64 requests at
+    // a time from ballots and a carry.  A run of several segments (sorted by key first), or one that would need more
+    // than KVB_RMAX rounds, numbers its requests 2v + 1 (not a read) / 2v (a read), v = requests before it that are
+    // not reads.
+    // A hot call-forwarding row that is deleted and inserted again and again is such a run (kvs_insert never checks
+    // for an existing row, so the reference's population holds duplicate rows of some keys: no closed form covers
+    // those): a hundred READs and dozens of refused ACQUIREs around one DELETE went one request per round, ~1.6 us
+    // each -- the p99 of r02's epoch latency.
+    enum : uint32_t { KVB_RMAX = 32768u };
+    uint16_t *Rpos = (uint16_t *)Lead;  // by sorted position; Lead and CarryCrow are free now
+    uint32_t *Rbits = (uint32_t *)CarryCrow;
+    static_assert(sizeof(Lead) >= 2 * KVB_NMAX && sizeof(CarryCrow) >= KVB_RMAX / 8, "round numbering scratch");
+    auto r_class = [&](uint32_t type) -> uint32_t {  // 0 R, 1 A, 2 B, 3 W
+      if (kv_pure_read<WL>(type)) return 0u;
+      if (WL == DINT_WL_TATP && type == 1) return 1u;
+      if (WL == DINT_WL_TATP && type == 2) return 2u;
+      return 3u;
+    };
     if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 9] = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t k = t; k < KVB_RMAX / 32; k += KVB_T) Rbits[k] = 0;
     uint32_t mylen = 0, tot;
-    for (uint32_t j = 0; j < ntile; j++) {
+    for (uint32_t j = 0; j < ntile; j++) {  // runs of several key segments: every request counts its predecessors
       const uint32_t p = j * KVB_T + t;
       uint32_t pos = 0xFFFFu;
       if (p < m && !kvb_bit(Msimple, p)) {
         const uint32_t bk_a = (uint32_t)kvb_last(Mbh, Ebh, 0, p + 1);
         const int bx = kvb_first(Mbh, Ebh, p + 1);
         const uint32_t bk_b = bx >= 0 ? (uint32_t)bx : m, myidx = k_idx(Sk[p]);
-        pos = 0;
-        for (uint32_t k = bk_a; k < bk_b; k++) pos += k_idx(Sk[k]) < myidx;
-        if (p == bk_a) mylen = max(mylen, bk_b - bk_a);
+        if (kvb_popc(Mhead, Phead, bk_a, bk_b) == 1) {
+          pos = 0xFFFEu;  // numbered by a wave below
+        } else {
+          uint32_t v = 0, nv = 0;
+          for (uint32_t k = bk_a; k < bk_b; k++) {
+            const bool other = !kv_pure_read<WL>(k_type(Sk[k]));
+            nv += other;
+            v += other && k_idx(Sk[k]) < myidx;
+          }
+          pos = 2u * v + (kv_pure_read<WL>(k_type(Sk[p])) ? 0u : 1u);
+          if (p == bk_a) mylen = max(mylen, 2u * nv + 1u);
+        }
       }
-      Rpos[p] = (uint16_t)pos;
+      if (p < m) Rpos[p] = (uint16_t)pos;
     }
-    {  // longest non-simple run (block max)
+    __syncthreads();
+    {  // runs of one key segment: the waves take them in turn
+      const uint64_t below = (1ull << lane) - 1ull;
+      auto top = [](uint64_t x) -> int { return x ? 63 - __clzll((long long)x) : -1; };        // highest set bit
+      auto above = [](int bit) -> uint64_t { return bit < 0 ? ~0ull : bit >= 63 ? 0ull : ~0ull << (bit + 1); };
+      uint32_t seen = 0;
+      for (uint32_t wd = 0; wd * 64 < m; wd++) {
+        for (uint64_t hb = Mbh[wd] & ~Msimple[wd]; hb; hb &= hb - 1) {
+          const uint32_t ra = wd * 64 + (uint32_t)__ffsll((unsigned long long)hb) - 1;
+          if ((seen++ & (KVB_W - 1)) != wave || Rpos[ra] != 0xFFFEu) continue;
+          const int bx = kvb_first(Mbh, Ebh, ra + 1);
+          const uint32_t rb = bx >= 0 ? (uint32_t)bx : m;
+          uint32_t nW = 0, nB = 0, nV = 0;
+          for (uint32_t c0 = ra; c0 < rb; c0 += 64) {
+            const uint32_t p = c0 + lane, cl = p < rb ? r_class(k_type(Sk[p])) : 0u;
+            nW += (uint32_t)__popcll(__ballot(cl == 3));
+            nB += (uint32_t)__popcll(__ballot(cl == 2));
+            nV += (uint32_t)__popcll(__ballot(cl != 0));
+          }
+          const uint32_t stride = 3u * nB + 3u;
+          const bool fancy = (nW + 1u) * stride <= KVB_RMAX;
+          if (lane == 0) mylen = max(mylen, fancy ? (nW + 1u) * stride : 2u * nV + 1u);
+          uint32_t wc = 0, jc = 0, af = 0, vc = 0;  // carries: W so far, ABORTs behind the last W, lock bytes with an ACQUIRE behind the last W / ABORT, not-reads so far
+          for (uint32_t c0 = ra; c0 < rb; c0 += 64) {
+            const uint32_t p = c0 + lane;
+            const bool valid = p < rb;
+            const uint64_t cur = valid ? Sk[p] : 0;
+            const uint32_t cl = valid ? r_class(k_type(cur)) : 0u, q = k_q(cur);
+            const uint64_t mW = __ballot(cl == 3), mB = __ballot(cl == 2), mV = __ballot(cl != 0);
+            uint64_t mA[4];
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) mA[i] = __ballot(cl == 1 && q == i);
+            uint32_t pos;
+            if (fancy) {
+              const int lw = top(mW & below), lwb = top((mW | mB) & below);
+              const uint32_t w = wc + (uint32_t)__popcll(mW & below);
+              const uint32_t jj = (lw < 0 ? jc : 0u) + (uint32_t)__popcll(mB & below & above(lw));
+              const uint64_t mine = q == 0 ? mA[0] : q == 1 ? mA[1] : q == 2 ? mA[2] : mA[3];
+              const bool follows = (mine & below & above(lwb)) != 0 || (lwb < 0 && ((af >> q) & 1u));
+              pos = w * stride + (cl == 0 ? 0u : cl == 1 ? 3u * jj + (follows ? 1u : 0u) : cl == 2 ? 3u * jj + 2u : stride - 1u);
+            } else {
+              pos = 2u * (vc + (uint32_t)__popcll(mV & below)) + (cl ? 1u : 0u);
+            }
+            if (valid) Rpos[p] = (uint16_t)pos;
+            const int tw = top(mW), twb = top(mW | mB);
+            wc += (uint32_t)__popcll(mW);
+            jc = (tw < 0 ? jc : 0u) + (uint32_t)__popcll(mB & above(tw));
+            if (twb >= 0) af = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) af |= (mA[i] & above(twb)) ? 1u << i : 0u;
+            vc += (uint32_t)__popcll(mV);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < ntile; j++) {
+      const uint32_t p = j * KVB_T + t;
+      const uint32_t pos = p < m ? Rpos[p] : 0xFFFFu;
+      if (pos != 0xFFFFu) atomicOr(&Rbits[pos >> 5], 1u << (pos & 31));
+    }
+    {  // rounds of the longest run (block max)
       uint32_t mx = mylen;
       for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, d, 64));
       if (lane == 0) Sred[wave] = mx;
@@ -1651,20 +1753,25 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       tot = 0;
       for (uint32_t w = 0; w < KVB_W; w++) tot = max(tot, Sred[w]);
     }
-    if (tr && t == 0) { tr[12] += tot; tr[13] += 1; }
-    for (uint32_t r = 0; r < tot; r++) {
-      for (uint32_t j = 0; j < ntile; j++) {
-        const uint32_t p = j * KVB_T + t;
-        if (p < m && Rpos[p] == r) {
-          const uint64_t cur = Sk[p];
-          const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk);
-          kv_do_request<WL>(rep + dint_view_off(V, k_idx(cur), F::MSG), k_type(cur), table, k_q(cur),
-                            (uint64_t)(gk - kv->gk_base[table]), kv, stats);
+    uint32_t nrounds = 0;
+    for (uint32_t rw = 0; rw * 32 < tot; rw++) {
+      for (uint32_t bits = Rbits[rw]; bits; bits &= bits - 1) {  // the same word for every thread
+        const uint32_t r = rw * 32 + (uint32_t)__ffs((int)bits) - 1;
+        nrounds++;
+        for (uint32_t j = 0; j < ntile; j++) {
+          const uint32_t p = j * KVB_T + t;
+          if (p < m && Rpos[p] == r) {
+            const uint64_t cur = Sk[p];
+            const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk);
+            kv_do_request<WL>(rep + dint_view_off(V, k_idx(cur), F::MSG), k_type(cur), table, k_q(cur),
+                              (uint64_t)(gk - kv->gk_base[table]), kv, stats);
+          }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      __syncthreads();
     }
+    if (tr && t == 0) { tr[12] += nrounds; tr[13] += 1; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();  // the next stretch sees this stretch's stores; LDS arrays are free again
   }

@@ -489,6 +489,10 @@ def _hot_tatp(n, p_hot, mix, seed, hot_key=(0, 7), existing=None, n_noise_sub=20
     (0.5, {0: 30, 1: 30, 2: 20, 12: 10, 13: 10}, (0, 7)),        # > 1024 ordering ops in a stretch: general path
     (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (0, 5_000_000)),   # the hot row does not exist
     (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (4, 7 | (1 << 32))),  # a CALL_FORWARDING row: inserts / deletes around it
+    # the hot CALL_FORWARDING row itself inserted (also when it exists: duplicate rows) and deleted: its runs go request
+    # by request, reads between two row changes in one round, refused ACQUIREs behind the first in one round
+    (0.3, {0: 85, 1: 10, 2: 2, 18: 1.5, 22: 1.5}, (4, 7 | (1 << 32))),
+    (0.02, {0: 85, 1: 12, 2: 1, 18: 1, 22: 1}, (4, 7 | (1 << 32))),
 ])
 def test_tatp_dominant_key_vs_oracle(p_hot, mix, hot_key):
     n_sub = 3000
