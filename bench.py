@@ -1039,6 +1039,35 @@ def bench_txn(args, world, rank, dev, transport, kind):
                   "epochs": E1 - E0, "equals_host_driver_run": bool(same), "overflow": gs["overflow"],
                   "what": "GPU-resident clients (k_txn_emit / k_txn_consume) + the three shard servers, closed loop, no host round trip"}
         del loop, gd
+        # ... and with the clients in two groups that take turns at the servers (GpuLoop): one group's consume / emit
+        # kernels run while the servers answer the other's batch.  Checked against a host run of two Drivers taking
+        # turns the same way for a few epochs; then timed from a restored state.
+        from dint_amd.driver import Driver
+        G, Cg, n_chk = 2, C // 2, 6
+        grp.restore()
+        hosts = [Driver(wl, Cg, n_rows, first_client=rank * C + g * Cg, zipf_theta=zipf) for g in range(G)]
+        for _ in range(n_chk):
+            for h in hosts:
+                h.consume(grp.submit(h.next()))
+        grp.restore()
+        gds = [GpuDriver(wl, Cg, n_rows, cap, first_client=rank * C + g * Cg, zipf_theta=zipf) for g in range(G)]
+        loop = GpuLoop(grp, gds)
+        loop.epochs(n_chk)
+        loop.sync()
+        same2 = all(g.stats()[k] == h.stats()[k] for g, h in zip(gds, hosts) for k in ("txns", "committed", "by_type", "committed_by_type"))
+        loop.epochs(E0)
+        loop.sync()
+        tx0 = sum(g.stats()["txns"] for g in gds)
+        t1 = time.perf_counter()
+        loop.epochs(E1 - E0)
+        loop.sync()
+        dtc = time.perf_counter() - t1
+        closed["two_groups"] = {"value": round((sum(g.stats()["txns"] for g in gds) - tx0) / dtc / 1e6, 3), "unit": "Mtxn/s",
+                                "ms_per_round": round(dtc / (E1 - E0) * 1e3, 5), "clients_per_group": Cg,
+                                "equals_host_run_of_two_drivers": bool(same2), "checked_epochs": n_chk,
+                                "overflow": sum(g.stats()["overflow"] for g in gds),
+                                "what": "the same clients in two groups taking turns at the servers, each group on its own stream"}
+        del loop, gds, hosts
 
     host = {}
     if world == 1 and grp.router is None and not args.no_host_path and not compact:
@@ -1197,7 +1226,7 @@ def parity_failures(out, path=""):
             p = f"{path}.{k}" if path else k
             if k in ("oracle_parity", "reference_parity") and isinstance(v, dict) and v.get("ok") is False:
                 bad.append(p)
-            elif k in ("pcie_parity_ok", "replay_equals_recorded", "equals_host_driver_run") and v is False:
+            elif k in ("pcie_parity_ok", "replay_equals_recorded", "equals_host_driver_run", "equals_host_run_of_two_drivers") and v is False:
                 bad.append(p)
             elif k == "error" and path.startswith("other_workloads"):
                 bad.append(p)

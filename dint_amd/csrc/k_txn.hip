@@ -11,7 +11,7 @@
 //                   -- batch s is ordered by client id, then send order -- so the request stream is bit-identical
 //                   to the host driver's: position = messages of smaller client ids to that shard (a workgroup scan
 //                   + a decoupled look-back over the workgroups before mine, which are handed out by ticket and
-//                   publish their totals first thing) + msg.ord.  The last workgroup writes the three batch sizes
+//                   publish their totals first thing, their inclusive prefixes as soon as they know them) + msg.ord.  The last workgroup writes the three batch sizes
 //                   for the engines (dint_submit_segments reads them on the device: no host round trip).
 //   k_txn_consume : every client copies the replies it waits for out of the (in place) reply arrays.
 #include <hip/hip_runtime.h>
@@ -25,6 +25,9 @@
 #include "txn_clients.h"
 
 #define TXG_TB 256u  // clients per workgroup
+#define TXG_AGG 0x40000000u  // look-back word: the workgroup's own message count ...
+#define TXG_PFX 0x80000000u  // ... or the count of all workgroups up to and including it
+#define TXG_VAL 0x3FFFFFFFu
 
 struct txg_stats {
   unsigned long long txns, committed, messages, by_type[8], committed_by_type[8], overflow;
@@ -38,7 +41,7 @@ __global__ void __launch_bounds__(TXG_TB)
 k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
            uint8_t *out2, uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t *counts, txg_stats *st, uint32_t dbg) {
   typedef typename T::Msg Msg;
-  __shared__ uint32_t Stile, Sw[3][TXG_TB / 64], Sbase[3], Sred[3][TXG_TB / 64];
+  __shared__ uint32_t Stile, Sw[3][TXG_TB / 64], Sbase[3];
   __shared__ unsigned long long Sst[TXG_NSTAT];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t == 0) Stile = atomicAdd(ticket, 1u);
@@ -78,29 +81,37 @@ k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, T
       tot[s] += Sw[s][w];
     }
   }
-  if (t < 3) __hip_atomic_store(&pub[tile * 4 + t], 0x80000000u | tot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- ... + the totals of the workgroups before mine (published long ago: they started earlier)
-  uint32_t part[3] = {0, 0, 0};
-  for (uint32_t k = t; k < tile && !(dbg & 1); k += TXG_TB) {
+  // ---- ... + the messages of the workgroups before mine: decoupled look-back.  A workgroup publishes its own totals
+  // first thing (TXG_AGG), then wave 0 walks back 64 workgroups at a time until, per shard, it meets one that already
+  // knows its inclusive prefix (TXG_PFX), and publishes its own.  (r02 summed ALL earlier totals in every workgroup:
+  // 2048^2 / 2 x 3 device-scope loads per epoch, 300 us of the 720 us closed-loop epoch.)  Workgroups are handed out by
+  // ticket, so the ones a look-back waits for are running.
+  if (t < 3) __hip_atomic_store(&pub[tile * 4 + t], TXG_AGG | tot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (wave == 0) {
+    uint32_t base[3] = {0, 0, 0};
+    uint32_t open = (tile == 0 || (dbg & 1)) ? 0u : 7u;  // shards whose prefix is not known yet
+    for (int k0 = (int)tile - 1; open; k0 -= 64) {
+      const int k = k0 - (int)lane;
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
-      uint32_t v;
-      do { v = __hip_atomic_load(&pub[k * 4 + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 31));
-      part[s] += v & 0x7FFFFFFFu;
+      for (int s = 0; s < 3; s++) {
+        if (!((open >> s) & 1u)) continue;
+        uint32_t v = TXG_PFX;  // before the first workgroup: prefix 0
+        if (k >= 0) do { v = __hip_atomic_load(&pub[k * 4 + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 30));
+        const uint64_t mp = __ballot((v & TXG_PFX) != 0);  // lane 0 is the nearest workgroup
+        const int stop = mp ? __ffsll((unsigned long long)mp) - 1 : 64;
+        uint32_t add = (int)lane <= stop ? v & TXG_VAL : 0u;
+        for (int d = 32; d > 0; d >>= 1) add += __shfl_xor(add, d, 64);
+        base[s] += add;
+        if (mp) open &= ~(1u << s);
+      }
     }
-  }
-#pragma unroll
-  for (int s = 0; s < 3; s++) {
-    uint32_t v = part[s];
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (lane == 0) Sred[s][wave] = v;
-  }
-  __syncthreads();
-  if (t < 3) {
-    uint32_t b = 0;
-    for (uint32_t w = 0; w < TXG_TB / 64; w++) b += Sred[t][w];
-    Sbase[t] = b;
-    if (tile == ntiles - 1) counts[t] = min(b + tot[t], cap);  // batch sizes of this epoch (read by the engines)
+    if (lane < 3) {
+      const uint32_t b = lane == 0 ? base[0] : lane == 1 ? base[1] : base[2];
+      const uint32_t mine = lane == 0 ? tot[0] : lane == 1 ? tot[1] : tot[2];
+      __hip_atomic_store(&pub[tile * 4 + lane], TXG_PFX | (b + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Sbase[lane] = b;
+      if (tile == ntiles - 1) counts[lane] = min(b + mine, cap);  // batch sizes of this epoch (read by the engines)
+    }
   }
   __syncthreads();
 

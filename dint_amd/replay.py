@@ -143,37 +143,49 @@ class Replay:
 
 
 class GpuLoop:
-    """The closed loop that never leaves the GPU: a :class:`dint_amd.driver.GpuDriver` and the three shard servers of a
-    :class:`ShardGroup`.  One epoch = emit kernel -> the three engines on their own streams, each answering its batch in
-    place (the batch size is read on the device) -> consume kernel; no host round trip, no PCIe.  With a router (several
-    GPUs, or the exchange forced on) the epoch's batches cross the exchange on the way: pack / unpack read the batch
-    sizes on the device as well (dint_route_item.d_n), and the home engines read theirs from the slot headers."""
+    """The closed loop that never leaves the GPU: :class:`dint_amd.driver.GpuDriver` clients and the three shard servers
+    of a :class:`ShardGroup`.  One epoch = emit kernel -> the three engines on their own streams, each answering its batch
+    in place (the batch size is read on the device) -> consume kernel; no host round trip, no PCIe.  With a router
+    (several GPUs, or the exchange forced on) the epoch's batches cross the exchange on the way: pack / unpack read the
+    batch sizes on the device as well (dint_route_item.d_n), and the home engines read theirs from the slot headers.
+
+    `gdriver` may be a list of drivers over disjoint client ranges (first_client): the groups take turns at the servers,
+    each on its own stream, so one group's consume / emit kernels run while the servers answer the other group's batch
+    (the reference's client threads are not in lock step either).  The order of the batches at the servers is fixed --
+    group 0, group 1, ..., group 0 -- so a host run that lets :class:`Driver` objects over the same client ranges take
+    turns the same way sees the same bytes."""
 
     def __init__(self, group: ShardGroup, gdriver):
-        assert gdriver.cap <= min(e.pass_max for e in group.engines)
-        if group.router is not None:
-            assert gdriver.cap <= group.router.n_max and group.router.multi is not None
-        self.g, self.d = group, gdriver
-        self.stream = torch.cuda.Stream()
+        self.ds = list(gdriver) if isinstance(gdriver, (list, tuple)) else [gdriver]
+        for d in self.ds:
+            assert d.cap <= min(e.pass_max for e in group.engines)
+            if group.router is not None:
+                assert d.cap <= group.router.n_max and group.router.multi is not None
+        assert group.router is None or len(self.ds) == 1  # the exchange has one set of slots in flight
+        self.g, self.d = group, self.ds[0]
+        self.streams = [torch.cuda.Stream() for _ in self.ds]
+        self.stream = self.streams[0]
         self.msg = group.msg
 
     def epochs(self, n: int) -> None:
-        xs = self.stream.cuda_stream
-        cap, msg, d = self.d.cap, self.msg, self.d
-        rt = self.g.router
+        msg, rt = self.msg, self.g.router
         for _ in range(n):
-            d.next(xs)
-            if rt is None:
-                for s, e in enumerate(self.g.engines):
-                    e.stream_wait(xs)
-                    e.submit_segments(d.batch_ptr[s], 1, cap, cap * msg, d.counts_ptr + 4 * s, 0)
-                    e.stream_signal(xs)
-            else:
-                with torch.cuda.stream(self.stream):  # Router.run waits for the current stream: the emit kernel
-                    rt.step(d.batch_ptr, [cap] * N_SHARDS, d.batch_ptr, d_n=[d.counts_ptr + 4 * s for s in range(N_SHARDS)])
-                rt.join(self.stream)
-            d.consume(xs)
+            for d, st in zip(self.ds, self.streams):
+                xs, cap = st.cuda_stream, d.cap
+                d.next(xs)
+                if rt is None:
+                    for s, e in enumerate(self.g.engines):
+                        e.stream_wait(xs)
+                        e.submit_segments(d.batch_ptr[s], 1, cap, cap * msg, d.counts_ptr + 4 * s, 0)
+                    for e in self.g.engines:  # only now: a signal makes xs wait for its engine, and a stream_wait issued
+                        e.stream_signal(xs)   # after it would make the next engine wait for this one (r02 did that)
+                else:
+                    with torch.cuda.stream(st):  # Router.run waits for the current stream: the emit kernel
+                        rt.step(d.batch_ptr, [cap] * N_SHARDS, d.batch_ptr, d_n=[d.counts_ptr + 4 * s for s in range(N_SHARDS)])
+                    rt.join(st)
+                d.consume(xs)
 
     def sync(self):
-        self.stream.synchronize()
+        for st in self.streams:
+            st.synchronize()
         self.g.sync()

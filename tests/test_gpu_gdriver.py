@@ -102,3 +102,30 @@ def test_gpu_loop_through_the_exchange(wl, n_rows, clients, zipf):
     for s in range(3):
         for t in range(5 if wl == W.TATP else 2):
             assert all((x == y).all() for x, y in zip(plain.engines[s].dump_rows(t), routed.engines[s].dump_rows(t)))
+
+
+@pytest.mark.parametrize("wl,n_rows,clients,zipf", [(W.TATP, 20_000, 6000, 0.8), (W.SMALLBANK, 50_000, 4000, 0.99 - 1e-9)])
+def test_gpu_loop_two_client_groups_take_turns(wl, n_rows, clients, zipf):
+    """two groups of GPU-resident clients (disjoint client ids) take turns at the servers, each on its own stream, so
+    one group's consume / emit kernels overlap the servers' work on the other group's batch; the host run that lets two
+    Drivers take turns the same way finishes the same transactions and leaves the same tables"""
+    from dint_amd.replay import GpuLoop, ShardGroup
+
+    epochs, cap = 50, 4 * clients + 64
+    a, b = ShardGroup(wl, n_rows, log_entries=400_000), ShardGroup(wl, n_rows, log_entries=400_000)
+    hosts = [Driver(wl, clients, n_rows, first_client=k * clients, zipf_theta=zipf) for k in range(2)]
+    for _ in range(epochs):
+        for h in hosts:
+            h.consume(a.submit(h.next()))
+    gpus = [GpuDriver(wl, clients, n_rows, cap, first_client=k * clients, zipf_theta=zipf) for k in range(2)]
+    loop = GpuLoop(b, gpus)
+    loop.epochs(epochs)
+    loop.sync()
+    for h, g in zip(hosts, gpus):
+        hs, gs = h.stats(), g.stats()
+        assert gs["overflow"] == 0 and hs["txns"] > 0
+        for k in ("txns", "committed", "by_type", "committed_by_type"):
+            assert gs[k] == hs[k], k
+    for s in range(3):
+        for t in range(5 if wl == W.TATP else 2):
+            assert all((x == y).all() for x, y in zip(a.engines[s].dump_rows(t), b.engines[s].dump_rows(t)))
