@@ -1287,6 +1287,11 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const uint64_t m2 = __ballot(simple && WL == DINT_WL_TATP && kv_lock_op<WL>(type));
       const uint64_t m3 = __ballot(simple && WL == DINT_WL_TATP && type == 1);
       if (lane == 0) { Msimple[p >> 6] = m0; Mwr[p >> 6] = m1; Mlk[p >> 6] = m2; Macq[p >> 6] = m3; }
+      if (WL == DINT_WL_SMALLBANK) {  // the lock ops by kind, for the grant walk below (pass D is done with Mlkseg)
+        const uint64_t k0 = __ballot(valid && type == 0), k1 = __ballot(valid && type == 1);
+        const uint64_t k2 = __ballot(valid && type == 2), k3 = __ballot(valid && type == 3);
+        if (lane == 0) { Mlkseg[0][p >> 6] = k0; Mlkseg[1][p >> 6] = k1; Mlkseg[2][p >> 6] = k2; Mlkseg[3][p >> 6] = k3; }
+      }
     }
     __syncthreads();
     if (wave == 0) kvb_build_pop(Mwr, Pwr);
@@ -1331,9 +1336,112 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     }
     __syncthreads();
 
+    // ---- smallbank: which ACQUIREs are granted (smallbank/udp/server_shard.cc:121-147).  The counters have no closed
+    // form, but only the grants are inherently serial -- versions and values do not depend on the counters (a COMMIT
+    // writes whatever the locks say, :163-173) and come from the write mask like store / tatp.  A key segment is walked
+    // 64 requests at a time with the op kinds as ballot masks and the counters in scalar registers (sb_walk: one
+    // iteration per mode change, not per request).  First every 64-chunk walks the segments that START in it, all
+    // chunks at once; then the segments that run on past their first chunk (at most one per chunk boundary) are taken
+    // to their end, one wave each, the op kinds of chunk c read out of lane c's registers.  (r02 walked the stretch
+    // wave after wave, tile after tile: 64 barrier-separated steps, 38 us of a hot account's 96 us stretch; this is
+    // ~20 us, what is left is the dependent chain of one wave over the ~50 chunks of the hot account.)  The grants land
+    // in Mlk (unused by smallbank otherwise), the counters a segment leaves in Carry[segment].
+    if (WL == DINT_WL_SMALLBANK) {
+      // returns the granted lanes of `rem` (ACQUIREs and RELEASEs of one key in request order); la = num_ex, lb = num_sh
+      auto sb_walk = [&](uint64_t rem, uint64_t mAS, uint64_t mAX, uint64_t mRS, uint64_t mRX, uint32_t &la, uint32_t &lb) -> uint64_t {
+        // The counters move between two modes.  FREE (num_ex == 0): every ACQUIRE_SHARED is granted (num_sh++),
+        // RELEASE_SHARED decrements, and nothing else happens until an EVENT: an ACQUIRE_EXCLUSIVE that finds
+        // num_sh == 0 (granted: num_ex = 1) or a RELEASE_EXCLUSIVE (num_ex wraps to 2^32 - 1, as the reference's
+        // unsigned counter does).  HELD (num_ex != 0): every ACQUIRE is rejected, RELEASE_SHARED still decrements,
+        // until the num_ex-th RELEASE_EXCLUSIVE.  Between events all lanes are resolved at once (num_sh before a lane
+        // = num_sh + ACQUIRE_SHAREDs - RELEASE_SHAREDs below it): a contended account changes mode rarely.
+        uint64_t G = 0;
+        while (rem) {
+          if (la == 0) {
+            const uint64_t blw = rem & lanemask_lt();
+            const uint32_t lb_before = lb + (uint32_t)__popcll(blw & mAS) - (uint32_t)__popcll(blw & mRS);
+            const bool me = (rem >> lane) & 1ull;
+            const uint64_t ev = __ballot(me && ((((mAX >> lane) & 1ull) && lb_before == 0) || ((mRX >> lane) & 1ull)));
+            const uint64_t upto = ev ? (ev & (0 - ev)) - 1ull : ~0ull;  // the lanes below the first event
+            const uint64_t seg = rem & upto;
+            G |= seg & mAS;
+            lb += (uint32_t)__popcll(seg & mAS) - (uint32_t)__popcll(seg & mRS);
+            rem &= ~upto;
+            if (ev) {
+              const uint64_t bit = ev & (0 - ev);
+              if (bit & mAX) { G |= bit; la = 1; } else la = 0xFFFFFFFFu;
+              rem &= ~bit;
+            }
+          } else {
+            uint64_t rx = rem & mRX;
+            const uint32_t nrx = (uint32_t)__popcll(rx);
+            if (nrx < la) {  // held to the end of these lanes
+              lb -= (uint32_t)__popcll(rem & mRS);
+              la -= nrx;
+              rem = 0;
+            } else {
+              for (uint32_t k = 1; k < la; k++) rx &= rx - 1;  // the la-th RELEASE_EXCLUSIVE (la is 1 unless the counter wrapped)
+              const uint64_t bit = rx & (0 - rx), upto = bit - 1ull;
+              lb -= (uint32_t)__popcll(rem & upto & mRS);
+              la = 0;
+              rem &= ~(upto | bit);
+            }
+          }
+        }
+        return G;
+      };
+      for (uint32_t c = wave; c * 64 < m; c += KVB_W) {  // the segments that start in chunk c, as far as the chunk goes
+        const uint32_t p = c * 64 + lane;
+        const bool simple = p < m && kvb_bit(Msimple, p);
+        const uint32_t seg_a = simple ? (uint32_t)kvb_last(Mhead, Ehead, 0, p + 1) : 0;
+        const uint32_t si = simple ? kvb_below(Mhead, Phead, p + 1) - 1 : 0;
+        const bool here = simple && seg_a >= c * 64;
+        uint64_t Gw = 0, todo = __ballot(here);
+        const uint64_t mAS = Mlkseg[0][c] & todo, mAX = Mlkseg[1][c] & todo, mRS = Mlkseg[2][c] & todo, mRX = Mlkseg[3][c] & todo;
+        while (todo) {
+          const int l0 = __ffsll((unsigned long long)todo) - 1;
+          const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(seg_a, l0), sa = (uint32_t)__builtin_amdgcn_readlane(si, l0);
+          const uint64_t mem = __ballot(here && seg_a == a);
+          todo &= ~mem;
+          uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)Carry[sa].la), lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)Carry[sa].lb);
+          Gw |= sb_walk(mem & (mAS | mAX | mRS | mRX), mAS, mAX, mRS, mRX, la, lb);
+          if ((int)lane == l0) { Carry[sa].la = la; Carry[sa].lb = lb; }
+        }
+        if (lane == 0) Mlk[c] = Gw;
+      }
+      __syncthreads();
+      uint64_t cross;  // chunk boundaries a segment crosses for the first time: lane c looks at boundary 64 c
+      {
+        const uint32_t b0 = lane * 64;
+        bool x = lane >= 1 && b0 < m && !kvb_bit(Mhead, b0) && kvb_bit(Msimple, b0);
+        if (x) x = kvb_last(Mhead, Ehead, 0, b0) >= (int)b0 - 64;  // else it crossed an earlier boundary first: taken there
+        cross = __ballot(x);
+      }
+      const uint64_t vAS = Mlkseg[0][lane], vAX = Mlkseg[1][lane], vRS = Mlkseg[2][lane], vRX = Mlkseg[3][lane];
+      for (uint32_t seen = 0; cross; cross &= cross - 1, seen++) {
+        if ((seen & (KVB_W - 1)) != wave) continue;
+        const uint32_t b0 = 64u * ((uint32_t)__ffsll((unsigned long long)cross) - 1);
+        const uint32_t a = (uint32_t)kvb_last(Mhead, Ehead, 0, b0);
+        const uint32_t sa = kvb_below(Mhead, Phead, a + 1) - 1;
+        const int nx = kvb_first(Mhead, Ehead, b0);
+        const uint32_t hb2 = nx >= 0 ? (uint32_t)nx : m;
+        uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)Carry[sa].la), lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)Carry[sa].lb);
+        for (uint32_t q0 = b0; q0 < hb2; q0 += 64) {  // the op kinds of chunk c come out of lane c's registers
+          const uint64_t in = hb2 - q0 >= 64 ? ~0ull : (1ull << (hb2 - q0)) - 1ull;
+          const int c = (int)(q0 >> 6);
+          const uint64_t mAS = readlane_u64(vAS, c) & in, mAX = readlane_u64(vAX, c) & in;
+          const uint64_t mRS = readlane_u64(vRS, c) & in, mRX = readlane_u64(vRX, c) & in;
+          const uint64_t G = sb_walk(mAS | mAX | mRS | mRX, mAS, mAX, mRS, mRX, la, lb);
+          if (lane == 0 && G) atomicOr((unsigned long long *)&Mlk[c], (unsigned long long)G);
+        }
+        if (lane == 0) { Carry[sa].la = la; Carry[sa].lb = lb; }
+      }
+      __syncthreads();
+    }
+
     // ---- tiles: outcomes and replies of the simple segments, 512 requests at a time.  Nothing a tile reads from
     // the table is written before the last tile is done, so the tiles' loads and stores stream back to back.
-    const bool walks = WL == DINT_WL_SMALLBANK || Sany;  // workgroup-uniform
+    const bool walks = WL != DINT_WL_SMALLBANK && Sany;  // workgroup-uniform
     if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
     struct kvb_out { uint8_t *msg; const uint8_t *from; uint32_t ver, code; bool simple, get; };
     auto outcome = [&](uint32_t j, kvb_out &o) {  // tile j: what each request answers, and where a read finds its value
@@ -1438,96 +1546,21 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           if (lane == 0) Msimple[p >> 6] = sm;
         }
       } else {
-        // smallbank: the counters have no closed form.  Every simple segment is walked in sorted order, wave after
-        // wave, with the running state {num_ex, num_sh, version, last writer} carried through Carry[segment] -- but
-        // only what is inherently serial is walked: whether each ACQUIRE is granted (smallbank/udp/server_shard.cc:
-        // 121-147) depends on the counters, one scalar loop over the wave's lock ops with the op kinds as 64-bit
-        // ballot masks and the counters in scalar registers.  Versions and values do not depend on the counters
-        // (a COMMIT writes whatever the locks say, :163-173): version seen = version + #writes below me, value seen =
-        // message of the last write below me, both straight from the write mask.
-        const uint64_t mAS = __ballot(simple && type == 0), mAX = __ballot(simple && type == 1);
-        const uint64_t mRS = __ballot(simple && type == 2), mRX = __ballot(simple && type == 3);
-        const uint64_t mWR = __ballot(simple && type != 0 && type != 1 && type != 2 && type != 3 && type != 17);  // 4 kCommitPrim, 5 kCommitBck
-        for (uint32_t wv = 0; wv < KVB_W; wv++) {
-          if (wave == wv) {
-            uint64_t todo = __ballot(simple);
-            while (todo) {  // one iteration per segment present in this wave's 64 lanes
-              const int l0 = __ffsll((unsigned long long)todo) - 1;
-              const uint32_t a = (uint32_t)__builtin_amdgcn_readlane(seg_a, l0);
-              const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane(si, l0);
-              const uint64_t mem = __ballot(simple && seg_a == a);
-              todo &= ~mem;
-              const kvb_carry st = Carry[sa];
-              uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.la), lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.lb);
-              const uint32_t ver = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.ver), miss = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.miss);
-              const int src = __builtin_amdgcn_readfirstlane(st.src);
-              const uint32_t fnd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(Lead[sa].found_link >> 31));
-              // Granted ACQUIREs.  The counters move between two modes.  FREE (num_ex == 0): every ACQUIRE_SHARED is
-              // granted (num_sh++), RELEASE_SHARED decrements, and nothing else happens until an EVENT: an
-              // ACQUIRE_EXCLUSIVE that finds num_sh == 0 (granted: num_ex = 1) or a RELEASE_EXCLUSIVE (num_ex wraps to
-              // 2^32 - 1, as the reference's unsigned counter does).  HELD (num_ex != 0): every ACQUIRE is rejected,
-              // RELEASE_SHARED still decrements, until the num_ex-th RELEASE_EXCLUSIVE.  Between events all lanes are
-              // resolved at once (num_sh before a lane = num_sh + ACQUIRE_SHAREDs - RELEASE_SHAREDs below it), so the
-              // loop runs once per mode change, not once per request: a contended account changes mode rarely.
-              uint64_t G = 0, rem = mem & (mAS | mAX | mRS | mRX);
-              while (rem) {
-                if (la == 0) {
-                  const uint64_t blw = rem & lanemask_lt();
-                  const uint32_t lb_before = lb + (uint32_t)__popcll(blw & mAS) - (uint32_t)__popcll(blw & mRS);
-                  const bool me = (rem >> lane) & 1ull;
-                  const uint64_t ev = __ballot(me && ((type == 1 && lb_before == 0) || type == 3));
-                  const uint64_t upto = ev ? (ev & (0 - ev)) - 1ull : ~0ull;  // the lanes below the first event
-                  const uint64_t seg = rem & upto;
-                  G |= seg & mAS;
-                  lb += (uint32_t)__popcll(seg & mAS) - (uint32_t)__popcll(seg & mRS);
-                  rem &= ~upto;
-                  if (ev) {
-                    const uint64_t bit = ev & (0 - ev);
-                    if (bit & mAX) { G |= bit; la = 1; } else la = 0xFFFFFFFFu;
-                    rem &= ~bit;
-                  }
-                } else {
-                  uint64_t rx = rem & mRX;
-                  const uint32_t nrx = (uint32_t)__popcll(rx);
-                  if (nrx < la) {  // held to the end of these lanes
-                    lb -= (uint32_t)__popcll(rem & mRS);
-                    la -= nrx;
-                    rem = 0;
-                  } else {
-                    for (uint32_t k = 1; k < la; k++) rx &= rx - 1;  // the la-th RELEASE_EXCLUSIVE (la is 1 unless the counter wrapped)
-                    const uint64_t bit = rx & (0 - rx), upto = bit - 1ull;
-                    lb -= (uint32_t)__popcll(rem & upto & mRS);
-                    la = 0;
-                    rem &= ~(upto | bit);
-                  }
-                }
-              }
-              const uint64_t wmask = fnd ? mem & mWR : 0ull, wlt = wmask & lanemask_lt();
-              if ((mem >> lane) & 1ull) {
-                const bool granted = (G >> lane) & 1ull;
-                my_ver = ver + (uint32_t)__popcll(wlt);
-                my_src = wlt ? (int)(lo + wv * 64 + 63u - (uint32_t)__clzll((long long)wlt)) : src;
-                switch (type) {  // smallbank/udp/server_shard.cc:121-173
-                  case 0: my_code = granted ? 7 : 8; my_get = granted ? fnd : 0; break;
-                  case 1: my_code = granted ? 9 : 10; my_get = granted ? fnd : 0; break;
-                  case 2: my_code = 11; my_get = 0; break;
-                  case 3: my_code = 12; my_get = 0; break;
-                  case 4: my_code = 13; my_get = 0; break;
-                  case 17: my_code = 18; my_get = fnd; break;  // WARMUP_READ
-                  default: my_code = 14; my_get = 0; break;    // 5 kCommitBck
-                }
-              }
-              if ((int)lane == l0) {
-                kvb_carry nx;
-                nx.la = la; nx.lb = lb;
-                nx.ver = ver + (uint32_t)__popcll(wmask);
-                nx.src = wmask ? (int)(lo + wv * 64 + 63u - (uint32_t)__clzll((long long)wmask)) : src;
-                nx.miss = miss + (fnd ? 0u : (uint32_t)__popcll(G) + (uint32_t)__popcll(mem & mWR));
-                Carry[sa] = nx;
-              }
-            }
+        // smallbank: the grants were settled before the tiles (Mlk); version seen = version + writes below me, value
+        // seen = message of the last write below me, both straight from the write mask
+        if (simple) {
+          const bool granted = kvb_bit(Mlk, p);
+          my_ver = ver0 + (found ? kvb_popc(Mwr, Pwr, seg_a, p) : 0);
+          my_src = found ? kvb_last(Mwr, Ewr, seg_a, p) : -1;
+          switch (type) {  // smallbank/udp/server_shard.cc:121-173
+            case 0: my_code = granted ? 7 : 8; my_get = granted ? found : 0; break;
+            case 1: my_code = granted ? 9 : 10; my_get = granted ? found : 0; break;
+            case 2: my_code = 11; break;
+            case 3: my_code = 12; break;
+            case 4: my_code = 13; break;
+            case 17: my_code = 18; my_get = found; break;  // WARMUP_READ
+            default: my_code = 14; break;                   // 5 kCommitBck
           }
-          __syncthreads();
         }
       }
       o.msg = msg; o.simple = simple; o.get = simple && my_get != 0; o.code = my_code; o.ver = my_ver; o.from = nullptr;
@@ -1580,8 +1613,11 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         int fin_src = -1;
         bool redo = false;  // the row was deleted and inserted again: it may have moved
         if (WL == DINT_WL_SMALLBANK) {
-          const kvb_carry st = Carry[t];
-          fin_la = st.la; fin_lb = st.lb; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
+          const uint32_t nw = kvb_popc(Mwr, Pwr, a, seg_b);
+          fin_la = Carry[t].la; fin_lb = Carry[t].lb;
+          fin_ver = L.ver0 + (found0 ? nw : 0);
+          fin_src = found0 ? kvb_last(Mwr, Ewr, a, seg_b) : -1;
+          nmiss = found0 ? 0 : nw + kvb_range_popc(Mlk, a, seg_b);  // every grant and every commit misses the row
         } else if (kvb_bit(Mstseg, a)) {
           const kv_rowst st = Crow[t];
           exists1 = st.exists; fin_ver = st.ver; fin_src = st.src; nmiss = st.miss;
