@@ -13,6 +13,7 @@ correction is calibrated for wide coalesced streams only -- see profiles/README.
 import glob
 import json
 import os
+import shutil
 import sqlite3
 import subprocess
 import sys
@@ -55,11 +56,12 @@ def main():
     wl = rest[rest.index("--workload") + 1] if "--workload" in rest else "tatp"
     out_dir = os.path.join(ROOT, "gpurun_out", f"{tag}_{wl}")
     os.makedirs(out_dir, exist_ok=True)
-    steps, warm = 40, 5
+    steps, warm, per_step = 12, 1, 16  # 208 passes per engine; bench.py's event-timed replay runs <= 200 of them last
     engines = 3 if wl in ("tatp", "smallbank") else 1
-    last = engines * min(steps + warm, 200)  # bench.py's event-timed replay = the last launches
-    base = [sys.executable, os.path.join(ROOT, "bench.py")] + rest + ["--steps", str(steps), "--warmup", str(warm),
-                                                                       "--no-cpu-baseline", "--no-rand64", "--no-host-path", "--no-closed-loop"]
+    last = engines * 190  # ... of which the last 190 per engine are averaged here
+    base = [sys.executable, os.path.join(ROOT, "bench.py")] + rest + ["--steps", str(steps), "--warmup", str(warm), "--per-step", str(per_step),
+                                                                       "--no-cpu-baseline", "--no-rand64", "--no-host-path", "--no-closed-loop",
+                                                                       "--no-other-workloads", "--no-shim"]
     env = dict(os.environ, TMPDIR="/tmp")
     passes = [("trace", ["--kernel-trace", "--stats"]), ("FETCH_SIZE", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
               ("WRITE_SIZE", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
@@ -76,8 +78,11 @@ def main():
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
         lines.append(f"# pass {name}: rc {r.returncode}: {' '.join(cmd[:6])} ... -- bench.py {' '.join(rest)}")
         if r.returncode != 0:
-            lines.append(r.stderr[-600:])
+            lines.append(r.stderr[-1500:])
+            print(lines[-2], lines[-1], flush=True)
             continue
+        if r.stdout and "parity" in r.stdout[-2000:]:
+            lines.append("# bench.py stdout tail: " + r.stdout[-300:].replace("\n", " "))
         for db in sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True)):
             rows = last_rows(db, last)
             for k, v in rows.items():
@@ -86,6 +91,7 @@ def main():
                 else:  # keep the trace pass's duration; counters from this pass
                     merged.setdefault(k, {}).update({a: b for a, b in v.items() if a not in ("avg_us", "max_us", "calls")})
                     merged[k].setdefault("avg_us_under_" + name, v.get("avg_us"))
+        shutil.rmtree(d, ignore_errors=True)  # the raw databases are tens of MB per pass; gpurun_out/ travels back
     kernels = {}
     for k, v in merged.items():
         kernels[k] = dict(v)
@@ -99,7 +105,7 @@ def main():
         commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         commit = None
-    res = {"workload": wl, "command": "bench.py " + " ".join(rest) + f" --steps {steps} --warmup {warm}", "launches": last,
+    res = {"workload": wl, "command": "bench.py " + " ".join(rest) + f" --steps {steps} --warmup {warm} --per-step {per_step}", "launches": last,
            "kernel_source_hash": kernel_source_hash(wl), "commit": commit, "kernels": kernels}
     os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "profiles", f"{'sq' if sq else 'traffic'}_{wl}.json"), "w") as f:
