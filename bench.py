@@ -35,7 +35,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # (GPU_MAX_HW_QUEUES is left at HIP's default of 4: raising it to 8 / 16 so that the exchange stream and RCCL's stream get
-# queues of their own HALVED the pipelined-exchange rate on MI355X -- tools/gpu_quick.sh, r02: 0.49 -> 1.04 ms per epoch.)
+# queues of their own HALVED the pipelined-exchange rate on MI355X -- r02, NOTEBOOK.md: 0.49 -> 1.04 ms per epoch.)
 
 BATCH = 65536
 KV_PASS = 1 << 20  # requests per kernel pass of the store / tatp / smallbank engines (dint_config.max_pass = 0)

@@ -75,7 +75,7 @@ k_kv_place(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_of
 #define KVB_HOT_MIN_LOCKS 256u     // ... the lock tables' threshold (k_locks.hip)
 #define KVB_MMAX 1024u             // ... if the key has at most this many writers + lock ops
 static_assert(KVB_NW == 64, "the per-word tables are built with one lane per mask word");
-// the thresholds can be overridden from the environment (tuning runs: tools/gpu_r02h.sh); read once per process
+// the thresholds can be overridden from the environment (tuning runs); read once per process
 static inline uint32_t dint_hot_min(const char *env, uint32_t dflt) {
   const char *v = getenv(env);
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;

@@ -446,7 +446,7 @@ int enqueue_chunk(dint_engine *e, const uint8_t *rq, uint8_t *rp, uint32_t m, ui
   if (int rc = slot_alloc(e, k)) return rc;
   if (!e->s_h2d) {
     if (!(e->cfg.flags & DINT_FLAG_COPY_STREAMS)) {
-      // default: copies on the engine's own stream.  Measured on MI355X (tools/gpu_ab.sh, r02): with three engines
+      // default: copies on the engine's own stream.  Measured on MI355X (same-box A/B, r02; NOTEBOOK.md): with three engines
       // in one process, two more streams per engine push the process past HIP's 4 hardware queues and -- depending on
       // which queues end up shared -- serialise the engines' kernel chains (TATP replay 1.2 instead of 1.7 G txn/s).
       // Several engines overlap each other's copies anyway; one engine alone wants DINT_FLAG_COPY_STREAMS.
