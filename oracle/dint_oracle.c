@@ -16,12 +16,14 @@
  *     written (the reference copies partially initialised stack structs,
  *     tatp/udp/tatp.h:291-307).
  *
- * PARITY PINNED for the six udp/ servers (the .npz fixtures and fasst_24m.json under tests/golden were recorded from the
- * UNMODIFIED reference servers, oracle/Makefile ref).  PARITY UNPINNED for the eBPF-only codes restated
- * here from the eBPF sources alone -- STORE INSERT (store/ebpf/store_kern.c:226-297), tatp
- * REJECT_LOCK_SAME_KEY (orc_tatp_same_key_mode, tatp/ebpf/lock_kern.c:289-298) and smallbank
- * WARMUP_READ (smallbank/ebpf/shard_user.c:179-186): no XDP program can be loaded in this image, so no
- * reference run exists to check them against.
+ * PARITY PINNED.  The six udp/ servers: the .npz fixtures, long_traces.json and fasst_24m.json under tests/golden were
+ * recorded from the UNMODIFIED reference servers (oracle/Makefile ref).  The eBPF flavour -- STORE INSERT
+ * (store/ebpf/store_kern.c:226-297), tatp REJECT_LOCK_SAME_KEY (orc_tatp_same_key_mode, tatp/ebpf/lock_kern.c:289-298),
+ * smallbank WARMUP_READ (smallbank/ebpf/shard_user.c:179-186), the signed counters of the eBPF lock tables: the
+ * UNMODIFIED *_kern.c / *_user.c compiled against a stub of the BPF helpers and run by oracle/ref_harness/ebpf/emu_main.c
+ * (oracle/Makefile ref_ebpf; fixtures tests/golden/ebpf_*.npz).  The transaction handlers: the UNMODIFIED
+ * caladan/client_udp_shard.cc against a synchronous stand-in for the runtime (oracle/Makefile ref_client;
+ * tests/golden/clients.npz).
  */
 #include "dint_oracle.h"
 

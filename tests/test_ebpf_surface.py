@@ -1,9 +1,9 @@
 """The eBPF-flavour protocol surface and the log drain (8f-4).
 
-These request / reply codes exist only in the reference's eBPF servers, which cannot be built here (no BPF target), so
-the oracle's restatement of the cited lines is the parity anchor ("parity unpinned" for these three codes, as
-DESIGN.md says): WARMUP_READ (smallbank/ebpf/shard_kern.c:585-667 + shard_user.c:179-186), REJECT_LOCK_SAME_KEY
-(tatp/ebpf/lock_kern.c:289-298) and the back-pressure replies REJECT_* / RETRY."""
+These request / reply codes exist only in the reference's eBPF servers: WARMUP_READ (smallbank/ebpf/shard_kern.c:585-667
++ shard_user.c:179-186), REJECT_LOCK_SAME_KEY (tatp/ebpf/lock_kern.c:289-298) and the back-pressure replies REJECT_* / RETRY.  These tests hold the engine to the
+oracle's restatement; the restatement itself is pinned to the unmodified eBPF programs run under the emulator
+(oracle/ref_harness/ebpf, tests/test_ebpf_golden.py)."""
 import numpy as np
 import pytest
 
