@@ -38,12 +38,26 @@ struct dint_shard {
   uint32_t index, count;  // count >= 1
 };
 
-// ~32 records per bin on average, so that almost every bin fits one 64-lane chunk (one wave resolves one bin); power
-// of two, <= DINT_KV_PMAX
+// lock tables: ~32 records per bin on average, so that almost every bin fits one 64-lane chunk (one wave resolves one
+// bin); power of two, <= DINT_KV_PMAX
 static inline uint32_t dint_pick_bins_kv(uint32_t n) {
   uint32_t p = 1;
   while (p < DINT_KV_PMAX && p * 32u < n) p <<= 1;
   return p;
+}
+// kv passes: any number of bins (bin = group % P), `load` records per bin on average.  32 by default: measured on the
+// TATP bench stream (tools/exp_binload.sh, profiles/r03_experiments.md section 5) 26 / 34 / 40 / 46 / 52 records per bin give
+// 2,002 / 2,066 / 2,043 / 1,902 / 1,730 Mtxn/s -- fuller waves do not pay (the pass is bound by its memory transactions
+// per request, not by instructions per wave) and the Poisson tail above 64 records goes to the big-bin workgroups.
+// What the free choice of P buys is a load that does not depend on n: a power of two left 16 records per bin for a pass
+// just above 32 * 2^k requests.  DINT_KV_BIN_LOAD overrides it for tuning runs.
+static inline uint32_t dint_pick_bins_load(uint32_t n, uint32_t load) {
+  if (load < 8) load = 8;
+  if (load > 56) load = 56;
+  uint64_t p = ((uint64_t)n + load - 1) / load;
+  if (p < 1) p = 1;
+  if (p > DINT_KV_PMAX) p = DINT_KV_PMAX;
+  return (uint32_t)p;
 }
 
 // ---- lock tables (lock_fasst, lock_2pl): k_locks.hip ----------------------------------------

@@ -106,15 +106,37 @@ struct kv_dev_mem {
 
 // ---- batch record of the kv passes: one 64-bit word per table request ------------------------------------
 //   bits 0..15            payload: type (5 bits, LOAD -> 31) | lock quadrant << 5 | 9 key-hash bits << 7
-//   bits 16..31+pbits     request index inside the pass   (n <= 2^(16+pbits); P = 2^pbits bins, ~32 records each)
-//   bits 32+pbits..63     group key >> pbits             (the low pbits bits are the bin id)
-__device__ static inline uint64_t kv_rec(uint32_t gk, uint32_t idx, uint32_t pay, uint32_t pbits) {
-  return ((uint64_t)(gk >> pbits) << (32 + pbits)) | ((uint64_t)idx << 16) | (pay & 0xFFFFu);
+//   bits 16..15+ibits     request index inside the pass   (n <= 2^ibits)
+//   bits 16+ibits..63     group key / P                   (the remainder is the bin id)
+// A pass is cut into P bins, bin = group % P, P = n / 32 (dint_pick_bins_load): ANY number, so that a bin holds ~32
+// records whatever n is (a power of two, r01-r03a, left 16-32).  Fuller bins were measured and do not pay.
+struct kv_cut { uint32_t P, ibits, magic; };  // magic = floor(2^32 / P), 0 for P = 1
+static inline kv_cut kv_make_cut(uint32_t P, uint32_t n) {
+  kv_cut c;
+  c.P = P;
+  c.ibits = 1;
+  while (c.ibits < 32 && (1ull << c.ibits) < n) c.ibits++;
+  c.magic = P > 1 ? (uint32_t)((1ull << 32) / P) : 0u;
+  return c;
+}
+__device__ static inline uint32_t kv_cut_div(uint32_t gk, const kv_cut &c, uint32_t *bin) {  // gk / P, *bin = gk % P
+  if (c.P <= 1) { *bin = 0; return gk; }
+  uint32_t q = __umulhi(gk, c.magic), r = gk - q * c.P;  // q is the quotient or one less
+  if (r >= c.P) { r -= c.P; q++; }
+  *bin = r;
+  return q;
+}
+__device__ static inline uint32_t kv_cut_gk(uint32_t gq, uint32_t bin, const kv_cut &c) { return gq * c.P + bin; }
+__device__ static inline uint64_t kv_rec(uint32_t gq, uint32_t idx, uint32_t pay, const kv_cut &c) {
+  return ((uint64_t)gq << (16 + c.ibits)) | ((uint64_t)idx << 16) | (pay & 0xFFFFu);
 }
 __device__ static inline uint32_t kv_rec_pay(uint64_t r) { return (uint32_t)r & 0xFFFFu; }
-__device__ static inline uint32_t kv_rec_idx(uint64_t r, uint32_t pbits) { return (uint32_t)(r >> 16) & ((1u << (16 + pbits)) - 1u); }
-__device__ static inline uint32_t kv_rec_gk(uint64_t r, uint32_t pbits, uint32_t bin) {
-  return ((uint32_t)(r >> (32 + pbits)) << pbits) | bin;
+__device__ static inline uint32_t kv_rec_idx(uint64_t r, const kv_cut &c) { return (uint32_t)(r >> 16) & (uint32_t)((1ull << c.ibits) - 1ull); }
+// sort key of a record: group / P | 9 key-hash bits | idx | 7 payload bits (type, lock quadrant)
+__device__ static inline uint64_t kv_sort_key(uint64_t r, const kv_cut &c) {
+  const uint32_t pay = kv_rec_pay(r);
+  return ((r >> (16 + c.ibits)) << (16 + c.ibits)) | ((uint64_t)((pay >> 7) & 511u) << (7 + c.ibits)) |
+         ((uint64_t)kv_rec_idx(r, c) << 7) | (pay & 0x7Fu);
 }
 
 // what one request is, from its wire bytes: shared by k_kv_count and k_kv_place
@@ -144,7 +166,7 @@ __device__ static inline kv_reqinfo kv_read_request(const uint8_t *m, bool live,
 template <int WL>
 __global__ void __launch_bounds__(KV_TB)
 k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
-           uint32_t pbits, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
+           kv_cut cut, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
            uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode, dint_view V) {
   using F = Fmt<WL>;
   __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
@@ -204,7 +226,7 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
   }
   if (live && !r.cls) atomicAdd(&stats->bad_requests, 1ULL);
 
-  uint32_t bin = KV_NONE, gk = 0, pay = 0;
+  uint32_t bin = KV_NONE, gq = 0, pay = 0;
   if (r.cls == 1) {
     const uint64_t h = dint_hash_key(r.key);
     const uint64_t g = dint_fastmod(h, kv->mod[r.table]);
@@ -219,8 +241,7 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
       // lock quadrant: lock_hash / hash_size, lock_hash = h % (4 * hash_size)
       const uint64_t hs = kv->mod[r.table].d, dq = dint_fastmod(h, kv->lockmod[r.table]) - g;  // 0, hs, 2hs or 3hs
       const uint32_t q = dq >= 2 * hs ? (dq >= 3 * hs ? 3u : 2u) : (dq >= hs ? 1u : 0u);
-      gk = kv->gk_base[r.table] + local;
-      bin = gk & ((1u << pbits) - 1u);
+      gq = kv_cut_div(kv->gk_base[r.table] + local, cut, &bin);
       pay = kv_pay(r.type, q, (uint32_t)(h >> 40) & 511u);  // the table is implied by the group key
     }
   }
@@ -243,7 +264,7 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
   }
   __syncthreads();
   if (bin != KV_NONE) mypos += Hc[e];
-  const uint64_t rec = kv_rec(gk, i, pay, pbits);
+  const uint64_t rec = kv_rec(gq, i, pay, cut);
   const bool over = bin != KV_NONE && mypos >= DINT_KV_BINCAP;
   if (bin != KV_NONE && !over) bins[(size_t)bin * DINT_KV_BINCAP + mypos] = rec;
   // overflow records: one reservation in the pass's list per workgroup
@@ -792,7 +813,7 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 
 // ---- k_kv_resolve: bins of <= 64 records, one wave each ---------------------------------------------------
 template <int WL>
-__device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const kv_dev *kv, uint32_t bin,
+__device__ static inline void kv_small_bin(uint8_t *rep, const kv_cut &cut, const kv_dev *kv, uint32_t bin,
                                            uint32_t *__restrict__ bin_cnt, const uint64_t *__restrict__ bins,
                                            dint_dev_stats *__restrict__ stats, int kv_force_rounds, const dint_view &V,
                                            uint64_t *trace) {
@@ -808,20 +829,16 @@ __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const k
   kv_stamp(tr, 1);
   // Sort the records by (bucket group, key hash, idx) in registers: groups commute, so any order that keeps each
   // group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in adjacent
-  // lanes -- no LDS, no rank bitmap, no hash.  Key: group >> pbits | 9 key-hash bits | idx (16 + pbits bits) | 7
-  // payload bits = 64 bits for every pbits.
+  // lanes -- no LDS, no rank bitmap, no hash.  Key: group / P | 9 key-hash bits | idx (ibits bits) | 7 payload bits
+  // (kv_sort_key): at most 56 bits for every cut.
   uint64_t w = ~0ull;  // empty lanes sort last
-  if (lane < c) {
-    const uint32_t pay = kv_rec_pay(r0);
-    w = ((r0 >> (32 + pbits)) << (32 + pbits)) | ((uint64_t)pay_kh(pay) << (23 + pbits)) |
-        ((uint64_t)kv_rec_idx(r0, pbits) << 7) | (pay & 0x7Fu);
-  }
+  if (lane < c) w = kv_sort_key(r0, cut);
   kv_stamp(tr, 2);
   w = wave_sort_u64(w);
   kv_stamp(tr, 3);
   const bool valid = lane < c;
-  const uint32_t gk = ((uint32_t)(w >> (32 + pbits)) << pbits) | bin, kh = (uint32_t)(w >> (23 + pbits)) & 511u;
-  const uint32_t idx = (uint32_t)(w >> 7) & ((1u << (16 + pbits)) - 1u);
+  const uint32_t gk = kv_cut_gk((uint32_t)(w >> (16 + cut.ibits)), bin, cut), kh = (uint32_t)(w >> (7 + cut.ibits)) & 511u;
+  const uint32_t idx = (uint32_t)(w >> 7) & (uint32_t)((1ull << cut.ibits) - 1ull);
   const uint32_t pay = (uint32_t)w & 0x7Fu;
   kv_chunk<WL>(rep, valid, valid ? idx : 0, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), kv, stats,
                kv_force_rounds, true, V, tr);
@@ -844,7 +861,7 @@ __device__ static inline void kv_small_bin(uint8_t *rep, uint32_t pbits, const k
 // A bin of more than KVB_NMAX records is cut into stretches along request-index buckets (every request of a
 // stretch precedes every request of the next one) and the stretches run one after the other.
 template <int WL>
-__device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *kv, uint32_t first,
+__device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, const kv_cut &cut, const kv_dev *kv, uint32_t first,
                                           uint32_t stride, uint32_t *__restrict__ bin_cnt,
                                           const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big,
                                           const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
@@ -853,7 +870,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   using F = Fmt<WL>;
   const int force_rounds = force_flags & 1, no_hot = force_flags & 2;
   const uint32_t hot_min = (uint32_t)force_flags >> 8 ? (uint32_t)force_flags >> 8 : KVB_HOT_MIN;
-  __shared__ uint64_t Sk[KVB_NMAX];           // the stretch: group >> pbits | key-hash bits | idx | type, quadrant
+  __shared__ uint64_t Sk[KVB_NMAX];           // the stretch: group / P | key-hash bits | idx | type, quadrant
   __shared__ uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
   __shared__ uint16_t Bwin[KVB_NBK];          // stretch each idx bucket belongs to
   __shared__ uint64_t Mhead[KVB_NW], Mbh[KVB_NW], Mbad[KVB_NW], Mlop[KVB_NW], Mst[KVB_NW], Mlkseg[4][KVB_NW],
@@ -879,7 +896,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
   // idx buckets for the stretches of a bin with more than KVB_NMAX records: 2^bs requests per bucket, <= KVB_NBK buckets
   const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 11 ? nbits - 11 : 0u;
   const uint32_t wcap = KVB_NMAX - (1u << bs);  // a stretch = the buckets whose exclusive record count / wcap is equal
-  const uint32_t sh_g = 32 + pbits, sh_k = 23 + pbits, idx_mask = (1u << (16 + pbits)) - 1u;
+  const uint32_t sh_g = 16 + cut.ibits, sh_k = 7 + cut.ibits, idx_mask = (uint32_t)((1ull << cut.ibits) - 1ull);
   auto k_idx = [&](uint64_t w) -> uint32_t { return (uint32_t)(w >> 7) & idx_mask; };
   auto k_type = [&](uint64_t w) -> uint32_t { return pay_type((uint32_t)w & 0x7Fu); };
   auto k_q = [&](uint64_t w) -> uint32_t { return pay_q((uint32_t)w & 0x7Fu); };
@@ -921,7 +938,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     __syncthreads();
 #pragma unroll 4
     for (uint32_t k = t; k < c; k += KVB_T) {
-      const uint32_t b = kv_rec_idx(rec_at(k), pbits) >> bs;
+      const uint32_t b = kv_rec_idx(rec_at(k), cut) >> bs;
       atomicAdd(&Bcnt[b >> 1], 1u << (16 * (b & 1)));
     }
     __syncthreads();
@@ -950,8 +967,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
     __syncthreads();
     // ---- gather the stretch (any order) as sort keys
     auto sort_key = [&](uint64_t r) -> uint64_t {
-      const uint32_t pay = kv_rec_pay(r);
-      return ((r >> sh_g) << sh_g) | ((uint64_t)pay_kh(pay) << sh_k) | ((uint64_t)kv_rec_idx(r, pbits) << 7) | (pay & 0x7Fu);
+      return kv_sort_key(r, cut);
     };
     if (c <= KVB_NMAX) {  // the whole bin
       for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = sort_key(rec_at(k));
@@ -968,7 +984,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
         for (uint32_t j = 0; j < 4; j++) {
           const uint32_t k = k0 + j * KVB_T + t;
           const uint64_t r = r4[j];
-          const bool in = k < c && Bwin[kv_rec_idx(r, pbits) >> bs] == win;
+          const bool in = k < c && Bwin[kv_rec_idx(r, cut) >> bs] == win;
           const uint64_t im = __ballot(in);
           uint32_t base = 0;
           if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
@@ -1108,7 +1124,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           __syncthreads();
           // 4. the row: one thread probes the bucket
           if (t == 0) {
-            const uint32_t gk = ((uint32_t)(hcur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk);
+            const uint32_t gk = kv_cut_gk((uint32_t)(hcur >> sh_g), bin, cut), table = kv_table_of(kv, gk);
             const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
             const kv_tab tb = kv->tab[table];
             const uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
@@ -1120,7 +1136,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           }
           __syncthreads();
           const uint32_t found = Hs[8], link = Hs[9], slot = Hs[10], ver0 = Hs[11], la0 = Hs[12];
-          const uint32_t hgk = ((uint32_t)(hcur >> sh_g) << pbits) | bin, htable = kv_table_of(kv, hgk);
+          const uint32_t hgk = kv_cut_gk((uint32_t)(hcur >> sh_g), bin, cut), htable = kv_table_of(kv, hgk);
           const uint64_t hbucket = (uint64_t)(hgk - kv->gk_base[htable]);
           const kv_tab htb = kv->tab[htable];
           uint8_t *hrow = kv_entry_ptr(htb, hbucket, link) + KV_VAL_OFF + slot * F::VS;  // meaningful when found
@@ -1308,7 +1324,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const uint32_t a = ha;
       if (kvb_bit(Msimple, a)) {
         const uint64_t cur = Sk[a];
-        const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk), q = k_q(cur);
+        const uint32_t gk = kv_cut_gk((uint32_t)(cur >> sh_g), bin, cut), table = kv_table_of(kv, gk), q = k_q(cur);
         const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
         const kv_tab tb = kv->tab[table];
         const uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
@@ -1448,7 +1464,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const uint32_t lo = j * KVB_T, hi = min(lo + KVB_T, m), p = lo + t;
       const bool valid = p < m;
       const uint64_t cur = Sk[p];
-      const uint32_t gk = valid ? ((uint32_t)(cur >> sh_g) << pbits) | bin : 0, idx = valid ? k_idx(cur) : 0;
+      const uint32_t gk = valid ? kv_cut_gk((uint32_t)(cur >> sh_g), bin, cut) : 0, idx = valid ? k_idx(cur) : 0;
       const uint32_t type = k_type(cur), table = valid ? kv_table_of(kv, gk) : 0;
       const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
       uint8_t *msg = rep + dint_view_off(V, idx, F::MSG);
@@ -1602,7 +1618,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
       const uint32_t a = ha;
       if (kvb_bit(Msimple, a)) {
         const uint64_t cur = Sk[a];
-        const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk), q = k_q(cur);
+        const uint32_t gk = kv_cut_gk((uint32_t)(cur >> sh_g), bin, cut), table = kv_table_of(kv, gk), q = k_q(cur);
         const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
         const kv_tab tb = kv->tab[table];
         uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
@@ -1798,7 +1814,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
           const uint32_t p = j * KVB_T + t;
           if (p < m && Rpos[p] == r) {
             const uint64_t cur = Sk[p];
-            const uint32_t gk = ((uint32_t)(cur >> sh_g) << pbits) | bin, table = kv_table_of(kv, gk);
+            const uint32_t gk = kv_cut_gk((uint32_t)(cur >> sh_g), bin, cut), table = kv_table_of(kv, gk);
             kv_do_request<WL>(rep + dint_view_off(V, k_idx(cur), F::MSG), k_type(cur), table, k_q(cur),
                               (uint64_t)(gk - kv->gk_base[table]), kv, stats);
           }
@@ -1825,7 +1841,7 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, uint32_t pbi
 // big-bin kernel on a second stream cost more in cross-stream event waits than the overlap gave; see DESIGN.md.)
 template <int WL>
 __global__ void __launch_bounds__(KVB_T, 4)
-k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+k_kv_resolve(uint8_t *rep, uint32_t n, kv_cut cut, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
              const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
              const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
              dint_view V) {
@@ -1836,10 +1852,10 @@ k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict_
   unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
   if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
   if (blockIdx.x < KVB_GRID) {
-    kv_big_bins<WL>(rep, n, pbits, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
+    kv_big_bins<WL>(rep, n, cut, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
   } else {
     const uint32_t bin = (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
-    if (bin < (1u << pbits)) kv_small_bin<WL>(rep, pbits, &Skv, bin, bin_cnt, bins, stats, force_flags & 1, V, trace);
+    if (bin < cut.P) kv_small_bin<WL>(rep, cut, &Skv, bin, bin_cnt, bins, stats, force_flags & 1, V, trace);
   }
   if (wg && (threadIdx.x & 63) == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1851,14 +1867,14 @@ k_kv_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, const kv_dev *__restrict_
 template <int WL>
 static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
                       int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
-  const uint32_t P = dint_pick_bins_kv(n);
-  uint32_t pbits = 0;
-  while ((1u << pbits) < P) pbits++;
+  static const uint32_t bin_load = dint_hot_min("DINT_KV_BIN_LOAD", 32);
+  const uint32_t P = dint_pick_bins_load(n, bin_load);
+  const kv_cut cut = kv_make_cut(P, n);
   const uint32_t nb = (n + KV_TB - 1) / KV_TB;  // <= 1024 for n <= DINT_KV_PASS
   const bool has_log = WL != DINT_WL_STORE;
   if (ev) hipEventRecord(ev[0], st);
   hipLaunchKernelGGL((k_kv_count<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
-                     log, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode, view);
+                     log, cut, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode, view);
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
                      s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr, s.stats);
@@ -1867,7 +1883,7 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
                      (const uint32_t *)s.bin_off, (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[3], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
-                     pbits, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
+                     cut, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
                      (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats,
                      kv.force_rounds | (int)(dint_hot_min("DINT_KV_HOT_MIN", 0) << 8), kv.d_trace, view);
   if (ev) hipEventRecord(ev[4], st);

@@ -38,7 +38,7 @@ void dint_driver_params(const dint_driver_config &c, TxParams *P, ZipfTable *zip
 
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
-k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
+k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
            uint8_t *out2, uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t *counts, txg_stats *st, uint32_t dbg) {
   typedef typename T::Msg Msg;
   __shared__ uint32_t Stile, Sw[3][TXG_TB / 64], Sbase[3];
@@ -52,13 +52,15 @@ k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, T
 
   // the client's header travels through registers: one coalesced 72 / 112-byte load here, one store at the end; the
   // working messages stay in memory and are touched only where the phase reads or writes them
-  typename T::Out o;
+  // the phase's message queue lives in LDS (dynamically indexed byte arrays: left to the compiler it went to scratch)
+  __shared__ typename T::Out So[TXG_TB];
+  typename T::Out &o = So[t];
   o.clear();
   typename T::Client c;
   if (valid) {
     c = cl[i];
-    c.m.base = store + i;  // message k of every client is one array (TxMsgs)
-    c.m.stride = n_clients;
+    c.m.base = store + (size_t)i * TX_DEV_MSG_STRIDE;  // message k of every client is one array of sectors (TxMsgs)
+    c.m.stride = (uint64_t)n_clients * TX_DEV_MSG_STRIDE;
     if (!(dbg & 2)) T::run(c, P, o);
   }
   uint32_t nmsg[3] = {0, 0, 0};
@@ -121,8 +123,12 @@ k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, T
   for (uint8_t k = 0; k < o.n; k++) {
     const uint32_t s = o.shard[k], pos = Sbase[s] + x[s] + o.ord[k];
     c.out_pos[k] = pos;
-    if (pos < cap) *(Msg *)(outs[s] + (size_t)pos * sizeof(Msg)) = o.materialize(c, k);
-    else lost++;
+    if (pos < cap) {
+      *(Msg *)(outs[s] + (size_t)pos * sizeof(Msg)) = o.materialize(c, k);
+    } else {  // no room in the batch: nothing is sent, nothing will come back -- the client message holds the request
+      lost++;
+      if (o.is_new(k) && o.dst[k] != TX_NO_DST) { Msg m = o.materialize(c, k); m.ord = 0; c.m[o.dst[k]] = m; }
+    }
   }
   if (valid) cl[i] = c;
   // ---- statistics: LDS first, then one device atomic per counter and workgroup
@@ -144,7 +150,7 @@ k_txn_emit(typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, T
 
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
-k_txn_consume(const typename T::Client *cl, typename T::Msg *store, uint32_t n_clients, const uint8_t *rep0,
+k_txn_consume(const typename T::Client *cl, uint8_t *store, uint32_t n_clients, const uint8_t *rep0,
               const uint8_t *rep1, const uint8_t *rep2, uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t ntiles) {
   typedef typename T::Msg Msg;
   const uint32_t i = blockIdx.x * TXG_TB + threadIdx.x;
@@ -154,12 +160,13 @@ k_txn_consume(const typename T::Client *cl, typename T::Msg *store, uint32_t n_c
   if (i >= n_clients) return;
   const uint8_t *reps[3] = {rep0, rep1, rep2};
   const typename T::Client c = cl[i];
-  Msg *m = store + i;  // message d of this client at m[d * n_clients]
+  uint8_t *m = store + (size_t)i * TX_DEV_MSG_STRIDE;  // message d of this client at m + d * n_clients * 64
   const uint8_t n = c.n_out;
   for (uint8_t k = 0; k < n; k++) {
     const uint8_t d = c.out_dst[k];
     const uint32_t pos = c.out_pos[k];
-    if (d != TX_NO_DST && pos < cap) m[(size_t)d * n_clients] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
+    if (d != TX_NO_DST && pos < cap)
+      *(Msg *)(m + (size_t)d * n_clients * TX_DEV_MSG_STRIDE) = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
   }
 }
 
@@ -187,7 +194,7 @@ int upload_clients(dint_gdriver *g) {
     memset(&h[i], 0, sizeof(Client));
     h[i].rng.s = 0xdeadbeefull + g->cfg.first_client + i;  // ClientLoop :1122
   }
-  const size_t bytes = h.size() * sizeof(Client), sbytes = h.size() * T::NMSG * sizeof(typename T::Msg);
+  const size_t bytes = h.size() * sizeof(Client), sbytes = h.size() * T::NMSG * (size_t)TX_DEV_MSG_STRIDE;
   if (hipMalloc(&g->d_clients, bytes) != hipSuccess || hipMalloc(&g->d_store, sbytes) != hipSuccess) return DINT_ENOMEM;
   if (hipMemcpy(g->d_clients, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;
   if (hipMemset(g->d_store, 0, sbytes) != hipSuccess) return DINT_EHIP;
@@ -262,11 +269,11 @@ int dint_gdriver_next(dint_gdriver_t *g, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (g->cfg.workload == DINT_WL_TATP)
     hipLaunchKernelGGL((k_txn_emit<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (TatpClient *)g->d_clients,
-                       (TatpMsg *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
+                       (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
                        g->d_counts, g->d_stats, g->dbg);
   else
     hipLaunchKernelGGL((k_txn_emit<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (SbClient *)g->d_clients,
-                       (SbMsg *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
+                       (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
                        g->d_counts, g->d_stats, g->dbg);
   if (hipGetLastError() != hipSuccess) return DINT_EHIP;
   g->awaiting = true;
@@ -281,10 +288,10 @@ int dint_gdriver_consume(dint_gdriver_t *g, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (g->cfg.workload == DINT_WL_TATP)
     hipLaunchKernelGGL((k_txn_consume<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const TatpClient *)g->d_clients,
-                       (TatpMsg *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
+                       (uint8_t *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
   else
     hipLaunchKernelGGL((k_txn_consume<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const SbClient *)g->d_clients,
-                       (SbMsg *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
+                       (uint8_t *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
   if (hipGetLastError() != hipSuccess) return DINT_EHIP;
   g->awaiting = false;
   return 0;

@@ -76,12 +76,21 @@ struct TxParams {
 // messages as it stands when the phase returns, with a type of its own (the reference re-uses one struct for the
 // LOG / BCK / PRIM copies of a row): the queue holds {shard, source message, type, reply destination} and the
 // caller materialises the wire message -- on the GPU that keeps a phase in registers instead of ~0.5 KB of scratch.
+//
+// A NEW request (a READ / ACQUIRE of a row: {type, table, key}, every other byte zero) never touches the working
+// messages on its way out: send_new() keeps the three fields in the queue, the wire message is built from them, and
+// the reply -- the whole message, key and table included -- is what fills the client message it is addressed to.
+// (Until r03 the request was first stored into that client message and read back by materialize(): on the GPU one
+// scattered 55-byte store and load per message, both dead -- NOTEBOOK.md section 4.)
 template <class Msg>
 struct TxOut {
   uint8_t n;
   uint8_t shard[TX_MAXOUT], dst[TX_MAXOUT], src[TX_MAXOUT], type[TX_MAXOUT], ord[TX_MAXOUT];
   uint8_t n_fin, fin_txn[2], fin_ok[2];
-  TX_HD void clear() { n = 0; n_fin = 0; }
+  uint16_t fresh;                // bit k: message k is a new request, built from table[k] / key[k]
+  uint8_t table[TX_MAXOUT];
+  uint64_t key[TX_MAXOUT];
+  TX_HD void clear() { n = 0; n_fin = 0; fresh = 0; }
   // queue client message `src_msg` (sent with type `ty`) for shard s; its reply lands in client message `d`
   TX_HD void send(uint32_t s, uint8_t src_msg, uint8_t ty, uint8_t d) {
     uint8_t j = 0;  // msg->ord = position in this phase's queue for shard s (client_udp_shard.cc:376-380)
@@ -93,9 +102,24 @@ struct TxOut {
     ord[n] = j;
     n++;
   }
+  // queue a new request {ty, tb, ky} for the key's primary (key % 3, client_udp_shard.cc:187); reply into message `d`
+  TX_HD void send_new(uint8_t ty, uint8_t tb, uint64_t ky, uint8_t d) {
+    fresh |= (uint16_t)(1u << n);
+    table[n] = tb;
+    key[n] = ky;
+    send((uint32_t)(ky % 3), d, ty, d);
+  }
+  TX_HD bool is_new(uint8_t k) const { return (fresh >> k) & 1u; }
   template <class Client>
   TX_HD Msg materialize(const Client &c, uint8_t k) const {
-    Msg m = c.m[src[k]];
+    Msg m;
+    if (is_new(k)) {
+      memset(&m, 0, sizeof m);
+      m.table = table[k];
+      m.key = key[k];
+    } else {
+      m = c.m[src[k]];
+    }
     m.type = type[k];
     m.ord = ord[k];
     return m;
@@ -117,15 +141,16 @@ enum : uint8_t { TT_GET_SUB = 0, TT_GET_NEW_DEST = 1, TT_GET_ACCESS = 2, TT_UPD_
 // the working messages of the running transaction (names as in the reference functions)
 enum : uint8_t { A_READ = 0, A_LOCK = 1, B_READ = 2, B_LOCK = 3, A_VER = 4, B_VER = 5, TMP0 = 6, TMP1 = 7, TMP2 = 8, TATP_NMSG = 9 };
 
-// A client's working messages: message k at base[k * stride].  The host driver keeps a client's messages together
-// (stride 1).  The device driver keeps message k of ALL clients together (base = store + client, stride = number of
-// clients): the lanes of a wave are consecutive clients, so one access of the wave is one run of consecutive 55-byte
-// messages -- with a client's messages contiguous every lane touched sectors of its own (k_txn_emit + k_txn_consume
-// 348 -> 317 us for 524,288 clients, tools/exp_emit.py; the divergent client logic itself is the larger part).
+// A client's working messages: message k at base + k * stride BYTES.  The host driver keeps a client's messages
+// together (stride = sizeof(M)).  The device driver keeps message k of ALL clients together, one 64-byte sector each
+// (base = store + 64 * client, stride = 64 * number of clients): the lanes of a wave are consecutive clients, one
+// access of the wave is one run of consecutive sectors, and a message never straddles two (packed at 55 bytes every
+// access touched 1.86 sectors on average).
+#define TX_DEV_MSG_STRIDE 64u
 template <class M> struct TxMsgs {
-  M *base;
-  uint32_t stride;
-  TX_HD M &operator[](uint32_t k) const { return base[(size_t)k * stride]; }
+  uint8_t *base;
+  uint64_t stride;
+  TX_HD M &operator[](uint32_t k) const { return *(M *)(base + (size_t)k * stride); }
 };
 
 // Client state = a 72-byte header (loaded and stored whole: on the GPU one coalesced access per client and phase)
@@ -157,16 +182,12 @@ TX_HD static inline uint32_t tatp_pick_sid(TxLcg &g, const TxParams &P) {
   return (x | y) % n;
 }
 
-TX_HD static inline TatpMsg tatp_mk(uint8_t type, uint8_t table, uint64_t key) {
-  TatpMsg m;
-  memset(&m, 0, sizeof m);
-  m.type = type; m.table = table; m.key = key;
-  return m;
-}
 TX_HD static inline uint64_t tatp_sf_key(const TatpClient &c) { return (uint64_t)c.s_id | ((uint64_t)c.sf_type << 32); }
 TX_HD static inline uint64_t tatp_cf_key(const TatpClient &c, uint32_t st) { return tatp_sf_key(c) | ((uint64_t)st << 40); }
 
 typedef TxOut<TatpMsg> TatpOut;
+// a new request {type, table, key} to the key's primary; the reply fills client message i
+TX_HD static inline void tatp_send_new(TatpOut &o, uint8_t i, uint8_t type, uint8_t table, uint64_t key) { o.send_new(type, table, key, i); }
 // send client message i to its primary (key % 3, :187); the reply comes back into the same message
 TX_HD static inline void tatp_send_prim(TatpClient &c, TatpOut &o, uint8_t i) { o.send((uint32_t)(c.m[i].key % 3), i, c.m[i].type, i); }
 // message i as it is now, to its primary, reply discarded
@@ -210,9 +231,8 @@ TX_HD static inline void tatp_emit_upd_sub(TatpClient &c, TatpOut &o) {  // TxnU
   for (;;) {
     switch (c.step) {
       case 1:  // execute: read + lock both rows :345-396
-        c.m[A_READ] = tatp_mk(T_READ, TB_SUB, c.s_id); c.m[A_LOCK] = tatp_mk(T_ACQ, TB_SUB, c.s_id);
-        c.m[B_READ] = tatp_mk(T_READ, TB_SF, tatp_sf_key(c)); c.m[B_LOCK] = tatp_mk(T_ACQ, TB_SF, tatp_sf_key(c));
-        tatp_send_prim(c, o, A_READ); tatp_send_prim(c, o, A_LOCK); tatp_send_prim(c, o, B_READ); tatp_send_prim(c, o, B_LOCK);
+        tatp_send_new(o, A_READ, T_READ, TB_SUB, c.s_id); tatp_send_new(o, A_LOCK, T_ACQ, TB_SUB, c.s_id);
+        tatp_send_new(o, B_READ, T_READ, TB_SF, tatp_sf_key(c)); tatp_send_new(o, B_LOCK, T_ACQ, TB_SF, tatp_sf_key(c));
         c.step = 2;
         return;
       case 2:
@@ -225,8 +245,7 @@ TX_HD static inline void tatp_emit_upd_sub(TatpClient &c, TatpOut &o) {  // TxnU
           memcpy(c.m[A_READ].val + 30, &bits, 2);
           c.m[B_READ].val[2] = (uint8_t)c.rng.next();  // data_a
         }
-        c.m[A_VER] = tatp_mk(T_READ, TB_SUB, c.s_id); c.m[B_VER] = tatp_mk(T_READ, TB_SF, tatp_sf_key(c));  // verify :433-447
-        tatp_send_prim(c, o, A_VER); tatp_send_prim(c, o, B_VER);
+        tatp_send_new(o, A_VER, T_READ, TB_SUB, c.s_id); tatp_send_new(o, B_VER, T_READ, TB_SF, tatp_sf_key(c));  // verify :433-447
         c.step = 3;
         return;
       case 3:
@@ -266,17 +285,15 @@ TX_HD static inline void tatp_emit_upd_sub(TatpClient &c, TatpOut &o) {  // TxnU
 
 TX_HD static inline void tatp_emit_upd_loc(TatpClient &c, TatpOut &o) {  // TxnUpdateLocation :574-728
   switch (c.step) {
-    case 1: c.m[B_READ] = tatp_mk(T_READ, TB_SEC, tx_sub_nbr(c.s_id)); tatp_send_prim(c, o, B_READ); c.step = 2; return;  // :583-592
+    case 1: tatp_send_new(o, B_READ, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :583-592
     case 2:
-      c.m[A_READ] = tatp_mk(T_READ, TB_SUB, c.s_id); c.m[A_LOCK] = tatp_mk(T_ACQ, TB_SUB, c.s_id);  // :605-618
-      tatp_send_prim(c, o, A_READ); tatp_send_prim(c, o, A_LOCK);
+      tatp_send_new(o, A_READ, T_READ, TB_SUB, c.s_id); tatp_send_new(o, A_LOCK, T_ACQ, TB_SUB, c.s_id);  // :605-618
       c.step = 3;
       return;
     case 3:
       if (c.m[A_LOCK].type == T_REJECT_LOCK) { tatp_finish(c, o, false); return; }  // :645
       memcpy(c.m[A_READ].val + 36, c.m[TMP2].val, 4);                              // vlr_location :650
-      c.m[A_VER] = tatp_mk(T_READ, TB_SUB, c.s_id);                                // verify :653-660
-      tatp_send_prim(c, o, A_VER);
+      tatp_send_new(o, A_VER, T_READ, TB_SUB, c.s_id);                             // verify :653-660
       c.step = 4;
       return;
     case 4:
@@ -295,12 +312,11 @@ TX_HD static inline void tatp_emit_upd_loc(TatpClient &c, TatpOut &o) {  // TxnU
 
 TX_HD static inline void tatp_emit_ins_cf(TatpClient &c, TatpOut &o) {  // TxnInsertCallForwarding :731-951
   switch (c.step) {
-    case 1: c.m[TMP0] = tatp_mk(T_READ, TB_SEC, tx_sub_nbr(c.s_id)); tatp_send_prim(c, o, TMP0); c.step = 2; return;  // :743-752
-    case 2: c.m[B_READ] = tatp_mk(T_READ, TB_SF, tatp_sf_key(c)); tatp_send_prim(c, o, B_READ); c.step = 3; return;   // :761-769
+    case 1: tatp_send_new(o, TMP0, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :743-752
+    case 2: tatp_send_new(o, B_READ, T_READ, TB_SF, tatp_sf_key(c)); c.step = 3; return;   // :761-769
     case 3:
       if (c.m[B_READ].type == T_NOT_EXIST) { tatp_finish(c, o, false); return; }  // :776
-      c.m[A_READ] = tatp_mk(T_READ, TB_CF, tatp_cf_key(c, c.start_time)); c.m[A_LOCK] = tatp_mk(T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :789-799
-      tatp_send_prim(c, o, A_READ); tatp_send_prim(c, o, A_LOCK);
+      tatp_send_new(o, A_READ, T_READ, TB_CF, tatp_cf_key(c, c.start_time)); tatp_send_new(o, A_LOCK, T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :789-799
       c.step = 4;
       return;
     case 4:
@@ -311,8 +327,7 @@ TX_HD static inline void tatp_emit_ins_cf(TatpClient &c, TatpOut &o) {  // TxnIn
       }
       c.m[A_READ].val[1] = 101;         // numberx[0] magic :842
       c.m[A_READ].val[0] = c.end_time;  // :843
-      c.m[B_VER] = tatp_mk(T_READ, TB_SF, tatp_sf_key(c)); c.m[A_VER] = tatp_mk(T_READ, TB_CF, tatp_cf_key(c, c.start_time));  // verify :846-859
-      tatp_send_prim(c, o, B_VER); tatp_send_prim(c, o, A_VER);
+      tatp_send_new(o, B_VER, T_READ, TB_SF, tatp_sf_key(c)); tatp_send_new(o, A_VER, T_READ, TB_CF, tatp_cf_key(c, c.start_time));  // verify :846-859
       c.step = 5;
       return;
     case 5:
@@ -333,10 +348,9 @@ TX_HD static inline void tatp_emit_ins_cf(TatpClient &c, TatpOut &o) {  // TxnIn
 
 TX_HD static inline void tatp_emit_del_cf(TatpClient &c, TatpOut &o) {  // TxnDeleteCallForwarding :954-1117
   switch (c.step) {
-    case 1: c.m[TMP0] = tatp_mk(T_READ, TB_SEC, tx_sub_nbr(c.s_id)); tatp_send_prim(c, o, TMP0); c.step = 2; return;  // :965-974
+    case 1: tatp_send_new(o, TMP0, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :965-974
     case 2:
-      c.m[A_READ] = tatp_mk(T_READ, TB_CF, tatp_cf_key(c, c.start_time)); c.m[A_LOCK] = tatp_mk(T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :983-997
-      tatp_send_prim(c, o, A_READ); tatp_send_prim(c, o, A_LOCK);
+      tatp_send_new(o, A_READ, T_READ, TB_CF, tatp_cf_key(c, c.start_time)); tatp_send_new(o, A_LOCK, T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :983-997
       c.step = 3;
       return;
     case 3:
@@ -345,8 +359,7 @@ TX_HD static inline void tatp_emit_del_cf(TatpClient &c, TatpOut &o) {  // TxnDe
         tatp_finish(c, o, false);
         return;
       }
-      c.m[A_VER] = tatp_mk(T_READ, TB_CF, tatp_cf_key(c, c.start_time));  // verify :1040-1046
-      tatp_send_prim(c, o, A_VER);
+      tatp_send_new(o, A_VER, T_READ, TB_CF, tatp_cf_key(c, c.start_time));  // verify :1040-1046
       c.step = 4;
       return;
     case 4:
@@ -367,19 +380,20 @@ TX_HD static inline void tatp_emit_del_cf(TatpClient &c, TatpOut &o) {  // TxnDe
 TX_HD static inline void tatp_emit(TatpClient &c, TatpOut &o) {
   switch (c.txn) {
     case TT_GET_SUB:  // TxnGetSubscriberData :177-199
-      if (c.step == 1) { c.m[A_READ] = tatp_mk(T_READ, TB_SUB, c.s_id); tatp_send_prim(c, o, A_READ); c.step = 2; }
+      // the reply is never looked at (the reference only asserts on it, :187-198): it is not kept
+      if (c.step == 1) { tatp_send_new(o, TX_NO_DST, T_READ, TB_SUB, c.s_id); c.step = 2; }
       else tatp_finish(c, o, true);
       return;
     case TT_GET_ACCESS:  // TxnGetAccessData :305-331
-      if (c.step == 1) { c.m[A_READ] = tatp_mk(T_READ, TB_AI, tatp_sf_key(c)); tatp_send_prim(c, o, A_READ); c.step = 2; }
+      if (c.step == 1) { tatp_send_new(o, A_READ, T_READ, TB_AI, tatp_sf_key(c)); c.step = 2; }
       else tatp_finish(c, o, c.m[A_READ].type != T_NOT_EXIST);
       return;
     case TT_GET_NEW_DEST:  // TxnGetNewDestination :202-302
-      if (c.step == 1) { c.m[A_READ] = tatp_mk(T_READ, TB_SF, tatp_sf_key(c)); tatp_send_prim(c, o, A_READ); c.step = 2; return; }
+      if (c.step == 1) { tatp_send_new(o, A_READ, T_READ, TB_SF, tatp_sf_key(c)); c.step = 2; return; }
       if (c.step == 2) {
         if (c.m[A_READ].type == T_NOT_EXIST || c.m[A_READ].val[0] == 0) { tatp_finish(c, o, false); return; }  // :239,244 (is_active)
         const uint32_t n = c.start_time / 8u + 1;                                                              // cf_to_fetch :212
-        for (uint32_t i = 0; i < n; i++) { c.m[TMP0 + i] = tatp_mk(T_READ, TB_CF, tatp_cf_key(c, i * 8)); tatp_send_prim(c, o, (uint8_t)(TMP0 + i)); }
+        for (uint32_t i = 0; i < n; i++) tatp_send_new(o, (uint8_t)(TMP0 + i), T_READ, TB_CF, tatp_cf_key(c, i * 8));
         c.step = 3;
         return;
       }
@@ -458,12 +472,6 @@ TX_HD static inline void sb_get_two_accounts(TxLcg &g, const TxParams &P, uint64
   *b = g.next() % n;
   while (*b == *a && n > 1) *b = g.next() % n;
 }
-TX_HD static inline SbMsg sb_mk(uint8_t type, uint8_t table, uint64_t key) {
-  SbMsg m;
-  memset(&m, 0, sizeof m);
-  m.type = type; m.table = table; m.key = key;
-  return m;
-}
 TX_HD static inline float sb_bal(const SbMsg &m) { float f; memcpy(&f, m.val + 4, 4); return f; }
 TX_HD static inline void sb_set_bal(SbMsg &m, float f) { memcpy(m.val + 4, &f, 4); }
 TX_HD static inline bool sb_granted(const SbMsg &m) { return m.type == S_GRANT_SH || m.type == S_GRANT_EX; }
@@ -474,42 +482,48 @@ TX_HD static inline void sb_begin(SbClient &c, const TxParams &P) {
   c.step = 1;
   c.rel = 0;
   c.n_write = 0;
-  // lock set of each transaction, in the order the reference pushes the messages
+  // lock set of each transaction, in the order the reference pushes the messages (the requests themselves: sb_lock_row)
   switch (c.txn) {
     case ST_AMALGAMATE:  // TxnAmalgamate :169-438: X(sav a0), X(chk a0), X(chk a1)
       sb_get_two_accounts(g, P, &c.a0, &c.a1);
-      c.m[0] = sb_mk(S_ACQ_EX, 0, c.a0); c.m[1] = sb_mk(S_ACQ_EX, 1, c.a0); c.m[2] = sb_mk(S_ACQ_EX, 1, c.a1);
       c.n_rows = 3;
       break;
     case ST_BALANCE:  // TxnBalance :441-578: S(sav), S(chk); read only
       sb_get_account(g, P, &c.a0);
-      c.m[0] = sb_mk(S_ACQ_SH, 0, c.a0); c.m[1] = sb_mk(S_ACQ_SH, 1, c.a0);
       c.n_rows = 2;
       break;
     case ST_DEPOSIT_CHECKING:  // TxnDepositChecking :581-684: X(chk); bal += 1.3
       sb_get_account(g, P, &c.a0);
       c.amount = 1.3f;
-      c.m[0] = sb_mk(S_ACQ_EX, 1, c.a0);
       c.n_rows = 1;
       break;
     case ST_SEND_PAYMENT:  // TxnSendPayment :687-932: X(chk a0), X(chk a1); move 5.0 if funds suffice
       sb_get_two_accounts(g, P, &c.a0, &c.a1);
       c.amount = 5.0f;
-      c.m[0] = sb_mk(S_ACQ_EX, 1, c.a0); c.m[1] = sb_mk(S_ACQ_EX, 1, c.a1);
       c.n_rows = 2;
       break;
     case ST_TRANSACT_SAVING:  // TxnTransactSaving :935-1038: X(sav); bal += 20.20
       sb_get_account(g, P, &c.a0);
       c.amount = 20.20f;
-      c.m[0] = sb_mk(S_ACQ_EX, 0, c.a0);
       c.n_rows = 1;
       break;
     default:  // TxnWriteCheck :1041-1240: S(sav), X(chk); chk -= 5 (+1 penalty when overdrawn)
       sb_get_account(g, P, &c.a0);
       c.amount = 5.0f;
-      c.m[0] = sb_mk(S_ACQ_SH, 0, c.a0); c.m[1] = sb_mk(S_ACQ_EX, 1, c.a0);
       c.n_rows = 2;
       break;
+  }
+}
+
+// row i of the transaction's lock set: {lock type, table (0 savings, 1 checking), account}
+TX_HD static inline void sb_lock_row(const SbClient &c, uint8_t i, uint8_t *type, uint8_t *table, uint64_t *key) {
+  switch (c.txn) {
+    case ST_AMALGAMATE: *type = S_ACQ_EX; *table = i == 0 ? 0 : 1; *key = i == 2 ? c.a1 : c.a0; return;
+    case ST_BALANCE: *type = S_ACQ_SH; *table = i; *key = c.a0; return;
+    case ST_DEPOSIT_CHECKING: *type = S_ACQ_EX; *table = 1; *key = c.a0; return;
+    case ST_SEND_PAYMENT: *type = S_ACQ_EX; *table = 1; *key = i == 0 ? c.a0 : c.a1; return;
+    case ST_TRANSACT_SAVING: *type = S_ACQ_EX; *table = 0; *key = c.a0; return;
+    default: *type = i == 0 ? S_ACQ_SH : S_ACQ_EX; *table = i; *key = c.a0; return;  // WriteCheck
   }
 }
 
@@ -541,7 +555,12 @@ TX_HD static inline void sb_emit(SbClient &c, SbOut &o) {
   for (;;) {
     switch (c.step) {
       case 1:  // acquire every lock of the transaction in one phase
-        for (uint8_t i = 0; i < c.n_rows; i++) o.send((uint32_t)(c.m[i].key % 3), i, c.m[i].type, i);
+        for (uint8_t i = 0; i < c.n_rows; i++) {
+          uint8_t ty, tb;
+          uint64_t ky;
+          sb_lock_row(c, i, &ty, &tb, &ky);
+          o.send_new(ty, tb, ky, i);
+        }
         c.step = 2;
         return;
       case 2: {

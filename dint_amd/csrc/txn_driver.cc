@@ -65,8 +65,8 @@ struct HostDriver final : dint_driver {
     for (uint32_t i = 0; i < c.n_clients; i++) {
       memset(&cl[i], 0, sizeof(Client));
       cl[i].rng.s = 0xdeadbeefull + c.first_client + i;  // ClientLoop :1122
-      cl[i].m.base = &store[(size_t)i * T::NMSG];
-      cl[i].m.stride = 1;
+      cl[i].m.base = (uint8_t *)&store[(size_t)i * T::NMSG];
+      cl[i].m.stride = sizeof(Msg);
     }
   }
   int msg_size() const override { return (int)sizeof(Msg); }
