@@ -26,10 +26,10 @@ static_assert(KV_TB == 1024, "block_hash_insert assumes 2048 slots");
 // Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area; make the pass's log tail
 // current; clear the counters the next pass will use (the big-bin lists and the published log counts alternate
 // between passes, so nothing has to be reset behind the resolve kernel).
-static __global__ void __launch_bounds__(256)
-k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
-          uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
-          dint_dev_stats *__restrict__ stats) {
+__device__ static inline void
+kv_scan_body(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
+             uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
+             dint_dev_stats *__restrict__ stats) {
   __shared__ uint32_t Sw[4];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 4) big_next[t] = 0;
@@ -50,18 +50,29 @@ k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, 
   }
   if (t == 0 && nbig) atomicAdd(&stats->big_bin_requests, (unsigned long long)run + (unsigned long long)nbig * DINT_KV_BINCAP);
 }
+static __global__ void __launch_bounds__(256)
+k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
+          uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
+          dint_dev_stats *__restrict__ stats) {
+  kv_scan_body(bin_cnt, bin_off, big, big_next, blk_pub_next, tail, stats);
+}
 
 // ---- k_kv_place ----------------------------------------------------------------------------------------
 // Overflow records (positions DINT_KV_BINCAP.. of a bin): from the pass's list into their bin's range.
 #define KV_PLACE_GRID 64u
-static __global__ void __launch_bounds__(KV_TB)
-k_kv_place(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off, const uint4 *__restrict__ ovl,
-           uint64_t *__restrict__ ovf) {
+__device__ static inline void
+kv_place_body(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off, const uint4 *__restrict__ ovl,
+              uint64_t *__restrict__ ovf) {
   const uint32_t novl = big[1];
   for (uint32_t i = blockIdx.x * KV_TB + threadIdx.x; i < novl; i += KV_PLACE_GRID * KV_TB) {
     const uint4 o = ovl[i];
     ovf[bin_off[o.z] + o.w - DINT_KV_BINCAP] = ((uint64_t)o.y << 32) | o.x;
   }
+}
+static __global__ void __launch_bounds__(KV_TB)
+k_kv_place(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off, const uint4 *__restrict__ ovl,
+           uint64_t *__restrict__ ovf) {
+  kv_place_body(big, bin_off, ovl, ovf);
 }
 
 // ---- big bins ----------------------------------------------------------------------------------------------

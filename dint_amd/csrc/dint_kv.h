@@ -48,6 +48,19 @@ int64_t dint_kv_read_locks(dint_kv *kv, uint32_t table, uint32_t *a, uint32_t *b
 // `view`: where request i lives (contiguous array, or the segments of a multi-GPU exchange buffer)
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
                     int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view = dint_flat_view());
+// the passes of several engines of one kv workload in one launch set (grid.y = engine), all on one stream: what a
+// closed-loop epoch or an exchange step hands the GPU's shard servers at the same moment (n > 0 for every engine)
+#define DINT_KV_MULTI_MAX 4u
+struct dint_kv_pass {
+  const void *d_req;
+  void *d_rep;
+  uint32_t n;
+  const dint_kv *kv;
+  dint_log log;
+  dint_scratch s;
+  dint_view view;
+};
+void dint_launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st);
 void dint_launch_home_kv(const void *d_req, uint32_t n, const dint_kv &kv, uint8_t *d_home, hipStream_t st);
 // wire message size / field offsets of a kv workload
 struct dint_kv_fmt {

@@ -437,6 +437,60 @@ int dint_submit_segments(dint_engine_t *e, void *d_base, uint32_t n_seg, uint32_
   return 0;
 }
 
+int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items, void *stream) {
+  if (!items || n_items == 0) return fail(DINT_EINVAL, "null argument");
+  for (uint32_t k = 0; k < n_items; k++) {
+    if (!items[k].engine) return fail(DINT_EINVAL, "null engine");
+    for (uint32_t j = 0; j < k; j++)
+      if (items[j].engine == items[k].engine) return fail(DINT_EINVAL, "an engine appears twice");
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : items[0].engine->stream;
+  bool one_set = n_items <= DINT_KV_MULTI_MAX;
+  for (uint32_t k = 0; k < n_items && one_set; k++) {
+    const dint_engine *e = items[k].engine;
+    const uint32_t wl = e->cfg.workload;
+    one_set = (wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) && wl == items[0].engine->cfg.workload &&
+              e->device == items[0].engine->device && items[k].n_seg > 0 && items[k].seg_cap >= 2 &&
+              (uint64_t)items[k].n_seg * items[k].seg_cap <= e->pass_max;
+  }
+  if (!one_set) {
+    for (uint32_t k = 0; k < n_items; k++)
+      if (int rc = dint_submit_segments(items[k].engine, items[k].d_base, items[k].n_seg, items[k].seg_cap, items[k].seg_stride,
+                                        items[k].d_cnt, items[k].cnt_stride, st))
+        return rc;
+    return 0;
+  }
+  std::vector<dint_engine *> es;
+  for (uint32_t k = 0; k < n_items; k++) es.push_back(items[k].engine);
+  std::sort(es.begin(), es.end());
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (dint_engine *e : es) locks.emplace_back(e->mu);  // address order: two calls that share engines cannot deadlock
+  HIP_TRY(hipSetDevice(items[0].engine->device));
+  dint_kv_pass pass[DINT_KV_MULTI_MAX];
+  for (uint32_t k = 0; k < n_items; k++) {
+    const dint_segments_item &it = items[k];
+    dint_engine *e = it.engine;
+    if (!it.d_base || !it.d_cnt) return fail(DINT_EINVAL, "null argument");
+    if (it.seg_stride < (uint64_t)it.seg_cap * e->msg_size) return fail(DINT_EINVAL, "seg_stride smaller than a segment");
+    if (int rc = order_stream(e, st)) return rc;
+    pass[k].d_req = it.d_base; pass[k].d_rep = it.d_base; pass[k].n = it.n_seg * it.seg_cap;
+    pass[k].kv = &e->kv; pass[k].log = e->log; pass[k].s = e->scratch;
+    pass[k].view = dint_seg_view(it.n_seg, it.seg_cap, it.seg_stride, it.d_cnt, it.cnt_stride);
+  }
+  dint_launch_kv_multi(pass, n_items, st);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  for (uint32_t k = 0; k < n_items; k++) {
+    dint_engine *e = items[k].engine;
+    std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
+    std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
+    if (int rc = mark_stream(e, st)) return rc;
+    e->batches++;
+    e->requests += pass[k].n;
+  }
+  return 0;
+}
+
 // ---- host buffers: pipelined H2D / kernels / D2H ---------------------------------------------------------------
 namespace {
 // enqueue chunk [off, off + m) of a host submission; returns its sequence number in *seq

@@ -164,10 +164,11 @@ __device__ static inline kv_reqinfo kv_read_request(const uint8_t *m, bool live,
 // so a hot key costs one device atomic per workgroup, not one per request.  Records at positions below
 // DINT_KV_BINCAP are stored in place; the others are listed for k_kv_place.
 template <int WL>
-__global__ void __launch_bounds__(KV_TB)
-k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
-           kv_cut cut, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
-           uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode, dint_view V) {
+__device__ static inline void
+kv_count_body(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
+              const kv_cut &cut, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
+              uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode,
+              const dint_view &V, uint32_t n_slices) {
   using F = Fmt<WL>;
   __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
   __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
@@ -293,7 +294,7 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
     __syncthreads();
     uint32_t base = 0;
     for (uint32_t w = 0; w < KV_TB / 64; w++) base += Swp[w] + (w < wv ? Swl[w] : 0);
-    if (tile == gridDim.x - 1 && t == 0) {  // the pass's new tail (k_kv_scan makes it current)
+    if (tile == n_slices - 1 && t == 0) {  // the pass's new tail (k_kv_scan makes it current)
       uint32_t total = base;
       for (uint32_t w = 0; w < KV_TB / 64; w++) total += Swl[w];
       log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
@@ -325,6 +326,14 @@ k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_d
       }
     }
   }
+}
+
+template <int WL>
+__global__ void __launch_bounds__(KV_TB)
+k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
+           kv_cut cut, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
+           uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode, dint_view V) {
+  kv_count_body<WL>(req, rep, n, kv, log, cut, bin_cnt, bins, big, ovl, blk_pub, stats, load_mode, V, gridDim.x);
 }
 
 // ---- optional per-wave timeline (DINT_KV_TRACE=1): lane 0 of every resolve wave stamps s_memtime at fixed
@@ -1840,27 +1849,95 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, const kv_cut
 // behind it on the same stream: the two then run one after the other, 67 + 55 us instead of 105 us, and putting the
 // big-bin kernel on a second stream cost more in cross-stream event waits than the overlap gave; see DESIGN.md.)
 template <int WL>
-__global__ void __launch_bounds__(KVB_T, 4)
-k_kv_resolve(uint8_t *rep, uint32_t n, kv_cut cut, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
-             dint_view V) {
+__device__ static inline void
+kv_resolve_body(uint8_t *rep, uint32_t n, const kv_cut &cut, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+                const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+                const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
+                const dint_view &V, uint32_t vb) {  // vb: this workgroup's number among the pass's (blockIdx.x of a single-engine launch)
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
   __syncthreads();
   // tracing: per workgroup {first wave in, last wave out} after the per-bin rows (10 ns ticks)
-  unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
+  unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * vb : nullptr;
   if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
-  if (blockIdx.x < KVB_GRID) {
-    kv_big_bins<WL>(rep, n, cut, &Skv, blockIdx.x, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
+  if (vb < KVB_GRID) {
+    kv_big_bins<WL>(rep, n, cut, &Skv, vb, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
   } else {
-    const uint32_t bin = (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
+    const uint32_t bin = (vb - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
     if (bin < cut.P) kv_small_bin<WL>(rep, cut, &Skv, bin, bin_cnt, bins, stats, force_flags & 1, V, trace);
   }
   if (wg && (threadIdx.x & 63) == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     atomicMax(&wg[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
+}
+
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 4)
+k_kv_resolve(uint8_t *rep, uint32_t n, kv_cut cut, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
+             dint_view V) {
+  kv_resolve_body<WL>(rep, n, cut, kv_g, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, trace, V, blockIdx.x);
+}
+
+// ---- the passes of SEVERAL engines in one launch set (grid.y = engine) ------------------------------------------
+// A closed-loop epoch (and a step of the multi-GPU exchange) hands every shard server of the GPU one batch at the same
+// moment.  On three streams that is a fork and a join per epoch -- two cross-stream dependencies of ~20 us each on the
+// critical path; with the engines' kernels side by side in one grid the epoch is one stream: count -> scan -> place ->
+// resolve, every launch covering all engines.  The engines stay independent (own tables, own scratch, own log).
+struct kv_pass_args {
+  const uint8_t *req;
+  uint8_t *rep;
+  uint32_t n, n_slices;
+  const kv_dev *kv;
+  dint_log log;
+  kv_cut cut;
+  uint32_t *bin_cnt;
+  uint64_t *bins;
+  uint32_t *big, *big_next, *bin_off, *blk_pub, *blk_pub_next;
+  uint4 *ovl;
+  uint64_t *ovf;
+  dint_dev_stats *stats;
+  uint64_t *trace;
+  int load_mode, force_flags;
+  uint32_t has_log, resolve_blocks;
+  dint_view V;
+};
+struct kv_multi_args { kv_pass_args e[DINT_KV_MULTI_MAX]; };
+
+template <int WL>
+__global__ void __launch_bounds__(KV_TB) k_kv_count_multi(kv_multi_args M) {
+  const kv_pass_args &A = M.e[blockIdx.y];
+  if (blockIdx.x >= A.n_slices) return;
+  kv_count_body<WL>(A.req, A.rep, A.n, A.kv, A.log, A.cut, A.bin_cnt, A.bins, A.big, A.ovl, A.blk_pub, A.stats, A.load_mode, A.V,
+                    A.n_slices);
+}
+static __global__ void __launch_bounds__(256) k_kv_scan_multi(kv_multi_args M) {
+  const kv_pass_args &A = M.e[blockIdx.y];
+  kv_scan_body(A.bin_cnt, A.bin_off, A.big, A.big_next, A.blk_pub_next, A.has_log ? A.log.tail : nullptr, A.stats);
+}
+static __global__ void __launch_bounds__(KV_TB) k_kv_place_multi(kv_multi_args M) {
+  const kv_pass_args &A = M.e[blockIdx.y];
+  kv_place_body(A.big, A.bin_off, A.ovl, A.ovf);
+}
+// One-dimensional grid, the big-bin workgroups of ALL engines first (workgroups are dispatched in index order, and a hot
+// bin's workgroup is the longest job of the launch: with grid.y = engine the last engine's hot bins started when the
+// first engines' small bins had been handed out, 154 us against ~100 for the three passes), then the engines' small bins.
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve_multi(kv_multi_args M, uint32_t n_eng) {
+  uint32_t e, vb;
+  if (blockIdx.x < n_eng * KVB_GRID) {
+    e = blockIdx.x % n_eng;
+    vb = blockIdx.x / n_eng;
+  } else {
+    uint32_t b = blockIdx.x - n_eng * KVB_GRID;
+    e = 0;
+    while (e + 1 < n_eng && b >= M.e[e].resolve_blocks - KVB_GRID) { b -= M.e[e].resolve_blocks - KVB_GRID; e++; }
+    vb = KVB_GRID + b;
+  }
+  const kv_pass_args &A = M.e[e];
+  kv_resolve_body<WL>(A.rep, A.n, A.cut, A.kv, A.bin_cnt, A.bins, A.big, A.bin_off, A.ovf, A.stats, A.force_flags, A.trace, A.V, vb);
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
@@ -1896,6 +1973,42 @@ void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &k
     case DINT_WL_STORE: launch_kv<DINT_WL_STORE>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
     case DINT_WL_TATP: launch_kv<DINT_WL_TATP>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
     default: launch_kv<DINT_WL_SMALLBANK>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
+  }
+}
+
+template <int WL>
+static void launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st) {
+  static const uint32_t bin_load = dint_hot_min("DINT_KV_BIN_LOAD", 32);
+  kv_multi_args M;
+  memset(&M, 0, sizeof M);
+  uint32_t max_slices = 0, sum_resolve = 0;
+  for (uint32_t k = 0; k < n_eng; k++) {
+    kv_pass_args &A = M.e[k];
+    const dint_kv_pass &q = p[k];
+    const uint32_t P = dint_pick_bins_load(q.n, bin_load);
+    A.req = (const uint8_t *)q.d_req; A.rep = (uint8_t *)q.d_rep; A.n = q.n; A.n_slices = (q.n + KV_TB - 1) / KV_TB;
+    A.kv = q.kv->d_dev; A.log = q.log; A.cut = kv_make_cut(P, q.n);
+    A.bin_cnt = q.s.bin_cnt; A.bins = q.s.bins; A.big = q.s.big; A.big_next = q.s.big_next; A.bin_off = q.s.bin_off;
+    A.blk_pub = q.s.blk_pub; A.blk_pub_next = q.s.blk_pub_next; A.ovl = q.s.ovl; A.ovf = q.s.ovf; A.stats = q.s.stats;
+    A.trace = nullptr; A.load_mode = 0;  // (the per-workgroup trace rows are numbered for single-engine launches)
+    A.force_flags = q.kv->force_rounds | (int)(dint_hot_min("DINT_KV_HOT_MIN", 0) << 8);
+    A.has_log = WL != DINT_WL_STORE; A.resolve_blocks = KVB_GRID + (P + KVB_W - 1) / KVB_W; A.V = q.view;
+    max_slices = std::max(max_slices, A.n_slices);
+    sum_resolve += A.resolve_blocks;
+  }
+  hipLaunchKernelGGL((k_kv_count_multi<WL>), dim3(max_slices, n_eng), dim3(KV_TB), 0, st, M);
+  hipLaunchKernelGGL(k_kv_scan_multi, dim3(1, n_eng), dim3(256), 0, st, M);
+  hipLaunchKernelGGL(k_kv_place_multi, dim3(KV_PLACE_GRID, n_eng), dim3(KV_TB), 0, st, M);
+  hipLaunchKernelGGL((k_kv_resolve_multi<WL>), dim3(sum_resolve), dim3(KVB_T), 0, st, M, n_eng);
+}
+
+// one pass of each of n_eng (<= DINT_KV_MULTI_MAX) engines of ONE kv workload, all on stream st
+void dint_launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st) {
+  if (n_eng == 0) return;
+  switch (p[0].kv->workload) {
+    case DINT_WL_STORE: launch_kv_multi<DINT_WL_STORE>(p, n_eng, st); break;
+    case DINT_WL_TATP: launch_kv_multi<DINT_WL_TATP>(p, n_eng, st); break;
+    default: launch_kv_multi<DINT_WL_SMALLBANK>(p, n_eng, st); break;
   }
 }
 

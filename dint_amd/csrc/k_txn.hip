@@ -13,7 +13,12 @@
 //                   + a decoupled look-back over the workgroups before mine, which are handed out by ticket and
 //                   publish their totals first thing, their inclusive prefixes as soon as they know them) + msg.ord.  The last workgroup writes the three batch sizes
 //                   for the engines (dint_submit_segments reads them on the device: no host round trip).
-//   k_txn_consume : every client copies the replies it waits for out of the (in place) reply arrays.
+//   k_txn_consume : every client copies the replies it waits for out of the (in place) reply arrays.  When consume
+//                   and the next emit are issued on the same stream (the closed loop does) the copy is FUSED into
+//                   k_txn_emit instead: the epoch's batches alternate between two buffer sets, so a client reads the
+//                   replies of epoch k from one set while the requests of epoch k+1 are written into the other -- one
+//                   kernel and one header load per epoch less, and the phase logic reads the replies it has just
+//                   copied while they are still in cache.
 #include <hip/hip_runtime.h>
 
 #include <new>
@@ -39,7 +44,8 @@ void dint_driver_params(const dint_driver_config &c, TxParams *P, ZipfTable *zip
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
 k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
-           uint8_t *out2, uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t *counts, txg_stats *st, uint32_t dbg) {
+           uint8_t *out2, const uint8_t *rep0, const uint8_t *rep1, const uint8_t *rep2, uint32_t cap, uint32_t *pub,
+           uint32_t *ticket, uint32_t *pub_other, uint32_t *ticket_other, uint32_t *counts, txg_stats *st, uint32_t dbg) {
   typedef typename T::Msg Msg;
   __shared__ uint32_t Stile, Sw[3][TXG_TB / 64], Sbase[3];
   __shared__ unsigned long long Sst[TXG_NSTAT];
@@ -49,6 +55,10 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
   __syncthreads();
   const uint32_t tile = Stile, i = tile * TXG_TB + t, ntiles = gridDim.x;
   const bool valid = i < n_clients;
+  // the look-back words and the ticket alternate between two sets: leave the other set clean for the next epoch (the
+  // kernel that used it has finished: same stream)
+  if (t < 4) pub_other[tile * 4 + t] = 0;
+  if (tile == 0 && t == 0) *ticket_other = 0;
 
   // the client's header travels through registers: one coalesced 72 / 112-byte load here, one store at the end; the
   // working messages stay in memory and are touched only where the phase reads or writes them
@@ -61,6 +71,15 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
     c = cl[i];
     c.m.base = store + (size_t)i * TX_DEV_MSG_STRIDE;  // message k of every client is one array of sectors (TxMsgs)
     c.m.stride = (uint64_t)n_clients * TX_DEV_MSG_STRIDE;
+    if (rep0) {  // fused consume: the replies of the previous epoch (the other buffer set), then the phase that reads them
+      const uint8_t *reps[3] = {rep0, rep1, rep2};
+      const uint8_t n = c.n_out;
+      for (uint8_t k = 0; k < n; k++) {
+        const uint8_t d = c.out_dst[k];
+        const uint32_t pos = c.out_pos[k];
+        if (d != TX_NO_DST && pos < cap) c.m[d] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
+      }
+    }
     if (!(dbg & 2)) T::run(c, P, o);
   }
   uint32_t nmsg[3] = {0, 0, 0};
@@ -151,12 +170,9 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
 k_txn_consume(const typename T::Client *cl, uint8_t *store, uint32_t n_clients, const uint8_t *rep0,
-              const uint8_t *rep1, const uint8_t *rep2, uint32_t cap, uint32_t *pub, uint32_t *ticket, uint32_t ntiles) {
+              const uint8_t *rep1, const uint8_t *rep2, uint32_t cap) {
   typedef typename T::Msg Msg;
   const uint32_t i = blockIdx.x * TXG_TB + threadIdx.x;
-  // leave the look-back words clean for the next emit (nothing else runs between consume and the next emit)
-  if (i < ntiles * 4) pub[i] = 0;
-  if (i == 0) *ticket = 0;
   if (i >= n_clients) return;
   const uint8_t *reps[3] = {rep0, rep1, rep2};
   const typename T::Client c = cl[i];
@@ -176,9 +192,15 @@ struct dint_gdriver {
   int device = 0;
   uint32_t cap = 0, ntiles = 0, msg = 0;
   bool awaiting = false;
+  bool fuse = true;            // DINT_TXN_FUSE=0: consume always in its own kernel
+  bool pending = false;        // a consume deferred into the next emit ...
+  hipStream_t pending_stream = nullptr;  // ... which was issued on this stream
+  hipStream_t next_stream = nullptr;     // stream of the last dint_gdriver_next
+  hipEvent_t ev_pending = nullptr;
+  uint32_t cur = 0;            // buffer set of the current epoch (the sets alternate)
   uint64_t epochs = 0;
   void *d_clients = nullptr, *d_store = nullptr;
-  uint8_t *d_batch[DINT_N_SHARDS] = {nullptr, nullptr, nullptr};
+  uint8_t *d_batch[2][DINT_N_SHARDS] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   uint32_t *d_counts = nullptr, *d_pub = nullptr, *d_ticket = nullptr, *d_zipf = nullptr;
   txg_stats *d_stats = nullptr;
   TxParams P{};
@@ -202,6 +224,23 @@ int upload_clients(dint_gdriver *g) {
 }
 }  // namespace
 
+namespace {
+template <class T>
+void launch_consume(dint_gdriver *g, hipStream_t st, uint32_t set) {
+  hipLaunchKernelGGL((k_txn_consume<T>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const typename T::Client *)g->d_clients,
+                     (uint8_t *)g->d_store, g->cfg.n_clients, g->d_batch[set][0], g->d_batch[set][1], g->d_batch[set][2], g->cap);
+}
+template <class T>
+void launch_emit(dint_gdriver *g, hipStream_t st, bool fused) {
+  const uint32_t b = g->cur, o = b ^ 1u;  // requests go into set b; the replies of the previous epoch sit in set o
+  hipLaunchKernelGGL((k_txn_emit<T>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (typename T::Client *)g->d_clients,
+                     (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[b][0], g->d_batch[b][1], g->d_batch[b][2],
+                     fused ? g->d_batch[o][0] : nullptr, fused ? g->d_batch[o][1] : nullptr, fused ? g->d_batch[o][2] : nullptr,
+                     g->cap, g->d_pub + (size_t)b * g->ntiles * 4, g->d_ticket + b, g->d_pub + (size_t)o * g->ntiles * 4,
+                     g->d_ticket + o, g->d_counts, g->d_stats, g->dbg);
+}
+}  // namespace
+
 extern "C" {
 
 int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t cap_per_shard, dint_gdriver_t **out) {
@@ -220,6 +259,7 @@ int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t 
   g->msg = cfg->workload == DINT_WL_TATP ? 55 : 23;
   g->ntiles = (cfg->n_clients + TXG_TB - 1) / TXG_TB;
   if (getenv("DINT_TXN_DBG")) g->dbg = (uint32_t)atoi(getenv("DINT_TXN_DBG"));
+  if (getenv("DINT_TXN_FUSE")) g->fuse = atoi(getenv("DINT_TXN_FUSE")) != 0;
   int rc = 0;
   try {
     ZipfTable zipf;
@@ -233,14 +273,16 @@ int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t 
   } catch (const std::bad_alloc &) {
     rc = DINT_ENOMEM;
   }
-  for (int s = 0; s < DINT_N_SHARDS && !rc; s++)
-    if (hipMalloc((void **)&g->d_batch[s], (size_t)g->cap * g->msg + 64) != hipSuccess) rc = DINT_ENOMEM;
-  if (!rc && (hipMalloc((void **)&g->d_counts, 16) != hipSuccess || hipMalloc((void **)&g->d_ticket, 4) != hipSuccess ||
-              hipMalloc((void **)&g->d_pub, (size_t)g->ntiles * 16) != hipSuccess ||
+  for (int b = 0; b < 2 && !rc; b++)
+    for (int s = 0; s < DINT_N_SHARDS && !rc; s++)
+      if (hipMalloc((void **)&g->d_batch[b][s], (size_t)g->cap * g->msg + 64) != hipSuccess) rc = DINT_ENOMEM;
+  if (!rc && hipEventCreateWithFlags(&g->ev_pending, hipEventDisableTiming) != hipSuccess) rc = DINT_EHIP;
+  if (!rc && (hipMalloc((void **)&g->d_counts, 16) != hipSuccess || hipMalloc((void **)&g->d_ticket, 8) != hipSuccess ||
+              hipMalloc((void **)&g->d_pub, (size_t)g->ntiles * 32) != hipSuccess ||
               hipMalloc((void **)&g->d_stats, sizeof(txg_stats)) != hipSuccess))
     rc = DINT_ENOMEM;
-  if (!rc && (hipMemset(g->d_counts, 0, 16) != hipSuccess || hipMemset(g->d_ticket, 0, 4) != hipSuccess ||
-              hipMemset(g->d_pub, 0, (size_t)g->ntiles * 16) != hipSuccess ||
+  if (!rc && (hipMemset(g->d_counts, 0, 16) != hipSuccess || hipMemset(g->d_ticket, 0, 8) != hipSuccess ||
+              hipMemset(g->d_pub, 0, (size_t)g->ntiles * 32) != hipSuccess ||
               hipMemset(g->d_stats, 0, sizeof(txg_stats)) != hipSuccess || hipDeviceSynchronize() != hipSuccess))
     rc = DINT_EHIP;
   if (rc) {
@@ -257,7 +299,9 @@ void dint_gdriver_destroy(dint_gdriver_t *g) {
   hipDeviceSynchronize();
   hipFree(g->d_clients);
   hipFree(g->d_store);
-  for (auto p : g->d_batch) hipFree(p);
+  for (auto &b : g->d_batch)
+    for (auto p : b) hipFree(p);
+  if (g->ev_pending) hipEventDestroy(g->ev_pending);
   hipFree(g->d_counts); hipFree(g->d_pub); hipFree(g->d_ticket); hipFree(g->d_zipf); hipFree(g->d_stats);
   delete g;
 }
@@ -267,37 +311,48 @@ int dint_gdriver_next(dint_gdriver_t *g, void *stream) {
   if (g->awaiting) return DINT_ESTATE;
   if (hipSetDevice(g->device) != hipSuccess) return DINT_EHIP;
   hipStream_t st = (hipStream_t)stream;
-  if (g->cfg.workload == DINT_WL_TATP)
-    hipLaunchKernelGGL((k_txn_emit<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (TatpClient *)g->d_clients,
-                       (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
-                       g->d_counts, g->d_stats, g->dbg);
-  else
-    hipLaunchKernelGGL((k_txn_emit<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (SbClient *)g->d_clients,
-                       (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket,
-                       g->d_counts, g->d_stats, g->dbg);
+  const bool tatp = g->cfg.workload == DINT_WL_TATP;
+  bool fused = false;
+  if (g->pending) {
+    if (st == g->pending_stream) {
+      fused = true;  // the replies are copied by the emit kernel itself
+    } else {  // consume was promised on another stream: run it there, and this stream behind it
+      if (tatp) launch_consume<TatpTraits>(g, g->pending_stream, g->cur); else launch_consume<SbTraits>(g, g->pending_stream, g->cur);
+      if (hipEventRecord(g->ev_pending, g->pending_stream) != hipSuccess || hipStreamWaitEvent(st, g->ev_pending, 0) != hipSuccess)
+        return DINT_EHIP;
+    }
+    g->pending = false;
+  }
+  g->cur ^= 1u;
+  if (tatp) launch_emit<TatpTraits>(g, st, fused); else launch_emit<SbTraits>(g, st, fused);
   if (hipGetLastError() != hipSuccess) return DINT_EHIP;
+  g->next_stream = st;
   g->awaiting = true;
   g->epochs++;
   return 0;
 }
 
+// The replies are in place in the current batches.  Issued on the stream of the last dint_gdriver_next (the closed
+// loop), the copy is deferred into the next emit kernel; the stream must then still exist at the next
+// dint_gdriver_next.  On any other stream (or with DINT_TXN_FUSE=0) it runs now, in a kernel of its own.
 int dint_gdriver_consume(dint_gdriver_t *g, void *stream) {
   if (!g) return DINT_EINVAL;
   if (!g->awaiting) return DINT_ESTATE;
   if (hipSetDevice(g->device) != hipSuccess) return DINT_EHIP;
   hipStream_t st = (hipStream_t)stream;
-  if (g->cfg.workload == DINT_WL_TATP)
-    hipLaunchKernelGGL((k_txn_consume<TatpTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const TatpClient *)g->d_clients,
-                       (uint8_t *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
-  else
-    hipLaunchKernelGGL((k_txn_consume<SbTraits>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const SbClient *)g->d_clients,
-                       (uint8_t *)g->d_store, g->cfg.n_clients, g->d_batch[0], g->d_batch[1], g->d_batch[2], g->cap, g->d_pub, g->d_ticket, g->ntiles);
-  if (hipGetLastError() != hipSuccess) return DINT_EHIP;
+  if (g->fuse && st == g->next_stream) {
+    g->pending = true;
+    g->pending_stream = st;
+  } else {
+    if (g->cfg.workload == DINT_WL_TATP) launch_consume<TatpTraits>(g, st, g->cur); else launch_consume<SbTraits>(g, st, g->cur);
+    if (hipGetLastError() != hipSuccess) return DINT_EHIP;
+  }
   g->awaiting = false;
   return 0;
 }
 
-void *dint_gdriver_batch(dint_gdriver_t *g, uint32_t shard) { return (g && shard < DINT_N_SHARDS) ? g->d_batch[shard] : nullptr; }
+// the CURRENT epoch's batch of a shard: the two buffer sets alternate, ask again after every dint_gdriver_next
+void *dint_gdriver_batch(dint_gdriver_t *g, uint32_t shard) { return (g && shard < DINT_N_SHARDS) ? g->d_batch[g->cur][shard] : nullptr; }
 const void *dint_gdriver_counts(dint_gdriver_t *g) { return g ? g->d_counts : nullptr; }
 uint32_t dint_gdriver_cap(const dint_gdriver_t *g) { return g ? g->cap : 0; }
 
@@ -307,7 +362,7 @@ int64_t dint_gdriver_read_batch(dint_gdriver_t *g, uint32_t shard, void *host, u
   uint32_t cnt[3];
   if (hipMemcpy(cnt, g->d_counts, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) return DINT_EHIP;
   const uint64_t n = cnt[shard] < cap_msgs ? cnt[shard] : cap_msgs;
-  if (host && n && hipMemcpy(host, g->d_batch[shard], n * g->msg, hipMemcpyDeviceToHost) != hipSuccess) return DINT_EHIP;
+  if (host && n && hipMemcpy(host, g->d_batch[g->cur][shard], n * g->msg, hipMemcpyDeviceToHost) != hipSuccess) return DINT_EHIP;
   return (int64_t)cnt[shard];
 }
 

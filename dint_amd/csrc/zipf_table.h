@@ -13,12 +13,18 @@
 
 #include <vector>
 
+// The table carries a coarse index behind the thresholds (cdf[n + b] = sample(b << 20) before the scatter, b = 0 ..
+// 4095, and cdf[n + 4096] = n - 1): a lookup brackets its binary search with two adjacent index words -- 8-10 dependent
+// loads over a 1M-row table instead of 20 (the GPU-resident clients draw a key per new transaction, a dependent chain
+// per lane).  The bracket contains the answer, so the result is the plain binary search's.
+#define ZIPF_IDX_BITS 12
+#define ZIPF_IDX_N ((1u << ZIPF_IDX_BITS) + 1u)
 struct ZipfTable {
-  std::vector<uint32_t> cdf;
+  std::vector<uint32_t> cdf;  // n thresholds, then ZIPF_IDX_N index words
   uint64_t n = 0;
   void init(uint64_t n_, double theta) {
     n = n_ ? n_ : 1;
-    cdf.resize(n);
+    cdf.assign(n + ZIPF_IDX_N, 0);
     double z = 0;
     for (uint64_t k = 1; k <= n; k++) z += pow((double)k, -theta);
     double run = 0;
@@ -28,15 +34,23 @@ struct ZipfTable {
       cdf[k] = c >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)c;
     }
     cdf[n - 1] = 0xFFFFFFFFu;
+    uint64_t k = 0;  // index: the smallest k with cdf[k] > b << 20, for ascending b
+    for (uint32_t b = 0; b < (1u << ZIPF_IDX_BITS); b++) {
+      const uint32_t x = b << (32 - ZIPF_IDX_BITS);
+      while (k < n - 1 && cdf[k] <= x) k++;
+      cdf[n + b] = (uint32_t)k;
+    }
+    cdf[n + (1u << ZIPF_IDX_BITS)] = (uint32_t)(n - 1);
   }
 };
 
-// the lookup, shared by host and device code (cdf = table of n thresholds)
+// the lookup, shared by host and device code (cdf = table of n thresholds + the index)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 static inline uint64_t zipf_lookup(const uint32_t *cdf, uint64_t n, uint32_t x) {
-  uint64_t lo = 0, hi = n - 1;  // the answer is in [lo, hi]; cdf[n-1] = 2^32-1 catches x = 2^32-1 as well
+  const uint32_t b = x >> (32 - ZIPF_IDX_BITS);
+  uint64_t lo = cdf[n + b], hi = cdf[n + b + 1];  // the answer is in [lo, hi]; cdf[n-1] = 2^32-1 catches x = 2^32-1 as well
   while (lo < hi) {
     const uint64_t mid = (lo + hi) >> 1;
     if (cdf[mid] > x) hi = mid; else lo = mid + 1;

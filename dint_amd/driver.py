@@ -94,9 +94,10 @@ class Driver:
 
 class GpuDriver:
     """The same closed-loop clients resident on the GPU (csrc/k_txn.hip, include/dint_driver.h dint_gdriver_*):
-    ``next(stream)`` emits the epoch's three request batches into device arrays (``batch(s)``, live sizes at
-    ``counts_ptr``), the shard servers answer in place, ``consume(stream)`` feeds the replies back.  The request
-    stream is bit-identical to :class:`Driver`'s."""
+    ``next(stream)`` emits the epoch's three request batches into device arrays (``batch_ptr[s]``, refreshed by every
+    ``next``; live sizes at ``counts_ptr``), the shard servers answer in place, ``consume(stream)`` feeds the replies
+    back (on the stream of ``next``: fused into the next emit kernel).  The request stream is bit-identical to
+    :class:`Driver`'s."""
 
     def __init__(self, workload: Workload, n_clients: int, n_rows: int, cap: int, *, first_client: int = 0,
                  zipf_theta: float | None = None, device: int = -1):
@@ -134,6 +135,8 @@ class GpuDriver:
         rc = self._L.dint_gdriver_next(self._h, stream)
         if rc:
             raise _lib.DintError(f"dint_gdriver_next failed: {rc}")
+        # the epoch's batches alternate between two buffer sets (replies of epoch k are read while epoch k+1 is written)
+        self.batch_ptr = [self._L.dint_gdriver_batch(self._h, s) for s in range(N_SHARDS)]
 
     def consume(self, stream: int = 0):
         rc = self._L.dint_gdriver_consume(self._h, stream)

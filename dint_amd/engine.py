@@ -199,6 +199,15 @@ class Engine:
         return {names[i].decode(): {"avg_us": us[i], "launches": cnt[i]} for i in range(k)}
 
 
+def submit_segments_multi(engines, d_bases, n_seg: int, seg_caps, seg_stride: int, d_cnts, cnt_stride: int, stream: int = 0):
+    """dint_submit_segments_multi: engine k answers its n_seg segments at d_bases[k] in place; the engines' kernels run
+    side by side in ONE set of launches on ONE stream (no fork / join across the engines' streams)"""
+    items = (_lib.SegmentsItem * len(engines))()
+    for k, e in enumerate(engines):
+        items[k] = _lib.SegmentsItem(e._h, _ptr(d_bases[k]), n_seg, seg_caps[k], seg_stride, _ptr(d_cnts[k]), cnt_stride)
+    _lib.check(engines[0]._L.dint_submit_segments_multi(items, len(engines), stream))
+
+
 def route_pack_multi(engines, d_reqs, counts, d_slots, seg_caps, seg_stride: int, d_cnts, cnt_stride: int, d_slot,
                      stream: int = 0, d_n=None) -> None:
     """dint_route_pack_multi: batch k (engine k's hash / modulus) into its slot d_slots[k] of every peer chunk, one set

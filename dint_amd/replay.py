@@ -12,13 +12,14 @@ which is what bench.py times (inputs resident in HBM when the timed region start
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
 import torch
 
 from .driver import N_SHARDS, Driver
-from .engine import Engine
+from .engine import Engine, submit_segments_multi
 from .sharded import Router
 from .wire import Workload
 
@@ -166,6 +167,10 @@ class GpuLoop:
         self.streams = [torch.cuda.Stream() for _ in self.ds]
         self.stream = self.streams[0]
         self.msg = group.msg
+        # one client group: the servers' kernels go on the clients' stream, all engines per launch
+        # (dint_submit_segments_multi).  Several groups take turns on streams of their own and overlap through the
+        # engines' streams.  DINT_LOOP_STREAMS=1 forces the per-engine streams (A/B runs).
+        self.one_stream = len(self.ds) == 1 and os.environ.get("DINT_LOOP_STREAMS", "0") != "1"
 
     def epochs(self, n: int) -> None:
         msg, rt = self.msg, self.g.router
@@ -173,7 +178,11 @@ class GpuLoop:
             for d, st in zip(self.ds, self.streams):
                 xs, cap = st.cuda_stream, d.cap
                 d.next(xs)
-                if rt is None:
+                if rt is None and self.one_stream:
+                    # the three servers' passes in one set of launches on the clients' stream: no fork / join at all
+                    submit_segments_multi(self.g.engines, d.batch_ptr, 1, [cap] * N_SHARDS, cap * msg,
+                                          [d.counts_ptr + 4 * s for s in range(N_SHARDS)], 0, xs)
+                elif rt is None:
                     for s, e in enumerate(self.g.engines):
                         e.stream_wait(xs)
                         e.submit_segments(d.batch_ptr[s], 1, cap, cap * msg, d.counts_ptr + 4 * s, 0)

@@ -30,6 +30,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .wire import Workload
+
 HDR = 64  # bytes of the chunk header: u32 live count of each server's slot
 
 
@@ -163,6 +165,14 @@ class Router:
         b = k % self.NBUF
         rp = self.recv[b].data_ptr()
         done = []
+        if self._one_set():  # all home engines in one set of launches on the first engine's stream
+            from .engine import submit_segments_multi
+            self.estream[0].wait_event(ev_fwd)
+            submit_segments_multi(self.engines, [rp + self.off[s] for s in range(self.S)], self.world, self.caps, self.chunk,
+                                  [rp + 4 * s for s in range(self.S)], self.chunk, self.estream[0].cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(self.estream[0])
+            return [ev]
         for s, e in enumerate(self.engines):
             if self.estream is not None:
                 self.estream[s].wait_event(ev_fwd)
@@ -172,6 +182,14 @@ class Router:
                 ev.record(self.estream[s])
                 done.append(ev)
         return done
+
+    def _one_set(self) -> bool:
+        """the S home engines' passes as one launch set (dint_submit_segments_multi): kv engines whose W segments fit one
+        kernel pass.  DINT_ROUTER_STREAMS=1 keeps one stream per engine (A/B runs)."""
+        if self.estream is None or self.S < 2 or self.S > 4 or os.environ.get("DINT_ROUTER_STREAMS", "0") == "1":
+            return False
+        kv = (int(Workload.STORE), int(Workload.TATP), int(Workload.SMALLBANK))
+        return all(int(getattr(e, "workload", -1)) in kv and self.world * c <= e.pass_max for e, c in zip(self.engines, self.caps))
 
     def _backward(self, k: int, ev_done, d_reqs, counts, d_reps, d_n=None):
         b = k % self.NBUF

@@ -267,6 +267,22 @@ int dint_route_unpack_multi(const dint_route_item *items, uint32_t n_items, uint
  * segments: seg_cap <= max_pass). */
 int dint_submit_segments(dint_engine_t *e, void *d_base, uint32_t n_seg, uint32_t seg_cap, uint64_t seg_stride,
                          const void *d_cnt, uint64_t cnt_stride, void *stream);
+/* (round 3; the config layout and DINT_ABI_VERSION are unchanged) the segments of SEVERAL engines (the shard servers of one GPU: same workload -- store, tatp or smallbank --
+ * same device) answered by ONE set of kernel launches on ONE stream, the engines' kernels side by side in one grid.  A
+ * closed-loop epoch or an exchange step hands every server its batch at the same moment; with one stream per engine that
+ * is a fork and a join across streams per step, with this call it is four launches on the caller's stream (NULL: the
+ * first engine's).  Each engine's history is what dint_submit_segments would have produced.  Batches that do not fit one
+ * kernel pass (n_seg * seg_cap > max_pass), lock / log engines and more than 4 items fall back to one
+ * dint_submit_segments per item on that stream. */
+typedef struct dint_segments_item {
+  dint_engine_t *engine;
+  void *d_base;
+  uint32_t n_seg, seg_cap;
+  uint64_t seg_stride;
+  const void *d_cnt;
+  uint64_t cnt_stride;
+} dint_segments_item;
+int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items, void *stream);
 /* d_home[i] = home shard (0..shard_count-1) of d_reqs[i], computed on the GPU with the
  * same hash/modulus the engine uses; 0xFF for requests that have no home (bad table). */
 int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d_home, void *stream);

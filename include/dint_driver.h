@@ -72,14 +72,17 @@ int dint_driver_get_stats(const dint_driver_t *d, dint_driver_stats *out);
  * host driver (tests compare the two streams) -- and writes the three batch sizes to device memory;
  * the shard servers answer IN PLACE (dint_submit_segments(engine_s, dint_gdriver_batch(d, s), 1, cap, cap * msg,
  * counts + s, 0, stream): one segment whose live count the engine reads on the device); dint_gdriver_consume
- * launches the kernel in which every client picks up its replies.  Nothing crosses PCIe.  `cap_per_shard` = slots of
- * each batch array; messages beyond it are dropped and counted (overflow: size it ~1.3x the expected batch). */
+ * makes every client pick up its replies -- in a kernel of its own, or, when it is issued on the stream of the last
+ * dint_gdriver_next (the closed loop), fused into the next emit kernel: the epoch's batches alternate between two buffer
+ * sets, so ask dint_gdriver_batch again after every dint_gdriver_next, and keep that stream alive until then.
+ * Nothing crosses PCIe.  `cap_per_shard` = slots of each batch array; messages beyond it are dropped and counted
+ * (overflow: size it ~1.3x the expected batch). */
 typedef struct dint_gdriver dint_gdriver_t;
 int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t cap_per_shard, dint_gdriver_t **out);
 void dint_gdriver_destroy(dint_gdriver_t *g);
 int dint_gdriver_next(dint_gdriver_t *g, void *stream);     /* must alternate with dint_gdriver_consume */
 int dint_gdriver_consume(dint_gdriver_t *g, void *stream);
-void *dint_gdriver_batch(dint_gdriver_t *g, uint32_t shard);  /* device pointer: cap_per_shard message slots */
+void *dint_gdriver_batch(dint_gdriver_t *g, uint32_t shard);  /* device pointer: the CURRENT epoch's cap_per_shard message slots */
 const void *dint_gdriver_counts(dint_gdriver_t *g);           /* device pointer: uint32_t[3] live messages per shard */
 uint32_t dint_gdriver_cap(const dint_gdriver_t *g);
 /* tests / debugging: synchronise and copy the current batch of `shard` to the host; returns its message count */

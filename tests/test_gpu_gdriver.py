@@ -13,12 +13,17 @@ pytestmark = pytest.mark.gpu
 W = wire.Workload
 
 
-@pytest.mark.parametrize("wl,n_rows,clients,zipf,epochs", [
-    (W.TATP, 20_000, 6000, 0.8, 100), (W.TATP, 3000, 5000, None, 100), (W.TATP, 1_000_000, 70_000, 0.8, 40),
-    (W.SMALLBANK, 50_000, 4000, 0.99 - 1e-9, 100), (W.SMALLBANK, 600_000, 5000, None, 100),
+@pytest.mark.parametrize("wl,n_rows,clients,zipf,epochs,fuse", [
+    (W.TATP, 20_000, 6000, 0.8, 100, 1), (W.TATP, 3000, 5000, None, 100, 1), (W.TATP, 1_000_000, 70_000, 0.8, 40, 1),
+    (W.SMALLBANK, 50_000, 4000, 0.99 - 1e-9, 100, 1), (W.SMALLBANK, 600_000, 5000, None, 100, 1),
+    (W.TATP, 20_000, 6000, 0.8, 60, 0), (W.SMALLBANK, 50_000, 4000, 0.99 - 1e-9, 60, 0),
 ])
-def test_gpu_driver_stream_is_bit_identical_to_the_host_driver(wl, n_rows, clients, zipf, epochs):
+def test_gpu_driver_stream_is_bit_identical_to_the_host_driver(wl, n_rows, clients, zipf, epochs, fuse, monkeypatch):
+    """fuse = 1: consume on the stream of next() is deferred into the next emit kernel (the batches alternate between
+    two buffer sets); fuse = 0 (DINT_TXN_FUSE=0): consume in a kernel of its own"""
     from dint_amd.replay import GpuLoop, ShardGroup
+
+    monkeypatch.setenv("DINT_TXN_FUSE", str(fuse))
 
     ga = ShardGroup(wl, n_rows, log_entries=400_000)   # served to the host driver
     gb = ShardGroup(wl, n_rows, log_entries=400_000)   # served to the GPU driver

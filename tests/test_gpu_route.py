@@ -201,6 +201,70 @@ def test_submit_segments_equals_contiguous(wl, cuts, cap):
         assert all((x == y).all() for x, y in zip(a.read_locks(), b.read_locks()))
 
 
+@pytest.mark.parametrize("wl", ["tatp", "smallbank", "fasst"])
+def test_submit_segments_multi_equals_one_call_per_engine(wl):
+    """dint_submit_segments_multi: three engines' segments in one set of launches (grid.y = engine) on the caller's
+    stream -- replies, tables, locks and log rings must equal three dint_submit_segments calls; different batch sizes per
+    engine, one empty segment, two rounds (the scratch lists alternate per pass).  Lock engines take the fallback (one
+    call per engine on that stream)."""
+    from dint_amd.engine import submit_segments_multi
+
+    sizes = [20_000, 7000, 13_000]
+    cuts = [[0, n // 3, n // 3, n] for n in sizes]
+    cap = 16_384
+    if wl == "tatp":
+        o = orc.TatpOracle(300, log_entries=200_000)
+        rows = [o.dump(t)[0] for t in range(5)]
+        gen = lambda k, r: tracegen.tatp_random(sizes[k], rows, seed=50 + 10 * r + k, n_sub_touch=40)  # noqa: E731
+
+        def mk():
+            e = _engine(W.TATP, n_rows=300, log_entries=200_000)
+            e.populate(300)
+            return e
+    elif wl == "smallbank":
+        gen = lambda k, r: tracegen.sb_random(sizes[k], seed=60 + 10 * r + k, n_acct_touch=30)  # noqa: E731
+
+        def mk():
+            e = _engine(W.SMALLBANK, n_rows=2000, log_entries=200_000)
+            e.populate(2000)
+            return e
+    else:
+        gen = lambda k, r: tracegen.fasst_random(sizes[k], seed=70 + 10 * r + k, n_hot=8, p_hot=0.6)  # noqa: E731
+        mk = lambda: _engine(W.FASST, n_slots=4801)  # noqa: E731
+    ones, multi = [mk() for _ in range(3)], [mk() for _ in range(3)]
+    st = torch.cuda.Stream()
+    for r in range(2):
+        reqs = [gen(k, r) for k in range(3)]
+        segs = [_segmented(reqs[k], cuts[k], cap) for k in range(3)]
+        stride = segs[0][1]
+        assert all(sg[1] == stride and sg[2] == 3 for sg in segs)
+        da = [torch.from_numpy(sg[0]).cuda() for sg in segs]
+        db = [torch.from_numpy(sg[0]).cuda() for sg in segs]
+        for k in range(3):
+            ones[k].submit_segments(da[k].data_ptr() + 64, 3, cap, stride, da[k].data_ptr(), stride)
+            ones[k].sync()
+        st.wait_stream(torch.cuda.current_stream())
+        submit_segments_multi(multi, [d.data_ptr() + 64 for d in db], 3, [cap] * 3, stride, [d.data_ptr() for d in db], stride,
+                              st.cuda_stream)
+        st.synchronize()
+        for k in range(3):
+            assert torch.equal(da[k], db[k]), (r, k)
+    for k in range(3):
+        if wl == "fasst":
+            assert all((x == y).all() for x, y in zip(ones[k].read_locks(), multi[k].read_locks()))
+            continue
+        for t in range(5 if wl == "tatp" else 2):
+            assert all((x == y).all() for x, y in zip(ones[k].dump_rows(t), multi[k].dump_rows(t)))
+        ra, ta = ones[k].read_log(200_000)
+        rb, tb = multi[k].read_log(200_000)
+        assert ta == tb and ra.tobytes() == rb.tobytes()
+        sa, sb = ones[k].stats(), multi[k].stats()
+        assert sa["bad_requests"] == sb["bad_requests"] and sa["missing_keys"] == sb["missing_keys"]
+    # a later per-engine call on the engine's own stream is ordered behind the multi call (order_stream)
+    req = gen(0, 5)
+    assert ones[0].submit(req).tobytes() == multi[0].submit(req).tobytes()
+
+
 def test_router_self_exchange_equals_plain_group():
     """world = 1 with the exchange forced on: pack -> self all-to-all -> segments -> unpack must change nothing"""
     from dint_amd.driver import Driver
