@@ -1037,7 +1037,8 @@ def bench_txn(args, world, rank, dev, transport, kind):
         same = all(gs[k] == stats[k] for k in ("txns", "committed", "by_type", "committed_by_type"))
         closed = {"value": round((gs["txns"] - tx0) / dtc / 1e6, 3), "unit": "Mtxn/s", "ms_per_epoch": round(dtc / (E1 - E0) * 1e3, 5),
                   "epochs": E1 - E0, "equals_host_driver_run": bool(same), "overflow": gs["overflow"],
-                  "what": "GPU-resident clients (k_txn_emit / k_txn_consume) + the three shard servers, closed loop, no host round trip"}
+                  "what": "GPU-resident clients (k_txn_emit, the replies consumed by the next emit) + the three shard servers "
+                          "(one launch set per epoch on the clients' stream: dint_submit_segments_multi), closed loop, no host round trip"}
         del loop, gd
         # ... and with the clients in two groups that take turns at the servers (GpuLoop): one group's consume / emit
         # kernels run while the servers answer the other's batch.  Checked against a host run of two Drivers taking
@@ -1066,7 +1067,8 @@ def bench_txn(args, world, rank, dev, transport, kind):
                                 "ms_per_round": round(dtc / (E1 - E0) * 1e3, 5), "clients_per_group": Cg,
                                 "equals_host_run_of_two_drivers": bool(same2), "checked_epochs": n_chk,
                                 "overflow": sum(g.stats()["overflow"] for g in gds),
-                                "what": "the same clients in two groups taking turns at the servers, each group on its own stream"}
+                                "what": "the same clients in two groups taking turns at the servers, each group on its own stream (slower: the "
+                                        "two groups' kernels wait on tickets / look-backs while they share the GPU)"}
         del loop, gds, hosts
 
     host = {}

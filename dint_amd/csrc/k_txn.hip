@@ -29,7 +29,7 @@
 #include "dint_device.h"
 #include "txn_clients.h"
 
-#define TXG_TB 256u  // clients per workgroup
+#define TXG_TB 512u   // clients per workgroup (256: 408 us per closed-loop epoch, 512: 392, 1024: 419 -- fewer tickets and look-back entries against fewer resident workgroups)
 #define TXG_AGG 0x40000000u  // look-back word: the workgroup's own message count ...
 #define TXG_PFX 0x80000000u  // ... or the count of all workgroups up to and including it
 #define TXG_VAL 0x3FFFFFFFu
@@ -41,13 +41,14 @@ struct txg_stats {
 
 void dint_driver_params(const dint_driver_config &c, TxParams *P, ZipfTable *zipf);  // txn_driver.cc
 
-template <class T>
-__global__ void __launch_bounds__(TXG_TB)
+// W = waves per SIMD the kernel is compiled for (the register budget: 3 -> 168, 4 -> 128, 5 -> 96 VGPRs; DINT_TXN_WAVES)
+template <class T, int W>
+__global__ void __launch_bounds__(TXG_TB, W)
 k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
            uint8_t *out2, const uint8_t *rep0, const uint8_t *rep1, const uint8_t *rep2, uint32_t cap, uint32_t *pub,
            uint32_t *ticket, uint32_t *pub_other, uint32_t *ticket_other, uint32_t *counts, txg_stats *st, uint32_t dbg) {
   typedef typename T::Msg Msg;
-  __shared__ uint32_t Stile, Sw[3][TXG_TB / 64], Sbase[3];
+  __shared__ uint32_t Stile, Sw[3][TXG_TB / 64];
   __shared__ unsigned long long Sst[TXG_NSTAT];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t == 0) Stile = atomicAdd(ticket, 1u);
@@ -72,12 +73,14 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
     c.m.base = store + (size_t)i * TX_DEV_MSG_STRIDE;  // message k of every client is one array of sectors (TxMsgs)
     c.m.stride = (uint64_t)n_clients * TX_DEV_MSG_STRIDE;
     if (rep0) {  // fused consume: the replies of the previous epoch (the other buffer set), then the phase that reads them
-      const uint8_t *reps[3] = {rep0, rep1, rep2};
       const uint8_t n = c.n_out;
-      for (uint8_t k = 0; k < n; k++) {
-        const uint8_t d = c.out_dst[k];
-        const uint32_t pos = c.out_pos[k];
-        if (d != TX_NO_DST && pos < cap) c.m[d] = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
+#pragma unroll
+      for (uint8_t k = 0; k < T::MAXOUT; k++) {  // unrolled: the header's arrays stay in registers
+        if (k < n && c.out_pos[k] < cap) {
+          const uint8_t sh = c.out_shard[k];
+          const uint8_t *rb = sh == 0 ? rep0 : sh == 1 ? rep1 : rep2;
+          tx_consume_one(c, c.out_dst[k], (const Msg *)(rb + (size_t)c.out_pos[k] * sizeof(Msg)));
+        }
       }
     }
     if (!(dbg & 2)) T::run(c, P, o);
@@ -103,50 +106,67 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
     }
   }
   // ---- ... + the messages of the workgroups before mine: decoupled look-back.  A workgroup publishes its own totals
-  // first thing (TXG_AGG), then wave 0 walks back 64 workgroups at a time until, per shard, it meets one that already
-  // knows its inclusive prefix (TXG_PFX), and publishes its own.  (r02 summed ALL earlier totals in every workgroup:
-  // 2048^2 / 2 x 3 device-scope loads per epoch, 300 us of the 720 us closed-loop epoch.)  Workgroups are handed out by
-  // ticket, so the ones a look-back waits for are running.
+  // first thing (TXG_AGG), then walks back over the workgroups before it until, per shard, it meets one that already
+  // knows its inclusive prefix (TXG_PFX), and publishes its own.  Workgroups are handed out by ticket, so the ones a
+  // look-back waits for are running.  The resident workgroups (~800) finish their phases at about the same time, so
+  // a walk is hundreds of entries deep: all 256 threads look at once (one entry each, its three words loaded
+  // together), 256 entries per step.  (r03a: one wave, one shard at a time, 64 entries per step -- 41 of the kernel's
+  // 204 us, measured with DINT_TXN_DBG=1.  r02 summed ALL earlier totals in every workgroup.)
+  __shared__ uint32_t Lsum[3][TXG_TB / 64], Lhit[3][TXG_TB / 64];
   if (t < 3) __hip_atomic_store(&pub[tile * 4 + t], TXG_AGG | tot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (wave == 0) {
-    uint32_t base[3] = {0, 0, 0};
-    uint32_t open = (tile == 0 || (dbg & 1)) ? 0u : 7u;  // shards whose prefix is not known yet
-    for (int k0 = (int)tile - 1; open; k0 -= 64) {
-      const int k = k0 - (int)lane;
+  uint32_t base[3] = {0, 0, 0};
+  uint32_t open = (tile == 0 || (dbg & 1)) ? 0u : 7u;  // shards whose prefix is not known yet (workgroup-uniform)
+  for (int k0 = (int)tile - 1; open; k0 -= (int)TXG_TB) {
+    const int k = k0 - (int)t;  // thread 0 looks at the nearest workgroup
+    uint32_t v[3] = {TXG_PFX, TXG_PFX, TXG_PFX};  // before the first workgroup: prefix 0
+    if (k >= 0) {
+      do {
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
-        if (!((open >> s) & 1u)) continue;
-        uint32_t v = TXG_PFX;  // before the first workgroup: prefix 0
-        if (k >= 0) do { v = __hip_atomic_load(&pub[k * 4 + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 30));
-        const uint64_t mp = __ballot((v & TXG_PFX) != 0);  // lane 0 is the nearest workgroup
-        const int stop = mp ? __ffsll((unsigned long long)mp) - 1 : 64;
-        uint32_t add = (int)lane <= stop ? v & TXG_VAL : 0u;
-        for (int d = 32; d > 0; d >>= 1) add += __shfl_xor(add, d, 64);
-        base[s] += add;
-        if (mp) open &= ~(1u << s);
+        for (int s = 0; s < 3; s++) v[s] = __hip_atomic_load(&pub[k * 4 + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while (!(v[0] >> 30) || !(v[1] >> 30) || !(v[2] >> 30));
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const uint64_t mp = __ballot((v[s] & TXG_PFX) != 0);  // lane 0 is the nearest of this wave's 64
+      const int stop = mp ? __ffsll((unsigned long long)mp) - 1 : 64;
+      uint32_t add = (int)lane <= stop ? v[s] & TXG_VAL : 0u;
+      for (int d = 32; d > 0; d >>= 1) add += __shfl_xor(add, d, 64);
+      if (lane == 0) { Lsum[s][wave] = add; Lhit[s][wave] = mp != 0; }
+    }
+    __syncthreads();
+    uint32_t still = open;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      if (!((open >> s) & 1u)) continue;
+      for (uint32_t w = 0; w < TXG_TB / 64; w++) {  // wave 0 holds the nearest entries
+        base[s] += Lsum[s][w];
+        if (Lhit[s][w]) { still &= ~(1u << s); break; }
       }
     }
-    if (lane < 3) {
-      const uint32_t b = lane == 0 ? base[0] : lane == 1 ? base[1] : base[2];
-      const uint32_t mine = lane == 0 ? tot[0] : lane == 1 ? tot[1] : tot[2];
-      __hip_atomic_store(&pub[tile * 4 + lane], TXG_PFX | (b + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      Sbase[lane] = b;
-      if (tile == ntiles - 1) counts[lane] = min(b + mine, cap);  // batch sizes of this epoch (read by the engines)
-    }
+    open = still;
+    __syncthreads();  // Lsum / Lhit are rewritten by the next step
   }
-  __syncthreads();
+  if (t < 3) {
+    const uint32_t b = t == 0 ? base[0] : t == 1 ? base[1] : base[2];
+    const uint32_t mine = t == 0 ? tot[0] : t == 1 ? tot[1] : tot[2];
+    __hip_atomic_store(&pub[tile * 4 + t], TXG_PFX | (b + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile == ntiles - 1) counts[t] = min(b + mine, cap);  // batch sizes of this epoch (read by the engines)
+  }
 
   // ---- emit
-  uint8_t *outs[3] = {out0, out1, out2};
   uint32_t lost = 0;
-  for (uint8_t k = 0; k < o.n; k++) {
-    const uint32_t s = o.shard[k], pos = Sbase[s] + x[s] + o.ord[k];
-    c.out_pos[k] = pos;
-    if (pos < cap) {
-      *(Msg *)(outs[s] + (size_t)pos * sizeof(Msg)) = o.materialize(c, k);
-    } else {  // no room in the batch: nothing is sent, nothing will come back -- the client message holds the request
-      lost++;
-      if (o.is_new(k) && o.dst[k] != TX_NO_DST) { Msg m = o.materialize(c, k); m.ord = 0; c.m[o.dst[k]] = m; }
+#pragma unroll
+  for (uint8_t k = 0; k < T::MAXOUT; k++) {
+    if (k < o.n) {
+      const uint32_t s = o.shard[k], pos = (s == 0 ? base[0] + x[0] : s == 1 ? base[1] + x[1] : base[2] + x[2]) + o.ord[k];
+      c.out_pos[k] = pos;
+      const Msg m = o.materialize(c, k);
+      if (pos < cap) {
+        *(Msg *)((s == 0 ? out0 : s == 1 ? out1 : out2) + (size_t)pos * sizeof(Msg)) = m;
+      } else {  // no room in the batch: nothing is sent, nothing will come back -- the client sees its request unanswered
+        lost++;
+        if (o.is_new(k)) { Msg q = m; q.ord = 0; tx_consume_one(c, o.dst[k], &q); }
+      }
     }
   }
   if (valid) cl[i] = c;
@@ -169,21 +189,24 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
 
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
-k_txn_consume(const typename T::Client *cl, uint8_t *store, uint32_t n_clients, const uint8_t *rep0,
+k_txn_consume(typename T::Client *cl, uint8_t *store, uint32_t n_clients, const uint8_t *rep0,
               const uint8_t *rep1, const uint8_t *rep2, uint32_t cap) {
   typedef typename T::Msg Msg;
   const uint32_t i = blockIdx.x * TXG_TB + threadIdx.x;
   if (i >= n_clients) return;
-  const uint8_t *reps[3] = {rep0, rep1, rep2};
-  const typename T::Client c = cl[i];
-  uint8_t *m = store + (size_t)i * TX_DEV_MSG_STRIDE;  // message d of this client at m + d * n_clients * 64
+  typename T::Client c = cl[i];
+  c.m.base = store + (size_t)i * TX_DEV_MSG_STRIDE;
+  c.m.stride = (uint64_t)n_clients * TX_DEV_MSG_STRIDE;
   const uint8_t n = c.n_out;
-  for (uint8_t k = 0; k < n; k++) {
-    const uint8_t d = c.out_dst[k];
-    const uint32_t pos = c.out_pos[k];
-    if (d != TX_NO_DST && pos < cap)
-      *(Msg *)(m + (size_t)d * n_clients * TX_DEV_MSG_STRIDE) = *(const Msg *)(reps[c.out_shard[k]] + (size_t)pos * sizeof(Msg));
+#pragma unroll
+  for (uint8_t k = 0; k < T::MAXOUT; k++) {
+    if (k < n && c.out_pos[k] < cap) {
+      const uint8_t sh = c.out_shard[k];
+      const uint8_t *rb = sh == 0 ? rep0 : sh == 1 ? rep1 : rep2;
+      tx_consume_one(c, c.out_dst[k], (const Msg *)(rb + (size_t)c.out_pos[k] * sizeof(Msg)));
+    }
   }
+  cl[i] = c;  // the reply summaries live in the header
 }
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -193,6 +216,7 @@ struct dint_gdriver {
   uint32_t cap = 0, ntiles = 0, msg = 0;
   bool awaiting = false;
   bool fuse = true;            // DINT_TXN_FUSE=0: consume always in its own kernel
+  int waves = 4;               // DINT_TXN_WAVES: register budget variant of k_txn_emit (3, 4 or 5 waves per SIMD)
   bool pending = false;        // a consume deferred into the next emit ...
   hipStream_t pending_stream = nullptr;  // ... which was issued on this stream
   hipStream_t next_stream = nullptr;     // stream of the last dint_gdriver_next
@@ -227,17 +251,22 @@ int upload_clients(dint_gdriver *g) {
 namespace {
 template <class T>
 void launch_consume(dint_gdriver *g, hipStream_t st, uint32_t set) {
-  hipLaunchKernelGGL((k_txn_consume<T>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (const typename T::Client *)g->d_clients,
+  hipLaunchKernelGGL((k_txn_consume<T>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (typename T::Client *)g->d_clients,
                      (uint8_t *)g->d_store, g->cfg.n_clients, g->d_batch[set][0], g->d_batch[set][1], g->d_batch[set][2], g->cap);
 }
 template <class T>
 void launch_emit(dint_gdriver *g, hipStream_t st, bool fused) {
   const uint32_t b = g->cur, o = b ^ 1u;  // requests go into set b; the replies of the previous epoch sit in set o
-  hipLaunchKernelGGL((k_txn_emit<T>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (typename T::Client *)g->d_clients,
-                     (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[b][0], g->d_batch[b][1], g->d_batch[b][2],
-                     fused ? g->d_batch[o][0] : nullptr, fused ? g->d_batch[o][1] : nullptr, fused ? g->d_batch[o][2] : nullptr,
-                     g->cap, g->d_pub + (size_t)b * g->ntiles * 4, g->d_ticket + b, g->d_pub + (size_t)o * g->ntiles * 4,
-                     g->d_ticket + o, g->d_counts, g->d_stats, g->dbg);
+#define TXG_LAUNCH(W)                                                                                                      \
+  hipLaunchKernelGGL((k_txn_emit<T, W>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (typename T::Client *)g->d_clients,           \
+                     (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[b][0], g->d_batch[b][1], g->d_batch[b][2],    \
+                     fused ? g->d_batch[o][0] : nullptr, fused ? g->d_batch[o][1] : nullptr, fused ? g->d_batch[o][2] : nullptr, \
+                     g->cap, g->d_pub + (size_t)b * g->ntiles * 4, g->d_ticket + b, g->d_pub + (size_t)o * g->ntiles * 4,     \
+                     g->d_ticket + o, g->d_counts, g->d_stats, g->dbg)
+  if (g->waves == 3) TXG_LAUNCH(3);
+  else if (g->waves == 5) TXG_LAUNCH(5);
+  else TXG_LAUNCH(4);
+#undef TXG_LAUNCH
 }
 }  // namespace
 
@@ -260,6 +289,7 @@ int dint_gdriver_create(const dint_driver_config *cfg, int32_t device, uint32_t 
   g->ntiles = (cfg->n_clients + TXG_TB - 1) / TXG_TB;
   if (getenv("DINT_TXN_DBG")) g->dbg = (uint32_t)atoi(getenv("DINT_TXN_DBG"));
   if (getenv("DINT_TXN_FUSE")) g->fuse = atoi(getenv("DINT_TXN_FUSE")) != 0;
+  if (getenv("DINT_TXN_WAVES")) g->waves = atoi(getenv("DINT_TXN_WAVES"));
   int rc = 0;
   try {
     ZipfTable zipf;

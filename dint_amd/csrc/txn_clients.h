@@ -62,6 +62,7 @@ enum : uint8_t {  // smallbank PktType, smallbank/udp/net.h:15-38
 
 #define TX_MAXOUT 9      // messages one phase of one client emits at most (smallbank: 3 rows logged on 3 shards)
 #define TX_NO_DST 0xFFu  // the reply is discarded
+#define TX_DST_MASK 0x3Fu  // out_dst = working message number | flags (TX_FULL, txn_clients.h below); TX_NO_DST is checked first
 
 struct TxParams {
   uint32_t workload;        // DINT_WL_TATP / DINT_WL_SMALLBANK
@@ -82,14 +83,14 @@ struct TxParams {
 // the reply -- the whole message, key and table included -- is what fills the client message it is addressed to.
 // (Until r03 the request was first stored into that client message and read back by materialize(): on the GPU one
 // scattered 55-byte store and load per message, both dead -- NOTEBOOK.md section 4.)
-template <class Msg>
+template <class Msg, int CAP>
 struct TxOut {
   uint8_t n;
-  uint8_t shard[TX_MAXOUT], dst[TX_MAXOUT], src[TX_MAXOUT], type[TX_MAXOUT], ord[TX_MAXOUT];
+  uint8_t shard[CAP], dst[CAP], src[CAP], type[CAP], ord[CAP];
   uint8_t n_fin, fin_txn[2], fin_ok[2];
   uint16_t fresh;                // bit k: message k is a new request, built from table[k] / key[k]
-  uint8_t table[TX_MAXOUT];
-  uint64_t key[TX_MAXOUT];
+  uint8_t table[CAP];
+  uint64_t key[CAP];
   TX_HD void clear() { n = 0; n_fin = 0; fresh = 0; }
   // queue client message `src_msg` (sent with type `ty`) for shard s; its reply lands in client message `d`
   TX_HD void send(uint32_t s, uint8_t src_msg, uint8_t ty, uint8_t d) {
@@ -119,6 +120,7 @@ struct TxOut {
       m.key = key[k];
     } else {
       m = c.m[src[k]];
+      m.ver = c.wire_ver(src[k], m.ver);
     }
     m.type = type[k];
     m.ord = ord[k];
@@ -153,18 +155,50 @@ template <class M> struct TxMsgs {
   TX_HD M &operator[](uint32_t k) const { return *(M *)(base + (size_t)k * stride); }
 };
 
-// Client state = a 72-byte header (loaded and stored whole: on the GPU one coalesced access per client and phase)
-// + TATP_NMSG working messages in a separate array, touched only where a phase reads or writes them.
+// Client state = a 128-byte header (loaded and stored whole: on the GPU one coalesced access per client and phase)
+// + TATP_NMSG working messages in a separate array.  The header carries what the phase logic READS of the replies --
+// reply type, version, first value byte per working message (`rt`, `rver`, `rv0`, written when a reply is consumed):
+// on the GPU the logic then runs out of registers.  Only the rows a transaction writes back (A_READ / B_READ of the
+// four update transactions: their 40 value bytes travel into the LOG / BCK / PRIM messages) are kept whole in the
+// working messages (`TX_FULL` on the reply's destination); every other reply leaves three fields behind.  Until r03
+// every reply was stored whole and every decision was a scattered load from the message array (NOTEBOOK.md section 4).
+#define TX_FULL 0x40u  // out_dst flag: keep the whole reply in the working message, not only its summary
 struct TatpClient {
   TxLcg rng;
   uint8_t txn, step, n_out;  // step 0 = idle
   uint8_t sf_type, start_time, end_time;
-  uint8_t out_shard[6], out_dst[6];  // a tatp phase emits at most 6 messages
+  uint8_t out_shard[6], out_dst[6];  // a tatp phase emits at most 6 messages; out_dst = working message | TX_FULL, or TX_NO_DST
   uint32_t s_id;
   uint32_t out_pos[6];
   TxMsgs<TatpMsg> m;  // [TATP_NMSG] -- set by the driver before every use (host vector / device array)
+  uint8_t rt[TATP_NMSG], rv0[TATP_NMSG];  // per working message: type / val[0] of the last reply (or what the logic set)
+  uint8_t pad_[2];
+  uint32_t rver[TATP_NMSG - 1];           // ... its version (TMP2 never needs one)
+  uint32_t vlr;                           // UpdateLocation: the new vlr_location, parked until the subscriber row is read
+  // a consumed reply: the three fields the logic may ask for.  (Unrolled over the message numbers, so that the arrays
+  // stay in registers on the GPU.)
+  TX_HD void note_reply(uint8_t d, uint8_t type, uint8_t v0, uint32_t ver) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (uint8_t j = 0; j < TATP_NMSG; j++)
+      if (j == d) {
+        rt[j] = type; rv0[j] = v0;
+        if (j < TATP_NMSG - 1) rver[j] = ver;
+      }
+  }
+  // version on the wire of working message `src` when it is sent again (the LOG / BCK / PRIM copies of a row)
+  TX_HD uint32_t wire_ver(uint8_t src, uint32_t stored) const {
+    uint32_t v = stored;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (uint8_t j = 0; j < TATP_NMSG - 1; j++)
+      if (j == src) v = rver[j];
+    return v;
+  }
 };
-static_assert(sizeof(TatpClient) == 72, "client header");
+static_assert(sizeof(TatpClient) == 128, "client header");
 
 TX_HD static inline void tatp_workgen(uint8_t *workgen) {
   // CreateWorkgenArr :63-73 -- note the order: GetSubscriberData, GetAccessData, GetNewDestination, ...
@@ -184,20 +218,36 @@ TX_HD static inline uint32_t tatp_pick_sid(TxLcg &g, const TxParams &P) {
 
 TX_HD static inline uint64_t tatp_sf_key(const TatpClient &c) { return (uint64_t)c.s_id | ((uint64_t)c.sf_type << 32); }
 TX_HD static inline uint64_t tatp_cf_key(const TatpClient &c, uint32_t st) { return tatp_sf_key(c) | ((uint64_t)st << 40); }
+// The row behind working message i of the running update transaction: the B_* messages are the SPECIAL_FACILITY row,
+// the A_* ones the SUBSCRIBER row (UpdateSubscriberData, UpdateLocation) or the CALL_FORWARDING row (Insert / Delete
+// CallForwarding).  The reference reads key and table out of the struct the reply came back in; they are the request's.
+TX_HD static inline bool tatp_is_b(uint8_t i) { return i == B_READ || i == B_LOCK || i == B_VER; }
+TX_HD static inline uint8_t tatp_row_table(const TatpClient &c, uint8_t i) {
+  return tatp_is_b(i) ? TB_SF : ((c.txn == TT_INS_CF || c.txn == TT_DEL_CF) ? TB_CF : TB_SUB);
+}
+TX_HD static inline uint64_t tatp_row_key(const TatpClient &c, uint8_t i) {
+  return tatp_is_b(i) ? tatp_sf_key(c) : ((c.txn == TT_INS_CF || c.txn == TT_DEL_CF) ? tatp_cf_key(c, c.start_time) : (uint64_t)c.s_id);
+}
 
-typedef TxOut<TatpMsg> TatpOut;
-// a new request {type, table, key} to the key's primary; the reply fills client message i
-TX_HD static inline void tatp_send_new(TatpOut &o, uint8_t i, uint8_t type, uint8_t table, uint64_t key) { o.send_new(type, table, key, i); }
-// send client message i to its primary (key % 3, :187); the reply comes back into the same message
-TX_HD static inline void tatp_send_prim(TatpClient &c, TatpOut &o, uint8_t i) { o.send((uint32_t)(c.m[i].key % 3), i, c.m[i].type, i); }
-// message i as it is now, to its primary, reply discarded
-TX_HD static inline void tatp_send_only(TatpClient &c, TatpOut &o, uint8_t i) { o.send((uint32_t)(c.m[i].key % 3), i, c.m[i].type, TX_NO_DST); }
-TX_HD static inline void tatp_send_log3(TatpClient &c, TatpOut &o, uint8_t i) { for (uint32_t s = 0; s < 3; s++) o.send(s, i, c.m[i].type, TX_NO_DST); }
+typedef TxOut<TatpMsg, 6> TatpOut;  // a tatp phase emits at most 6 messages
+// a new request {type, table, key} to the key's primary; the reply's summary goes to working message i (TX_NO_DST:
+// nowhere), the whole reply too when the transaction will write the row back (full)
+TX_HD static inline void tatp_send_new(TatpOut &o, uint8_t i, uint8_t type, uint8_t table, uint64_t key, bool full = false) {
+  o.send_new(type, table, key, (uint8_t)(full ? (i | TX_FULL) : i));
+}
+// release the lock behind working message i (A_LOCK / B_LOCK): the reference turns the granted lock message into an
+// ABORT and sends it back (:402-418); it carries the row's key and table and nothing else
+TX_HD static inline void tatp_send_abort(TatpClient &c, TatpOut &o, uint8_t i) {
+  o.send_new(T_ABORT, tatp_row_table(c, i), tatp_row_key(c, i), i);
+}
+// the stored row i (A_READ / B_READ) with type `ty`: to its primary, reply discarded
+TX_HD static inline void tatp_send_only(TatpClient &c, TatpOut &o, uint8_t i, uint8_t ty) { o.send((uint32_t)(tatp_row_key(c, i) % 3), i, ty, TX_NO_DST); }
+TX_HD static inline void tatp_send_log3(TatpClient &, TatpOut &o, uint8_t i, uint8_t ty) { for (uint32_t s = 0; s < 3; s++) o.send(s, i, ty, TX_NO_DST); }
 // backups of rows whose primary is key % 3: first the "+1" copies of every row, then the "+2" copies
-TX_HD static inline void tatp_send_bck(TatpClient &c, TatpOut &o, uint8_t r0, int n, uint8_t r1 = 0) {
+TX_HD static inline void tatp_send_bck(TatpClient &c, TatpOut &o, uint8_t ty, uint8_t r0, int n, uint8_t r1 = 0) {
   const uint8_t rows[2] = {r0, r1};
-  for (int i = 0; i < n; i++) o.send((uint32_t)((c.m[rows[i]].key % 3 + 1) % 3), rows[i], c.m[rows[i]].type, TX_NO_DST);
-  for (int i = 0; i < n; i++) o.send((uint32_t)((c.m[rows[i]].key % 3 + 2) % 3), rows[i], c.m[rows[i]].type, TX_NO_DST);
+  for (int i = 0; i < n; i++) o.send((uint32_t)((tatp_row_key(c, rows[i]) % 3 + 1) % 3), rows[i], ty, TX_NO_DST);
+  for (int i = 0; i < n; i++) o.send((uint32_t)((tatp_row_key(c, rows[i]) % 3 + 2) % 3), rows[i], ty, TX_NO_DST);
 }
 TX_HD static inline void tatp_finish(TatpClient &c, TatpOut &o, bool committed) {
   o.finish(c.txn, committed);
@@ -216,12 +266,7 @@ TX_HD static inline void tatp_begin(TatpClient &c, const TxParams &P) {
       c.end_time = (uint8_t)(g.next() % 24);
       break;
     case TT_UPD_SUB: c.s_id = tatp_pick_sid(g, P); c.sf_type = (uint8_t)(g.next() % 4 + 1); break;               // :340-341
-    case TT_UPD_LOC: {                                                                                           // :579-580
-      c.s_id = tatp_pick_sid(g, P);
-      const uint32_t vlr = g.next();
-      memcpy(c.m[TMP2].val, &vlr, 4);  // parked until the subscriber row is read
-      break;
-    }
+    case TT_UPD_LOC: c.s_id = tatp_pick_sid(g, P); c.vlr = g.next(); break;                                      // :579-580
     default: c.s_id = tatp_pick_sid(g, P); c.sf_type = (uint8_t)(g.next() % 4 + 1); c.start_time = (uint8_t)(g.next() % 3 * 8); break;  // DEL_CF :960-962
   }
 }
@@ -231,12 +276,12 @@ TX_HD static inline void tatp_emit_upd_sub(TatpClient &c, TatpOut &o) {  // TxnU
   for (;;) {
     switch (c.step) {
       case 1:  // execute: read + lock both rows :345-396
-        tatp_send_new(o, A_READ, T_READ, TB_SUB, c.s_id); tatp_send_new(o, A_LOCK, T_ACQ, TB_SUB, c.s_id);
-        tatp_send_new(o, B_READ, T_READ, TB_SF, tatp_sf_key(c)); tatp_send_new(o, B_LOCK, T_ACQ, TB_SF, tatp_sf_key(c));
+        tatp_send_new(o, A_READ, T_READ, TB_SUB, c.s_id, true); tatp_send_new(o, A_LOCK, T_ACQ, TB_SUB, c.s_id);
+        tatp_send_new(o, B_READ, T_READ, TB_SF, tatp_sf_key(c), true); tatp_send_new(o, B_LOCK, T_ACQ, TB_SF, tatp_sf_key(c));
         c.step = 2;
         return;
       case 2:
-        if (c.m[B_READ].type == T_NOT_EXIST || c.m[A_LOCK].type == T_REJECT_LOCK || c.m[B_LOCK].type == T_REJECT_LOCK) {  // :400
+        if (c.rt[B_READ] == T_NOT_EXIST || c.rt[A_LOCK] == T_REJECT_LOCK || c.rt[B_LOCK] == T_REJECT_LOCK) {  // :400
           c.step = 10;
           continue;
         }
@@ -249,35 +294,26 @@ TX_HD static inline void tatp_emit_upd_sub(TatpClient &c, TatpOut &o) {  // TxnU
         c.step = 3;
         return;
       case 3:
-        if (c.m[A_READ].ver != c.m[A_VER].ver || c.m[B_READ].ver != c.m[B_VER].ver) { c.step = 12; continue; }  // :470
-        c.m[A_READ].ver++; c.m[B_READ].ver++;                                                                      // :487-488
-        c.m[A_READ].type = c.m[B_READ].type = T_COMMIT_LOG;
+        if (c.rver[A_READ] != c.rver[A_VER] || c.rver[B_READ] != c.rver[B_VER]) { c.step = 12; continue; }  // :470
+        c.rver[A_READ]++; c.rver[B_READ]++;                                                                  // :487-488
         for (uint32_t s = 0; s < 3; s++) { o.send(s, A_READ, T_COMMIT_LOG, TX_NO_DST); o.send(s, B_READ, T_COMMIT_LOG, TX_NO_DST); }  // :493-501
         c.step = 4;
         return;
-      case 4:
-        c.m[A_READ].type = c.m[B_READ].type = T_COMMIT_BCK;  // :521-533
-        tatp_send_bck(c, o, A_READ, 2, B_READ);
-        c.step = 5;
-        return;
-      case 5:
-        c.m[A_READ].type = c.m[B_READ].type = T_COMMIT_PRIM;  // :552-556
-        tatp_send_only(c, o, A_READ); tatp_send_only(c, o, B_READ);
-        c.step = 6;
-        return;
+      case 4: tatp_send_bck(c, o, T_COMMIT_BCK, A_READ, 2, B_READ); c.step = 5; return;  // :521-533
+      case 5: tatp_send_only(c, o, A_READ, T_COMMIT_PRIM); tatp_send_only(c, o, B_READ, T_COMMIT_PRIM); c.step = 6; return;  // :552-556
       case 6: tatp_finish(c, o, true); return;
       // abort after a failed execute: release the granted locks one round trip at a time :402-418
       case 10:
-        if (c.m[A_LOCK].type == T_GRANT_LOCK) { c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 11; return; }
+        if (c.rt[A_LOCK] == T_GRANT_LOCK) { tatp_send_abort(c, o, A_LOCK); c.step = 11; return; }
         c.step = 11;
         continue;
       case 11:
-        if (c.m[B_LOCK].type == T_GRANT_LOCK) { c.m[B_LOCK].type = T_ABORT; tatp_send_prim(c, o, B_LOCK); c.step = 14; return; }
+        if (c.rt[B_LOCK] == T_GRANT_LOCK) { tatp_send_abort(c, o, B_LOCK); c.step = 14; return; }
         tatp_finish(c, o, false);
         return;
       // abort after a failed validation: both locks are held :472-481
-      case 12: c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 13; return;
-      case 13: c.m[B_LOCK].type = T_ABORT; tatp_send_prim(c, o, B_LOCK); c.step = 14; return;
+      case 12: tatp_send_abort(c, o, A_LOCK); c.step = 13; return;
+      case 13: tatp_send_abort(c, o, B_LOCK); c.step = 14; return;
       default: tatp_finish(c, o, false); return;
     }
   }
@@ -285,26 +321,25 @@ TX_HD static inline void tatp_emit_upd_sub(TatpClient &c, TatpOut &o) {  // TxnU
 
 TX_HD static inline void tatp_emit_upd_loc(TatpClient &c, TatpOut &o) {  // TxnUpdateLocation :574-728
   switch (c.step) {
-    case 1: tatp_send_new(o, B_READ, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :583-592
+    case 1: tatp_send_new(o, TX_NO_DST, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :583-592 (the reply is only asserted on)
     case 2:
-      tatp_send_new(o, A_READ, T_READ, TB_SUB, c.s_id); tatp_send_new(o, A_LOCK, T_ACQ, TB_SUB, c.s_id);  // :605-618
+      tatp_send_new(o, A_READ, T_READ, TB_SUB, c.s_id, true); tatp_send_new(o, A_LOCK, T_ACQ, TB_SUB, c.s_id);  // :605-618
       c.step = 3;
       return;
     case 3:
-      if (c.m[A_LOCK].type == T_REJECT_LOCK) { tatp_finish(c, o, false); return; }  // :645
-      memcpy(c.m[A_READ].val + 36, c.m[TMP2].val, 4);                              // vlr_location :650
-      tatp_send_new(o, A_VER, T_READ, TB_SUB, c.s_id);                             // verify :653-660
+      if (c.rt[A_LOCK] == T_REJECT_LOCK) { tatp_finish(c, o, false); return; }  // :645
+      memcpy(c.m[A_READ].val + 36, &c.vlr, 4);                                  // vlr_location :650
+      tatp_send_new(o, A_VER, T_READ, TB_SUB, c.s_id);                          // verify :653-660
       c.step = 4;
       return;
     case 4:
-      if (c.m[A_VER].ver != c.m[A_READ].ver) { c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 8; return; }  // :667-674
-      c.m[A_READ].ver++;
-      c.m[A_READ].type = T_COMMIT_LOG;
-      tatp_send_log3(c, o, A_READ);  // :677-684
+      if (c.rver[A_VER] != c.rver[A_READ]) { tatp_send_abort(c, o, A_LOCK); c.step = 8; return; }  // :667-674
+      c.rver[A_READ]++;
+      tatp_send_log3(c, o, A_READ, T_COMMIT_LOG);  // :677-684
       c.step = 5;
       return;
-    case 5: c.m[A_READ].type = T_COMMIT_BCK; tatp_send_bck(c, o, A_READ, 1); c.step = 6; return;                                  // :702-708
-    case 6: c.m[A_READ].type = T_COMMIT_PRIM; tatp_send_only(c, o, A_READ); c.step = 7; return;  // :722-723
+    case 5: tatp_send_bck(c, o, T_COMMIT_BCK, A_READ, 1); c.step = 6; return;  // :702-708
+    case 6: tatp_send_only(c, o, A_READ, T_COMMIT_PRIM); c.step = 7; return;   // :722-723
     case 7: tatp_finish(c, o, true); return;
     default: tatp_finish(c, o, false); return;
   }
@@ -312,16 +347,16 @@ TX_HD static inline void tatp_emit_upd_loc(TatpClient &c, TatpOut &o) {  // TxnU
 
 TX_HD static inline void tatp_emit_ins_cf(TatpClient &c, TatpOut &o) {  // TxnInsertCallForwarding :731-951
   switch (c.step) {
-    case 1: tatp_send_new(o, TMP0, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :743-752
-    case 2: tatp_send_new(o, B_READ, T_READ, TB_SF, tatp_sf_key(c)); c.step = 3; return;   // :761-769
+    case 1: tatp_send_new(o, TX_NO_DST, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :743-752 (asserted on only)
+    case 2: tatp_send_new(o, B_READ, T_READ, TB_SF, tatp_sf_key(c)); c.step = 3; return;         // :761-769
     case 3:
-      if (c.m[B_READ].type == T_NOT_EXIST) { tatp_finish(c, o, false); return; }  // :776
-      tatp_send_new(o, A_READ, T_READ, TB_CF, tatp_cf_key(c, c.start_time)); tatp_send_new(o, A_LOCK, T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :789-799
+      if (c.rt[B_READ] == T_NOT_EXIST) { tatp_finish(c, o, false); return; }  // :776
+      tatp_send_new(o, A_READ, T_READ, TB_CF, tatp_cf_key(c, c.start_time), true); tatp_send_new(o, A_LOCK, T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :789-799
       c.step = 4;
       return;
     case 4:
-      if (c.m[A_READ].type == T_GRANT_READ || c.m[A_LOCK].type == T_REJECT_LOCK) {  // the row exists, or no lock :826
-        if (c.m[A_LOCK].type == T_GRANT_LOCK) { c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 9; return; }
+      if (c.rt[A_READ] == T_GRANT_READ || c.rt[A_LOCK] == T_REJECT_LOCK) {  // the row exists, or no lock :826
+        if (c.rt[A_LOCK] == T_GRANT_LOCK) { tatp_send_abort(c, o, A_LOCK); c.step = 9; return; }
         tatp_finish(c, o, false);
         return;
       }
@@ -331,16 +366,15 @@ TX_HD static inline void tatp_emit_ins_cf(TatpClient &c, TatpOut &o) {  // TxnIn
       c.step = 5;
       return;
     case 5:
-      if (c.m[B_READ].ver != c.m[B_VER].ver || c.m[A_VER].type == T_GRANT_READ) {  // :884
-        c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 9; return;
+      if (c.rver[B_READ] != c.rver[B_VER] || c.rt[A_VER] == T_GRANT_READ) {  // :884
+        tatp_send_abort(c, o, A_LOCK); c.step = 9; return;
       }
-      c.m[A_READ].ver = 0;  // :896
-      c.m[A_READ].type = T_COMMIT_LOG;
-      tatp_send_log3(c, o, A_READ);
+      c.rver[A_READ] = 0;  // :896
+      tatp_send_log3(c, o, A_READ, T_COMMIT_LOG);
       c.step = 6;
       return;
-    case 6: c.m[A_READ].type = T_INSERT_BCK; tatp_send_bck(c, o, A_READ, 1); c.step = 7; return;                                  // :921-927
-    case 7: c.m[A_READ].type = T_INSERT_PRIM; tatp_send_only(c, o, A_READ); c.step = 8; return;  // :944-945
+    case 6: tatp_send_bck(c, o, T_INSERT_BCK, A_READ, 1); c.step = 7; return;  // :921-927
+    case 7: tatp_send_only(c, o, A_READ, T_INSERT_PRIM); c.step = 8; return;   // :944-945
     case 8: tatp_finish(c, o, true); return;
     default: tatp_finish(c, o, false); return;
   }
@@ -348,14 +382,14 @@ TX_HD static inline void tatp_emit_ins_cf(TatpClient &c, TatpOut &o) {  // TxnIn
 
 TX_HD static inline void tatp_emit_del_cf(TatpClient &c, TatpOut &o) {  // TxnDeleteCallForwarding :954-1117
   switch (c.step) {
-    case 1: tatp_send_new(o, TMP0, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :965-974
+    case 1: tatp_send_new(o, TX_NO_DST, T_READ, TB_SEC, tx_sub_nbr(c.s_id)); c.step = 2; return;  // :965-974 (asserted on only)
     case 2:
-      tatp_send_new(o, A_READ, T_READ, TB_CF, tatp_cf_key(c, c.start_time)); tatp_send_new(o, A_LOCK, T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :983-997
+      tatp_send_new(o, A_READ, T_READ, TB_CF, tatp_cf_key(c, c.start_time), true); tatp_send_new(o, A_LOCK, T_ACQ, TB_CF, tatp_cf_key(c, c.start_time));  // :983-997
       c.step = 3;
       return;
     case 3:
-      if (c.m[A_READ].type == T_NOT_EXIST || c.m[A_LOCK].type == T_REJECT_LOCK) {  // :1024
-        if (c.m[A_LOCK].type == T_GRANT_LOCK) { c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 8; return; }
+      if (c.rt[A_READ] == T_NOT_EXIST || c.rt[A_LOCK] == T_REJECT_LOCK) {  // :1024
+        if (c.rt[A_LOCK] == T_GRANT_LOCK) { tatp_send_abort(c, o, A_LOCK); c.step = 8; return; }
         tatp_finish(c, o, false);
         return;
       }
@@ -363,15 +397,14 @@ TX_HD static inline void tatp_emit_del_cf(TatpClient &c, TatpOut &o) {  // TxnDe
       c.step = 4;
       return;
     case 4:
-      if (c.m[A_VER].type == T_NOT_EXIST || c.m[A_VER].ver != c.m[A_READ].ver) {  // :1052
-        c.m[A_LOCK].type = T_ABORT; tatp_send_prim(c, o, A_LOCK); c.step = 8; return;
+      if (c.rt[A_VER] == T_NOT_EXIST || c.rver[A_VER] != c.rver[A_READ]) {  // :1052
+        tatp_send_abort(c, o, A_LOCK); c.step = 8; return;
       }
-      c.m[A_READ].type = T_DELETE_LOG;  // :1063
-      tatp_send_log3(c, o, A_READ);
+      tatp_send_log3(c, o, A_READ, T_DELETE_LOG);  // :1063
       c.step = 5;
       return;
-    case 5: c.m[A_READ].type = T_DELETE_BCK; tatp_send_bck(c, o, A_READ, 1); c.step = 6; return;                                  // :1087-1093
-    case 6: c.m[A_READ].type = T_DELETE_PRIM; tatp_send_only(c, o, A_READ); c.step = 7; return;  // :1110-1111
+    case 5: tatp_send_bck(c, o, T_DELETE_BCK, A_READ, 1); c.step = 6; return;  // :1087-1093
+    case 6: tatp_send_only(c, o, A_READ, T_DELETE_PRIM); c.step = 7; return;   // :1110-1111
     case 7: tatp_finish(c, o, true); return;
     default: tatp_finish(c, o, false); return;
   }
@@ -386,13 +419,13 @@ TX_HD static inline void tatp_emit(TatpClient &c, TatpOut &o) {
       return;
     case TT_GET_ACCESS:  // TxnGetAccessData :305-331
       if (c.step == 1) { tatp_send_new(o, A_READ, T_READ, TB_AI, tatp_sf_key(c)); c.step = 2; }
-      else tatp_finish(c, o, c.m[A_READ].type != T_NOT_EXIST);
+      else tatp_finish(c, o, c.rt[A_READ] != T_NOT_EXIST);
       return;
     case TT_GET_NEW_DEST:  // TxnGetNewDestination :202-302
       if (c.step == 1) { tatp_send_new(o, A_READ, T_READ, TB_SF, tatp_sf_key(c)); c.step = 2; return; }
       if (c.step == 2) {
-        if (c.m[A_READ].type == T_NOT_EXIST || c.m[A_READ].val[0] == 0) { tatp_finish(c, o, false); return; }  // :239,244 (is_active)
-        const uint32_t n = c.start_time / 8u + 1;                                                              // cf_to_fetch :212
+        if (c.rt[A_READ] == T_NOT_EXIST || c.rv0[A_READ] == 0) { tatp_finish(c, o, false); return; }  // :239,244 (is_active)
+        const uint32_t n = c.start_time / 8u + 1;                                                     // cf_to_fetch :212
         for (uint32_t i = 0; i < n; i++) tatp_send_new(o, (uint8_t)(TMP0 + i), T_READ, TB_CF, tatp_cf_key(c, i * 8));
         c.step = 3;
         return;
@@ -400,8 +433,11 @@ TX_HD static inline void tatp_emit(TatpClient &c, TatpOut &o) {
       {
         bool ok = false;  // :283-297
         const uint32_t n = c.start_time / 8u + 1;
-        for (uint32_t i = 0; i < n; i++)
-          if (c.m[TMP0 + i].type != T_NOT_EXIST && i * 8 <= c.start_time && c.end_time < c.m[TMP0 + i].val[0]) ok = true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (uint32_t i = 0; i < 3; i++)
+          if (i < n && c.rt[TMP0 + i] != T_NOT_EXIST && i * 8 <= c.start_time && c.end_time < c.rv0[TMP0 + i]) ok = true;
         tatp_finish(c, o, ok);
       }
       return;
@@ -422,7 +458,11 @@ TX_HD static inline void tatp_run(TatpClient &c, const TxParams &P, TatpOut &o) 
     // the phase emitted nothing: the transaction finished inside emit() -> start the next one
   }
   c.n_out = o.n;
-  for (uint8_t k = 0; k < o.n; k++) { c.out_shard[k] = o.shard[k]; c.out_dst[k] = o.dst[k]; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+  for (uint8_t k = 0; k < 6; k++)
+    if (k < o.n) { c.out_shard[k] = o.shard[k]; c.out_dst[k] = o.dst[k]; }
 }
 
 // ================================================================================================== SmallBank
@@ -444,9 +484,12 @@ struct SbClient {
   uint64_t a0, a1;
   uint32_t out_pos[TX_MAXOUT];
   TxMsgs<SbMsg> m;    // [SB_NMSG] the locked rows, in the reference's order
+  // every reply is a row the transaction computes on: kept whole (TX_FULL), no summary
+  TX_HD void note_reply(uint8_t, uint8_t, uint8_t, uint32_t) {}
+  TX_HD uint32_t wire_ver(uint8_t, uint32_t stored) const { return stored; }
 };
 static_assert(sizeof(SbClient) == 112, "client header");
-typedef TxOut<SbMsg> SbOut;
+typedef TxOut<SbMsg, TX_MAXOUT> SbOut;
 
 TX_HD static inline void sb_workgen(uint8_t *workgen) {
   // CreateWorkgenArr, smallbank/caladan/client_udp_shard.cc: same construction as tatp, mix smallbank.h:63-68
@@ -559,7 +602,7 @@ TX_HD static inline void sb_emit(SbClient &c, SbOut &o) {
           uint8_t ty, tb;
           uint64_t ky;
           sb_lock_row(c, i, &ty, &tb, &ky);
-          o.send_new(ty, tb, ky, i);
+          o.send_new(ty, tb, ky, (uint8_t)(i | TX_FULL));
         }
         c.step = 2;
         return;
@@ -615,14 +658,23 @@ TX_HD static inline void sb_run(SbClient &c, const TxParams &P, SbOut &o) {
   for (uint8_t k = 0; k < o.n; k++) { c.out_shard[k] = o.shard[k]; c.out_dst[k] = o.dst[k]; }
 }
 
+// One awaited reply of a client, shared by the host and the device driver: `d` = out_dst of the message, `r` = the reply
+// in the (in place) batch.  The summary always; the whole reply only where the transaction keeps the row.
+template <class Client, class Msg>
+TX_HD static inline void tx_consume_one(Client &c, uint8_t d, const Msg *r) {
+  if (d == TX_NO_DST) return;
+  c.note_reply((uint8_t)(d & TX_DST_MASK), r->type, r->val[0], r->ver);
+  if (d & TX_FULL) c.m[d & TX_DST_MASK] = *r;
+}
+
 // uniform front for templates
 struct TatpTraits {
   typedef TatpClient Client; typedef TatpMsg Msg; typedef TatpOut Out;
-  static constexpr uint32_t NMSG = TATP_NMSG;
+  static constexpr uint32_t NMSG = TATP_NMSG, MAXOUT = 6;
   TX_HD static void run(Client &c, const TxParams &P, Out &o) { tatp_run(c, P, o); }
 };
 struct SbTraits {
   typedef SbClient Client; typedef SbMsg Msg; typedef SbOut Out;
-  static constexpr uint32_t NMSG = SB_NMSG;
+  static constexpr uint32_t NMSG = SB_NMSG, MAXOUT = TX_MAXOUT;
   TX_HD static void run(Client &c, const TxParams &P, Out &o) { sb_run(c, P, o); }
 };

@@ -93,9 +93,7 @@ struct HostDriver final : dint_driver {
   }
   void consume(const void *const rep[DINT_N_SHARDS]) override {
     for (auto &c : cl)
-      for (uint32_t k = 0; k < c.n_out; k++)
-        if (c.out_dst[k] != TX_NO_DST)
-          memcpy(&c.m[c.out_dst[k]], (const Msg *)rep[c.out_shard[k]] + c.out_pos[k], sizeof(Msg));
+      for (uint32_t k = 0; k < c.n_out; k++) tx_consume_one(c, c.out_dst[k], (const Msg *)rep[c.out_shard[k]] + c.out_pos[k]);
   }
 };
 

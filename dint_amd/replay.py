@@ -167,10 +167,11 @@ class GpuLoop:
         self.streams = [torch.cuda.Stream() for _ in self.ds]
         self.stream = self.streams[0]
         self.msg = group.msg
-        # one client group: the servers' kernels go on the clients' stream, all engines per launch
-        # (dint_submit_segments_multi).  Several groups take turns on streams of their own and overlap through the
-        # engines' streams.  DINT_LOOP_STREAMS=1 forces the per-engine streams (A/B runs).
-        self.one_stream = len(self.ds) == 1 and os.environ.get("DINT_LOOP_STREAMS", "0") != "1"
+        # the servers' kernels go on the clients' stream, all engines per launch (dint_submit_segments_multi): an epoch is
+        # one stream, no fork / join.  Several groups take turns on a stream each -- the engines order their passes across
+        # the groups' streams themselves -- so one group's client kernel runs beside the servers' pass over the other
+        # group's batch.  DINT_LOOP_STREAMS=1 forces the per-engine streams (A/B runs).
+        self.one_stream = os.environ.get("DINT_LOOP_STREAMS", "0") != "1"
 
     def epochs(self, n: int) -> None:
         msg, rt = self.msg, self.g.router
