@@ -997,7 +997,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
         n_tab = sum(int(hist[c]) for c in alg_tab if c not in log_types)
         f_big = big_req / max(1, n_tab)
         cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b),
-                "k_kv_count+k_kv_scan+k_kv_place": (avg.get("k_kv_count", 0.0) + avg.get("k_kv_scan", 0.0) + avg.get("k_kv_place", 0.0), tab_b + log_b)}
+                "k_kv_count+k_kv_scan_place": (avg.get("k_kv_count", 0.0) + avg.get("k_kv_scan_place", 0.0), tab_b + log_b)}
         dom = max(cand, key=lambda k: cand[k][0])
         dom_us, alg = cand[dom][0], cand[dom][1] / max(1, launches)
         achieved = alg / (dom_us * 1e-6) / 1e9

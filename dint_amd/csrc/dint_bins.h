@@ -1,7 +1,9 @@
 // dint_bins.h -- the pass machinery every workload's kernels share (included by k_kv.hip and k_locks.hip; everything
 // here has internal linkage).  One pass = count (each request reserves a position in the bin of its group; the
-// reservations of a workgroup on one bin are merged in an LDS hash) -> k_kv_scan (ranges of the overflow area for the
-// bins of more than DINT_KV_BINCAP records) -> k_kv_place (overflow records into their range) -> resolve.  Also the
+// reservations of a workgroup on one bin are merged in an LDS hash) -> k_kv_scan_place (ranges of the overflow area for
+// the bins of more than DINT_KV_BINCAP records, overflow records into their range; it also makes the pass's log tail
+// current and clears the counters the next pass will use -- the big-bin lists and the published log counts alternate
+// between passes, so nothing has to be reset behind the resolve kernel) -> resolve.  Also the
 // helpers of the big-bin workgroups: an LDS / register bitonic sort of a stretch of <= KVB_NMAX 64-bit keys, and O(1)
 // range queries (bits set, last / next set bit) over 4096-bit masks of the sorted stretch.
 #pragma once
@@ -22,57 +24,58 @@ __device__ static inline uint32_t block_hash_insert(uint32_t *keys, uint32_t k) 
 }
 static_assert(KV_TB == 1024, "block_hash_insert assumes 2048 slots");
 
-// ---- k_kv_scan: one workgroup ---------------------------------------------------------------------------
-// Give every listed bin (more than DINT_KV_BINCAP records) its range of the overflow area; make the pass's log tail
-// current; clear the counters the next pass will use (the big-bin lists and the published log counts alternate
-// between passes, so nothing has to be reset behind the resolve kernel).
+#define KV_PLACE_GRID 64u
+// ---- k_kv_scan_place: scan and place in ONE launch ---------------------------------------------------------------
+// (r01-r03a: two launches, ~5 us of launch + dependency per pass -- a tenth of a 64k-request lock pass.)  Every one of
+// the KV_PLACE_GRID workgroups runs the scan of the big-bin list itself (a few hundred entries) and stores the same
+// bin_off[] words; what a workgroup reads back are its OWN stores (behind a workgroup-scope fence and barrier), so
+// nothing has to cross between workgroups inside the kernel.  Workgroup 0 does what the scan kernel did on the side (the next pass's counters, the log tail, the stats).
 __device__ static inline void
-kv_scan_body(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
-             uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
-             dint_dev_stats *__restrict__ stats) {
-  __shared__ uint32_t Sw[4];
+kv_scan_place_body(const uint32_t *__restrict__ bin_cnt, uint32_t *bin_off, const uint32_t *__restrict__ big,
+                   uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
+                   dint_dev_stats *__restrict__ stats, const uint4 *__restrict__ ovl, uint64_t *__restrict__ ovf) {
+  __shared__ uint32_t Sw[KV_TB / 64];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t < 4) big_next[t] = 0;
-  for (uint32_t k = t; k < 1024; k += 256) blk_pub_next[k] = 0;
-  if (t == 0 && tail) tail[0] = tail[1];
-  const uint32_t nbig = big[0];
+  const bool first = blockIdx.x == 0;
+  if (first) {
+    if (t < 4) big_next[t] = 0;
+    blk_pub_next[t] = 0;
+    if (t == 0 && tail) tail[0] = tail[1];
+  }
+  const uint32_t nbig = big[0], novl = big[1];
+  if (nbig == 0) return;  // no bin above DINT_KV_BINCAP records: nothing was listed for placement either
   uint32_t run = 0;
-  for (uint32_t lo = 0; lo < nbig; lo += 256) {  // workgroup-uniform trip count; one trip unless the pass is very skewed
+  for (uint32_t lo = 0; lo < nbig; lo += KV_TB) {  // workgroup-uniform trip count; one trip unless the pass is very skewed
     const uint32_t bin = lo + t < nbig ? big[4 + lo + t] : KV_NONE;
     const uint32_t extra = bin != KV_NONE ? bin_cnt[bin] - DINT_KV_BINCAP : 0;
     uint32_t tot, x = wave_excl_scan_u32(extra, &tot);
     __syncthreads();
     if (lane == 0) Sw[wave] = tot;
     __syncthreads();
-    for (uint32_t w = 0; w < wave; w++) x += Sw[w];
+    uint32_t all = 0;
+    for (uint32_t w = 0; w < KV_TB / 64; w++) {
+      if (w < wave) x += Sw[w];
+      all += Sw[w];
+    }
     if (bin != KV_NONE) bin_off[bin] = run + x;
-    run += Sw[0] + Sw[1] + Sw[2] + Sw[3];
+    run += all;
   }
-  if (t == 0 && nbig) atomicAdd(&stats->big_bin_requests, (unsigned long long)run + (unsigned long long)nbig * DINT_KV_BINCAP);
-}
-static __global__ void __launch_bounds__(256)
-k_kv_scan(const uint32_t *__restrict__ bin_cnt, uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ big,
-          uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
-          dint_dev_stats *__restrict__ stats) {
-  kv_scan_body(bin_cnt, bin_off, big, big_next, blk_pub_next, tail, stats);
-}
-
-// ---- k_kv_place ----------------------------------------------------------------------------------------
-// Overflow records (positions DINT_KV_BINCAP.. of a bin): from the pass's list into their bin's range.
-#define KV_PLACE_GRID 64u
-__device__ static inline void
-kv_place_body(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off, const uint4 *__restrict__ ovl,
-              uint64_t *__restrict__ ovf) {
-  const uint32_t novl = big[1];
-  for (uint32_t i = blockIdx.x * KV_TB + threadIdx.x; i < novl; i += KV_PLACE_GRID * KV_TB) {
+  if (first && t == 0) atomicAdd(&stats->big_bin_requests, (unsigned long long)run + (unsigned long long)nbig * DINT_KV_BINCAP);
+  // workgroup scope only: the waves of a workgroup share one CU, hence one L1 and one L2 -- a device-scope fence here
+  // writes the L2s back across the XCDs (measured: 70 us instead of 10)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * KV_TB + t; i < novl; i += KV_PLACE_GRID * KV_TB) {
     const uint4 o = ovl[i];
-    ovf[bin_off[o.z] + o.w - DINT_KV_BINCAP] = ((uint64_t)o.y << 32) | o.x;
+    const uint32_t off = __hip_atomic_load(&bin_off[o.z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ovf[off + o.w - DINT_KV_BINCAP] = ((uint64_t)o.y << 32) | o.x;
   }
 }
 static __global__ void __launch_bounds__(KV_TB)
-k_kv_place(const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off, const uint4 *__restrict__ ovl,
-           uint64_t *__restrict__ ovf) {
-  kv_place_body(big, bin_off, ovl, ovf);
+k_kv_scan_place(const uint32_t *__restrict__ bin_cnt, uint32_t *bin_off, const uint32_t *__restrict__ big,
+                uint32_t *__restrict__ big_next, uint32_t *__restrict__ blk_pub_next, uint32_t *tail,
+                dint_dev_stats *__restrict__ stats, const uint4 *__restrict__ ovl, uint64_t *__restrict__ ovf) {
+  kv_scan_place_body(bin_cnt, bin_off, big, big_next, blk_pub_next, tail, stats, ovl, ovf);
 }
 
 // ---- big bins ----------------------------------------------------------------------------------------------

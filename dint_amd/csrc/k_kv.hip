@@ -14,8 +14,8 @@
 //                  record in place (positions < 64) or on the pass's overflow list; count the log requests.
 //                  Log requests are finished here: the canonical 64-byte record goes to ring position
 //                  tail + (#log requests below i)   [deterministic: an exclusive scan, not an atomic].
-//   k_kv_scan    : give every bin with more than 64 records (the big-bin list) a range of the overflow area.
-//   k_kv_place   : move the overflow records there.
+//   k_kv_scan_place : give every bin with more than 64 records (the big-bin list) a range of the overflow area and move
+//                  the overflow records there (one launch: every workgroup runs the short scan itself).
 //   k_kv_resolve : every bin, one launch.  A bin of <= 64 records (the common case: ~32 per bin) is one wave: sorted
 //                  by (bucket group, key hash, idx) in registers and handled as one chunk (kv_chunk).  A bigger bin
 //                  (hot keys) is one 512-thread workgroup: sorted in LDS, ballot masks over the whole sorted stretch
@@ -1913,13 +1913,9 @@ __global__ void __launch_bounds__(KV_TB) k_kv_count_multi(kv_multi_args M) {
   kv_count_body<WL>(A.req, A.rep, A.n, A.kv, A.log, A.cut, A.bin_cnt, A.bins, A.big, A.ovl, A.blk_pub, A.stats, A.load_mode, A.V,
                     A.n_slices);
 }
-static __global__ void __launch_bounds__(256) k_kv_scan_multi(kv_multi_args M) {
+static __global__ void __launch_bounds__(KV_TB) k_kv_scan_place_multi(kv_multi_args M) {
   const kv_pass_args &A = M.e[blockIdx.y];
-  kv_scan_body(A.bin_cnt, A.bin_off, A.big, A.big_next, A.blk_pub_next, A.has_log ? A.log.tail : nullptr, A.stats);
-}
-static __global__ void __launch_bounds__(KV_TB) k_kv_place_multi(kv_multi_args M) {
-  const kv_pass_args &A = M.e[blockIdx.y];
-  kv_place_body(A.big, A.bin_off, A.ovl, A.ovf);
+  kv_scan_place_body(A.bin_cnt, A.bin_off, A.big, A.big_next, A.blk_pub_next, A.has_log ? A.log.tail : nullptr, A.stats, A.ovl, A.ovf);
 }
 // One-dimensional grid, the big-bin workgroups of ALL engines first (workgroups are dispatched in index order, and a hot
 // bin's workgroup is the longest job of the launch: with grid.y = engine the last engine's hot bins started when the
@@ -1953,17 +1949,15 @@ static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv 
   hipLaunchKernelGGL((k_kv_count<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
                      log, cut, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode, view);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
-                     s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr, s.stats);
+  hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
+                     (const uint32_t *)s.big, s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr, s.stats,
+                     (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(k_kv_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.big,
-                     (const uint32_t *)s.bin_off, (const uint4 *)s.ovl, s.ovf);
-  if (ev) hipEventRecord(ev[3], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
                      cut, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
                      (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats,
                      kv.force_rounds | (int)(dint_hot_min("DINT_KV_HOT_MIN", 0) << 8), kv.d_trace, view);
-  if (ev) hipEventRecord(ev[4], st);
+  if (ev) hipEventRecord(ev[3], st);
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
@@ -1997,8 +1991,7 @@ static void launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t s
     sum_resolve += A.resolve_blocks;
   }
   hipLaunchKernelGGL((k_kv_count_multi<WL>), dim3(max_slices, n_eng), dim3(KV_TB), 0, st, M);
-  hipLaunchKernelGGL(k_kv_scan_multi, dim3(1, n_eng), dim3(256), 0, st, M);
-  hipLaunchKernelGGL(k_kv_place_multi, dim3(KV_PLACE_GRID, n_eng), dim3(KV_TB), 0, st, M);
+  hipLaunchKernelGGL(k_kv_scan_place_multi, dim3(KV_PLACE_GRID, n_eng), dim3(KV_TB), 0, st, M);
   hipLaunchKernelGGL((k_kv_resolve_multi<WL>), dim3(sum_resolve), dim3(KVB_T), 0, st, M, n_eng);
 }
 

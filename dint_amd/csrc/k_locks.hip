@@ -13,7 +13,7 @@
 //                        one bin are merged in an LDS hash, so a hot slot costs one device atomic per workgroup -- and
 //                        store the 64-bit record {slot, idx, op} in place (positions < 64) or on the overflow list;
 //                        copy the request bytes to the reply array.
-//   k_kv_scan / _place : ranges of the overflow area for the bins of more than 64 records (shared with the kv passes)
+//   k_kv_scan_place    : ranges of the overflow area for the bins of more than 64 records (shared with the kv passes)
 //   k_lock_resolve     : one wave per bin of <= 64 records: sort by (slot, idx) in registers -- slots commute, so any
 //                        order that keeps each slot's requests in request order is serial-equivalent -- fetch every
 //                        slot's 8-byte word once, resolve all slots of the chunk at once (lock_fasst: closed form
@@ -878,10 +878,8 @@ static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *tabl
   hipLaunchKernelGGL((k_lock_count<WL>), dim3((n + KV_TB - 1) / KV_TB), dim3(KV_TB), 0, st, (const uint8_t *)d_req,
                      (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_kv_scan, dim3(1), dim3(256), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off, (const uint32_t *)s.big,
-                     s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats);
-  hipLaunchKernelGGL(k_kv_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.big,
-                     (const uint32_t *)s.bin_off, (const uint4 *)s.ovl, s.ovf);
+  hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
+                     (const uint32_t *)s.big, s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats, (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_lock_resolve_big<Ops>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, table, s.bin_cnt,
                      (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
