@@ -7,9 +7,10 @@
 // Every request touches exactly one bucket of one table (lock_hash % hash_size == kvs bucket), or only
 // the log ring.  Requests on different buckets commute; requests on one bucket apply in request order.
 //
-// One pass (n <= 2^20 requests) = four kernels (the shared ones live in dint_bins.h):
+// One pass (n <= 2^20 requests) = three kernels (the shared one lives in dint_bins.h); the passes of several engines can
+// share one set of launches (k_kv_*_multi, dint_launch_kv_multi):
 //   k_kv_count   : one thread per request -- copy the message to the reply array, classify, hash, reserve a position
-//                  in bin = group & (P-1) (P ~ n / 32) -- merged per workgroup in an LDS hash, so a hot key costs one
+//                  in bin = group % P (P = n / 32: any number, kv_cut) -- merged per workgroup in an LDS hash, so a hot key costs one
 //                  device atomic per workgroup -- and store the {bucket group, idx, type | quadrant | key-hash bits}
 //                  record in place (positions < 64) or on the pass's overflow list; count the log requests.
 //                  Log requests are finished here: the canonical 64-byte record goes to ring position
