@@ -185,19 +185,19 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0,
              const dint_view &view = dint_flat_view()) {
   if (int rc = order_stream(e, st)) return rc;
-  static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve_big", "k_lock_resolve"};
+  static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
   static const char *const kv_names[] = {"k_kv_count", "k_kv_scan_place", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                        timer_events(e, 4, lock_names), view);
+                        timer_events(e, 3, lock_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
     case DINT_WL_2PL:
       dint_launch_2pl(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                      timer_events(e, 4, lock_names), view);
+                      timer_events(e, 3, lock_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;

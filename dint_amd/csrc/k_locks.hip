@@ -14,16 +14,16 @@
 //                        store the 64-bit record {slot, idx, op} in place (positions < 64) or on the overflow list;
 //                        copy the request bytes to the reply array.
 //   k_kv_scan_place    : ranges of the overflow area for the bins of more than 64 records (shared with the kv passes)
-//   k_lock_resolve     : one wave per bin of <= 64 records: sort by (slot, idx) in registers -- slots commute, so any
-//                        order that keeps each slot's requests in request order is serial-equivalent -- fetch every
-//                        slot's 8-byte word once, resolve all slots of the chunk at once (lock_fasst: closed form
-//                        with ballots; lock_2pl: the counters are walked per slot with wave-uniform registers), write
-//                        each changed word back once.  No LDS, no global atomics.
-//   k_lock_resolve_big : one 512-thread workgroup per bigger bin (a hot slot): the bin is sorted in LDS a stretch of <=
-//                        4096 records at a time; slots whose requests sit inside one 64-record chunk are resolved as
-//                        above, all chunks in parallel; a slot whose requests cross chunks is walked by one wave with
-//                        the slot's word in registers -- O(requests), where r01 re-ranked the bin once per 512-record
-//                        window (O(c^2 / 512)) and kept 1 GB of worst-case scratch.
+//   k_lock_resolve     : every bin of the pass in one launch.  One wave per bin of <= 64 records: sort by (slot, idx) in
+//                        registers -- slots commute, so any order that keeps each slot's requests in request order is
+//                        serial-equivalent -- fetch every slot's 8-byte word once, resolve all slots of the chunk at
+//                        once (lock_fasst: closed form with ballots; lock_2pl: the counters are walked per slot with
+//                        wave-uniform registers), write each changed word back once.  No LDS, no global atomics.
+//                        One 512-thread workgroup per bigger bin (a hot slot; workgroups 0 .. 511 walk the list): the bin
+//                        is sorted in LDS a stretch of <= 4096 records at a time; slots whose requests sit inside one
+//                        64-record chunk are resolved as above, all chunks in parallel; a slot whose requests cross
+//                        chunks is walked by one wave with the slot's word in registers -- O(requests), where r01
+//                        re-ranked the bin once per 512-record window (O(c^2 / 512)) and kept 1 GB of worst-case scratch.
 // The table is an array of uint2 in HBM: fasst {lock, ver}, 2pl {num_ex, num_sh}.
 #include "dint_bins.h"
 
@@ -332,10 +332,10 @@ __device__ static inline void lk_chunk(uint8_t *rep, const dint_view &V, uint2 *
 }
 
 template <class Ops>
-__global__ void __launch_bounds__(256, 4)
-k_lock_resolve(uint8_t *rep, uint32_t pbits, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
-               const uint64_t *__restrict__ bins, dint_view V) {
-  const uint32_t lane = threadIdx.x & 63, bin = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ static inline void
+lk_small_bin(uint8_t *rep, uint32_t pbits, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
+             const uint64_t *__restrict__ bins, const dint_view &V, uint32_t bin) {
+  const uint32_t lane = threadIdx.x & 63;
   if (bin >= (1u << pbits)) return;
   const uint64_t r0 = bins[(size_t)bin * DINT_KV_BINCAP + lane];  // speculative (the bin region always exists): overlaps the counter load
   const uint32_t c = bin_cnt[bin];
@@ -350,16 +350,17 @@ k_lock_resolve(uint8_t *rep, uint32_t pbits, uint2 *__restrict__ table, uint32_t
 
 // ---- big bins: one 512-thread workgroup each ---------------------------------------------------------------------
 template <class Ops>
-__global__ void __launch_bounds__(KVB_T)
-k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
-                   const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-                   const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, dint_view V) {
-  const uint32_t bin_first = big[4 + blockIdx.x];  // speculative: in flight together with the list length
+__device__ static inline void
+lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
+            const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+            const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, const dint_view &V, const uint32_t vb,
+            const uint32_t n_walk) {  // workgroup vb of the n_walk that walk the big-bin list
+  const uint32_t bin_first = big[4 + vb];  // speculative: in flight together with the list length
   const uint32_t nbig = big[0];
-  if (blockIdx.x >= nbig) return;
+  if (vb >= nbig) return;
   // tracing (DINT_KV_TRACE=1): phase stamps of this workgroup's first bin, 10 ns ticks
-  unsigned long long *tw = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x : nullptr;
-#define LK_STAMP(k) do { if (tw && threadIdx.x == 0 && bi == blockIdx.x && win == 0) tw[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  unsigned long long *tw = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * vb : nullptr;
+#define LK_STAMP(k) do { if (tw && threadIdx.x == 0 && bi == vb && win == 0) tw[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   __shared__ uint64_t Sk[KVB_NMAX];
   __shared__ uint32_t Bcnt[KVB_NBK / 2];
   __shared__ uint16_t Bwin[KVB_NBK];
@@ -382,11 +383,11 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
   // precedes every request of the next one)
   const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 11 ? nbits - 11 : 0u;
   const uint32_t wcap = KVB_NMAX - (1u << bs);
-  for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-    const uint32_t bin = bi == blockIdx.x ? bin_first : big[4 + bi];
+  for (uint32_t bi = vb; bi < nbig; bi += n_walk) {
+    const uint32_t bin = bi == vb ? bin_first : big[4 + bi];
     __syncthreads();
     const uint32_t c = bin_cnt[bin];
-    if (tw && threadIdx.x == 0 && bi == blockIdx.x) { tw[0] = __builtin_amdgcn_s_memrealtime(); tw[8] = c; tw[9] = nbig; }
+    if (tw && threadIdx.x == 0 && bi == vb) { tw[0] = __builtin_amdgcn_s_memrealtime(); tw[8] = c; tw[9] = nbig; }
     const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
     const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;
     auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
@@ -442,7 +443,7 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
       for (uint32_t j = 1; j < 8; j++) best = Hs[j] > Hs[best] ? j : best;
       const uint32_t hot_n = Hs[best], hslot = cand[best];
       __syncthreads();
-      if (tw && t == 0 && bi == blockIdx.x) { tw[10] = __builtin_amdgcn_s_memrealtime(); tw[13] = hot_n; }
+      if (tw && t == 0 && bi == vb) { tw[10] = __builtin_amdgcn_s_memrealtime(); tw[13] = hot_n; }
       if (hot_n >= hot_min && 2 * hot_n >= c) {  // workgroup-uniform
         LK_FOR_RECORDS({
           if (lk_slot(r) == hslot) {
@@ -491,7 +492,7 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
         __syncthreads();
         uint2 st = table[hslot];  // workgroup-uniform address
         const uint2 st_in = st;
-        if (tw && t == 0 && bi == blockIdx.x) tw[11] = __builtin_amdgcn_s_memrealtime();
+        if (tw && t == 0 && bi == vb) tw[11] = __builtin_amdgcn_s_memrealtime();
         if (Ops::CLOSED) {
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __syncthreads();  // everyone holds the slot's word before anyone can write it
@@ -580,7 +581,7 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
           }
         }
         if (t == 0 && (st.x != st_in.x || st.y != st_in.y)) table[hslot] = st;
-        if (tw && t == 0 && bi == blockIdx.x) tw[12] = __builtin_amdgcn_s_memrealtime();
+        if (tw && t == 0 && bi == vb) tw[12] = __builtin_amdgcn_s_memrealtime();
         hslot_done = hslot;
         c_rest = c - hot_n;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -866,6 +867,20 @@ k_lock_resolve_big(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t
   }
 }
 
+// ---- k_lock_resolve: every bin of the pass, one launch ----------------------------------------------------------------
+// Workgroups 0 .. KVB_GRID-1 walk the big-bin list (most exit at once), each wave of the others resolves one bin of <= 64
+// records.  The two kinds own disjoint bins, hence disjoint slots, so the hot slots are resolved beside the bulk of the
+// pass -- as the kv passes always did.  (r01-r03a: two launches, k_lock_resolve_big then the 256-thread
+// k_lock_resolve: for a 64k-request pass one launch gap of ~5 us and the small bins' 4 us behind the hot slot's 23.)
+template <class Ops>
+__global__ void __launch_bounds__(KVB_T)
+k_lock_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
+               const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+               const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, dint_view V) {
+  if (blockIdx.x < KVB_GRID) lk_big_bins<Ops>(rep, n, table, bin_cnt, bins, big, bin_off, ovf, hot_min, trace, V, blockIdx.x, KVB_GRID);
+  else lk_small_bin<Ops>(rep, pbits, table, bin_cnt, bins, V, (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6));
+}
+
 // ------------------------------------------------------------------------------------------
 template <int WL, class Ops>
 static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,
@@ -881,13 +896,10 @@ static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *tabl
   hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
                      (const uint32_t *)s.big, s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats, (const uint4 *)s.ovl, s.ovf);
   if (ev) hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL((k_lock_resolve_big<Ops>), dim3(KVB_GRID), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, table, s.bin_cnt,
-                     (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+  hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits,
+                     table, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
                      (const uint64_t *)s.ovf, dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS), s.lock_trace, view);
   if (ev) hipEventRecord(ev[3], st);
-  hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3((P + 3) / 4), dim3(256), 0, st, (uint8_t *)d_rep, pbits, table, s.bin_cnt,
-                     (const uint64_t *)s.bins, view);
-  if (ev) hipEventRecord(ev[4], st);
 }
 
 void dint_launch_fasst(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,
