@@ -11,14 +11,15 @@
 //                   -- batch s is ordered by client id, then send order -- so the request stream is bit-identical
 //                   to the host driver's: position = messages of smaller client ids to that shard (a workgroup scan
 //                   + a decoupled look-back over the workgroups before mine, which are handed out by ticket and
-//                   publish their totals first thing, their inclusive prefixes as soon as they know them) + msg.ord.  The last workgroup writes the three batch sizes
-//                   for the engines (dint_submit_segments reads them on the device: no host round trip).
-//   k_txn_consume : every client copies the replies it waits for out of the (in place) reply arrays.  When consume
-//                   and the next emit are issued on the same stream (the closed loop does) the copy is FUSED into
-//                   k_txn_emit instead: the epoch's batches alternate between two buffer sets, so a client reads the
-//                   replies of epoch k from one set while the requests of epoch k+1 are written into the other -- one
-//                   kernel and one header load per epoch less, and the phase logic reads the replies it has just
-//                   copied while they are still in cache.
+//                   publish their totals first thing, their inclusive prefixes as soon as they know them) + msg.ord.
+//                   The last workgroup writes the three batch sizes for the engines (dint_submit_segments* read them
+//                   on the device: no host round trip).
+//   k_txn_consume : every client takes what it needs of the replies it waits for out of the (in place) reply arrays:
+//                   type / version / first value byte into its header, the whole reply where the transaction keeps the
+//                   row (tx_consume_one).  When consume and the next emit are issued on the same stream (the closed
+//                   loop does) this is FUSED into k_txn_emit instead: the epoch's batches alternate between two buffer
+//                   sets, so a client reads the replies of epoch k from one set while the requests of epoch k+1 are
+//                   written into the other -- one kernel and one header load per epoch less.
 #include <hip/hip_runtime.h>
 
 #include <new>
@@ -61,9 +62,10 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
   if (t < 4) pub_other[tile * 4 + t] = 0;
   if (tile == 0 && t == 0) *ticket_other = 0;
 
-  // the client's header travels through registers: one coalesced 72 / 112-byte load here, one store at the end; the
-  // working messages stay in memory and are touched only where the phase reads or writes them
-  // the phase's message queue lives in LDS (dynamically indexed byte arrays: left to the compiler it went to scratch)
+  // the client's header travels through registers: one 128 / 112-byte load here, one store at the end.  It carries
+  // what the phase logic reads of the replies (tatp); the working messages stay in memory and are touched only where a
+  // transaction keeps a whole row.  The phase's message queue lives in LDS (dynamically indexed byte arrays: left to
+  // the compiler it went to scratch).
   __shared__ typename T::Out So[TXG_TB];
   typename T::Out &o = So[t];
   o.clear();
@@ -108,10 +110,10 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
   // ---- ... + the messages of the workgroups before mine: decoupled look-back.  A workgroup publishes its own totals
   // first thing (TXG_AGG), then walks back over the workgroups before it until, per shard, it meets one that already
   // knows its inclusive prefix (TXG_PFX), and publishes its own.  Workgroups are handed out by ticket, so the ones a
-  // look-back waits for are running.  The resident workgroups (~800) finish their phases at about the same time, so
-  // a walk is hundreds of entries deep: all 256 threads look at once (one entry each, its three words loaded
-  // together), 256 entries per step.  (r03a: one wave, one shard at a time, 64 entries per step -- 41 of the kernel's
-  // 204 us, measured with DINT_TXN_DBG=1.  r02 summed ALL earlier totals in every workgroup.)
+  // look-back waits for are running.  The resident workgroups (hundreds) finish their phases at about the same time,
+  // so a walk is hundreds of entries deep: all TXG_TB threads look at once (one entry each, its three words loaded
+  // together), TXG_TB entries per step.  (r03a: one wave, one shard at a time, 64 entries per step -- 41 of the
+  // kernel's 204 us, measured with DINT_TXN_DBG=1.  r02 summed ALL earlier totals in every workgroup.)
   __shared__ uint32_t Lsum[3][TXG_TB / 64], Lhit[3][TXG_TB / 64];
   if (t < 3) __hip_atomic_store(&pub[tile * 4 + t], TXG_AGG | tot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t base[3] = {0, 0, 0};
