@@ -42,10 +42,35 @@ struct txg_stats {
 
 void dint_driver_params(const dint_driver_config &c, TxParams *P, ZipfTable *zipf);  // txn_driver.cc
 
+// The client headers live in HBM as dword COLUMNS (word j of client i at cols[j * n_clients + i]): the lanes of a wave
+// are consecutive clients, so every load / store instruction of a header is one contiguous 256-byte run -- whole
+// sectors, two cache lines per instruction.  (As an array of 128-byte structs every 16-byte piece of an instruction
+// went to a line of its own: 64 lines per instruction, and partial-sector writes on the way back.)
+// The words of `m` (where the client's working messages live: set by the kernel on every load) do not travel.
+template <class C> using c_m_t = decltype(C::m);
+template <class C>
+__device__ static inline bool txg_is_m(uint32_t j) { return j >= offsetof(C, m) / 4 && j < (offsetof(C, m) + sizeof(c_m_t<C>)) / 4; }
+template <class C>
+__device__ static inline void txg_load_client(C &c, const uint32_t *cols, uint32_t n_clients, uint32_t i) {
+  static_assert(sizeof(C) % 4 == 0 && offsetof(C, m) % 4 == 0, "client header in dwords");
+  uint32_t w[sizeof(C) / 4];
+#pragma unroll
+  for (uint32_t j = 0; j < sizeof(C) / 4; j++) w[j] = txg_is_m<C>(j) ? 0u : cols[(size_t)j * n_clients + i];
+  __builtin_memcpy(&c, w, sizeof(C));
+}
+template <class C>
+__device__ static inline void txg_store_client(const C &c, uint32_t *cols, uint32_t n_clients, uint32_t i) {
+  uint32_t w[sizeof(C) / 4];
+  __builtin_memcpy(w, &c, sizeof(C));
+#pragma unroll
+  for (uint32_t j = 0; j < sizeof(C) / 4; j++)
+    if (!txg_is_m<C>(j)) cols[(size_t)j * n_clients + i] = w[j];
+}
+
 // W = waves per SIMD the kernel is compiled for (the register budget: 3 -> 168, 4 -> 128, 5 -> 96 VGPRs; DINT_TXN_WAVES)
 template <class T, int W>
 __global__ void __launch_bounds__(TXG_TB, W)
-k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
+k_txn_emit(uint32_t *cl, uint8_t *store, uint32_t n_clients, TxParams P, uint8_t *out0, uint8_t *out1,
            uint8_t *out2, const uint8_t *rep0, const uint8_t *rep1, const uint8_t *rep2, uint32_t cap, uint32_t *pub,
            uint32_t *ticket, uint32_t *pub_other, uint32_t *ticket_other, uint32_t *counts, txg_stats *st, uint32_t dbg) {
   typedef typename T::Msg Msg;
@@ -71,7 +96,7 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
   o.clear();
   typename T::Client c;
   if (valid) {
-    c = cl[i];
+    txg_load_client(c, cl, n_clients, i);
     c.m.base = store + (size_t)i * TX_DEV_MSG_STRIDE;  // message k of every client is one array of sectors (TxMsgs)
     c.m.stride = (uint64_t)n_clients * TX_DEV_MSG_STRIDE;
     if (rep0) {  // fused consume: the replies of the previous epoch (the other buffer set), then the phase that reads them
@@ -171,7 +196,7 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
       }
     }
   }
-  if (valid) cl[i] = c;
+  if (valid) txg_store_client(c, cl, n_clients, i);
   // ---- statistics: LDS first, then one device atomic per counter and workgroup
   if (valid) {
     atomicAdd(&Sst[offsetof(txg_stats, messages) / 8], (unsigned long long)o.n);
@@ -191,12 +216,13 @@ k_txn_emit(typename T::Client *cl, uint8_t *store, uint32_t n_clients, TxParams 
 
 template <class T>
 __global__ void __launch_bounds__(TXG_TB)
-k_txn_consume(typename T::Client *cl, uint8_t *store, uint32_t n_clients, const uint8_t *rep0,
+k_txn_consume(uint32_t *cl, uint8_t *store, uint32_t n_clients, const uint8_t *rep0,
               const uint8_t *rep1, const uint8_t *rep2, uint32_t cap) {
   typedef typename T::Msg Msg;
   const uint32_t i = blockIdx.x * TXG_TB + threadIdx.x;
   if (i >= n_clients) return;
-  typename T::Client c = cl[i];
+  typename T::Client c;
+  txg_load_client(c, cl, n_clients, i);
   c.m.base = store + (size_t)i * TX_DEV_MSG_STRIDE;
   c.m.stride = (uint64_t)n_clients * TX_DEV_MSG_STRIDE;
   const uint8_t n = c.n_out;
@@ -208,7 +234,7 @@ k_txn_consume(typename T::Client *cl, uint8_t *store, uint32_t n_clients, const 
       tx_consume_one(c, c.out_dst[k], (const Msg *)(rb + (size_t)c.out_pos[k] * sizeof(Msg)));
     }
   }
-  cl[i] = c;  // the reply summaries live in the header
+  txg_store_client(c, cl, n_clients, i);  // the reply summaries live in the header
 }
 
 // ------------------------------------------------------------------------------------------------- host side
@@ -237,12 +263,17 @@ namespace {
 template <class T>
 int upload_clients(dint_gdriver *g) {
   typedef typename T::Client Client;
-  std::vector<Client> h(g->cfg.n_clients);
-  for (uint32_t i = 0; i < g->cfg.n_clients; i++) {
-    memset(&h[i], 0, sizeof(Client));
-    h[i].rng.s = 0xdeadbeefull + g->cfg.first_client + i;  // ClientLoop :1122
+  const size_t n = g->cfg.n_clients, nw = sizeof(Client) / 4;
+  std::vector<uint32_t> h(n * nw);  // dword columns: word j of client i at h[j * n + i] (txg_load_client)
+  for (size_t i = 0; i < n; i++) {
+    Client c;
+    memset(&c, 0, sizeof(Client));
+    c.rng.s = 0xdeadbeefull + g->cfg.first_client + i;  // ClientLoop :1122
+    uint32_t w[sizeof(Client) / 4];
+    memcpy(w, &c, sizeof(Client));
+    for (size_t j = 0; j < nw; j++) h[j * n + i] = w[j];
   }
-  const size_t bytes = h.size() * sizeof(Client), sbytes = h.size() * T::NMSG * (size_t)TX_DEV_MSG_STRIDE;
+  const size_t bytes = h.size() * 4, sbytes = n * T::NMSG * (size_t)TX_DEV_MSG_STRIDE;
   if (hipMalloc(&g->d_clients, bytes) != hipSuccess || hipMalloc(&g->d_store, sbytes) != hipSuccess) return DINT_ENOMEM;
   if (hipMemcpy(g->d_clients, h.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return DINT_EHIP;
   if (hipMemset(g->d_store, 0, sbytes) != hipSuccess) return DINT_EHIP;
@@ -253,14 +284,14 @@ int upload_clients(dint_gdriver *g) {
 namespace {
 template <class T>
 void launch_consume(dint_gdriver *g, hipStream_t st, uint32_t set) {
-  hipLaunchKernelGGL((k_txn_consume<T>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (typename T::Client *)g->d_clients,
+  hipLaunchKernelGGL((k_txn_consume<T>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (uint32_t *)g->d_clients,
                      (uint8_t *)g->d_store, g->cfg.n_clients, g->d_batch[set][0], g->d_batch[set][1], g->d_batch[set][2], g->cap);
 }
 template <class T>
 void launch_emit(dint_gdriver *g, hipStream_t st, bool fused) {
   const uint32_t b = g->cur, o = b ^ 1u;  // requests go into set b; the replies of the previous epoch sit in set o
 #define TXG_LAUNCH(W)                                                                                                      \
-  hipLaunchKernelGGL((k_txn_emit<T, W>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (typename T::Client *)g->d_clients,           \
+  hipLaunchKernelGGL((k_txn_emit<T, W>), dim3(g->ntiles), dim3(TXG_TB), 0, st, (uint32_t *)g->d_clients,                     \
                      (uint8_t *)g->d_store, g->cfg.n_clients, g->P, g->d_batch[b][0], g->d_batch[b][1], g->d_batch[b][2],    \
                      fused ? g->d_batch[o][0] : nullptr, fused ? g->d_batch[o][1] : nullptr, fused ? g->d_batch[o][2] : nullptr, \
                      g->cap, g->d_pub + (size_t)b * g->ntiles * 4, g->d_ticket + b, g->d_pub + (size_t)o * g->ntiles * 4,     \
