@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Long reference-made traces for the four workloads whose committed .npz fixtures are short: lock_2pl,
-log_server, store, smallbank.  Each trace -- 3,000,000 requests -- is generated from seeds by code in this repository
+"""Long reference-made traces for the workloads whose committed .npz fixtures are short: lock_2pl,
+log_server, store, smallbank -- and tatp (the closed loop of the restated clients at the reference's 7M subscribers).  Each trace -- 3,000,000 requests -- is generated from seeds by code in this repository
 (tests/long_traces.py: the restated lock_2pl / smallbank clients in closed loop against CPU oracle servers, seeded
 streams for the other two), replayed through the UNMODIFIED reference udp/ server (oracle/_ref/ref_*, compile-time
 sizes) and only hashes are committed: of the request stream, of the reference's reply stream (whole and a 1M prefix)
@@ -36,7 +36,7 @@ def main():
         req, rep = lt.TRACES[wl](lt.oracle_servers(wl))  # closed loop / stream against the CPU oracle
         ref = orc.ref_replay(lt.REF_NAME[wl], req, dump=wl in ("lock_2pl", "log_server"))
         ref_rep = ref[0]
-        if wl in ("store", "smallbank"):  # rows the trace never wrote still hold the reference's populate-time stack bytes
+        if wl in ("store", "smallbank", "tatp"):  # rows the trace never wrote still hold the reference's populate-time stack bytes
             a, b = orc.mask_populate_garbage(wl, ref_rep.copy()), orc.mask_populate_garbage(wl, rep.copy())
         else:
             a, b = ref_rep, rep

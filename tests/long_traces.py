@@ -9,12 +9,13 @@ from dint_amd.driver import Driver, tpl_trace
 from dint_amd.workloads import Zipf
 
 N = 3_000_000
-REF_NAME = {"lock_2pl": "lock_2pl", "log_server": "log_server", "store": "store", "smallbank": "smallbank"}
+REF_NAME = {"lock_2pl": "lock_2pl", "log_server": "log_server", "store": "store", "smallbank": "smallbank", "tatp": "tatp"}
 PARAMS = {
     "lock_2pl": {"slots": 36_000_000, "workers": 4096, "key_space": 24_000_000, "zipf": 0.8, "seed": 2024},
     "log_server": {"ring": 1_000_000, "seed": 2025},
     "store": {"subscribers": 2_000_000, "zipf": 0.8, "p_set": 0.2, "p_missing": 0.03, "seed": 2026},
     "smallbank": {"accounts": 24_000_000, "clients": 4096, "server": 0},
+    "tatp": {"subscribers": 7_000_000, "clients": 16_384, "server": 0, "log_entries": 1_000_000},
 }
 
 
@@ -36,6 +37,8 @@ def oracle_servers(wl):
     if wl == "store":
         n = PARAMS[wl]["subscribers"]
         return [_Oracle(orc.StoreOracle(n * 18 // 4, n))]
+    if wl == "tatp":
+        return [_Oracle(orc.TatpOracle(PARAMS[wl]["subscribers"], log_entries=PARAMS[wl]["log_entries"])) for _ in range(3)]
     return [_Oracle(orc.SmallbankOracle(PARAMS[wl]["accounts"])) for _ in range(3)]
 
 
@@ -89,7 +92,24 @@ def smallbank(servers):
     return np.concatenate(reqs)[:N], np.concatenate(reps)[:N]
 
 
-TRACES = {"lock_2pl": lock_2pl, "log_server": log_server, "store": store, "smallbank": smallbank}
+def tatp(servers):
+    """shard server 0's stream of 16,384 restated reference clients (the seven transactions in the reference's mix, its own
+    subscriber distribution tatp_nurand) in closed loop against three shard servers at the reference's 7M subscribers:
+    reads, lock grants and refusals, commits to primary / backups / logs, CALL_FORWARDING inserts and deletes"""
+    p = PARAMS["tatp"]
+    d = Driver(wire.Workload.TATP, p["clients"], p["subscribers"])
+    reqs, reps, n = [], [], 0
+    while n < N:
+        rq = d.next()
+        rp = [servers[s].submit(rq[s]) for s in range(3)]
+        d.consume(rp)
+        reqs.append(rq[p["server"]])
+        reps.append(rp[p["server"]])
+        n += len(rq[p["server"]])
+    return np.concatenate(reqs)[:N], np.concatenate(reps)[:N]
+
+
+TRACES = {"lock_2pl": lock_2pl, "log_server": log_server, "store": store, "smallbank": smallbank, "tatp": tatp}
 
 
 def reply_types(wl, rep):

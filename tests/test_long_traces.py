@@ -1,5 +1,5 @@
 """Long reference-made traces (tests/golden/long_traces.json, made by tests/golden/make_long.py): 3,000,000 requests each
-for lock_2pl, log_server, store and smallbank, replayed through the UNMODIFIED reference udp/ servers at their
+for lock_2pl, log_server, store, smallbank and tatp, replayed through the UNMODIFIED reference udp/ servers at their
 compile-time sizes; hashes of the reply streams are committed.  The traces are regenerated here (tests/long_traces.py)
 -- the closed-loop ones through the servers under test, so a single wrong grant would send the clients down another
 path and change the request hash -- and compared: the CPU oracle (not gpu), the engines at two pass sizes (gpu)."""
@@ -25,7 +25,7 @@ def sha(a) -> str:
 def _check(wl, req, rep):
     f = FIX[wl]
     assert len(req) == f["n_requests"] and sha(req) == f["req_sha256"], "the trace itself differs (a reply sent a client down another path, or a generator drifted)"
-    rep = orc.mask_populate_garbage(wl, rep) if wl in ("store", "smallbank") else rep
+    rep = orc.mask_populate_garbage(wl, rep) if wl in ("store", "smallbank", "tatp") else rep
     assert sha(rep[:1 << 20]) == f["rep_prefix_1m_sha256"]
     assert sha(rep) == f["rep_sha256"]
     assert lt.reply_types(wl, rep) == f["reply_types"]
@@ -41,6 +41,14 @@ def test_oracle_long_trace(wl):
 def test_oracle_long_trace_smallbank():
     req, rep = lt.TRACES["smallbank"](lt.oracle_servers("smallbank"))
     _check("smallbank", req, rep)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("DINT_LONG_TATP") != "1", reason="three 7M-subscriber CPU oracles: ~10 minutes of page faults "
+                    "in the build container (set DINT_LONG_TATP=1); tests/golden/make_long.py ran it when the fixture was made")
+def test_oracle_long_trace_tatp():
+    req, rep = lt.TRACES["tatp"](lt.oracle_servers("tatp"))
+    _check("tatp", req, rep)
 
 
 # ------------------------------------------------------------------------------------------------- GPU
@@ -109,3 +117,28 @@ def test_gpu_long_trace_smallbank():
     e2 = Engine(W.SMALLBANK, n_rows=n)
     e2.populate(n)
     _check("smallbank", req, _replay(e2, req, 1 << 20))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_long_trace_tatp():
+    """the headline workload at the reference's own size: 16,384 restated clients in closed loop against three GPU shard
+    servers of 7M subscribers; server 0's 3M requests and replies against the hashes of the unmodified
+    tatp/udp/server_shard.cc on the same stream (a single wrong grant sends the clients down another path), then the
+    stream again through a fresh engine in passes of 2^20"""
+    from dint_amd.engine import Engine
+
+    p = lt.PARAMS["tatp"]
+
+    def mk():
+        e = Engine(W.TATP, n_rows=p["subscribers"], log_entries=p["log_entries"])
+        e.populate(p["subscribers"])
+        return e
+
+    engs = [mk() for _ in range(3)]
+    req, rep = lt.tatp(engs)
+    _check("tatp", req, rep)
+    st = engs[p["server"]].stats()
+    assert st["bad_requests"] == 0
+    del engs
+    _check("tatp", req, _replay(mk(), req, 1 << 20))
