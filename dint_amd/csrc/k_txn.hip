@@ -100,13 +100,27 @@ k_txn_emit(uint32_t *cl, uint8_t *store, uint32_t n_clients, TxParams P, uint8_t
     c.m.base = store + (size_t)i * TX_DEV_MSG_STRIDE;  // message k of every client is one array of sectors (TxMsgs)
     c.m.stride = (uint64_t)n_clients * TX_DEV_MSG_STRIDE;
     if (rep0) {  // fused consume: the replies of the previous epoch (the other buffer set), then the phase that reads them
+      // The three fields of every awaited reply first, ALL loads in flight together (unconditional, from slot 0 of
+      // the batch where there is nothing to read: one round trip instead of one per reply), then the summaries; whole
+      // rows, where a transaction keeps them, behind that.
       const uint8_t n = c.n_out;
+      const Msg *rp[T::MAXOUT];
+      uint8_t r_ty[T::MAXOUT], r_v0[T::MAXOUT];
+      uint32_t r_ver[T::MAXOUT];
 #pragma unroll
       for (uint8_t k = 0; k < T::MAXOUT; k++) {  // unrolled: the header's arrays stay in registers
-        if (k < n && c.out_pos[k] < cap) {
-          const uint8_t sh = c.out_shard[k];
-          const uint8_t *rb = sh == 0 ? rep0 : sh == 1 ? rep1 : rep2;
-          tx_consume_one(c, c.out_dst[k], (const Msg *)(rb + (size_t)c.out_pos[k] * sizeof(Msg)));
+        const bool use = k < n && c.out_pos[k] < cap && c.out_dst[k] != TX_NO_DST;
+        const uint8_t sh = use ? c.out_shard[k] : 0;
+        const uint8_t *rb = sh == 0 ? rep0 : sh == 1 ? rep1 : rep2;
+        rp[k] = (const Msg *)(rb + (size_t)(use ? c.out_pos[k] : 0u) * sizeof(Msg));
+        r_ty[k] = rp[k]->type; r_v0[k] = rp[k]->val[0]; r_ver[k] = rp[k]->ver;
+      }
+#pragma unroll
+      for (uint8_t k = 0; k < T::MAXOUT; k++) {
+        const uint8_t d = c.out_dst[k];
+        if (k < n && c.out_pos[k] < cap && d != TX_NO_DST) {
+          c.note_reply((uint8_t)(d & TX_DST_MASK), r_ty[k], r_v0[k], r_ver[k]);
+          if (d & TX_FULL) c.m[d & TX_DST_MASK] = *rp[k];
         }
       }
     }

@@ -13,11 +13,12 @@
 
 #include <vector>
 
-// The table carries a coarse index behind the thresholds (cdf[n + b] = sample(b << 20) before the scatter, b = 0 ..
-// 4095, and cdf[n + 4096] = n - 1): a lookup brackets its binary search with two adjacent index words -- 8-10 dependent
+// The table carries a coarse index behind the thresholds (cdf[n + b] = sample(b << 16) before the scatter, b = 0 ..
+// 65535, and cdf[n + 65536] = n - 1): a lookup brackets its binary search with two adjacent index words -- ~5 dependent
 // loads over a 1M-row table instead of 20 (the GPU-resident clients draw a key per new transaction, a dependent chain
-// per lane).  The bracket contains the answer, so the result is the plain binary search's.
-#define ZIPF_IDX_BITS 12
+// per lane: 63 % of k_txn_emit's wave cycles are waits).  The bracket contains the answer, so the result is the plain
+// binary search's.
+#define ZIPF_IDX_BITS 16
 #define ZIPF_IDX_N ((1u << ZIPF_IDX_BITS) + 1u)
 struct ZipfTable {
   std::vector<uint32_t> cdf;  // n thresholds, then ZIPF_IDX_N index words
@@ -34,7 +35,7 @@ struct ZipfTable {
       cdf[k] = c >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)c;
     }
     cdf[n - 1] = 0xFFFFFFFFu;
-    uint64_t k = 0;  // index: the smallest k with cdf[k] > b << 20, for ascending b
+    uint64_t k = 0;  // index: the smallest k with cdf[k] > b << (32 - ZIPF_IDX_BITS), for ascending b
     for (uint32_t b = 0; b < (1u << ZIPF_IDX_BITS); b++) {
       const uint32_t x = b << (32 - ZIPF_IDX_BITS);
       while (k < n - 1 && cdf[k] <= x) k++;

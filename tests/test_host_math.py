@@ -29,7 +29,7 @@ def test_indexed_zipf_lookup_equals_plain_binary_search(hm, n, theta):
     rng = np.random.default_rng(n)
     xs = rng.integers(0, 1 << 32, 400_000, dtype=np.uint64).astype(np.uint32)
     # the edges of every index bucket and of the 32-bit range
-    edges = (np.arange(0, 4097, dtype=np.uint64) << np.uint64(20))
+    edges = (np.arange(0, 65537, dtype=np.uint64) << np.uint64(16))  # ZIPF_IDX_BITS = 16
     edges = np.clip(np.concatenate([edges, edges + 1, edges - 1]), 0, (1 << 32) - 1).astype(np.uint32)
     xs = np.ascontiguousarray(np.concatenate([xs, edges]))
     assert hm.zipf_mismatches(n, theta, xs.ctypes.data, len(xs)) == 0
