@@ -270,8 +270,8 @@ int dint_submit_segments(dint_engine_t *e, void *d_base, uint32_t n_seg, uint32_
 /* (round 3; the config layout and DINT_ABI_VERSION are unchanged) the segments of SEVERAL engines (the shard servers of one GPU: same workload -- store, tatp or smallbank --
  * same device) answered by ONE set of kernel launches on ONE stream, the engines' kernels side by side in one grid.  A
  * closed-loop epoch or an exchange step hands every server its batch at the same moment; with one stream per engine that
- * is a fork and a join across streams per step, with this call it is four launches on the caller's stream (NULL: the
- * first engine's).  Each engine's history is what dint_submit_segments would have produced.  Batches that do not fit one
+ * is a fork and a join across streams per step, with this call it is three launches on the caller's stream (NULL: the
+ * first engine's).  Every engine appears at most once in `items` (DINT_EINVAL otherwise).  Each engine's history is what dint_submit_segments would have produced.  Batches that do not fit one
  * kernel pass (n_seg * seg_cap > max_pass), lock / log engines and more than 4 items fall back to one
  * dint_submit_segments per item on that stream. */
 typedef struct dint_segments_item {
