@@ -8,6 +8,7 @@ object with ``submit``).
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -63,7 +64,10 @@ class Driver:
             self._L.dint_driver_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter exit the HIP runtime may already be gone (module teardown order): the process is ending anyway
+        if not sys.is_finalizing():
+            self.close()
 
     def next(self):
         """Requests of the next epoch: list of 3 numpy arrays (copies) of packed wire structs."""
@@ -129,7 +133,10 @@ class GpuDriver:
             self._L.dint_gdriver_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter exit the HIP runtime may already be gone (module teardown order): the process is ending anyway
+        if not sys.is_finalizing():
+            self.close()
 
     def next(self, stream: int = 0):
         rc = self._L.dint_gdriver_next(self._h, stream)
@@ -203,7 +210,10 @@ class FasstClient:
             self._L.dint_fasst_client_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter exit the HIP runtime may already be gone (module teardown order): the process is ending anyway
+        if not sys.is_finalizing():
+            self.close()
 
     def next(self) -> np.ndarray:
         p = self._L.dint_fasst_client_next(self._h)

@@ -9,6 +9,7 @@ wire structs (:mod:`dint_amd.wire`); ``submit_device`` works on HBM-resident buf
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -48,7 +49,10 @@ class Pinned:
             self._L.dint_free_pinned(self.ptr)
             self.ptr = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter exit the HIP runtime may already be gone (module teardown order): the process is ending anyway
+        if not sys.is_finalizing():
+            self.close()
 
 
 class Engine:
@@ -74,7 +78,10 @@ class Engine:
             self._L.dint_engine_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter exit the HIP runtime may already be gone (module teardown order): the process is ending anyway
+        if not sys.is_finalizing():
+            self.close()
 
     # ---- hot path ---------------------------------------------------------
     def submit(self, reqs: np.ndarray) -> np.ndarray:

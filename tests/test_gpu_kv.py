@@ -395,10 +395,13 @@ def test_pass_size_does_not_change_the_answer(max_pass):
 
 
 @pytest.mark.parametrize("wl,n,touch", [("store", 1_000_000, 20_000), ("store", 400_000, 1), ("tatp", 1_000_000, 30_000),
-                                        ("tatp", 300_000, 2), ("smallbank", 1_000_000, 40_000), ("smallbank", 250_000, 1)])
+                                        ("tatp", 300_000, 2), ("smallbank", 1_000_000, 40_000), ("smallbank", 250_000, 1),
+                                        ("store", 1_000_000, 250), ("smallbank", 1_000_000, 900)])
 def test_one_pass_of_up_to_a_million_requests(wl, n, touch):
     """The largest passes (20-bit request index, 32768 bins), spread wide and piled on one or two hot keys (bins of
-    10^5 records: hundreds of 512-request windows cut along request-index buckets)."""
+    10^5 records: hundreds of 512-request windows cut along request-index buckets) -- and over a few thousand keys of
+    ~300 requests each: thousands of big bins, so that every workgroup of k_kv_scan_place runs its scan of the big-bin
+    list in several trips."""
     if wl == "store":
         req = tracegen.store_random(n, seed=n + touch, n_sub_touch=touch, p_set=0.4, p_insert=0.02)
         eng = _engine(W.STORE, n_rows=100_000)
