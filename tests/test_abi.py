@@ -57,3 +57,13 @@ def test_product_path_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cc", ".c")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_segments_multi_rejects_bad_arguments_without_a_device():
+    """dint_submit_segments_multi checks its items before it touches a device: no items, a null engine"""
+    L = _lib.load()
+    assert L.dint_submit_segments_multi(None, 0, None) < 0
+    items = (_lib.SegmentsItem * 2)()
+    assert L.dint_submit_segments_multi(items, 2, None) < 0  # engine == NULL
+    assert b"null" in L.dint_last_error()
+    assert C.sizeof(_lib.SegmentsItem) == 48  # {engine, d_base, n_seg, seg_cap, seg_stride, d_cnt, cnt_stride}
