@@ -142,13 +142,19 @@ int mark_stream(dint_engine *e, hipStream_t st) {  // end of a call that enqueue
   return 0;
 }
 
+// The routing calls are ordered the same way, in a domain of their own: a caller's stream is never touched after the
+// call that used it (mark_route_stream records ev_route_order on it before that call returns -- ADVICE r03).
 int order_route_stream(dint_engine *e, hipStream_t st) {
+  if (!e->ev_route_order) HIP_TRY(hipEventCreateWithFlags(&e->ev_route_order, hipEventDisableTiming));
   if (e->route_last_stream && e->route_last_stream != st) {
-    if (!e->ev_route_order) HIP_TRY(hipEventCreateWithFlags(&e->ev_route_order, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(e->ev_route_order, e->route_last_stream));
+    if (e->route_last_stream == e->stream) HIP_TRY(hipEventRecord(e->ev_route_order, e->stream));
     HIP_TRY(hipStreamWaitEvent(st, e->ev_route_order, 0));
   }
   e->route_last_stream = st;
+  return 0;
+}
+int mark_route_stream(dint_engine *e, hipStream_t st) {  // end of a routing call that enqueued on `st`
+  if (st != e->stream && e->route_last_stream == st) HIP_TRY(hipEventRecord(e->ev_route_order, st));
   return 0;
 }
 
@@ -460,6 +466,13 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
         return rc;
     return 0;
   }
+  // every argument is checked before an engine is locked or a stream ordered: an EINVAL on item k must not leave the
+  // engines of items 0 .. k-1 with a new last_stream and a stale ordering event
+  for (uint32_t k = 0; k < n_items; k++) {
+    const dint_segments_item &it = items[k];
+    if (!it.d_base || !it.d_cnt) return fail(DINT_EINVAL, "null argument");
+    if (it.seg_stride < (uint64_t)it.seg_cap * it.engine->msg_size) return fail(DINT_EINVAL, "seg_stride smaller than a segment");
+  }
   std::vector<dint_engine *> es;
   for (uint32_t k = 0; k < n_items; k++) es.push_back(items[k].engine);
   std::sort(es.begin(), es.end());
@@ -470,8 +483,6 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
   for (uint32_t k = 0; k < n_items; k++) {
     const dint_segments_item &it = items[k];
     dint_engine *e = it.engine;
-    if (!it.d_base || !it.d_cnt) return fail(DINT_EINVAL, "null argument");
-    if (it.seg_stride < (uint64_t)it.seg_cap * e->msg_size) return fail(DINT_EINVAL, "seg_stride smaller than a segment");
     if (int rc = order_stream(e, st)) return rc;
     pass[k].d_req = it.d_base; pass[k].d_rep = it.d_base; pass[k].n = it.n_seg * it.seg_cap;
     pass[k].kv = &e->kv; pass[k].log = e->log; pass[k].s = e->scratch;
@@ -647,6 +658,8 @@ int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64
   dint_launch_route_pack(jobs, n_items, seg_stride, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  for (uint32_t k = 0; k < n_items; k++)
+    if (int rc = mark_route_stream(items[k].engine, st)) return rc;
   return 0;
 }
 

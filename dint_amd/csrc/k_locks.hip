@@ -487,7 +487,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
               if (Bm[4 * t + j]) ex = (int)((4 * t + j) * 32 + 31 - (uint32_t)__clz(Bm[4 * t + j]));
             }
           }
-          if (t == KVB_T - 1) { Pw[TPL_HOT_NMAX / 32] = (uint16_t)base; Hs[7] = (uint32_t)ex; }  // totals: COMMITs / last op of all
+          if (t == KVB_T - 1) { Hs[6] = base; Hs[7] = (uint32_t)ex; }  // totals: COMMITs (a 32-bit word: 65,536 COMMITs on one slot do not fit Pw's 16 bits) / last op of all
         }
         __syncthreads();
         uint2 st = table[hslot];  // workgroup-uniform address
@@ -510,7 +510,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
           if (t == 0) {
             const uint32_t lastop = Hs[7];
             if (lastop != ~0u) st.x = (Bacq[lastop >> 5] >> (lastop & 31u)) & 1u;
-            st.y += Pw[TPL_HOT_NMAX / 32];
+            st.y += Hs[6];
           }
         } else {
           for (uint32_t r0 = 0; r0 < hot_n; r0 += TPL_HOT_WIN) {

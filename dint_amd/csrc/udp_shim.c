@@ -31,7 +31,7 @@
  *
  *   dint_udp_server --workload {fasst|2pl|log|store|tatp|smallbank} [--rows N] [--slots N] [--populate N]
  *                   [--bind 10.10.1.1] [--port 20230] [--batch 4096] [--deadline-us 100] [--threads 2] [--shed]
- *                   [--caladan] [--device 0]
+ *                   [--caladan [--idle-s 120]] [--device 0]
  */
 #define _GNU_SOURCE
 #include <arpa/inet.h>
@@ -57,6 +57,10 @@
 #define MAX_MSG 64    /* >= the largest wire struct (55 B) */
 
 static volatile sig_atomic_t g_stop = 0;
+/* --caladan: when each data socket (indexed by fd) last received a datagram; written by the socket threads, read by the
+ * control thread, which closes sockets nobody has used for --idle-s seconds (a stale value only delays a reap) */
+static volatile uint64_t *g_fd_seen = NULL;
+static uint64_t g_fd_cap = 0;
 static void on_signal(int s) { (void)s; g_stop = 1; }
 
 static uint64_t now_us(void) {
@@ -73,6 +77,7 @@ struct options {
   int port, device;
   uint32_t batch, deadline_us, threads;
   int shed, caladan;
+  uint32_t idle_s;               /* --caladan: a data socket idle for this long is closed (0 = never) */
 };
 
 static int parse_workload(const char *s, uint32_t *out) {
@@ -219,6 +224,7 @@ static void *socket_thread(void *arg) {
         const int nr = epoll_wait(w->efd, &ev, 1, (flags & MSG_DONTWAIT) ? 0 : 100);
         rfd = nr > 0 ? ev.data.fd : -1;
         got = nr > 0 ? recvmmsg(rfd, mm, want, MSG_DONTWAIT, NULL) : -1;
+        if (got > 0 && g_fd_seen && rfd >= 0 && (uint64_t)rfd < g_fd_cap) g_fd_seen[rfd] = now_us();  /* the control thread reaps idle data sockets */
       } else {
         got = recvmmsg(w->fd, mm, want, flags, NULL);
       }
@@ -279,6 +285,15 @@ static void *socket_thread(void *arg) {
 
 /* ---- --caladan: the control port (lock_fasst/caladan/server.cc:93-132) ------------------------------------------- */
 struct control_arg { const struct options *o; struct worker *ws; };
+struct dsock { int fd, efd; };
+static void dsock_close(struct dsock *d) {
+  epoll_ctl(d->efd, EPOLL_CTL_DEL, d->fd, NULL);
+  close(d->fd);
+}
+/* The handshake is unauthenticated and every request opens up to 730 sockets, so the live set is bounded three ways
+ * (ADVICE r03): a request that fails half way gives back what it opened; the total stays below the process's file
+ * limit (raised to the hard limit at start-up) -- a request that does not fit is refused and logged, not half served;
+ * sockets nobody has sent to for --idle-s seconds (clients that left) are closed. */
 static void *control_thread(void *p) {
   struct control_arg *c = (struct control_arg *)p;
   const struct options *o = c->o;
@@ -291,15 +306,36 @@ static void *control_thread(void *p) {
   if (fd < 0 || bind(fd, (struct sockaddr *)&addr, sizeof addr) < 0) { perror("control port"); g_stop = 1; return NULL; }
   struct timeval tv = {0, 100000};
   setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+  const uint64_t max_live = g_fd_cap > 64 + 8 * (uint64_t)o->threads ? g_fd_cap - 64 - 8 * (uint64_t)o->threads : 0;
+  struct dsock *live = (struct dsock *)calloc(max_live ? max_live : 1, sizeof *live);
+  uint64_t n_live = 0, last_reap = now_us(), refused = 0;
   uint32_t next = 0;
+  if (!live) { fprintf(stderr, "out of memory\n"); g_stop = 1; close(fd); return NULL; }
   while (!g_stop) {
+    const uint64_t t = now_us();
+    if (o->idle_s && t - last_reap >= 1000000ull) {  /* once a second: close what has been idle for --idle-s */
+      uint64_t keep = 0;
+      for (uint64_t k = 0; k < n_live; k++) {
+        if (t - g_fd_seen[live[k].fd] >= (uint64_t)o->idle_s * 1000000ull) dsock_close(&live[k]);
+        else live[keep++] = live[k];
+      }
+      n_live = keep;
+      last_reap = t;
+    }
     int32_t nports = 0;  /* net_req {int nports}, proto.h:38-40 */
     struct sockaddr_in cli;
     socklen_t len = sizeof cli;
     if (recvfrom(fd, &nports, sizeof nports, 0, (struct sockaddr *)&cli, &len) != (ssize_t)sizeof nports) continue;
     if (nports <= 0 || nports > 730) continue;  /* the answer must fit one datagram (server.cc:121-123: rt::UdpConn::kMaxPayloadSize) */
+    if (n_live + (uint64_t)nports > max_live) {
+      if (refused++ % 64 == 0)
+        fprintf(stderr, "handshake refused: %d ports asked, %llu of %llu data sockets live (raise `ulimit -n` or lower --idle-s)\n",
+                nports, (unsigned long long)n_live, (unsigned long long)max_live);
+      continue;  /* no answer: the client's handshake times out, as against a server that is not there */
+    }
     uint8_t resp[4 + 2 * 730];
     memcpy(resp, &nports, 4);  /* net_resp {int nports; uint16_t ports[]}, proto.h:42-45 */
+    const uint64_t first = n_live;
     int ok = 1;
     for (int32_t i = 0; i < nports && ok; i++) {
       int dfd = socket(AF_INET, SOCK_DGRAM | SOCK_NONBLOCK, 0);
@@ -307,7 +343,12 @@ static void *control_thread(void *p) {
       da.sin_port = 0;  /* any free port, as rt::UdpConn::Listen({0, 0}) */
       socklen_t dl = sizeof da;
       int buf = 4 << 20;
-      if (dfd < 0 || bind(dfd, (struct sockaddr *)&da, sizeof da) < 0 || getsockname(dfd, (struct sockaddr *)&da, &dl) < 0) { ok = 0; break; }
+      if (dfd < 0 || (uint64_t)dfd >= g_fd_cap || bind(dfd, (struct sockaddr *)&da, sizeof da) < 0 ||
+          getsockname(dfd, (struct sockaddr *)&da, &dl) < 0) {
+        if (dfd >= 0) close(dfd);
+        ok = 0;
+        break;
+      }
       setsockopt(dfd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
       setsockopt(dfd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
       const uint16_t port = ntohs(da.sin_port);  /* host order: Caladan's netaddr.port is host order (client_caladan.cc:305-308) */
@@ -316,16 +357,27 @@ static void *control_thread(void *p) {
       memset(&ev, 0, sizeof ev);
       ev.events = EPOLLIN;
       ev.data.fd = dfd;
-      if (epoll_ctl(c->ws[next++ % o->threads].efd, EPOLL_CTL_ADD, dfd, &ev) < 0) ok = 0;
+      const int efd = c->ws[next++ % o->threads].efd;
+      g_fd_seen[dfd] = now_us();
+      if (epoll_ctl(efd, EPOLL_CTL_ADD, dfd, &ev) < 0) { close(dfd); ok = 0; break; }
+      live[n_live].fd = dfd;
+      live[n_live++].efd = efd;
     }
-    if (ok) sendto(fd, resp, (size_t)(4 + 2 * nports), 0, (struct sockaddr *)&cli, len);
+    if (ok) {
+      sendto(fd, resp, (size_t)(4 + 2 * nports), 0, (struct sockaddr *)&cli, len);
+    } else {  /* give back what this request opened; the client gets no answer and asks again */
+      fprintf(stderr, "handshake failed after %llu of %d ports: %s\n", (unsigned long long)(n_live - first), nports, strerror(errno));
+      while (n_live > first) dsock_close(&live[--n_live]);
+    }
   }
+  for (uint64_t k = 0; k < n_live; k++) dsock_close(&live[k]);
+  free(live);
   close(fd);
   return NULL;
 }
 
 int main(int argc, char **argv) {
-  struct options o = {DINT_WL_FASST, 0, 0, 0, 0, "10.10.1.1", 20230, 0, 4096, 100, 2, 0, 0};
+  struct options o = {DINT_WL_FASST, 0, 0, 0, 0, "10.10.1.1", 20230, 0, 4096, 100, 2, 0, 0, 120};
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i], *v = (i + 1 < argc) ? argv[i + 1] : NULL;
 #define NEED_V if (!v) { fprintf(stderr, "%s needs a value\n", a); return 2; } i++
@@ -341,6 +393,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(a, "--threads")) { NEED_V; o.threads = (uint32_t)strtoul(v, NULL, 10); }
     else if (!strcmp(a, "--shed")) { o.shed = 1; }
     else if (!strcmp(a, "--caladan")) { o.caladan = 1; }
+    else if (!strcmp(a, "--idle-s")) { NEED_V; o.idle_s = (uint32_t)strtoul(v, NULL, 10); }
     else { fprintf(stderr, "unknown option %s\n", a); return 2; }
   }
   const uint32_t batch_max = o.workload == DINT_WL_LOG ? DINT_MICRO_BATCH : DINT_KV_PASS_MAX;  /* one kernel pass */
@@ -371,6 +424,17 @@ int main(int argc, char **argv) {
 
   signal(SIGINT, on_signal);
   signal(SIGTERM, on_signal);
+  if (o.caladan) {  /* every client thread gets a data socket: take the file limit the process may have */
+    struct rlimit rl;
+    if (getrlimit(RLIMIT_NOFILE, &rl) == 0) {
+      if (rl.rlim_cur < rl.rlim_max) { rl.rlim_cur = rl.rlim_max; setrlimit(RLIMIT_NOFILE, &rl); getrlimit(RLIMIT_NOFILE, &rl); }
+      g_fd_cap = rl.rlim_cur == RLIM_INFINITY || rl.rlim_cur > (1u << 20) ? (1u << 20) : (uint64_t)rl.rlim_cur;
+    } else {
+      g_fd_cap = 1024;
+    }
+    g_fd_seen = (volatile uint64_t *)calloc(g_fd_cap, sizeof(uint64_t));
+    if (!g_fd_seen) { fprintf(stderr, "out of memory\n"); return 1; }
+  }
   struct worker *ws = (struct worker *)calloc(o.threads, sizeof *ws);
   if (!ws) { fprintf(stderr, "out of memory\n"); return 1; }
   for (uint32_t t = 0; t < o.threads; t++) {

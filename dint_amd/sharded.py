@@ -285,10 +285,12 @@ class Router:
         before = self.overflow()
         self.step(d_req, [len(r) for r in reqs], d_rep, track=True)
         self.sync()
-        over = self.overflow() != before
+        # route_overflow is per sender: the ranks first AGREE on whether any slot filled (a rank that raised before the
+        # collective would leave the others waiting in it for ever -- ADVICE r03), then all raise or all grow
+        over = bool(self.ex.max_int([int(self.overflow() != before)])[0])
         if over and on_overflow == "raise":
-            raise RuntimeError("exchange slot overflow: raise the slot capacities (Router.set_caps)")
+            raise RuntimeError("exchange slot overflow on some rank: raise the slot capacities (Router.set_caps)")
         out = [np.frombuffer(d.cpu().numpy().tobytes(), r.dtype) for d, r in zip(d_rep, reqs)]
-        if self.ex.max_int([int(over)])[0]:  # every rank rebuilds its buffers together
+        if over:  # every rank rebuilds its buffers together
             self.grow_caps()
         return out

@@ -207,3 +207,61 @@ def test_shim_caladan_port_handshake():
     finally:
         out = srv.stop()
     assert "requests=6600" in out
+
+
+def _n_sockets(pid):
+    n = 0
+    for f in os.listdir(f"/proc/{pid}/fd"):
+        try:
+            n += os.readlink(f"/proc/{pid}/fd/{f}").startswith("socket:")
+        except OSError:
+            pass
+    return n
+
+
+def test_shim_caladan_data_sockets_are_bounded_and_reaped():
+    """every handshake opens up to 730 data sockets.  The shim must (a) refuse -- not half serve -- a
+    handshake that does not fit under the process's file limit, and keep serving smaller ones; (b) close data sockets
+    nobody has sent to for --idle-s seconds, so that clients coming and going do not exhaust the limit."""
+    import resource
+
+    def limit():
+        resource.setrlimit(resource.RLIMIT_NOFILE, (400, 400))
+
+    port = _free_udp_port()
+    p = subprocess.Popen([SERVER, "--bind", "127.0.0.1", "--port", str(port), "--workload", "fasst", "--slots", "65536",
+                          "--batch", "64", "--threads", "2", "--caladan", "--idle-s", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, preexec_fn=limit)
+    try:
+        assert "ready" in p.stdout.readline()
+        base = _n_sockets(p.pid)
+        ctl = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        ctl.settimeout(1.0)
+        ctl.sendto(struct.pack("<i", 500), ("127.0.0.1", port))  # more than the limit leaves room for
+        with pytest.raises(socket.timeout):
+            ctl.recvfrom(4096)
+        assert _n_sockets(p.pid) == base  # nothing half-opened stays behind
+        ctl.settimeout(5)
+        ctl.sendto(struct.pack("<i", 40), ("127.0.0.1", port))
+        d, _ = ctl.recvfrom(4096)
+        ports = struct.unpack("<i40H", d)[1:]
+        assert len(set(ports)) == 40 and _n_sockets(p.pid) == base + 40
+        # keep ONE of them busy; the 39 others are idle and must be gone within a few seconds
+        c = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        c.settimeout(5)
+        req = tracegen.fasst_random(1, seed=3, n_hot=1, p_hot=0.0).tobytes()
+        t_end = time.time() + 4.0
+        while time.time() < t_end:
+            c.sendto(req, ("127.0.0.1", ports[7]))
+            assert len(c.recvfrom(64)[0]) == len(req)
+            time.sleep(0.2)
+        assert _n_sockets(p.pid) == base + 1
+        # and the room they gave back can be handed out again, over and over
+        for _ in range(3):
+            ctl.sendto(struct.pack("<i", 300), ("127.0.0.1", port))
+            d, _ = ctl.recvfrom(4096)
+            assert struct.unpack("<i", d[:4])[0] == 300
+            time.sleep(2.5)
+    finally:
+        p.send_signal(signal.SIGTERM)
+        p.communicate(timeout=20)
