@@ -12,7 +12,8 @@
 #define DINT_MICRO 65536u          // log append: max requests per kernel pass
 #define DINT_KV_PASS 1048576u      // every other workload: max requests per kernel pass (idx fits 20 bits)
 #define DINT_KV_PMAX 32768u        // ... and max bins per pass
-#define DINT_KV_BINCAP 64u         // records a bin holds in place; the rest goes to the pass's overflow area
+#define DINT_KV_BINCAP 64u         // lock tables: records a bin holds in place; the rest goes to the pass's overflow area
+#define DINT_KV_CMAX 2048u         // kv workloads: coarse bins per pass at most (k_kv.hip: a two-level partition)
 
 // ---- fasthash64 ------------------------------------------------------------------------
 __host__ __device__ static inline uint64_t dint_mix(uint64_t h) {

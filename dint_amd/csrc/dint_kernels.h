@@ -30,6 +30,10 @@ struct dint_scratch {
   uint32_t *bin_off;   // [DINT_KV_PMAX] start of a big bin's records DINT_KV_BINCAP.. in `ovf`
   uint4 *ovl;          // [pass_max] overflow records as counted: {record lo, record hi, bin, position in bin}
   uint64_t *ovf;       // [pass_max] overflow records grouped by bin
+  // ---- kv workloads (k_kv.hip): the coarse bins of the two-level partition; their overflow list is `ovl` with two
+  // uint4 per entry, the 8-byte records of the big subs go to `ovf`
+  uint4 *kbins = nullptr;          // [C][cap] 16-byte records {key, group / C | idx | payload}
+  uint64_t kbins_slots = 0;        // records `kbins` holds: C * cap never exceeds it
   uint64_t *lock_trace = nullptr;  // DINT_KV_TRACE=1 on a lock engine: per big-bin workgroup 16 s_memrealtime stamps
                                    // of its first bin, at word DINT_KV_PMAX * 16 + 16 * workgroup (dint_kv_trace_read)
 };

@@ -193,7 +193,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
   if (int rc = order_stream(e, st)) return rc;
   static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
-  static const char *const kv_names[] = {"k_kv_count", "k_kv_scan_place", "k_kv_resolve"};
+  static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
@@ -214,7 +214,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 3, kv_names), view);
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 2, kv_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
@@ -313,13 +313,18 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   add_region(e, e->scratch.stats, sizeof(dint_dev_stats));
   if (wl != DINT_WL_LOG) {  // the bins of one pass: 64 records in place per bin + the pass's overflow area
     TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_KV_PMAX * sizeof(uint32_t)));
-    TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
+    if (is_kv) {  // coarse bins of 16-byte records: C * cap = C * (2 ceil(n / C) + 64) <= 2 n + 66 C
+      e->scratch.kbins_slots = 2ull * e->pass_max + 66ull * DINT_KV_CMAX;
+      TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
+    } else {
+      TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
+    }
     TRY(dev_alloc((void **)&e->scratch.blk_pub, 2 * 1024 * sizeof(uint32_t)));
     e->scratch.blk_pub_next = e->scratch.blk_pub + 1024;
     TRY(dev_alloc((void **)&e->scratch.big, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
     e->scratch.big_next = e->scratch.big + (4 + DINT_KV_PMAX);
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
-    TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4), false));
+    TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4) * (is_kv ? 2 : 1), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
     if ((e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL) && getenv("DINT_KV_TRACE")) {
       TRY(dev_alloc((void **)&e->kv.d_trace, (size_t)DINT_KV_TRACE_WORDS * 8, true));
@@ -376,6 +381,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   for (void *p : e->snap) hipFree(p);
   hipFree(e->scratch.bin_cnt);
   hipFree(e->scratch.bins);
+  hipFree(e->scratch.kbins);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
   hipFree(std::min(e->scratch.blk_pub, e->scratch.blk_pub_next));

@@ -7,28 +7,32 @@
 // Every request touches exactly one bucket of one table (lock_hash % hash_size == kvs bucket), or only
 // the log ring.  Requests on different buckets commute; requests on one bucket apply in request order.
 //
-// One pass (n <= 2^20 requests) = three kernels (the shared one lives in dint_bins.h); the passes of several engines can
-// share one set of launches (k_kv_*_multi, dint_launch_kv_multi):
-//   k_kv_count   : one thread per request -- copy the message to the reply array, classify, hash, reserve a position
-//                  in bin = group % P (P = n / 32: any number, kv_cut) -- merged per workgroup in an LDS hash, so a hot key costs one
-//                  device atomic per workgroup -- and store the {bucket group, idx, type | quadrant | key-hash bits}
-//                  record in place (positions < 64) or on the pass's overflow list; count the log requests.
-//                  Log requests are finished here: the canonical 64-byte record goes to ring position
-//                  tail + (#log requests below i)   [deterministic: an exclusive scan, not an atomic].
-//   k_kv_scan_place : give every bin with more than 64 records (the big-bin list) a range of the overflow area and move
-//                  the overflow records there (one launch: every workgroup runs the short scan itself).
-//   k_kv_resolve : every bin, one launch.  A bin of <= 64 records (the common case: ~32 per bin) is one wave: sorted
-//                  by (bucket group, key hash, idx) in registers and handled as one chunk (kv_chunk).  A bigger bin
-//                  (hot keys) is one 512-thread workgroup: sorted in LDS, ballot masks over the whole sorted stretch
-//                  with O(1) range tables, then leaders / 512-request tiles / write-back (kv_big_bins).  Inside a
-//                  chunk or stretch, several requests on ONE key are resolved in closed form (version = v0 + #writers
-//                  below, value = message of the last writer below, lock = last lock op below); what the closed
-//                  forms do not cover runs in rounds (k-th request of a bucket run in round k, workgroup fence
-//                  between rounds), so every request sees the table exactly as the serial reference would.  The
-//                  table is the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
+// One pass (n <= 2^20 requests) = two kernels, a TWO-LEVEL partition; the passes of several engines share one set of
+// launches (grid.y / grid ranges = engine, dint_launch_kv_multi):
+//   k_kv_part    : KV_TB * RPT requests per workgroup -- copy the messages to the reply array, classify, hash, count the
+//                  records per COARSE bin (coarse = group % C, C ~ n / 512, any number: kv_cut) in LDS, reserve each run
+//                  with one device atomic per (workgroup, coarse bin) and store the 16-byte records {key, group / C |
+//                  idx | type | lock quadrant | 9 key-hash bits}; a coarse bin holds `cap` records in place, a hot
+//                  key's excess goes to the pass's overflow list.  Log requests are finished here: the canonical
+//                  64-byte record goes to ring position tail + (#log requests below i)  [deterministic: an exclusive
+//                  scan, not an atomic].
+//   k_kv_resolve : one 512-thread workgroup per coarse bin.  It splits the bin's records by sub = (group / C) % 64 in
+//                  LDS and packs neighbouring subs into chunks of <= 64 records; every chunk is one wave: sorted by
+//                  (bucket group, key hash, idx) in registers and resolved at once (kv_chunk).  A sub of more than 64
+//                  records (a hot key) is resolved by the whole workgroup afterwards: sorted in LDS, ballot masks over
+//                  the whole sorted stretch with O(1) range tables, then leaders / 512-request tiles / write-back
+//                  (kv_big_bin).  Inside a chunk or stretch, several requests on ONE key are resolved in closed form
+//                  (version = v0 + #writers below, value = message of the last writer below, lock = last lock op
+//                  below); what the closed forms do not cover runs in rounds (k-th request of a bucket run in round k,
+//                  workgroup fence between rounds), so every request sees the table exactly as the serial reference
+//                  would.  The table is the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
+// (r01-r03: one level, bin = group % (n / 32), 8-byte records, three launches: one returning device atomic and one
+// partial-sector scatter per request in the count kernel, a key gather per request and half-empty waves in the resolve
+// kernel.  NOTEBOOK.md section 1.)
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/dint_abi.h"
@@ -159,182 +163,245 @@ __device__ static inline kv_reqinfo kv_read_request(const uint8_t *m, bool live,
   return r;
 }
 
-// ---- k_kv_count --------------------------------------------------------------------------------------
-// One thread per request: copy the message to the reply array, classify, hash, reserve a position in the bin
-// of the request's bucket group.  The reservations of one workgroup on one bin are merged in an LDS hash first,
-// so a hot key costs one device atomic per workgroup, not one per request.  Records at positions below
-// DINT_KV_BINCAP are stored in place; the others are listed for k_kv_place.
-template <int WL>
-__device__ static inline void
-kv_count_body(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
-              const kv_cut &cut, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
-              uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode,
-              const dint_view &V, uint32_t n_slices) {
+// ---- one pass of one engine, as the kernels see it -------------------------------------------------------------
+// A pass is a TWO-LEVEL partition (r04).  Level 1, k_kv_part: the requests are cut into C coarse
+// bins, coarse = group % C with C ~ n / 512 (ANY number: kv_cut), by workgroups of KV_TB * RPT requests that count
+// their records per coarse bin in LDS and reserve each run with ONE device atomic per (workgroup, coarse bin) --
+// ~0.2 atomics per request where the one-level pass (bin = group % (n / 32), r01-r03) paid ~0.95 and an 8-byte
+// partial-sector scatter per request.  A record is 16 bytes and carries the request's KEY, so the resolve kernel never
+// gathers it from the message array again: {key, group / C | idx | type | lock quadrant | 9 key-hash bits}.  Level 2,
+// k_kv_resolve: one workgroup per coarse bin splits its ~512 records by sub = (group / C) % 64 in LDS, packs
+// neighbouring subs into chunks of <= 64 records and hands each chunk to a wave (kv_chunk: sorted in registers, the
+// closed forms); a sub of more than 64 records -- a hot key -- is resolved by the whole workgroup afterwards
+// (kv_big_bin).  Two launches per pass instead of three.
+struct kv_pass_args {
+  const uint8_t *req;
+  uint8_t *rep;
+  uint32_t n, n_tiles;
+  const kv_dev *kv;
+  dint_log log;
+  kv_cut cut;            // cut.P = C coarse bins
+  uint32_t cap;          // records a coarse bin holds in place; the rest goes to the pass's overflow list
+  uint32_t lcap;         // records of a coarse bin's small subs that are resolved from LDS (<= KVR_LCAP)
+  uint32_t *bin_cnt;     // [C] records per coarse bin (the resolve workgroups leave them zero)
+  uint4 *kbins;          // [C][cap] records
+  uint32_t *big, *big_next;  // {[0] records handed to the big-sub path (bump pointer into ovf), [1] overflow-list entries, [2] tiles handed out}
+  uint32_t *blk_pub, *blk_pub_next;
+  uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
+  uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
+  dint_dev_stats *stats;
+  int load_mode, force_flags;
+  uint32_t has_log;
+  dint_view V;
+};
+struct kv_multi_args { kv_pass_args e[DINT_KV_MULTI_MAX]; };
+
+__device__ static inline uint64_t u4_key(const uint4 &r) { return ((uint64_t)r.y << 32) | r.x; }
+__device__ static inline uint64_t u4_meta(const uint4 &r) { return ((uint64_t)r.w << 32) | r.z; }
+
+// K 16-byte vectors per thread of a tile's messages, request array -> reply array: unconditional loads at clamped indices
+// (branch-free, so the loads stay in flight together) and unconditional stores (a clamped lane rewrites vector nv-1 with
+// the same bytes).  A pack expansion, not a loop over an array: private arrays that survive to the backend are promoted to
+// LDS (64 KB per workgroup) or left in scratch.
+template <uint32_t... Ks>
+__device__ __forceinline__ static void kv_copy_tile(const uint4 *__restrict__ s, uint4 *__restrict__ d, uint32_t nv, uint32_t t,
+                                                    std::integer_sequence<uint32_t, Ks...>) {
+  const uint4 v[] = {s[min(t + Ks * KV_TB, nv - 1)]...};
+  ((d[min(t + Ks * KV_TB, nv - 1)] = v[Ks]), ...);
+}
+
+// ---- k_kv_part --------------------------------------------------------------------------------------------------
+// KV_TB threads, RPT requests per thread (request j of thread t of tile T: index T * KV_TB * RPT + j * KV_TB + t).  Copy the
+// messages to the reply array, classify, hash, count per coarse bin in LDS, reserve the runs, store the records.  Log
+// requests are finished here: the canonical 64-byte record goes to ring position tail + (#log requests below i)
+// [deterministic: an exclusive scan over the tiles by decoupled look-back, not an atomic].
+template <int RPT>
+struct kv_part_lds {
+  uint32_t Hc[DINT_KV_CMAX];  // records of this tile per coarse bin; then the position of the tile's first one
+  uint32_t Sov[2];            // overflow records of the tile; their place in the pass's list
+  uint32_t Stile;
+  uint32_t Swl[KV_TB / 64 * RPT], Swp[KV_TB / 64];
+};
+template <int WL, int RPT>
+__device__ __forceinline__ static void kv_part_body(const kv_pass_args &A, kv_part_lds<RPT> &S) {
   using F = Fmt<WL>;
-  __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
-  __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
-  __shared__ uint32_t Sov[2];         // overflow records of the workgroup; their place in the pass's list
-  __shared__ uint32_t Stile;
-  __shared__ uint32_t Swl[KV_TB / 64], Swp[KV_TB / 64];
+  constexpr uint32_t T = KV_TB * RPT, NWV = KV_TB / 64;
+  auto &Hc = S.Hc; auto &Sov = S.Sov; auto &Stile = S.Stile; auto &Swl = S.Swl; auto &Swp = S.Swp;
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  // The workgroup's slice of the pass is handed out in start order (a ticket, not blockIdx), so the slices before
-  // mine belong to workgroups that are already running: what the log-position look-back below waits for.
-  if (t == 0) Stile = atomicAdd(&big[2], 1u);
+  const uint32_t n = A.n, C = A.cut.P;
+  const kv_dev *__restrict__ kv = A.kv;
+  const uint8_t *__restrict__ req = A.req;
+  uint8_t *rep = A.rep;
+  // tiles are handed out in start order (a ticket, not blockIdx), so the tiles before mine belong to workgroups that
+  // are already running: what the log-position look-back below waits for
+  if (t == 0) { Stile = atomicAdd(&A.big[2], 1u); Sov[0] = 0; }
   if (blockIdx.x == 0 && t < KV_NLISTS)  // entries freed by earlier passes become reusable
     for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t);
-  Hb[t] = KV_NONE; Hb[t + KV_TB] = KV_NONE;
-  Hc[t] = 0; Hc[t + KV_TB] = 0;
+  for (uint32_t k = t; k < C; k += KV_TB) Hc[k] = 0;
   __syncthreads();
   const uint32_t tile = Stile;
-  const uint32_t i = tile * KV_TB + t;
-  bool live;  // a segmented pass (multi-GPU exchange) has padding slots: they are no requests at all
-  const size_t moff = dint_view_off(V, i < n ? i : 0, F::MSG, &live);
-  live = live && i < n;
-  const uint8_t *m = req + moff;
-  const kv_reqinfo r = kv_read_request<WL>(m, live, kv, load_mode);
-  // log requests of this slice: publish the count at once (tatp / smallbank)
-  const uint64_t lm = __ballot(r.cls == 2);
+  kv_reqinfo r[RPT];
+  size_t moff[RPT];
+  uint64_t lm[RPT];
+  uint32_t idx[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; j++) {
+    idx[j] = tile * T + (uint32_t)j * KV_TB + t;
+    bool live;  // a segmented pass (multi-GPU exchange) has padding slots: they are no requests at all
+    moff[j] = dint_view_off(A.V, idx[j] < n ? idx[j] : 0, F::MSG, &live);
+    live = live && idx[j] < n;
+    r[j] = kv_read_request<WL>(req + moff[j], live, kv, A.load_mode);
+    lm[j] = __ballot(r[j].cls == 2);
+    if (live && !r[j].cls) atomicAdd(&A.stats->bad_requests, 1ULL);
+  }
+  // log requests of this tile: publish the count at once (tatp / smallbank)
   if (WL != DINT_WL_STORE) {
-    if (lane == 0) Swl[wv] = (uint32_t)__popcll(lm);
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++) Swl[j * NWV + wv] = (uint32_t)__popcll(lm[j]);
+    }
     __syncthreads();
     if (t == 0) {
       uint32_t c = 0;
-      for (uint32_t w = 0; w < KV_TB / 64; w++) c += Swl[w];
-      __hip_atomic_store(&blk_pub[tile], 0x80000000u | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t w = 0; w < NWV * RPT; w++) c += Swl[w];
+      __hip_atomic_store(&A.blk_pub[tile], 0x80000000u | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-
-  // copy this slice's messages to the reply array (replies are the request mutated in place).  All loads of a
-  // thread are issued before its first store: one memory round trip for the KV_TB * MSG <= 55 KiB of the slice.
+  // copy this tile's messages to the reply array (replies are the request mutated in place; the bytes a request type
+  // does not define are echoed, so the copy cannot be left to the resolve kernel without reading every message there
+  // a second time).  All loads of a thread are issued before its first store.
   if (rep != req) {
-    const size_t lo = (size_t)tile * KV_TB * F::MSG;
-    const size_t hi = min((size_t)n * F::MSG, lo + (size_t)KV_TB * F::MSG);
+    const size_t lo = (size_t)tile * T * F::MSG;
+    const size_t hi = min((size_t)n * F::MSG, lo + (size_t)T * F::MSG);
     if ((((uintptr_t)req | (uintptr_t)rep) & 15) == 0) {
-      const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 3520 vectors
+      constexpr uint32_t K = (T * F::MSG / 16 + KV_TB - 1) / KV_TB;
+      const uint32_t nv = (uint32_t)((hi - lo) / 16);
       const uint4 *s = (const uint4 *)(req + lo);
       uint4 *d = (uint4 *)(rep + lo);
-      if (nv) {
-        // unconditional loads at clamped indices (branch-free, so the four loads stay in flight together)
-        const uint32_t a0 = min(t, nv - 1), a1 = min(t + KV_TB, nv - 1);
-        const uint32_t a2 = min(t + 2 * KV_TB, nv - 1), a3 = min(t + 3 * KV_TB, nv - 1);
-        const uint4 v0 = s[a0], v1 = s[a1], v2 = s[a2], v3 = s[a3];
-        // ... and unconditional stores: a clamped lane rewrites vector nv-1 with the same bytes
-        d[a0] = v0; d[a1] = v1; d[a2] = v2; d[a3] = v3;
-      }
+      if (nv) kv_copy_tile(s, d, nv, t, std::make_integer_sequence<uint32_t, K>());
       for (size_t k = lo + (size_t)nv * 16 + t; k < hi; k += KV_TB) rep[k] = req[k];
     } else {
       for (size_t k = lo + t; k < hi; k += KV_TB) rep[k] = req[k];
     }
   }
-  if (live && !r.cls) atomicAdd(&stats->bad_requests, 1ULL);
 
-  uint32_t bin = KV_NONE, gq = 0, pay = 0;
-  if (r.cls == 1) {
-    const uint64_t h = dint_hash_key(r.key);
-    const uint64_t g = dint_fastmod(h, kv->mod[r.table]);
-    uint32_t local = (uint32_t)g;
-    bool mine = true;
-    if (kv->shard_count > 1) {
-      mine = (uint32_t)(g % kv->shard_count) == kv->shard_index;
-      if (!mine && !load_mode) atomicAdd(&stats->foreign_requests, 1ULL);
-      local = (uint32_t)(g / kv->shard_count);
-    }
-    if (mine) {
-      // lock quadrant: lock_hash / hash_size, lock_hash = h % (4 * hash_size)
-      const uint64_t hs = kv->mod[r.table].d, dq = dint_fastmod(h, kv->lockmod[r.table]) - g;  // 0, hs, 2hs or 3hs
-      const uint32_t q = dq >= 2 * hs ? (dq >= 3 * hs ? 3u : 2u) : (dq >= hs ? 1u : 0u);
-      gq = kv_cut_div(kv->gk_base[r.table] + local, cut, &bin);
-      pay = kv_pay(r.type, q, (uint32_t)(h >> 40) & 511u);  // the table is implied by the group key
-    }
-  }
-  uint32_t e = 0, mypos = 0;
-  if (bin != KV_NONE) {
-    e = block_hash_insert(Hb, bin);
-    mypos = atomicAdd(&Hc[e], 1u);
-  }
-  if (t == 0) Sov[0] = 0;
-  __syncthreads();
+  uint32_t coarse[RPT], mypos[RPT];
+  uint64_t meta[RPT];
 #pragma unroll
-  for (uint32_t k = 0; k < 2; k++) {
-    const uint32_t sl = t + k * KV_TB;
-    if (Hb[sl] != KV_NONE) {
-      const uint32_t cnt = Hc[sl], base = atomicAdd(&bin_cnt[Hb[sl]], cnt);
-      Hc[sl] = base;
-      // the workgroup whose records cross position DINT_KV_BINCAP lists the bin for the big-bin workgroups
-      if (base <= DINT_KV_BINCAP && base + cnt > DINT_KV_BINCAP) big[4 + atomicAdd(&big[0], 1u)] = Hb[sl];
+  for (int j = 0; j < RPT; j++) {
+    coarse[j] = KV_NONE; mypos[j] = 0; meta[j] = 0;
+    if (r[j].cls == 1) {
+      const uint64_t h = dint_hash_key(r[j].key);
+      const uint64_t g = dint_fastmod(h, kv->mod[r[j].table]);
+      uint32_t local = (uint32_t)g;
+      bool mine = true;
+      if (kv->shard_count > 1) {
+        mine = (uint32_t)(g % kv->shard_count) == kv->shard_index;
+        if (!mine && !A.load_mode) atomicAdd(&A.stats->foreign_requests, 1ULL);
+        local = (uint32_t)(g / kv->shard_count);
+      }
+      if (mine) {
+        // lock quadrant: lock_hash / hash_size, lock_hash = h % (4 * hash_size)
+        const uint64_t hs = kv->mod[r[j].table].d, dq = dint_fastmod(h, kv->lockmod[r[j].table]) - g;  // 0, hs, 2hs or 3hs
+        const uint32_t q = dq >= 2 * hs ? (dq >= 3 * hs ? 3u : 2u) : (dq >= hs ? 1u : 0u);
+        const uint32_t gq = kv_cut_div(kv->gk_base[r[j].table] + local, A.cut, &coarse[j]);
+        meta[j] = kv_rec(gq, idx[j], kv_pay(r[j].type, q, (uint32_t)(h >> 40) & 511u), A.cut);  // the table is implied by the group key
+        mypos[j] = atomicAdd(&Hc[coarse[j]], 1u);
+      }
     }
   }
   __syncthreads();
-  if (bin != KV_NONE) mypos += Hc[e];
-  const uint64_t rec = kv_rec(gq, i, pay, cut);
-  const bool over = bin != KV_NONE && mypos >= DINT_KV_BINCAP;
-  if (bin != KV_NONE && !over) bins[(size_t)bin * DINT_KV_BINCAP + mypos] = rec;
-  // overflow records: one reservation in the pass's list per workgroup
-  uint32_t orank = 0;
-  if (over) orank = atomicAdd(&Sov[0], 1u);
+  for (uint32_t c = t; c < C; c += KV_TB) {
+    const uint32_t cnt = Hc[c];
+    if (cnt) Hc[c] = atomicAdd(&A.bin_cnt[c], cnt);
+  }
+  __syncthreads();
+  uint32_t orank[RPT];
+  bool over[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; j++) {
+    over[j] = false; orank[j] = 0;
+    if (coarse[j] != KV_NONE) {
+      const uint32_t pos = Hc[coarse[j]] + mypos[j];
+      if (pos < A.cap) {
+        A.kbins[(size_t)coarse[j] * A.cap + pos] = make_uint4((uint32_t)r[j].key, (uint32_t)(r[j].key >> 32), (uint32_t)meta[j], (uint32_t)(meta[j] >> 32));
+      } else {  // a coarse bin that holds a hot key: one reservation in the pass's overflow list per tile
+        over[j] = true;
+        orank[j] = atomicAdd(&Sov[0], 1u);
+      }
+    }
+  }
   __syncthreads();
   if (Sov[0]) {  // workgroup-uniform
-    if (t == 0) Sov[1] = atomicAdd(&big[1], Sov[0]);
+    if (t == 0) Sov[1] = atomicAdd(&A.big[1], Sov[0]);
     __syncthreads();
-    if (over) ovl[Sov[1] + orank] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
+#pragma unroll
+    for (int j = 0; j < RPT; j++)
+      if (over[j]) {
+        uint4 *o = A.ovl + 2 * (size_t)(Sov[1] + orank[j]);
+        o[0] = make_uint4((uint32_t)r[j].key, (uint32_t)(r[j].key >> 32), (uint32_t)meta[j], (uint32_t)(meta[j] >> 32));
+        o[1] = make_uint4(coarse[j], 0u, 0u, 0u);
+      }
   }
 
-  // ---- log requests: the canonical 64-byte record at ring position tail + (#log requests below i)
-  // [deterministic: an exclusive scan, not an atomic].  The slices before mine published their counts long ago
-  // (first thing they did); one count per thread, polled until it is there.
+  // ---- log requests: the canonical 64-byte record at ring position tail + (#log requests below i).  The tiles
+  // before mine published their counts long ago (first thing they did); one count per thread, polled until it is there.
   if (WL != DINT_WL_STORE) {
+    const dint_log log = A.log;
     uint32_t part = 0;
     if (t < tile) {
       uint32_t v;
-      do { v = __hip_atomic_load(&blk_pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 31));
+      do { v = __hip_atomic_load(&A.blk_pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 31));
       part = v & 0x7FFFFFFFu;
     }
     uint32_t tot;
     wave_excl_scan_u32(part, &tot);
     if (lane == 0) Swp[wv] = tot;
     __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < KV_TB / 64; w++) base += Swp[w] + (w < wv ? Swl[w] : 0);
-    if (tile == n_slices - 1 && t == 0) {  // the pass's new tail (k_kv_scan makes it current)
-      uint32_t total = base;
-      for (uint32_t w = 0; w < KV_TB / 64; w++) total += Swl[w];
+    uint32_t base = 0, tile_total = 0;
+    for (uint32_t w = 0; w < NWV; w++) base += Swp[w];
+    for (uint32_t w = 0; w < NWV * RPT; w++) tile_total += Swl[w];
+    if (tile == A.n_tiles - 1 && t == 0) {  // the pass's new tail (the resolve kernel makes it current)
+      const uint32_t total = base + tile_total;
       log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
       *(unsigned long long *)(log.tail + 2) += total;  // records ever appended (dint_log_drain)
     }
-    if (r.cls == 2) {
-      const uint32_t pos_in_batch = base + (uint32_t)__popcll(lm & lanemask_lt());
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      if (r[j].cls != 2) continue;
+      uint32_t pos_in_batch = base + (uint32_t)__popcll(lm[j] & lanemask_lt());
+      for (uint32_t w = 0; w < (uint32_t)j * NWV + wv; w++) pos_in_batch += Swl[w];
       const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
       uint8_t *e8 = log.ring + (size_t)pos * 64;
+      const uint8_t *m = req + moff[j];
       const uint32_t ver = ld_u32(m + F::VER);
-      uint8_t *rp = rep + moff;
-      if (WL == DINT_WL_TATP && r.type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
-        *(uint64_t *)e8 = r.key;
-        *(uint2 *)(e8 + 48) = make_uint2(ver, 1u | (r.table << 8));
+      uint8_t *rp = rep + moff[j];
+      if (WL == DINT_WL_TATP && r[j].type == 24) {  // kDeleteLog: no val copy  (server_shard.cc:196-207)
+        *(uint64_t *)e8 = r[j].key;
+        *(uint2 *)(e8 + 48) = make_uint2(ver, 1u | (r[j].table << 8));
         rp[F::TYPE] = 27;
       } else {  // kCommitLog  (tatp server_shard.cc:182-194, smallbank server_shard.cc:175-186)
-        uint32_t w[16];
-        __builtin_memcpy(&w[0], &r.key, 8);
-#pragma unroll
-        for (uint32_t k = 0; k < F::VS / 4; k++) w[2 + k] = ld_u32(m + F::VAL + 4 * k);
+        // (scalars, not a word array: see kv_copy_tile)
+        const uint8_t *v8 = m + F::VAL;
         uint4 *e4 = (uint4 *)e8;
-        e4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        e4[0] = make_uint4((uint32_t)r[j].key, (uint32_t)(r[j].key >> 32), ld_u32(v8), ld_u32(v8 + 4));
         if (F::VS == 40) {
-          e4[1] = make_uint4(w[4], w[5], w[6], w[7]);
-          e4[2] = make_uint4(w[8], w[9], w[10], w[11]);
+          e4[1] = make_uint4(ld_u32(v8 + 8), ld_u32(v8 + 12), ld_u32(v8 + 16), ld_u32(v8 + 20));
+          e4[2] = make_uint4(ld_u32(v8 + 24), ld_u32(v8 + 28), ld_u32(v8 + 32), ld_u32(v8 + 36));
         }
-        *(uint2 *)(e8 + 48) = make_uint2(ver, r.table << 8);
+        *(uint2 *)(e8 + 48) = make_uint2(ver, r[j].table << 8);
         rp[F::TYPE] = (WL == DINT_WL_TATP) ? 17 : 15;
       }
     }
   }
 }
 
-template <int WL>
-__global__ void __launch_bounds__(KV_TB)
-k_kv_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, const kv_dev *__restrict__ kv, dint_log log,
-           kv_cut cut, uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
-           uint4 *__restrict__ ovl, uint32_t *blk_pub, dint_dev_stats *__restrict__ stats, int load_mode, dint_view V) {
-  kv_count_body<WL>(req, rep, n, kv, log, cut, bin_cnt, bins, big, ovl, blk_pub, stats, load_mode, V, gridDim.x);
+template <int WL, int RPT>
+__global__ void __launch_bounds__(KV_TB) k_kv_part(kv_multi_args M) {
+  const kv_pass_args &A = M.e[blockIdx.y];
+  if (blockIdx.x >= A.n_tiles) return;
+  __shared__ kv_part_lds<RPT> S;
+  kv_part_body<WL, RPT>(A, S);
 }
 
 // ---- optional per-wave timeline (DINT_KV_TRACE=1): lane 0 of every resolve wave stamps s_memtime at fixed
@@ -545,13 +612,14 @@ __device__ static inline uint64_t run_mask(uint64_t heads, uint64_t le, uint64_t
 
 template <int WL>
 __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, uint32_t gk, uint32_t kh, uint32_t type,
-                                       uint32_t table, uint32_t q, const kv_dev *kv, dint_dev_stats *__restrict__ stats,
-                                       int force_rounds, bool last_chunk, const dint_view &V, uint64_t *tr = nullptr) {
+                                       uint32_t table, uint32_t q, uint64_t key_in, const kv_dev *kv,
+                                       dint_dev_stats *__restrict__ stats, int force_rounds, bool last_chunk, const dint_view &V,
+                                       uint64_t *tr = nullptr) {
   using F = Fmt<WL>;
   const int lane = (int)lane_id();
   const uint64_t lt = lanemask_lt(), le = lt | (1ull << lane);
   uint8_t *msg = rep + dint_view_off(V, idx, F::MSG);
-  const uint64_t key = valid ? ld_u64(msg + F::KEY) : 0;
+  const uint64_t key = valid ? key_in : 0;  // the record carries the key: no gather from the message array
   const uint64_t bucket = valid ? (uint64_t)(gk - kv->gk_base[table]) : 0;
 
   // ---- bucket runs and key segments
@@ -821,42 +889,27 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   kv_stamp(tr, 8);
 }
 
-// ---- k_kv_resolve: bins of <= 64 records, one wave each ---------------------------------------------------
-template <int WL>
-__device__ static inline void kv_small_bin(uint8_t *rep, const kv_cut &cut, const kv_dev *kv, uint32_t bin,
-                                           uint32_t *__restrict__ bin_cnt, const uint64_t *__restrict__ bins,
-                                           dint_dev_stats *__restrict__ stats, int kv_force_rounds, const dint_view &V,
-                                           uint64_t *trace) {
-  const uint32_t lane = threadIdx.x & 63;
-  uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;
-  kv_stamp_real(tr, 10);
-  kv_stamp(tr, 0);
-  const uint64_t r0 = bins[(size_t)bin * DINT_KV_BINCAP + lane];  // speculative (the bin region always exists): overlaps the counter load
-  const uint32_t c = bin_cnt[bin];
-  if (c == 0 || c > DINT_KV_BINCAP) return;  // larger bins are on the big-bin list
-  if (tr && lane == 0) { tr[15] = c; tr[14] = 0; }
-  if (lane == 0) bin_cnt[bin] = 0;  // leave the counters clean for the next pass
-  kv_stamp(tr, 1);
-  // Sort the records by (bucket group, key hash, idx) in registers: groups commute, so any order that keeps each
-  // group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in adjacent
-  // lanes -- no LDS, no rank bitmap, no hash.  Key: group / P | 9 key-hash bits | idx (ibits bits) | 7 payload bits
-  // (kv_sort_key): at most 56 bits for every cut.
-  uint64_t w = ~0ull;  // empty lanes sort last
-  if (lane < c) w = kv_sort_key(r0, cut);
-  kv_stamp(tr, 2);
-  w = wave_sort_u64(w);
-  kv_stamp(tr, 3);
-  const bool valid = lane < c;
-  const uint32_t gk = kv_cut_gk((uint32_t)(w >> (16 + cut.ibits)), bin, cut), kh = (uint32_t)(w >> (7 + cut.ibits)) & 511u;
-  const uint32_t idx = (uint32_t)(w >> 7) & (uint32_t)((1ull << cut.ibits) - 1ull);
-  const uint32_t pay = (uint32_t)w & 0x7Fu;
-  kv_chunk<WL>(rep, valid, valid ? idx : 0, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), kv, stats,
-               kv_force_rounds, true, V, tr);
-  kv_stamp(tr, 9);
-  kv_stamp_real(tr, 11);
-}
 
-// ---- big bins (more than DINT_KV_BINCAP records: hot keys), one 512-thread workgroup each -----------------------
+// ---- LDS of the big path: one struct, so that the coarse-bin split (kvr_lds) can share the buffer ---------------------
+struct kvb_lds {
+  uint64_t Sk[KVB_NMAX];           // the stretch: group / P | key-hash bits | idx | type, quadrant
+  uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
+  uint16_t Bwin[KVB_NBK];          // stretch each idx bucket belongs to
+  uint64_t Mhead[KVB_NW], Mbh[KVB_NW], Mbad[KVB_NW], Mlop[KVB_NW], Mst[KVB_NW], Mlkseg[4][KVB_NW], Mstseg[KVB_NW], Mrs[KVB_NW],
+      Msimple[KVB_NW], Mwr[KVB_NW], Mlk[KVB_NW], Macq[KVB_NW];
+  kvb_pop Pbad, Plop, Pst, Plkseg[4], Pstseg, Pwr, Phead;
+  kvb_edge Ehead, Ebh, Ewr, Elk;
+  uint64_t Mbail[KVB_W];           // tile-local
+  __attribute__((aligned(8))) kvb_lead Lead[KVB_T];  // by key segment number (a stretch with more segments runs request by request)
+  __attribute__((aligned(8))) uint8_t CarryCrow[KVB_T * (sizeof(kv_rowst) > sizeof(kvb_carry) ? sizeof(kv_rowst) : sizeof(kvb_carry))];
+  uint16_t HeadPos[KVB_T];         // sorted position of each segment's head
+  uint32_t Sany, Swn;
+  uint32_t Sred[KVB_W];
+  uint32_t Hs[16];                 // dominant-key path: candidate counts, flags, the row's location
+  int Hc[2][KVB_W];                // ... wave carries of its prefix tables
+};
+
+// ---- big subs (more than 64 records on one sub of a coarse bin: hot keys), the whole 512-thread workgroup -----------
 // The same algorithm as kv_chunk, over up to KVB_NMAX requests at a time:
 //   sort the bin by (bucket group, key hash, request index) in LDS; the requests of one key are then one segment of
 //   the sorted order, however many there are.  Ballot masks over the WHOLE sorted stretch (heads, writers, lock ops,
@@ -871,38 +924,27 @@ __device__ static inline void kv_small_bin(uint8_t *rep, const kv_cut &cut, cons
 // A bin of more than KVB_NMAX records is cut into stretches along request-index buckets (every request of a
 // stretch precedes every request of the next one) and the stretches run one after the other.
 template <int WL>
-__device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, const kv_cut &cut, const kv_dev *kv, uint32_t first,
-                                          uint32_t stride, uint32_t *__restrict__ bin_cnt,
-                                          const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big,
-                                          const uint32_t *__restrict__ bin_off, const uint64_t *__restrict__ ovf,
-                                          dint_dev_stats *__restrict__ stats, int force_flags, const dint_view &V,
-                                          uint64_t *trace) {
+__device__ __attribute__((noinline)) static void
+kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_t bin, const uint64_t *__restrict__ recs,
+           uint32_t c, dint_dev_stats *__restrict__ stats, int force_flags, const dint_view V, uint8_t *lds_raw) {
   using F = Fmt<WL>;
   const int force_rounds = force_flags & 1, no_hot = force_flags & 2;
   const uint32_t hot_min = (uint32_t)force_flags >> 8 ? (uint32_t)force_flags >> 8 : KVB_HOT_MIN;
-  __shared__ uint64_t Sk[KVB_NMAX];           // the stretch: group / P | key-hash bits | idx | type, quadrant
-  __shared__ uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
-  __shared__ uint16_t Bwin[KVB_NBK];          // stretch each idx bucket belongs to
-  __shared__ uint64_t Mhead[KVB_NW], Mbh[KVB_NW], Mbad[KVB_NW], Mlop[KVB_NW], Mst[KVB_NW], Mlkseg[4][KVB_NW],
-      Mstseg[KVB_NW], Mrs[KVB_NW], Msimple[KVB_NW], Mwr[KVB_NW], Mlk[KVB_NW], Macq[KVB_NW];
-  __shared__ kvb_pop Pbad, Plop, Pst, Plkseg[4], Pstseg, Pwr;
-  __shared__ kvb_edge Ehead, Ebh, Ewr, Elk;
-  __shared__ uint64_t Mbail[KVB_W];           // tile-local
-  __shared__ __attribute__((aligned(8))) kvb_lead Lead[KVB_T];  // by key segment number (a stretch with more segments runs request by request)
+  kvb_lds &LB = *(kvb_lds *)lds_raw;
+  auto &Sk = LB.Sk; auto &Bcnt = LB.Bcnt; auto &Bwin = LB.Bwin;
+  auto &Mhead = LB.Mhead; auto &Mbh = LB.Mbh; auto &Mbad = LB.Mbad; auto &Mlop = LB.Mlop; auto &Mst = LB.Mst; auto &Mlkseg = LB.Mlkseg;
+  auto &Mstseg = LB.Mstseg; auto &Mrs = LB.Mrs; auto &Msimple = LB.Msimple; auto &Mwr = LB.Mwr; auto &Mlk = LB.Mlk; auto &Macq = LB.Macq;
+  auto &Pbad = LB.Pbad; auto &Plop = LB.Plop; auto &Pst = LB.Pst; auto &Plkseg = LB.Plkseg; auto &Pstseg = LB.Pstseg; auto &Pwr = LB.Pwr;
+  auto &Ehead = LB.Ehead; auto &Ebh = LB.Ebh; auto &Ewr = LB.Ewr; auto &Elk = LB.Elk;
+  auto &Mbail = LB.Mbail; auto &Lead = LB.Lead; auto &CarryCrow = LB.CarryCrow; auto &HeadPos = LB.HeadPos; auto &Phead = LB.Phead;
+  auto &Sany = LB.Sany; auto &Swn = LB.Swn; auto &Sred = LB.Sred; auto &Hs = LB.Hs; auto &Hc = LB.Hc;
   // smallbank walks its counters through Carry[segment], store / tatp the row machine of segments with an INSERT /
   // DELETE through Crow[segment]: never both in one instantiation, so they share one buffer
-  __shared__ __attribute__((aligned(8))) uint8_t CarryCrow[KVB_T * (sizeof(kv_rowst) > sizeof(kvb_carry) ? sizeof(kv_rowst) : sizeof(kvb_carry))];
   kvb_carry *Carry = (kvb_carry *)CarryCrow;
   kv_rowst *Crow = (kv_rowst *)CarryCrow;
-  __shared__ uint16_t HeadPos[KVB_T];         // sorted position of each segment's head
-  __shared__ kvb_pop Phead;
-  __shared__ uint32_t Sany, Swn;
-  __shared__ uint32_t Sred[KVB_W];
-  __shared__ uint32_t Hs[16];                 // dominant-key path: candidate counts, flags, the row's location
-  __shared__ int Hc[2][KVB_W];                // ... wave carries of its prefix tables
+  uint64_t *const trace = nullptr;  // (the per-phase stamps of r02 / r03 tuning runs: compiled out)
+  const uint32_t bi = 0, first = 0;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // k_kv_count listed the bins with more than DINT_KV_BINCAP records; this workgroup takes entries first, first + stride, ...
-  const uint32_t nbig = big[0];
   // idx buckets for the stretches of a bin with more than KVB_NMAX records: 2^bs requests per bucket, <= KVB_NBK buckets
   const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 11 ? nbits - 11 : 0u;
   const uint32_t wcap = KVB_NMAX - (1u << bs);  // a stretch = the buckets whose exclusive record count / wcap is equal
@@ -932,15 +974,9 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, const kv_cut
     }
     return kind;
   };
-  for (uint32_t bi = first; bi < nbig; bi += stride) {
-  const uint32_t bin = big[4 + bi];
-  __syncthreads();  // the previous bin's LDS is free
-  const uint32_t c = bin_cnt[bin];
-  uint64_t *tr = trace ? trace + (size_t)bin * 16 : nullptr;  // [8] start, [9] end (10 ns), [12] rounds, [13] stretches, [14] c
-  if (tr && t == 0) { tr[8] = __builtin_amdgcn_s_memrealtime(); tr[14] = c; tr[12] = 0; tr[13] = 0; }
-  const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
-  const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;  // records DINT_KV_BINCAP.. of the bin
-  auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
+  __syncthreads();  // the LDS buffer is free (the chunk path, or the previous big sub, is done with it)
+  uint64_t *const tr = nullptr;
+  auto rec_at = [&](uint32_t k) -> uint64_t { return recs[k]; };
 
   uint32_t nwin = 1;
   if (c > KVB_NMAX) {
@@ -970,7 +1006,6 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, const kv_cut
     nwin = (c - 1) / wcap + 1;  // upper bound: the last one may be empty
   }
   __syncthreads();
-  if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
 
   for (uint32_t win = 0; win < nwin; win++) {
     if (t == 0) Swn = 0;
@@ -1838,172 +1873,257 @@ __device__ static inline void kv_big_bins(uint8_t *rep, uint32_t n, const kv_cut
     __syncthreads();  // the next stretch sees this stretch's stores; LDS arrays are free again
   }
   if (tr && t == 0) tr[9] = __builtin_amdgcn_s_memrealtime();
-  }
 }
 
-// ---- k_kv_resolve: every bin of the pass, one launch ------------------------------------------------------
-// Workgroups 0 .. KVB_GRID-1 walk the big-bin list (kv_big_bins); each wave of the others resolves one bin of
-// <= DINT_KV_BINCAP records (kv_small_bin).  The two kinds own disjoint bins, hence disjoint buckets, so they run
-// side by side: the hot keys' stretches overlap the bulk of the pass instead of preceding it.  The launch carries
-// the big-bin path's footprint (~75 KB of LDS, 128 VGPRs): two workgroups = 16 waves per CU.  (r02 also measured
-// the split form -- big bins in a kernel of their own, the one-wave-per-bin kernel at 91 VGPRs / 5 waves per SIMD
-// behind it on the same stream: the two then run one after the other, 67 + 55 us instead of 105 us, and putting the
-// big-bin kernel on a second stream cost more in cross-stream event waits than the overlap gave; see DESIGN.md.)
-template <int WL>
-__device__ static inline void
-kv_resolve_body(uint8_t *rep, uint32_t n, const kv_cut &cut, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-                const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-                const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
-                const dint_view &V, uint32_t vb) {  // vb: this workgroup's number among the pass's (blockIdx.x of a single-engine launch)
-  __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
-  for (uint32_t k = threadIdx.x; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)kv_g)[k];
-  __syncthreads();
-  // tracing: per workgroup {first wave in, last wave out} after the per-bin rows (10 ns ticks)
-  unsigned long long *wg = trace ? (unsigned long long *)trace + (size_t)DINT_KV_PMAX * 16 + 16 * vb : nullptr;
-  if (wg && threadIdx.x == 0) wg[0] = __builtin_amdgcn_s_memrealtime();
-  if (vb < KVB_GRID) {
-    kv_big_bins<WL>(rep, n, cut, &Skv, vb, KVB_GRID, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, V, trace);
-  } else {
-    const uint32_t bin = (vb - KVB_GRID) * KVB_W + (threadIdx.x >> 6);
-    if (bin < cut.P) kv_small_bin<WL>(rep, cut, &Skv, bin, bin_cnt, bins, stats, force_flags & 1, V, trace);
-  }
-  if (wg && (threadIdx.x & 63) == 0) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    atomicMax(&wg[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  }
-}
-
-template <int WL>
-__global__ void __launch_bounds__(KVB_T, 4)
-k_kv_resolve(uint8_t *rep, uint32_t n, kv_cut cut, const kv_dev *__restrict__ kv_g, uint32_t *__restrict__ bin_cnt,
-             const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-             const uint64_t *__restrict__ ovf, dint_dev_stats *__restrict__ stats, int force_flags, uint64_t *trace,
-             dint_view V) {
-  kv_resolve_body<WL>(rep, n, cut, kv_g, bin_cnt, bins, big, bin_off, ovf, stats, force_flags, trace, V, blockIdx.x);
-}
-
-// ---- the passes of SEVERAL engines in one launch set (grid.y = engine) ------------------------------------------
-// A closed-loop epoch (and a step of the multi-GPU exchange) hands every shard server of the GPU one batch at the same
-// moment.  On three streams that is a fork and a join per epoch -- two cross-stream dependencies of ~20 us each on the
-// critical path; with the engines' kernels side by side in one grid the epoch is one stream: count -> scan -> place ->
-// resolve, every launch covering all engines.  The engines stay independent (own tables, own scratch, own log).
-struct kv_pass_args {
-  const uint8_t *req;
-  uint8_t *rep;
-  uint32_t n, n_slices;
-  const kv_dev *kv;
-  dint_log log;
-  kv_cut cut;
-  uint32_t *bin_cnt;
-  uint64_t *bins;
-  uint32_t *big, *big_next, *bin_off, *blk_pub, *blk_pub_next;
-  uint4 *ovl;
-  uint64_t *ovf;
-  dint_dev_stats *stats;
-  uint64_t *trace;
-  int load_mode, force_flags;
-  uint32_t has_log, resolve_blocks;
-  dint_view V;
+// ---- k_kv_resolve: one workgroup per coarse bin -------------------------------------------------------------------
+// LDS of the workgroup: the records of the bin's small subs, split by sub (KVR_LCAP * 16 B) -- or, afterwards, the big
+// path's stretch machinery (kvb_lds); the two never live at the same time and share one buffer.
+#define KVR_LCAP 1024u   // records of a coarse bin's small subs that fit the LDS split (the average bin holds ~512)
+#define KVR_F 64u        // subs per coarse bin = lanes of the wave that lays them out
+struct kvr_lds {
+  uint4 rec[KVR_LCAP];         // records of the small subs, sub after sub
+  uint32_t hist[KVR_F];        // records per sub
+  uint32_t cur[KVR_F];         // ... placed so far
+  uint32_t off[KVR_F + 1];     // start of each small sub in rec[]
+  uint32_t bigoff[KVR_F];      // start of each big sub's 8-byte records in ovf[], KV_NONE for a small sub
+  uint2 chs[KVR_F];            // chunks: [first, last) record in rec[]
+  uint32_t nch;
 };
-struct kv_multi_args { kv_pass_args e[DINT_KV_MULTI_MAX]; };
+static_assert(sizeof(kvr_lds) <= sizeof(kvb_lds), "the coarse-bin split shares the big path's LDS buffer");
 
 template <int WL>
-__global__ void __launch_bounds__(KV_TB) k_kv_count_multi(kv_multi_args M) {
-  const kv_pass_args &A = M.e[blockIdx.y];
-  if (blockIdx.x >= A.n_slices) return;
-  kv_count_body<WL>(A.req, A.rep, A.n, A.kv, A.log, A.cut, A.bin_cnt, A.bins, A.big, A.ovl, A.blk_pub, A.stats, A.load_mode, A.V,
-                    A.n_slices);
-}
-static __global__ void __launch_bounds__(KV_TB) k_kv_scan_place_multi(kv_multi_args M) {
-  const kv_pass_args &A = M.e[blockIdx.y];
-  kv_scan_place_body(A.bin_cnt, A.bin_off, A.big, A.big_next, A.blk_pub_next, A.has_log ? A.log.tail : nullptr, A.stats, A.ovl, A.ovf);
-}
-// One-dimensional grid, the big-bin workgroups of ALL engines first (workgroups are dispatched in index order, and a hot
-// bin's workgroup is the longest job of the launch: with grid.y = engine the last engine's hot bins started when the
-// first engines' small bins had been handed out, 154 us against ~100 for the three passes), then the engines' small bins.
-template <int WL>
-__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve_multi(kv_multi_args M, uint32_t n_eng) {
-  uint32_t e, vb;
-  if (blockIdx.x < n_eng * KVB_GRID) {
-    e = blockIdx.x % n_eng;
-    vb = blockIdx.x / n_eng;
-  } else {
-    uint32_t b = blockIdx.x - n_eng * KVB_GRID;
-    e = 0;
-    while (e + 1 < n_eng && b >= M.e[e].resolve_blocks - KVB_GRID) { b -= M.e[e].resolve_blocks - KVB_GRID; e++; }
-    vb = KVB_GRID + b;
+__device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev *kv, uint32_t coarse, uint8_t *lds_raw,
+                                            uint2 *Sbig /* [KVR_F] {offset in ovf, records} of the bin's big subs */) {
+  kvr_lds &L = *(kvr_lds *)lds_raw;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const kv_cut &cut = A.cut;
+  const uint32_t C = cut.P, cap = A.cap, sh = 16 + cut.ibits;
+  const uint32_t idx_mask = (uint32_t)((1ull << cut.ibits) - 1ull);
+  const uint4 *__restrict__ recs = A.kbins + (size_t)coarse * cap;
+  const uint32_t cnt = A.bin_cnt[coarse];
+  if (cnt == 0) return;  // workgroup-uniform
+  const uint32_t n_in = min(cnt, cap);
+  const uint32_t novl = cnt > cap ? A.big[1] : 0u;  // my records beyond `cap` are somewhere in the pass's overflow list
+  if (t < KVR_F) { L.hist[t] = 0; L.cur[t] = 0; }
+  // the first two records of every thread stay in registers between the two phases (the usual bin is read once)
+  const uint4 r0 = t < n_in ? recs[t] : make_uint4(0, 0, 0, 0);
+  const uint4 r1 = t + KVB_T < n_in ? recs[t + KVB_T] : make_uint4(0, 0, 0, 0);
+  __syncthreads();  // every thread has read cnt
+  if (t == 0) A.bin_cnt[coarse] = 0;  // leave the counters clean for the next pass
+  auto for_each_record = [&](auto &&f) {
+    if (t < n_in) f(r0);
+    if (t + KVB_T < n_in) f(r1);
+    for (uint32_t k = t + 2 * KVB_T; k < n_in; k += KVB_T) f(recs[k]);
+    for (uint32_t k = t; k < novl; k += KVB_T)
+      if (A.ovl[2 * (size_t)k + 1].x == coarse) f(A.ovl[2 * (size_t)k]);
+  };
+  // ---- phase A: records per sub
+  for_each_record([&](const uint4 &r) { atomicAdd(&L.hist[(uint32_t)(u4_meta(r) >> sh) & (KVR_F - 1)], 1u); });
+  __syncthreads();
+  // ---- layout (one wave, a lane per sub): small subs get a range of rec[], big subs a range of ovf[]; neighbouring
+  // small subs are packed into chunks of <= 64 records, greedily
+  if (wave == 0) {
+    const uint32_t h = L.hist[lane];
+    bool big = h > 64;
+    uint32_t stot, sc = big ? 0u : h, soff = wave_excl_scan_u32(sc, &stot);
+    if (stot > A.lcap) {  // more small-sub records than the LDS split holds (wave-uniform): every sub takes the big path
+      big = h > 0; sc = 0; soff = 0; stot = 0;
+    }
+    uint32_t btot, bc = big ? h : 0u, boff = wave_excl_scan_u32(bc, &btot);
+    uint32_t gbase = 0;
+    if (lane == 0 && btot) {
+      gbase = atomicAdd(&A.big[0], btot);
+      atomicAdd(&A.stats->big_bin_requests, (unsigned long long)btot);
+    }
+    gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+    L.off[lane] = soff;
+    if (lane == 63) L.off[KVR_F] = stot;
+    L.bigoff[lane] = big ? gbase + boff : KV_NONE;
+    Sbig[lane] = make_uint2(big ? gbase + boff : 0u, big ? h : 0u);
+    // next[l] = the sub after the chunk that starts at sub l: the largest e in (l, 64] with off[e] - off[l] <= 64
+    // (a small sub alone always fits).  Binary search over the lanes' registers, the same trip count for every lane.
+    uint32_t lo = lane + 1, hi = KVR_F;
+#pragma unroll
+    for (int it = 0; it < 7; it++) {
+      const uint32_t mid = min((lo + hi + 1) >> 1, KVR_F);
+      const uint32_t v = (uint32_t)__shfl((int)soff, (int)(mid & (KVR_F - 1)), 64);
+      const uint32_t om = mid == KVR_F ? stot : v;
+      if (lo < hi) {
+        if (om - soff <= 64u) lo = mid; else hi = mid - 1;
+      }
+    }
+    uint32_t s = 0, nch = 0;
+    while (s < KVR_F) {  // wave-uniform walk over the chunk starts
+      const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)s);
+      const uint32_t os = (uint32_t)__builtin_amdgcn_readlane((int)soff, (int)s);
+      const uint32_t oe = e >= KVR_F ? stot : (uint32_t)__builtin_amdgcn_readlane((int)soff, (int)e);
+      if (oe > os) {
+        if (lane == 0) L.chs[nch] = make_uint2(os, oe);
+        nch++;
+      }
+      s = e;
+    }
+    if (lane == 0) L.nch = nch;
   }
+  __syncthreads();
+  // ---- phase B: every record to its sub's range
+  for_each_record([&](const uint4 &r) {
+    const uint64_t m = u4_meta(r);
+    const uint32_t sub = (uint32_t)(m >> sh) & (KVR_F - 1);
+    const uint32_t pos = atomicAdd(&L.cur[sub], 1u), bo = L.bigoff[sub];
+    if (bo == KV_NONE) L.rec[L.off[sub] + pos] = r;
+    else A.ovf[bo + pos] = ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull));  // the big path's record: group / (64 C) | idx | payload
+  });
+  __syncthreads();
+  // ---- the chunks, one wave each: sort by (group / C, key hash, idx) in registers -- groups commute, so any order that
+  // keeps each group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in
+  // adjacent lanes.  The sort word carries the lane the record came from; key and payload follow by one shuffle each.
+  const uint32_t nch = L.nch;
+  for (uint32_t ch = wave; ch < nch; ch += KVB_W) {
+    const uint2 ab = L.chs[ch];
+    const uint32_t c = ab.y - ab.x;
+    const bool has = lane < c;
+    const uint4 r = has ? L.rec[ab.x + lane] : make_uint4(0, 0, 0, 0);
+    const uint64_t key0 = u4_key(r), m = u4_meta(r);
+    const uint32_t pay0 = kv_rec_pay(m);
+    uint64_t w = ~0ull;  // empty lanes sort last
+    if (has) w = ((m >> sh) << (15 + cut.ibits)) | ((uint64_t)pay_kh(pay0) << (6 + cut.ibits)) | ((uint64_t)((uint32_t)(m >> 16) & idx_mask) << 6) | lane;
+    w = wave_sort_u64(w);
+    const bool valid = lane < c;
+    const int src = (int)((uint32_t)w & 63u);
+    const uint64_t key = shfl_u64(key0, src);
+    const uint32_t pay = (uint32_t)__shfl((int)pay0, src, 64);
+    const uint32_t gk = kv_cut_gk((uint32_t)(w >> (15 + cut.ibits)), coarse, cut), kh = (uint32_t)(w >> (6 + cut.ibits)) & 511u;
+    const uint32_t idx = (uint32_t)(w >> 6) & idx_mask;
+    kv_chunk<WL>(A.rep, valid, valid ? idx : 0, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), key, kv, A.stats,
+                 A.force_flags & 1, true, A.V);
+  }
+}
+
+// The launch carries the big path's footprint (~73 KB of LDS, 128 VGPRs): two workgroups = 16 waves per CU.  The big
+// path is a function of its own (noinline), so that its register pressure -- it spills at 128 VGPRs -- stays out of the
+// chunk path's allocation (the chunk path alone needs 89 VGPRs and no scratch).
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
+  __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
+  __shared__ uint2 Sbig[KVR_F];
+  uint32_t e = 0, b = blockIdx.x;
+  while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
   const kv_pass_args &A = M.e[e];
-  kv_resolve_body<WL>(A.rep, A.n, A.cut, A.kv, A.bin_cnt, A.bins, A.big, A.bin_off, A.ovf, A.stats, A.force_flags, A.trace, A.V, vb);
+  const uint32_t t = threadIdx.x;
+  for (uint32_t k = t; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)A.kv)[k];
+  if (t < KVR_F) Sbig[t] = make_uint2(0u, 0u);
+  if (b == 0) {  // what the next pass will find: its counters zero, the log tail current
+    if (t < 4) A.big_next[t] = 0;
+    for (uint32_t k = t; k < 1024; k += KVB_T) A.blk_pub_next[k] = 0;
+    if (t == 0 && A.has_log) A.log.tail[0] = A.log.tail[1];
+  }
+  __syncthreads();
+  kv_coarse_bin<WL>(A, &Skv, b, Lraw, Sbig);
+  // ---- the bin's big subs (hot keys), one after the other, by the whole workgroup
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __syncthreads();
+  kv_cut cut2 = A.cut;
+  cut2.P = A.cut.P * KVR_F;
+  for (uint32_t sub = 0; sub < KVR_F; sub++) {
+    const uint2 bs = Sbig[sub];  // workgroup-uniform
+    if (bs.y == 0) continue;
+    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, b + A.cut.P * sub, A.ovf + bs.x, bs.y, A.stats, A.force_flags, A.V, Lraw);
+  }
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
+// coarse bins of a pass: ~`load` records each (512: one chunk per wave of the resolve workgroup), any number
+static inline uint32_t kv_pick_coarse(uint32_t n, uint32_t load) {
+  uint64_t c = ((uint64_t)n + load - 1) / load;
+  if (c < 1) c = 1;
+  if (c > DINT_KV_CMAX) c = DINT_KV_CMAX;
+  return (uint32_t)c;
+}
+static uint32_t kv_env(const char *name, uint32_t dflt) {
+  const char *v = getenv(name);
+  return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
+static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log,
+                         const dint_scratch &s, int load_mode, const dint_view &view, uint32_t rpt) {
+  // tuning / test knobs, read at every launch (a getenv is noise next to a launch): DINT_KV_COARSE_LOAD = records per
+  // coarse bin, DINT_KV_CAP = records a coarse bin holds in place (small values exercise the overflow list),
+  // DINT_KV_LCAP = records of a bin's small subs resolved from LDS (small values exercise the all-big fallback)
+  const uint32_t load = std::max(64u, kv_env("DINT_KV_COARSE_LOAD", 512));
+  const uint32_t C = kv_pick_coarse(n, load);
+  const uint32_t mean = (n + C - 1) / C;
+  uint32_t cap = 2 * mean + 64;
+  cap = std::min(cap, (uint32_t)(s.kbins_slots / C));
+  cap = std::max(1u, std::min(cap, kv_env("DINT_KV_CAP", cap)));
+  A.req = (const uint8_t *)d_req; A.rep = (uint8_t *)d_rep; A.n = n;
+  A.n_tiles = (n + KV_TB * rpt - 1) / (KV_TB * rpt);
+  A.kv = kv.d_dev; A.log = log; A.cut = kv_make_cut(C, n); A.cap = cap;
+  A.lcap = std::min(KVR_LCAP, kv_env("DINT_KV_LCAP", KVR_LCAP));
+  A.bin_cnt = s.bin_cnt; A.kbins = s.kbins; A.big = s.big; A.big_next = s.big_next;
+  A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.stats = s.stats;
+  A.load_mode = load_mode;
+  A.force_flags = kv.force_rounds | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
+  A.has_log = kv.workload != DINT_WL_STORE;
+  A.V = view;
+}
+
 template <int WL>
-static void launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
-                      int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
-  static const uint32_t bin_load = dint_hot_min("DINT_KV_BIN_LOAD", 32);
-  const uint32_t P = dint_pick_bins_load(n, bin_load);
-  const kv_cut cut = kv_make_cut(P, n);
-  const uint32_t nb = (n + KV_TB - 1) / KV_TB;  // <= 1024 for n <= DINT_KV_PASS
-  const bool has_log = WL != DINT_WL_STORE;
+static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_t st, hipEvent_t *ev) {
+  uint32_t max_tiles = 0, sum_c = 0;
+  for (uint32_t k = 0; k < n_eng; k++) {
+    max_tiles = std::max(max_tiles, M.e[k].n_tiles);
+    sum_c += M.e[k].cut.P;
+  }
   if (ev) hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL((k_kv_count<WL>), dim3(nb), dim3(KV_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, kv.d_dev,
-                     log, cut, s.bin_cnt, s.bins, s.big, s.ovl, s.blk_pub, s.stats, load_mode, view);
+  if (rpt == 1) hipLaunchKernelGGL((k_kv_part<WL, 1>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
+  else if (rpt == 2) hipLaunchKernelGGL((k_kv_part<WL, 2>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
+  else hipLaunchKernelGGL((k_kv_part<WL, 4>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
-                     (const uint32_t *)s.big, s.big_next, s.blk_pub_next, has_log ? log.tail : nullptr, s.stats,
-                     (const uint4 *)s.ovl, s.ovf);
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
   if (ev) hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n,
-                     cut, kv.d_dev, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big,
-                     (const uint32_t *)s.bin_off, (const uint64_t *)s.ovf, s.stats,
-                     kv.force_rounds | (int)(dint_hot_min("DINT_KV_HOT_MIN", 0) << 8), kv.d_trace, view);
-  if (ev) hipEventRecord(ev[3], st);
+}
+
+// requests per thread of k_kv_part: longer tiles = fewer, longer runs per (tile, coarse bin), but a pass must still
+// fill the GPU's 256 CUs
+static inline uint32_t kv_pick_rpt(uint32_t n_total) {
+  const uint32_t forced = kv_env("DINT_KV_RPT", 0);
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  return n_total >= 1024u * 1024u ? 4u : n_total >= 256u * 1024u ? 2u : 1u;
+}
+
+static void launch_kv_dispatch(uint32_t workload, kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_t st, hipEvent_t *ev) {
+  switch (workload) {
+    case DINT_WL_STORE: launch_kv_passes<DINT_WL_STORE>(M, n_eng, rpt, st, ev); break;
+    case DINT_WL_TATP: launch_kv_passes<DINT_WL_TATP>(M, n_eng, rpt, st, ev); break;
+    default: launch_kv_passes<DINT_WL_SMALLBANK>(M, n_eng, rpt, st, ev); break;
+  }
 }
 
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
                     int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
   if (n == 0) return;
-  switch (kv.workload) {
-    case DINT_WL_STORE: launch_kv<DINT_WL_STORE>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
-    case DINT_WL_TATP: launch_kv<DINT_WL_TATP>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
-    default: launch_kv<DINT_WL_SMALLBANK>(d_req, d_rep, n, kv, log, s, load_mode, st, ev, view); break;
-  }
-}
-
-template <int WL>
-static void launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st) {
-  static const uint32_t bin_load = dint_hot_min("DINT_KV_BIN_LOAD", 32);
   kv_multi_args M;
   memset(&M, 0, sizeof M);
-  uint32_t max_slices = 0, sum_resolve = 0;
-  for (uint32_t k = 0; k < n_eng; k++) {
-    kv_pass_args &A = M.e[k];
-    const dint_kv_pass &q = p[k];
-    const uint32_t P = dint_pick_bins_load(q.n, bin_load);
-    A.req = (const uint8_t *)q.d_req; A.rep = (uint8_t *)q.d_rep; A.n = q.n; A.n_slices = (q.n + KV_TB - 1) / KV_TB;
-    A.kv = q.kv->d_dev; A.log = q.log; A.cut = kv_make_cut(P, q.n);
-    A.bin_cnt = q.s.bin_cnt; A.bins = q.s.bins; A.big = q.s.big; A.big_next = q.s.big_next; A.bin_off = q.s.bin_off;
-    A.blk_pub = q.s.blk_pub; A.blk_pub_next = q.s.blk_pub_next; A.ovl = q.s.ovl; A.ovf = q.s.ovf; A.stats = q.s.stats;
-    A.trace = nullptr; A.load_mode = 0;  // (the per-workgroup trace rows are numbered for single-engine launches)
-    A.force_flags = q.kv->force_rounds | (int)(dint_hot_min("DINT_KV_HOT_MIN", 0) << 8);
-    A.has_log = WL != DINT_WL_STORE; A.resolve_blocks = KVB_GRID + (P + KVB_W - 1) / KVB_W; A.V = q.view;
-    max_slices = std::max(max_slices, A.n_slices);
-    sum_resolve += A.resolve_blocks;
-  }
-  hipLaunchKernelGGL((k_kv_count_multi<WL>), dim3(max_slices, n_eng), dim3(KV_TB), 0, st, M);
-  hipLaunchKernelGGL(k_kv_scan_place_multi, dim3(KV_PLACE_GRID, n_eng), dim3(KV_TB), 0, st, M);
-  hipLaunchKernelGGL((k_kv_resolve_multi<WL>), dim3(sum_resolve), dim3(KVB_T), 0, st, M, n_eng);
+  const uint32_t rpt = kv_pick_rpt(n);
+  kv_fill_pass(M.e[0], d_req, d_rep, n, kv, log, s, load_mode, view, rpt);
+  launch_kv_dispatch(kv.workload, M, 1, rpt, st, ev);
 }
 
-// one pass of each of n_eng (<= DINT_KV_MULTI_MAX) engines of ONE kv workload, all on stream st
+// one pass of each of n_eng (<= DINT_KV_MULTI_MAX) engines of ONE kv workload, all on stream st: a closed-loop epoch
+// (and a step of the multi-GPU exchange) hands every shard server of the GPU one batch at the same moment; with the
+// engines' kernels side by side in one grid the epoch is one stream, no fork and join over engine streams.  The engines
+// stay independent (own tables, own scratch, own log).
 void dint_launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st) {
   if (n_eng == 0) return;
-  switch (p[0].kv->workload) {
-    case DINT_WL_STORE: launch_kv_multi<DINT_WL_STORE>(p, n_eng, st); break;
-    case DINT_WL_TATP: launch_kv_multi<DINT_WL_TATP>(p, n_eng, st); break;
-    default: launch_kv_multi<DINT_WL_SMALLBANK>(p, n_eng, st); break;
-  }
+  kv_multi_args M;
+  memset(&M, 0, sizeof M);
+  uint32_t n_total = 0;
+  for (uint32_t k = 0; k < n_eng; k++) n_total += p[k].n;
+  const uint32_t rpt = kv_pick_rpt(n_total);
+  for (uint32_t k = 0; k < n_eng; k++) kv_fill_pass(M.e[k], p[k].d_req, p[k].d_rep, p[k].n, *p[k].kv, p[k].log, p[k].s, 0, p[k].view, rpt);
+  launch_kv_dispatch(p[0].kv->workload, M, n_eng, rpt, st, nullptr);
 }
 
 // ---- home shard of each request (multi-GPU routing): global bucket % shard_count -------------------------

@@ -528,3 +528,41 @@ def test_store_dominant_key_vs_oracle():
         got, want = eng.submit(req), o.replay(req)
         assert got.tobytes() == want.tobytes()
     assert _same_rows(eng.dump_rows(0), o.dump())
+
+
+# ---------------------------------------------------------------- the two-level partition's own corners
+@pytest.mark.parametrize("knob", [("DINT_KV_CAP", "24"), ("DINT_KV_LCAP", "96"), ("DINT_KV_RPT", "1"), ("DINT_KV_RPT", "2"),
+                                  ("DINT_KV_RPT", "4"), ("DINT_KV_COARSE_LOAD", "4096"), ("DINT_KV_COARSE_LOAD", "64")])
+@pytest.mark.parametrize("wl", ["store", "tatp", "smallbank"])
+def test_partition_corners(wl, knob, monkeypatch):
+    """k_kv_part / k_kv_resolve away from their usual operating point (the knobs are read at every launch):
+    DINT_KV_CAP = 24 records in place per coarse bin, so most records travel through the pass's overflow list;
+    DINT_KV_LCAP = 96 records in the LDS split, so most coarse bins take the everything-is-a-big-sub fallback;
+    1, 2 and 4 requests per thread of the partition kernel; coarse bins of ~4096 records (every bin spills over its LDS
+    split) and of ~64 records (one chunk per bin)."""
+    monkeypatch.setenv(*knob)
+    if wl == "store":
+        req = tracegen.store_random(70_000, seed=13, n_sub_touch=900, p_set=0.4, p_insert=0.05)
+        eng = _engine(W.STORE, n_rows=5000)
+        o = orc.StoreOracle(5000 * 18 // 4, 1500); eng.populate(1500)
+    elif wl == "tatp":
+        o = orc.TatpOracle(5000, populate_n=900)
+        req = tracegen.tatp_random(70_000, [o.dump(t)[0] for t in range(5)], seed=14, n_sub_touch=900)
+        eng = _engine(W.TATP, n_rows=5000); eng.populate(900)
+    else:
+        req = tracegen.sb_random(70_000, seed=15, n_acct_touch=900)
+        eng = _engine(W.SMALLBANK, n_rows=5000); eng.populate(900)
+        o = orc.SmallbankOracle(5000, populate_n=900)
+    want = o.replay(req)
+    got = np.concatenate([eng.submit(req[:50_000]), eng.submit(req[50_000:50_100]), eng.submit(req[50_100:])])
+    assert got.tobytes() == want.tobytes()
+    if wl == "tatp":
+        for t in range(5):
+            assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+        _tatp_locks(eng, o)
+        ring, tail = eng.read_log(1_000_000)
+        assert tail == o.tail and (np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64) == o.ring).all()
+    elif wl == "smallbank":
+        _sb_state(eng, o)
+    else:
+        assert _same_rows(eng.dump_rows(0), o.dump())

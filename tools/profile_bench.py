@@ -102,9 +102,14 @@ def main():
     from bench import kernel_source_hash
 
     try:
-        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
     except Exception:
         commit = None
+    if not commit:  # the GPU box gets a snapshot without .git: tools/gpurun.sh leaves the id (and a dirty mark) here
+        try:
+            commit = open(os.path.join(ROOT, ".commit_id")).read().strip() or None
+        except OSError:
+            commit = None
     res = {"workload": wl, "command": "bench.py " + " ".join(rest) + f" --steps {steps} --warmup {warm} --per-step {per_step}", "launches": last,
            "kernel_source_hash": kernel_source_hash(wl), "commit": commit, "kernels": kernels}
     os.makedirs(os.path.join(ROOT, "gpurun_out", "profiles"), exist_ok=True)
