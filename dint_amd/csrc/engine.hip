@@ -316,6 +316,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     if (is_kv) {  // coarse bins of 16-byte records: C * cap = C * (2 ceil(n / C) + 64) <= 2 n + 66 C
       e->scratch.kbins_slots = 2ull * e->pass_max + 66ull * DINT_KV_CMAX;
       TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
+      TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_CMAX * 64 * sizeof(uint4), false));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
     }
@@ -382,6 +383,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bin_cnt);
   hipFree(e->scratch.bins);
   hipFree(e->scratch.kbins);
+  hipFree(e->scratch.bigq);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
   hipFree(std::min(e->scratch.blk_pub, e->scratch.blk_pub_next));

@@ -189,9 +189,11 @@ struct kv_pass_args {
   uint32_t *blk_pub, *blk_pub_next;
   uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
   uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
+  uint4 *bigq;           // LATE: the pass's big subs {bin, offset in ovf, records, -} for k_kv_big; big[3] = how many
   dint_dev_stats *stats;
   int load_mode, force_flags;
   uint32_t has_log;
+  uint64_t *trace;       // DINT_KV_TRACE=1: 32 words per resolve workgroup (10 ns stamps of its phases), else nullptr
   dint_view V;
 };
 struct kv_multi_args { kv_pass_args e[DINT_KV_MULTI_MAX]; };
@@ -410,7 +412,7 @@ __global__ void __launch_bounds__(KV_TB) k_kv_part(kv_multi_args M) {
 __device__ static inline void kv_stamp(uint64_t *tr, uint32_t k) {
   if (tr) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (lane_id() == 0) tr[k] = __builtin_amdgcn_s_memtime();
+    if (lane_id() == 0) tr[k] = __builtin_amdgcn_s_memrealtime();
   }
 }
 // device-wide constant-rate clock (100 MHz), comparable across waves: [10] = wave start, [11] = wave end
@@ -1893,23 +1895,20 @@ static_assert(sizeof(kvr_lds) <= sizeof(kvb_lds), "the coarse-bin split shares t
 
 template <int WL>
 __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev *kv, uint32_t coarse, uint8_t *lds_raw,
-                                            uint2 *Sbig /* [KVR_F] {offset in ovf, records} of the bin's big subs */) {
+                                            uint2 *Sbig /* [KVR_F] {offset in ovf, records} of the bin's big subs */,
+                                            uint32_t cnt, const uint4 &r0, const uint4 &r1, uint64_t *tr) {
   kvr_lds &L = *(kvr_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const kv_cut &cut = A.cut;
   const uint32_t C = cut.P, cap = A.cap, sh = 16 + cut.ibits;
   const uint32_t idx_mask = (uint32_t)((1ull << cut.ibits) - 1ull);
   const uint4 *__restrict__ recs = A.kbins + (size_t)coarse * cap;
-  const uint32_t cnt = A.bin_cnt[coarse];
   if (cnt == 0) return;  // workgroup-uniform
   const uint32_t n_in = min(cnt, cap);
   const uint32_t novl = cnt > cap ? A.big[1] : 0u;  // my records beyond `cap` are somewhere in the pass's overflow list
-  if (t < KVR_F) { L.hist[t] = 0; L.cur[t] = 0; }
-  // the first two records of every thread stay in registers between the two phases (the usual bin is read once)
-  const uint4 r0 = t < n_in ? recs[t] : make_uint4(0, 0, 0, 0);
-  const uint4 r1 = t + KVB_T < n_in ? recs[t + KVB_T] : make_uint4(0, 0, 0, 0);
-  __syncthreads();  // every thread has read cnt
-  if (t == 0) A.bin_cnt[coarse] = 0;  // leave the counters clean for the next pass
+  // (the first two records of every thread -- r0, r1, loaded by the kernel together with the counter -- stay in
+  // registers between the two phases: the usual bin is read once)
+  if (t == 0) A.bin_cnt[coarse] = 0;  // leave the counters clean for the next pass (every thread read it before the kernel's barrier)
   auto for_each_record = [&](auto &&f) {
     if (t < n_in) f(r0);
     if (t + KVB_T < n_in) f(r1);
@@ -1920,6 +1919,7 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   // ---- phase A: records per sub
   for_each_record([&](const uint4 &r) { atomicAdd(&L.hist[(uint32_t)(u4_meta(r) >> sh) & (KVR_F - 1)], 1u); });
   __syncthreads();
+  if (tr && t == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
   // ---- layout (one wave, a lane per sub): small subs get a range of rec[], big subs a range of ovf[]; neighbouring
   // small subs are packed into chunks of <= 64 records, greedily
   if (wave == 0) {
@@ -1964,8 +1964,10 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
       s = e;
     }
     if (lane == 0) L.nch = nch;
+    if (tr && lane == 0) { tr[14] = cnt; tr[15] = btot; tr[16] = nch; }
   }
   __syncthreads();
+  if (tr && t == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
   // ---- phase B: every record to its sub's range
   for_each_record([&](const uint4 &r) {
     const uint64_t m = u4_meta(r);
@@ -1975,6 +1977,7 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     else A.ovf[bo + pos] = ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull));  // the big path's record: group / (64 C) | idx | payload
   });
   __syncthreads();
+  if (tr && t == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
   // ---- the chunks, one wave each: sort by (group / C, key hash, idx) in registers -- groups commute, so any order that
   // keeps each group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in
   // adjacent lanes.  The sort word carries the lane the record came from; key and payload follow by one shuffle each.
@@ -1989,6 +1992,8 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     uint64_t w = ~0ull;  // empty lanes sort last
     if (has) w = ((m >> sh) << (15 + cut.ibits)) | ((uint64_t)pay_kh(pay0) << (6 + cut.ibits)) | ((uint64_t)((uint32_t)(m >> 16) & idx_mask) << 6) | lane;
     w = wave_sort_u64(w);
+    uint64_t *ctr = (tr && ch == 0) ? tr + 2 : nullptr;  // the first chunk's kv_chunk stamps 4 .. 8 land in tr[6 .. 10]
+    if (ctr && lane == 0) tr[5] = __builtin_amdgcn_s_memrealtime();
     const bool valid = lane < c;
     const int src = (int)((uint32_t)w & 63u);
     const uint64_t key = shfl_u64(key0, src);
@@ -1996,40 +2001,92 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     const uint32_t gk = kv_cut_gk((uint32_t)(w >> (15 + cut.ibits)), coarse, cut), kh = (uint32_t)(w >> (6 + cut.ibits)) & 511u;
     const uint32_t idx = (uint32_t)(w >> 6) & idx_mask;
     kv_chunk<WL>(A.rep, valid, valid ? idx : 0, gk, kh, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), key, kv, A.stats,
-                 A.force_flags & 1, true, A.V);
+                 A.force_flags & 1, true, A.V, ctr);
   }
 }
 
 // The launch carries the big path's footprint (~73 KB of LDS, 128 VGPRs): two workgroups = 16 waves per CU.  The big
 // path is a function of its own (noinline), so that its register pressure -- it spills at 128 VGPRs -- stays out of the
 // chunk path's allocation (the chunk path alone needs 89 VGPRs and no scratch).
-template <int WL>
+// LATE = the big subs are not resolved here but listed for k_kv_big, a launch of its own behind this one: the chunk
+// workgroups then carry 17 KB of LDS and ~90 VGPRs, and a hot key no longer waits for its coarse bin's chunks
+// (DINT_KV_LATE_BIG=1; measured against the in-place form in NOTEBOOK.md).
+template <int WL, bool LATE>
 __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
-  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[LATE ? sizeof(kvr_lds) : sizeof(kvb_lds)];
   __shared__ uint2 Sbig[KVR_F];
   uint32_t e = 0, b = blockIdx.x;
   while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
   const kv_pass_args &A = M.e[e];
   const uint32_t t = threadIdx.x;
-  for (uint32_t k = t; k < sizeof(kv_dev) / 4; k += KVB_T) ((uint32_t *)&Skv)[k] = ((const uint32_t *)A.kv)[k];
-  if (t < KVR_F) Sbig[t] = make_uint2(0u, 0u);
+  uint64_t *tr = A.trace ? A.trace + 32 * (size_t)blockIdx.x : nullptr;
+  if (tr && t == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
+  // everything the workgroup needs from memory before its LDS phases, in flight together: the table descriptors, the
+  // bin's record count and -- without waiting for the count: the bin's region always exists -- its first 2 x 512 records
+  // (the counter is loaded LAST: the compiler makes it a scalar at once -- a wait -- and the loads issued before it ride
+  // on the same round trip)
+  static_assert(sizeof(kv_dev) / 4 <= KVB_T, "one word of the table descriptors per thread");
+  const uint4 *__restrict__ recs = A.kbins + (size_t)b * A.cap;
+  const uint4 r0 = t < A.cap ? recs[t] : make_uint4(0, 0, 0, 0);
+  const uint4 r1 = t + KVB_T < A.cap ? recs[t + KVB_T] : make_uint4(0, 0, 0, 0);
+  const uint32_t kvw = t < sizeof(kv_dev) / 4 ? ((const uint32_t *)A.kv)[t] : 0u;
+  const uint32_t cnt = A.bin_cnt[b];
+  if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = kvw;
+  if (t < KVR_F) {
+    Sbig[t] = make_uint2(0u, 0u);
+    kvr_lds &L = *(kvr_lds *)Lraw;
+    L.hist[t] = 0; L.cur[t] = 0;
+  }
   if (b == 0) {  // what the next pass will find: its counters zero, the log tail current
     if (t < 4) A.big_next[t] = 0;
     for (uint32_t k = t; k < 1024; k += KVB_T) A.blk_pub_next[k] = 0;
     if (t == 0 && A.has_log) A.log.tail[0] = A.log.tail[1];
   }
   __syncthreads();
-  kv_coarse_bin<WL>(A, &Skv, b, Lraw, Sbig);
+  if (tr && t == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
+  kv_coarse_bin<WL>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr);
   // ---- the bin's big subs (hot keys), one after the other, by the whole workgroup
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __syncthreads();
+  if (tr && t == 0) tr[11] = __builtin_amdgcn_s_memrealtime();
+  if (LATE) {
+    if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big
+      const uint2 bs = Sbig[t];
+      const uint64_t m = __ballot(bs.y != 0);
+      uint32_t base = 0;
+      if (t == 0 && m) base = atomicAdd(&A.big[3], (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (bs.y) A.bigq[base + (uint32_t)__popcll(m & lanemask_lt())] = make_uint4(b + A.cut.P * t, bs.x, bs.y, 0u);
+    }
+  } else {
+    kv_cut cut2 = A.cut;
+    cut2.P = A.cut.P * KVR_F;
+    for (uint32_t sub = 0; sub < KVR_F; sub++) {
+      const uint2 bs = Sbig[sub];  // workgroup-uniform
+      if (bs.y == 0) continue;
+      kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, b + A.cut.P * sub, A.ovf + bs.x, bs.y, A.stats, A.force_flags, A.V, Lraw);
+    }
+  }
+  if (tr && t == 0) { tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
+}
+
+// LATE: the pass's big subs, KVB_GRID workgroups per engine taking them in turn (longest job of a pass: a hot key)
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_big(kv_multi_args M) {
+  __shared__ kv_dev Skv;
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
+  const kv_pass_args &A = M.e[blockIdx.y];
+  const uint32_t nq = A.big[3];
+  if (blockIdx.x >= nq) return;
+  const uint32_t t = threadIdx.x;
+  if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = ((const uint32_t *)A.kv)[t];
+  __syncthreads();
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
-  for (uint32_t sub = 0; sub < KVR_F; sub++) {
-    const uint2 bs = Sbig[sub];  // workgroup-uniform
-    if (bs.y == 0) continue;
-    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, b + A.cut.P * sub, A.ovf + bs.x, bs.y, A.stats, A.force_flags, A.V, Lraw);
+  for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
+    const uint4 d = A.bigq[i];
+    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + d.y, d.z, A.stats, A.force_flags, A.V, Lraw);
   }
 }
 
@@ -2063,9 +2120,11 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.lcap = std::min(KVR_LCAP, kv_env("DINT_KV_LCAP", KVR_LCAP));
   A.bin_cnt = s.bin_cnt; A.kbins = s.kbins; A.big = s.big; A.big_next = s.big_next;
   A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.stats = s.stats;
+  A.bigq = s.bigq;
   A.load_mode = load_mode;
   A.force_flags = kv.force_rounds | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
   A.has_log = kv.workload != DINT_WL_STORE;
+  A.trace = kv.d_trace;
   A.V = view;
 }
 
@@ -2081,7 +2140,12 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   else if (rpt == 2) hipLaunchKernelGGL((k_kv_part<WL, 2>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   else hipLaunchKernelGGL((k_kv_part<WL, 4>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+  if (kv_env("DINT_KV_LATE_BIG", 0)) {
+    hipLaunchKernelGGL((k_kv_resolve<WL, true>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+    hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
+  } else {
+    hipLaunchKernelGGL((k_kv_resolve<WL, false>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+  }
   if (ev) hipEventRecord(ev[2], st);
 }
 

@@ -197,6 +197,12 @@ class Engine:
         (10 ns ticks)."""
         out = np.zeros(32768 * 16 + 16 * 8192, "<u8")
         _lib.check(self._L.dint_kv_trace_read(self._h, out.ctypes.data, out.size))
+        if self.workload in (Workload.STORE, Workload.TATP, Workload.SMALLBANK):
+            # kv engines (r04): 32 words per resolve workgroup -- [0] in, [1] descriptors / count / first records there,
+            # [2] records counted per sub, [3] laid out, [4] placed, [5] first chunk sorted, [6..10] that chunk's kv_chunk
+            # stamps (run / segment masks, rows located, replies, write-backs, rounds), [11] chunks done, [12] big subs
+            # done, [13] coarse bin, [14] records, [15] records in big subs, [16] chunks
+            return out[:2048 * 32].reshape(2048, 32)
         bins = out[:32768 * 16].reshape(32768, 16)
         return (bins, out[32768 * 16:].reshape(8192, 16)) if workgroups else bins
 

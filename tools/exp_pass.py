@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""One tatp shard server alone on the GPU, no tracing: per-kernel event times and wall time per pass.
-usage: exp_pass.py [clients] [theta]"""
+"""One tatp shard server alone on the GPU: per-kernel event times and wall time per pass; with DINT_KV_TRACE=1 also the
+phase timeline of the resolve workgroups (10 ns stamps, engine.kv_trace).
+usage: [DINT_KV_TRACE=1] exp_pass.py [clients] [theta] [workload]"""
 import json
 import os
 import sys
@@ -16,10 +17,11 @@ from dint_amd.replay import Replay, ShardGroup, record  # noqa: E402
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 theta = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
-n_sub, E = 1_000_000, 24
-grp = ShardGroup(wire.Workload.TATP, n_sub)
+wl = {"tatp": wire.Workload.TATP, "smallbank": wire.Workload.SMALLBANK}[sys.argv[3] if len(sys.argv) > 3 else "tatp"]
+n_sub, E = (1_000_000 if wl == wire.Workload.TATP else 10_000_000), 24
+grp = ShardGroup(wl, n_sub)
 grp.sync(); grp.snapshot()
-d = Driver(wire.Workload.TATP, C, n_sub, zipf_theta=theta if theta > 0 else None)
+d = Driver(wl, C, n_sub, zipf_theta=theta if theta > 0 else None)
 trace, done = record(d, grp, E)
 grp.sync(); grp.restore()
 rp = Replay(trace, grp.msg)
@@ -33,11 +35,35 @@ for rep in range(2):
     grp.sync()
     wall = (time.perf_counter() - t0) / E * 1e6
 grp.restore()
+if os.environ.get("DINT_KV_TRACE"):
+    eng.kv_trace()
 eng.timing_enable(True)
 for e in range(E):
     eng.submit_device(rp.d_req[e][0], rp.counts[e][0], rp.d_rep[e][0], 0)
 grp.sync()
 n = float(np.mean([rp.counts[e][0] for e in range(E)]))
-print(json.dumps({"clients": C, "theta": theta, "requests_per_pass": round(n), "wall_us_per_pass": round(wall, 1),
-                  "Mreq_s_alone": round(n / wall, 1),
-                  "kernels_us": {k: round(v["avg_us"], 2) for k, v in eng.timing_read().items()}}))
+out = {"clients": C, "theta": theta, "requests_per_pass": round(n), "wall_us_per_pass": round(wall, 1),
+       "Mreq_s_alone": round(n / wall, 1), "kernels_us": {k: round(v["avg_us"], 2) for k, v in eng.timing_read().items()}}
+if os.environ.get("DINT_KV_TRACE"):
+    tr = eng.kv_trace().astype(np.int64)
+    tr = tr[tr[:, 0] > 0]
+    t0 = tr[:, 0].min()
+    names = ["in", "loaded", "counted", "laid_out", "placed", "sorted", "masks", "located", "replied", "written", "rounds", "chunks_done", "bigs_done"]
+    ph = {}
+    for k in range(1, 13):
+        ok = (tr[:, k] > 0) & (tr[:, k - 1] > 0)
+        dd = (tr[ok, k] - tr[ok, k - 1]) / 100.0
+        if len(dd):
+            ph[names[k]] = [round(float(dd.mean()), 2), round(float(np.percentile(dd, 95)), 2), round(float(dd.max()), 2)]
+    out["phases_us_mean_p95_max"] = ph
+    start = (tr[:, 0] - t0) / 100.0
+    end = (tr[:, 12] - t0) / 100.0
+    out["wg_start_us_max"] = round(float(start.max()), 2)
+    out["wg_end_us_mean_max"] = [round(float(end.mean()), 2), round(float(end.max()), 2)]
+    order = np.argsort(-(tr[:, 12] - tr[:, 0]))[:6]
+    out["longest_wgs"] = [{"bin": int(tr[i, 13]), "records": int(tr[i, 14]), "in_big_subs": int(tr[i, 15]), "chunks": int(tr[i, 16]),
+                           "start": round(float(start[i]), 1), "chunks_us": round(float(tr[i, 11] - tr[i, 0]) / 100.0, 1),
+                           "bigs_us": round(float(tr[i, 12] - tr[i, 11]) / 100.0, 1)} for i in order]
+    out["records_per_wg_mean_max"] = [round(float(tr[:, 14].mean()), 1), int(tr[:, 14].max())]
+    out["wgs_with_big_subs"] = int((tr[:, 15] > 0).sum())
+print(json.dumps(out))
