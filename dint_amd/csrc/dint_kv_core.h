@@ -74,6 +74,18 @@ struct kv_tab {
   unsigned long long *pend_head;  // [KV_NLISTS]
 };
 
+// Device build: the table descriptors reach the kernels through memory (a kv_dev in HBM, copied to LDS), so the compiler
+// sees GENERIC pointers and would access the tables with flat instructions -- which count against the LDS counter as well
+// and so serialise with the shuffles and LDS accesses around them.  The tables (and the messages) live in HBM; the hot
+// accessors say so with address-space-1 pointers (a cast to address space 1 and back is folded away: the ACCESS has to go
+// through the qualified type).  Host build (the CPU unit tests of this layout): plain pointers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KV_G(T) __attribute__((address_space(1))) T
+#else
+#define KV_G(T) T
+#endif
+#define KV_LD(T, p) (*(const KV_G(T) *)(p))
+#define KV_ST(T, p, v) (*(KV_G(T) *)(p) = (v))
 KV_HD static inline uint8_t *kv_entry_ptr(const kv_tab &t, uint64_t bucket, uint32_t link) {
   const uint64_t e = (link == KV_INLINE) ? bucket : t.n_local + (uint64_t)(link - 2u);
   return t.entries + e * (uint64_t)t.stride;
@@ -86,6 +98,13 @@ KV_HD static inline void kv_hdr_copy(kv_hdr &d, const kv_hdr &s) {
   d.key[0] = s.key[0]; d.key[1] = s.key[1]; d.key[2] = s.key[2]; d.key[3] = s.key[3];
   d.ver[0] = s.ver[0]; d.ver[1] = s.ver[1]; d.ver[2] = s.ver[2]; d.ver[3] = s.ver[3];
   d.validw = s.validw; d.next = s.next; d.head = s.head; d.lockw = s.lockw;
+}
+// a header from table memory (HBM) into registers
+KV_HD static inline void kv_hdr_load(kv_hdr &d, const void *p) {
+  const KV_G(kv_hdr) *s = (const KV_G(kv_hdr) *)p;
+  d.key[0] = s->key[0]; d.key[1] = s->key[1]; d.key[2] = s->key[2]; d.key[3] = s->key[3];
+  d.ver[0] = s->ver[0]; d.ver[1] = s->ver[1]; d.ver[2] = s->ver[2]; d.ver[3] = s->ver[3];
+  d.validw = s->validw; d.next = s->next; d.head = s->head; d.lockw = s->lockw;
 }
 KV_HD static inline bool kv_valid(const kv_hdr &h, uint32_t slot) { return (h.validw >> (8 * slot)) & 0xFFu; }
 
@@ -159,17 +178,21 @@ struct kv_res {
 // alias as far as the compiler knows, and a load/store/load/store chain would cost one memory round trip per
 // word on the GPU.  Entry values are 4-byte aligned; message values are not (packed wire structs) -> memcpy.
 KV_HD static inline void kv_copy_words(uint8_t *dst, const uint8_t *src, uint32_t bytes) {
+  // (packed / may_alias word types: message values are unaligned; in the device build both sides are HBM, see KV_G)
+  typedef uint32_t __attribute__((aligned(1), may_alias)) kv_w32;
+  const KV_G(kv_w32) *s = (const KV_G(kv_w32) *)src;
+  KV_G(kv_w32) *d = (KV_G(kv_w32) *)dst;
   uint32_t w[10];
   if (bytes == 40) {
 #pragma unroll
-    for (uint32_t k = 0; k < 10; k++) __builtin_memcpy(&w[k], src + 4 * k, 4);
+    for (uint32_t k = 0; k < 10; k++) w[k] = s[k];
 #pragma unroll
-    for (uint32_t k = 0; k < 10; k++) __builtin_memcpy(dst + 4 * k, &w[k], 4);
+    for (uint32_t k = 0; k < 10; k++) d[k] = w[k];
   } else {
 #pragma unroll
-    for (uint32_t k = 0; k < 2; k++) __builtin_memcpy(&w[k], src + 4 * k, 4);
+    for (uint32_t k = 0; k < 2; k++) w[k] = s[k];
 #pragma unroll
-    for (uint32_t k = 0; k < 2; k++) __builtin_memcpy(dst + 4 * k, &w[k], 4);
+    for (uint32_t k = 0; k < 2; k++) d[k] = w[k];
   }
 }
 
@@ -189,7 +212,7 @@ KV_HD static inline kv_res kv_apply(const kv_tab &t, uint64_t bucket, const kv_h
     // the inline entry's header is already in registers (it does not change between the caller's load and here)
     kv_hdr h;
     if (cur == KV_INLINE) { kv_hdr_copy(h, H); inline_linked = true; }
-    else kv_hdr_copy(h, *kv_entry_hdr(t, bucket, cur));
+    else kv_hdr_load(h, kv_entry_hdr(t, bucket, cur));
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) {
       if (want_match && !matched && kv_valid(h, i) && h.key[i] == key) {
@@ -294,7 +317,7 @@ KV_HD static inline kv_where kv_locate(const kv_tab &t, uint64_t bucket, const k
   for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
     kv_hdr h;
     if (cur == KV_INLINE) kv_hdr_copy(h, H);
-    else kv_hdr_copy(h, *kv_entry_hdr(t, bucket, cur));
+    else kv_hdr_load(h, kv_entry_hdr(t, bucket, cur));
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++)
       if (!w.found && kv_valid(h, i) && h.key[i] == key) { w.found = 1; w.link = cur; w.slot = i; w.ver = h.ver[i]; }
@@ -314,7 +337,7 @@ KV_HD static inline bool kv_has_dup(const kv_tab &t, uint64_t bucket, const kv_h
   for (uint32_t steps = 0; cur != KV_NULL && steps < KV_MAX_CHAIN; steps++) {
     kv_hdr h;
     if (cur == KV_INLINE) kv_hdr_copy(h, H);
-    else kv_hdr_copy(h, *kv_entry_hdr(t, bucket, cur));
+    else kv_hdr_load(h, kv_entry_hdr(t, bucket, cur));
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++)
       if ((!first || i > w.slot) && kv_valid(h, i) && h.key[i] == key) return true;

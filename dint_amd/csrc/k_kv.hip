@@ -444,7 +444,7 @@ __device__ static inline void kv_do_request(uint8_t *msg, uint32_t type, uint32_
   uint8_t *ie = kv_entry_ptr(t, bucket, KV_INLINE);
   // ---- load phase
   kv_hdr H;
-  kv_hdr_copy(H, *(const kv_hdr *)ie);
+  kv_hdr_load(H, ie);
   uint2 cnt = make_uint2(0, 0);
   if (WL == DINT_WL_SMALLBANK) cnt = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);  // {num_ex, num_sh}
   const uint64_t key = ld_u64(msg + F::KEY);
@@ -645,10 +645,9 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
     ie = kv_entry_ptr(t, bucket, KV_INLINE);
   }
   if (head) {
-    kv_hdr_copy(H, *(const kv_hdr *)ie);
+    kv_hdr_load(H, ie);
     if (WL == DINT_WL_SMALLBANK) {
-      const uint2 c = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q);
-      la0 = c.x; lb0 = c.y;
+      la0 = KV_LD(uint32_t, ie + KV_SB_LOCK_OFF + 8 * q); lb0 = KV_LD(uint32_t, ie + KV_SB_LOCK_OFF + 8 * q + 4);
     }
   }
   const uint64_t hkey = shfl_u64(key, hl);
@@ -843,20 +842,23 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
     if (found0 && exists1 && !redo) {  // the row stays where it is: value / version of the last writer
       if (fin_src >= 0) {
         kv_copy_words(row, rep + dint_view_off(V, fin_idx, F::MSG) + F::VAL, F::VS);
-        kv_entry_hdr(t, bucket, link)->ver[slot] = fin_ver;
+        KV_ST(uint32_t, &kv_entry_hdr(t, bucket, link)->ver[slot], fin_ver);
       }
     } else if (found0 != exists1 || redo) {  // apply the net INSERT / DELETE (or DELETE + INSERT) to the chain once
       if (redo) {
         kv_apply<kv_dev_mem>(t, bucket, H, KV_ACT_DEL, key, nullptr, 0, blockIdx.x);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        kv_hdr_copy(H, *(const kv_hdr *)ie);
+        kv_hdr_load(H, ie);
       }
       const kv_res r = kv_apply<kv_dev_mem>(t, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key,
                                             rep + dint_view_off(V, fin_idx, F::MSG) + F::VAL, fin_ver, blockIdx.x);
       if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
     }
-    if (WL == DINT_WL_TATP && fin_la != la0) ie[KV_LOCKB_OFF + q] = (uint8_t)fin_la;
-    if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * q) = make_uint2(fin_la, fin_lb);
+    if (WL == DINT_WL_TATP && fin_la != la0) KV_ST(uint8_t, ie + KV_LOCKB_OFF + q, (uint8_t)fin_la);
+    if (WL == DINT_WL_SMALLBANK && (fin_la != la0 || fin_lb != lb0)) {
+      KV_ST(uint32_t, ie + KV_SB_LOCK_OFF + 8 * q, fin_la);
+      KV_ST(uint32_t, ie + KV_SB_LOCK_OFF + 8 * q + 4, fin_lb);
+    }
     if (nmiss) atomicAdd(&stats->missing_keys, (unsigned long long)nmiss);
   }
   kv_stamp(tr, 7);
@@ -925,8 +927,10 @@ struct kvb_lds {
 //   one lock word, a bad key or several inserts / deletes run request by request after the tiles.
 // A bin of more than KVB_NMAX records is cut into stretches along request-index buckets (every request of a
 // stretch precedes every request of the next one) and the stretches run one after the other.
+// (always inlined: as a function of its own it takes the LDS buffer as a GENERIC pointer -- every LDS access becomes a
+// flat instruction and the stretch machinery, which lives in LDS, runs at half speed: 117 -> 170 us for the r04a hot pass)
 template <int WL>
-__device__ __attribute__((noinline)) static void
+__device__ __forceinline__ static void
 kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_t bin, const uint64_t *__restrict__ recs,
            uint32_t c, dint_dev_stats *__restrict__ stats, int force_flags, const dint_view V, uint8_t *lds_raw) {
   using F = Fmt<WL>;
@@ -1176,7 +1180,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
             const kv_tab tb = kv->tab[table];
             const uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
             kv_hdr H;
-            kv_hdr_copy(H, *(const kv_hdr *)ie);
+            kv_hdr_load(H, ie);
             const kv_where wh = kv_locate(tb, bucket, H, hkey);
             Hs[8] = wh.found; Hs[9] = wh.link; Hs[10] = wh.slot; Hs[11] = wh.ver;
             Hs[12] = WL == DINT_WL_TATP ? (H.lockw >> (8 * hq)) & 0xFFu : 0;
@@ -1376,7 +1380,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
         const kv_tab tb = kv->tab[table];
         const uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
         kv_hdr H;
-        kv_hdr_copy(H, *(const kv_hdr *)ie);
+        kv_hdr_load(H, ie);
         const uint64_t key = ld_u64(rep + dint_view_off(V, k_idx(cur), F::MSG) + F::KEY);
         uint32_t la0 = 0, lb0 = 0;
         if (WL == DINT_WL_SMALLBANK) {
@@ -1712,12 +1716,12 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           }
         } else if (found0 != exists1 || redo) {  // apply the net INSERT / DELETE (or DELETE + INSERT) to the chain once
           kv_hdr H;
-          kv_hdr_copy(H, *(const kv_hdr *)ie);
+          kv_hdr_load(H, ie);
           const uint64_t key = ld_u64(rep + dint_view_off(V, k_idx(cur), F::MSG) + F::KEY);
           if (redo) {
             kv_apply<kv_dev_mem>(tb, bucket, H, KV_ACT_DEL, key, nullptr, 0, blockIdx.x);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            kv_hdr_copy(H, *(const kv_hdr *)ie);
+            kv_hdr_load(H, ie);
           }
           const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, H, exists1 ? KV_ACT_INS : KV_ACT_DEL, key, (uint8_t *)fin_val,
                                                 fin_ver, blockIdx.x);
@@ -1893,10 +1897,12 @@ struct kvr_lds {
 };
 static_assert(sizeof(kvr_lds) <= sizeof(kvb_lds), "the coarse-bin split shares the big path's LDS buffer");
 
-template <int WL>
+template <int WL, uint32_t NT>
 __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev *kv, uint32_t coarse, uint8_t *lds_raw,
                                             uint2 *Sbig /* [KVR_F] {offset in ovf, records} of the bin's big subs */,
-                                            uint32_t cnt, const uint4 &r0, const uint4 &r1, uint64_t *tr) {
+                                            uint32_t cnt, const uint4 &r0, const uint4 &r1, uint64_t *tr,
+                                            const uint32_t (&pf_head)[2], const uint8_t *const (&pf_entries)[2],
+                                            const uint64_t (&pf_stride)[2], const uint64_t (&pf_nlocal)[2], uint32_t &pf_sink) {
   kvr_lds &L = *(kvr_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const kv_cut &cut = A.cut;
@@ -1911,9 +1917,9 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   if (t == 0) A.bin_cnt[coarse] = 0;  // leave the counters clean for the next pass (every thread read it before the kernel's barrier)
   auto for_each_record = [&](auto &&f) {
     if (t < n_in) f(r0);
-    if (t + KVB_T < n_in) f(r1);
-    for (uint32_t k = t + 2 * KVB_T; k < n_in; k += KVB_T) f(recs[k]);
-    for (uint32_t k = t; k < novl; k += KVB_T)
+    if (t + NT < n_in) f(r1);
+    for (uint32_t k = t + 2 * NT; k < n_in; k += NT) f(recs[k]);
+    for (uint32_t k = t; k < novl; k += NT)
       if (A.ovl[2 * (size_t)k + 1].x == coarse) f(A.ovl[2 * (size_t)k]);
   };
   // ---- phase A: records per sub
@@ -1929,13 +1935,15 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     if (stot > A.lcap) {  // more small-sub records than the LDS split holds (wave-uniform): every sub takes the big path
       big = h > 0; sc = 0; soff = 0; stot = 0;
     }
-    uint32_t btot, bc = big ? h : 0u, boff = wave_excl_scan_u32(bc, &btot);
-    uint32_t gbase = 0;
-    if (lane == 0 && btot) {
-      gbase = atomicAdd(&A.big[0], btot);
-      atomicAdd(&A.stats->big_bin_requests, (unsigned long long)btot);
+    uint32_t btot = 0, boff = 0, gbase = 0;
+    if (__ballot(big)) {  // (wave-uniform; the usual bin has no big sub)
+      boff = wave_excl_scan_u32(big ? h : 0u, &btot);
+      if (lane == 0) {
+        gbase = atomicAdd(&A.big[0], btot);
+        atomicAdd(&A.stats->big_bin_requests, (unsigned long long)btot);
+      }
+      gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
     }
-    gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
     L.off[lane] = soff;
     if (lane == 63) L.off[KVR_F] = stot;
     L.bigoff[lane] = big ? gbase + boff : KV_NONE;
@@ -1976,13 +1984,17 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     if (bo == KV_NONE) L.rec[L.off[sub] + pos] = r;
     else A.ovf[bo + pos] = ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull));  // the big path's record: group / (64 C) | idx | payload
   });
+  // second stage of the prefetch: the headers are here by now; chains that start in an overflow entry
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+    if (pf_head[j] >= 2u) pf_sink += KV_LD(uint32_t, pf_entries[j] + (pf_nlocal[j] + (uint64_t)(pf_head[j] - 2u)) * pf_stride[j] + KV_VALID_OFF);
   __syncthreads();
   if (tr && t == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
   // ---- the chunks, one wave each: sort by (group / C, key hash, idx) in registers -- groups commute, so any order that
   // keeps each group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in
   // adjacent lanes.  The sort word carries the lane the record came from; key and payload follow by one shuffle each.
   const uint32_t nch = L.nch;
-  for (uint32_t ch = wave; ch < nch; ch += KVB_W) {
+  for (uint32_t ch = wave; ch < nch; ch += NT / 64) {
     const uint2 ab = L.chs[ch];
     const uint32_t c = ab.y - ab.x;
     const bool has = lane < c;
@@ -2009,13 +2021,14 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
 // path is a function of its own (noinline), so that its register pressure -- it spills at 128 VGPRs -- stays out of the
 // chunk path's allocation (the chunk path alone needs 89 VGPRs and no scratch).
 // LATE = the big subs are not resolved here but listed for k_kv_big, a launch of its own behind this one: the chunk
-// workgroups then carry 17 KB of LDS and ~90 VGPRs, and a hot key no longer waits for its coarse bin's chunks
-// (DINT_KV_LATE_BIG=1; measured against the in-place form in NOTEBOOK.md).
-template <int WL, bool LATE>
-__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
+// workgroups then carry 19 KB of LDS and ~100 VGPRs without scratch, and the big path is compiled on its own.
+// NT = threads per workgroup (512: two workgroups = 16 waves per CU; 256 with bins half the size: five = 20 waves).
+template <int WL, bool LATE, uint32_t NT>
+__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 5) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[LATE ? sizeof(kvr_lds) : sizeof(kvb_lds)];
   __shared__ uint2 Sbig[KVR_F];
+  static_assert(LATE || NT == KVB_T, "the big path is written for KVB_T threads");
   uint32_t e = 0, b = blockIdx.x;
   while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
   const kv_pass_args &A = M.e[e];
@@ -2023,13 +2036,13 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
   uint64_t *tr = A.trace ? A.trace + 32 * (size_t)blockIdx.x : nullptr;
   if (tr && t == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
   // everything the workgroup needs from memory before its LDS phases, in flight together: the table descriptors, the
-  // bin's record count and -- without waiting for the count: the bin's region always exists -- its first 2 x 512 records
+  // bin's record count and -- without waiting for the count: the bin's region always exists -- its first 2 x NT records
   // (the counter is loaded LAST: the compiler makes it a scalar at once -- a wait -- and the loads issued before it ride
   // on the same round trip)
-  static_assert(sizeof(kv_dev) / 4 <= KVB_T, "one word of the table descriptors per thread");
+  static_assert(sizeof(kv_dev) / 4 <= NT, "one word of the table descriptors per thread");
   const uint4 *__restrict__ recs = A.kbins + (size_t)b * A.cap;
   const uint4 r0 = t < A.cap ? recs[t] : make_uint4(0, 0, 0, 0);
-  const uint4 r1 = t + KVB_T < A.cap ? recs[t + KVB_T] : make_uint4(0, 0, 0, 0);
+  const uint4 r1 = t + NT < A.cap ? recs[t + NT] : make_uint4(0, 0, 0, 0);
   const uint32_t kvw = t < sizeof(kv_dev) / 4 ? ((const uint32_t *)A.kv)[t] : 0u;
   const uint32_t cnt = A.bin_cnt[b];
   if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = kvw;
@@ -2040,16 +2053,36 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
   }
   if (b == 0) {  // what the next pass will find: its counters zero, the log tail current
     if (t < 4) A.big_next[t] = 0;
-    for (uint32_t k = t; k < 1024; k += KVB_T) A.blk_pub_next[k] = 0;
+    for (uint32_t k = t; k < 1024; k += NT) A.blk_pub_next[k] = 0;
     if (t == 0 && A.has_log) A.log.tail[0] = A.log.tail[1];
   }
   __syncthreads();
   if (tr && t == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
-  kv_coarse_bin<WL>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr);
-  // ---- the bin's big subs (hot keys), one after the other, by the whole workgroup
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  __syncthreads();
-  if (tr && t == 0) tr[11] = __builtin_amdgcn_s_memrealtime();
+  // PREFETCH: the bucket header of every record this thread holds, now -- the chunk that will need it is ~6 us of LDS
+  // work away (count, lay out, place, sort), and a header that has reached this XCD's L2 by then costs a fraction of
+  // the HBM round trip.  The 16 bytes with the chain head come back into registers: a bucket whose chain starts in an
+  // overflow entry gets that entry's header prefetched too, after the split (kv_locate would find it another round trip
+  // later).  smallbank: also the sector with the values and the counters.
+  uint32_t pf_head[2] = {KV_NULL, KV_NULL}, pf_sink = 0;
+  const uint8_t *pf_entries[2] = {nullptr, nullptr};
+  uint64_t pf_stride[2] = {0, 0}, pf_nlocal[2] = {0, 0};
+  if (!(A.force_flags & 4)) {
+    const uint32_t n_in = min(cnt, A.cap);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint4 &r = j ? r1 : r0;
+      if (t + (uint32_t)j * NT < n_in) {
+        const uint32_t gk = kv_cut_gk((uint32_t)(u4_meta(r) >> (16 + A.cut.ibits)), b, A.cut);
+        const kv_tab &tb = Skv.tab[kv_table_of(&Skv, gk)];
+        const uint8_t *ie = tb.entries + (uint64_t)(gk - Skv.gk_base[kv_table_of(&Skv, gk)]) * tb.stride;
+        pf_head[j] = KV_LD(uint32_t, ie + KV_VALID_OFF + 8);  // kv_hdr::head
+        pf_entries[j] = tb.entries; pf_stride[j] = tb.stride; pf_nlocal[j] = tb.n_local;
+        if (WL == DINT_WL_SMALLBANK) pf_sink += KV_LD(uint32_t, ie + KV_SB_LOCK_OFF);
+      }
+    }
+  }
+  kv_coarse_bin<WL, NT>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr, pf_head, pf_entries, pf_stride, pf_nlocal, pf_sink);
+  asm volatile("" ::"v"(pf_sink));  // (the prefetched words are "used")
   if (LATE) {
     if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big
       const uint2 bs = Sbig[t];
@@ -2059,7 +2092,12 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
       if (bs.y) A.bigq[base + (uint32_t)__popcll(m & lanemask_lt())] = make_uint4(b + A.cut.P * t, bs.x, bs.y, 0u);
     }
+    if (tr && t == 0) { tr[11] = tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
   } else {
+    // ---- the bin's big subs (hot keys), one after the other, by the whole workgroup
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    if (tr && t == 0) tr[11] = __builtin_amdgcn_s_memrealtime();
     kv_cut cut2 = A.cut;
     cut2.P = A.cut.P * KVR_F;
     for (uint32_t sub = 0; sub < KVR_F; sub++) {
@@ -2067,13 +2105,14 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
       if (bs.y == 0) continue;
       kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, b + A.cut.P * sub, A.ovf + bs.x, bs.y, A.stats, A.force_flags, A.V, Lraw);
     }
+    if (tr && t == 0) { tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
   }
-  if (tr && t == 0) { tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
 }
 
 // LATE: the pass's big subs, KVB_GRID workgroups per engine taking them in turn (longest job of a pass: a hot key)
+// (one workgroup per CU: a pass has a few hundred big subs at most, and at 256 VGPRs the stretch machinery does not spill)
 template <int WL>
-__global__ void __launch_bounds__(KVB_T, 4) k_kv_big(kv_multi_args M) {
+__global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __shared__ kv_dev Skv;
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
   const kv_pass_args &A = M.e[blockIdx.y];
@@ -2103,12 +2142,15 @@ static uint32_t kv_env(const char *name, uint32_t dflt) {
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
+// threads per resolve workgroup (DINT_KV_WG = 256 | 512) and the records per coarse bin that go with them
+static inline uint32_t kv_resolve_threads() { return kv_env("DINT_KV_LATE_BIG", 1) && kv_env("DINT_KV_WG", 512) == 256 ? 256u : 512u; }
+
 static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log,
                          const dint_scratch &s, int load_mode, const dint_view &view, uint32_t rpt) {
   // tuning / test knobs, read at every launch (a getenv is noise next to a launch): DINT_KV_COARSE_LOAD = records per
   // coarse bin, DINT_KV_CAP = records a coarse bin holds in place (small values exercise the overflow list),
   // DINT_KV_LCAP = records of a bin's small subs resolved from LDS (small values exercise the all-big fallback)
-  const uint32_t load = std::max(64u, kv_env("DINT_KV_COARSE_LOAD", 512));
+  const uint32_t load = std::min(8192u, std::max(64u, kv_env("DINT_KV_COARSE_LOAD", kv_resolve_threads())));
   const uint32_t C = kv_pick_coarse(n, load);
   const uint32_t mean = (n + C - 1) / C;
   uint32_t cap = 2 * mean + 64;
@@ -2122,7 +2164,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.stats = s.stats;
   A.bigq = s.bigq;
   A.load_mode = load_mode;
-  A.force_flags = kv.force_rounds | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
+  A.force_flags = kv.force_rounds | (kv_env("DINT_KV_NO_PREFETCH", 0) ? 4 : 0) | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
   A.has_log = kv.workload != DINT_WL_STORE;
   A.trace = kv.d_trace;
   A.V = view;
@@ -2130,6 +2172,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
 
 template <int WL>
 static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_t st, hipEvent_t *ev) {
+  const uint32_t nt = kv_resolve_threads();
   uint32_t max_tiles = 0, sum_c = 0;
   for (uint32_t k = 0; k < n_eng; k++) {
     max_tiles = std::max(max_tiles, M.e[k].n_tiles);
@@ -2140,11 +2183,12 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   else if (rpt == 2) hipLaunchKernelGGL((k_kv_part<WL, 2>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   else hipLaunchKernelGGL((k_kv_part<WL, 4>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   if (ev) hipEventRecord(ev[1], st);
-  if (kv_env("DINT_KV_LATE_BIG", 0)) {
-    hipLaunchKernelGGL((k_kv_resolve<WL, true>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+  if (kv_env("DINT_KV_LATE_BIG", 1)) {
+    if (nt == 256) hipLaunchKernelGGL((k_kv_resolve<WL, true, 256>), dim3(sum_c), dim3(256), 0, st, M, n_eng);
+    else hipLaunchKernelGGL((k_kv_resolve<WL, true, 512>), dim3(sum_c), dim3(512), 0, st, M, n_eng);
     hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
   } else {
-    hipLaunchKernelGGL((k_kv_resolve<WL, false>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+    hipLaunchKernelGGL((k_kv_resolve<WL, false, 512>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
   }
   if (ev) hipEventRecord(ev[2], st);
 }
