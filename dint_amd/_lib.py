@@ -22,7 +22,7 @@ SYMBOLS = [
     "dint_home_shard", "dint_bench_rand64", "dint_timing_enable", "dint_timing_read", "dint_kv_trace_read",
     "dint_submit_async", "dint_wait", "dint_alloc_pinned", "dint_free_pinned", "dint_engine_stream", "dint_max_pass",
     "dint_stream_wait", "dint_stream_signal", "dint_route_pack", "dint_route_unpack", "dint_submit_segments",
-    "dint_log_drain", "dint_refuse", "dint_route_pack_multi", "dint_route_unpack_multi", "dint_bench_access",
+    "dint_log_drain", "dint_refuse", "dint_route_pack_multi", "dint_route_unpack_multi", "dint_bench_access", "dint_selftest",
     "dint_submit_segments_multi",
 ]
 
@@ -103,6 +103,7 @@ def load() -> C.CDLL:
         "dint_restore": (C.c_int, [vp]),
         "dint_home_shard": (C.c_int, [vp, vp, u32, vp, vp]),
         "dint_bench_rand64": (C.c_int, [i32, u64, u64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "dint_selftest": (C.c_int, [i32]),
         "dint_bench_access": (C.c_int, [i32, u64, u64, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "dint_kv_trace_read": (C.c_int, [vp, vp, u64]),
         "dint_timing_enable": (C.c_int, [vp, C.c_int]),

@@ -122,8 +122,55 @@ __device__ static inline uint32_t wave_excl_scan_u32(uint32_t v, uint32_t *total
   return x - v;
 }
 
+// ---- the value of lane (lane ^ J), J a power of two --------------------------------------------------------------
+// r01-r03 exchanged with __shfl_xor, which is a ds_bpermute whatever J is: an LDS-crossbar round trip of ~50 ns, and
+// the 21 steps of the sort network below depend on one another -- 2 us per sorted chunk, a tenth of a resolve
+// workgroup's life.  18 of the 21 steps stay inside a row of 16 lanes, where a DPP move does the exchange at VALU speed
+// (J = 1, 2: quad_perm; 8: row_ror:8; 4: row_shl:4 into banks 0 / 2 and row_shr:4 into banks 1 / 3); the three steps
+// across rows use gfx950's v_permlane16_swap / v_permlane32_swap.  DINT_SORT_BPERMUTE builds the portable form
+// (dint_selftest compares the two on the device).
+template <uint32_t J>
+__device__ __forceinline__ static uint32_t lane_xor_u32(uint32_t v) {
+#ifdef DINT_SORT_BPERMUTE
+  return (uint32_t)__shfl_xor((int)v, (int)J, 64);
+#else
+  if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) {
+    const int a = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);                              // row_shl:4 -> lanes with bit 2 clear
+    return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xF, 0xA, false);                                // row_shr:4 -> lanes with bit 2 set
+  } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false); // row_ror:8
+  else if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // {odd rows <- even rows, even rows <- odd rows}
+    return (threadIdx.x & 16) ? r[0] : r[1];
+  } else {
+    static_assert(J == 32, "lane_xor_u32: J = 1, 2, 4, 8, 16, 32");
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {upper half <- lower half, lower half <- upper half}
+    return (threadIdx.x & 32) ? r[0] : r[1];
+  }
+#endif
+}
+template <uint32_t K, uint32_t J>
+__device__ __forceinline__ static void wave_sort_step(uint64_t &w, uint32_t lane) {
+  const uint32_t lo = lane_xor_u32<J>((uint32_t)w), hi = lane_xor_u32<J>((uint32_t)(w >> 32));
+  const uint64_t o = ((uint64_t)hi << 32) | lo;
+  const bool up = (lane & K) == 0;           // this K-block sorts ascending
+  const bool low = (lane & J) == 0;          // lower lane of the pair
+  w = (low == up) ? (w < o ? w : o) : (w < o ? o : w);
+  if constexpr (J > 1) wave_sort_step<K, J / 2>(w, lane);
+}
+template <uint32_t K>
+__device__ __forceinline__ static void wave_sort_stage(uint64_t &w, uint32_t lane) {
+  wave_sort_step<K, K / 2>(w, lane);
+  if constexpr (K < 64) wave_sort_stage<K * 2>(w, lane);
+}
 // 64 keys, one per lane, ascending (bitonic network over the wave, 21 compare-exchange steps)
 __device__ static inline uint64_t wave_sort_u64(uint64_t w) {
+  wave_sort_stage<2>(w, lane_id());
+  return w;
+}
+// ... the portable form (ds_bpermute exchanges), kept as the reference of dint_selftest
+__device__ static inline uint64_t wave_sort_u64_ref(uint64_t w) {
   const uint32_t lane = lane_id();
 #pragma unroll
   for (uint32_t k = 2; k <= 64; k <<= 1) {
@@ -131,8 +178,8 @@ __device__ static inline uint64_t wave_sort_u64(uint64_t w) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       const uint32_t lo = __shfl_xor((uint32_t)w, (int)j, 64), hi = __shfl_xor((uint32_t)(w >> 32), (int)j, 64);
       const uint64_t o = ((uint64_t)hi << 32) | lo;
-      const bool up = (lane & k) == 0;           // this k-block sorts ascending
-      const bool low = (lane & j) == 0;          // lower lane of the pair
+      const bool up = (lane & k) == 0;
+      const bool low = (lane & j) == 0;
       w = (low == up) ? (w < o ? w : o) : (w < o ? o : w);
     }
   }

@@ -129,3 +129,31 @@ extern "C" int dint_bench_rand64(int32_t device, uint64_t bytes, uint64_t n_acce
                                  double *out_aps, double *out_s) {
   return dint_bench_access(device, bytes, n_access, write_back ? BM_RMW : BM_GATHER, 64, 8, out_aps, out_s);
 }
+
+// ---- dint_selftest: device primitives against their portable forms -------------------------------------------------
+// bit 0 of the result: the wave sort network built from DPP / permlane exchanges (dint_device.h) orders 64-bit keys
+// differently from the ds_bpermute network; bit 1: a single lane exchange differs.  0 = all equal.
+__global__ void __launch_bounds__(256) k_selftest(uint64_t seed, uint32_t *bad) {
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t w = dint_hash_key(seed + tid);
+  if ((tid >> 6) & 1) w &= 0xFFFFull;                 // waves full of duplicates
+  if (((tid >> 6) & 3) == 2 && (tid & 7) == 0) w = ~0ull;  // ... and of "empty lane" keys
+  if (wave_sort_u64(w) != wave_sort_u64_ref(w)) atomicOr(bad, 1u);
+  const uint32_t v = (uint32_t)w;
+  if (lane_xor_u32<1>(v) != (uint32_t)__shfl_xor((int)v, 1, 64) || lane_xor_u32<2>(v) != (uint32_t)__shfl_xor((int)v, 2, 64) ||
+      lane_xor_u32<4>(v) != (uint32_t)__shfl_xor((int)v, 4, 64) || lane_xor_u32<8>(v) != (uint32_t)__shfl_xor((int)v, 8, 64) ||
+      lane_xor_u32<16>(v) != (uint32_t)__shfl_xor((int)v, 16, 64) || lane_xor_u32<32>(v) != (uint32_t)__shfl_xor((int)v, 32, 64))
+    atomicOr(bad, 2u);
+}
+extern "C" int dint_selftest(int32_t device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DINT_ENODEV;
+  if (device >= 0 && hipSetDevice(device) != hipSuccess) return DINT_ENODEV;
+  uint32_t *d_bad = nullptr, h_bad = 0;
+  if (hipMalloc((void **)&d_bad, 4) != hipSuccess) return DINT_ENOMEM;
+  hipMemset(d_bad, 0, 4);
+  for (uint64_t s = 1; s <= 4; s++) hipLaunchKernelGGL(k_selftest, dim3(512), dim3(256), 0, 0, s * 0x123456789ULL, d_bad);
+  const hipError_t e = hipMemcpy(&h_bad, d_bad, 4, hipMemcpyDeviceToHost);
+  hipFree(d_bad);
+  return e == hipSuccess ? (int)h_bad : DINT_EHIP;
+}

@@ -189,7 +189,7 @@ struct kv_pass_args {
   uint32_t *blk_pub, *blk_pub_next;
   uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
   uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
-  uint4 *bigq;           // LATE: the pass's big subs {bin, offset in ovf, records, -} for k_kv_big; big[3] = how many
+  uint4 *bigq;           // the pass's big subs {bin, offset in ovf, records, -} for k_kv_big; big[3] = how many
   dint_dev_stats *stats;
   int load_mode, force_flags;
   uint32_t has_log;
@@ -559,6 +559,18 @@ __device__ static inline bool kv_lock_op(uint32_t type) {  // touches the bucket
   if (WL == DINT_WL_TATP) return type == 1 || type == 2 || type == 12 || type == 18 || type == 22;
   return type <= 3;
 }
+// requests whose reply may carry a row (val + ver) / whose message carries a value that is stored or read by others
+template <int WL>
+__device__ static inline bool kv_may_get(uint32_t type) {
+  if (WL == DINT_WL_SMALLBANK) return type <= 1 || type == 17;  // granted ACQUIREs, WARMUP_READ
+  return type == 0;                                               // READ
+}
+template <int WL>
+__device__ static inline bool kv_carries_val(uint32_t type) {
+  if (WL == DINT_WL_STORE) return type == 1 || type == 2;                                 // SET, INSERT
+  if (WL == DINT_WL_TATP) return type == 12 || type == 13 || type == 18 || type == 19;    // COMMIT_*, INSERT_*
+  return type == 4 || type == 5;                                                          // COMMIT_*
+}
 // One step of a key's row machine {exists, version, last writer} (store / tatp), in request order.  Used for key
 // segments that contain an INSERT or DELETE; plain segments use the ballot closed form.  Returns the reply code of
 // a row op (0 for lock-only requests, whose code comes from the lock machine).
@@ -650,6 +662,18 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
       la0 = KV_LD(uint32_t, ie + KV_SB_LOCK_OFF + 8 * q); lb0 = KV_LD(uint32_t, ie + KV_SB_LOCK_OFF + 8 * q + 4);
     }
   }
+  // The value words of a request live in registers from here on (r04b: two dependent round trips and a fence less
+  // per chunk).  A request that CARRIES a value (SET / COMMIT / INSERT) loads it now, together with the headers: reads
+  // behind it in the same pass take it by shuffle, and the segment's last writer stores it into the row itself.  A
+  // request that may READ a row loads it speculatively as soon as the header is there (below).
+  constexpr uint32_t NW = F::VS / 4;
+  uint32_t w[NW];
+#pragma unroll
+  for (uint32_t k = 0; k < NW; k++) w[k] = 0;
+  if (valid && kv_carries_val<WL>(type)) {
+#pragma unroll
+    for (uint32_t k = 0; k < NW; k++) w[k] = ld_u32(msg + F::VAL + 4 * k);
+  }
   const uint64_t hkey = shfl_u64(key, hl);
   const uint64_t m_bad = __ballot(valid && !(key == hkey && (kv_simple_op<WL>(type) || kv_struct_op<WL>(type))));
   const uint64_t m_lockop = __ballot(valid && kv_lock_op<WL>(type));
@@ -671,6 +695,22 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   bool simple = valid && (m_bad & run) == 0 && !lock_clash && __popcll(m_stseg & run) <= 1 && !force_rounds;
   const bool structural = (m_struct & seg) != 0;  // my key segment inserts / deletes: row machine by walk
   kv_stamp(tr, 4);
+  // the row, speculatively: where the key sits in the bucket's INLINE entry (the usual case) the readers of the segment
+  // load it now, while the leaders walk the chains of the buckets that overflowed (kv_locate: another round trip) --
+  // whether the row really is the first match in chain order is known when they are back
+  int spec = -1;
+  if (head) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (spec < 0 && kv_valid(H, (uint32_t)i) && H.key[i] == key) spec = i;
+  }
+  spec = __shfl(spec, hl, 64);
+  const bool spec_ld = valid && spec >= 0 && kv_may_get<WL>(type);
+  if (spec_ld) {
+    const uint8_t *sr = ie + KV_VAL_OFF + (uint32_t)spec * F::VS;
+#pragma unroll
+    for (uint32_t k = 0; k < NW; k++) w[k] = KV_LD(uint32_t, sr + 4 * k);
+  }
   bool leader = head && simple;
   uint32_t dupf = 0;  // a second row with my key exists (duplicate inserts of an earlier pass): no closed form for deletes
   if (leader) {
@@ -820,27 +860,49 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
   }
 
   // ---- 3. replies of the simple segments, all lanes in parallel
-  const uint32_t src_idx = __shfl(idx, my_src >= 0 ? my_src : lane, 64);
   const uint32_t fin_idx = __shfl(idx, fin_src >= 0 ? fin_src : lane, 64);
+  const int seg_fin_src = __shfl(fin_src, hl, 64);          // my segment's last writer ...
+  const uint32_t seg_fin_ver = __shfl(fin_ver, hl, 64);     // ... and the version it leaves
+  const bool getting = simple && my_get != 0;
+  if (__ballot(getting && my_src >= 0)) {  // (wave-uniform) the value of the last writer below me: out of that lane's registers
+#pragma unroll
+    for (uint32_t k = 0; k < NW; k++) {
+      const uint32_t o = (uint32_t)__shfl((int)w[k], my_src >= 0 ? my_src : lane, 64);
+      if (getting && my_src >= 0) w[k] = o;
+    }
+  }
   uint8_t *row = nullptr;
   if (simple) {
     row = kv_entry_ptr(t, bucket, link) + KV_VAL_OFF + slot * F::VS;  // meaningful when the row was found
     if (my_get) {
-      const uint8_t *from = my_src >= 0 ? rep + dint_view_off(V, src_idx, F::MSG) + F::VAL : row;
-      kv_copy_words(msg + F::VAL, from, F::VS);
+      // the row itself: the speculative load was the right one unless the key's first match lies in an overflow entry
+      if (my_src < 0 && !(spec_ld && link == KV_INLINE && slot == (uint32_t)spec)) {
+#pragma unroll
+        for (uint32_t k = 0; k < NW; k++) w[k] = KV_LD(uint32_t, row + 4 * k);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < NW; k++) st_u32(msg + F::VAL + 4 * k, w[k]);
       st_u32(msg + F::VER, my_ver);
     }
     msg[F::TYPE] = (uint8_t)my_code;
+    // ---- 4a. the row of a plain segment: value and version of its last writer, stored by that writer (every load of
+    // the chunk has been consumed by now, so nothing has to be waited for between the replies and these stores)
+    if (!structural && (found & 1u) && seg_fin_src == lane) {
+#pragma unroll
+      for (uint32_t k = 0; k < NW; k++) KV_ST(uint32_t, row + 4 * k, w[k]);
+      KV_ST(uint32_t, &kv_entry_hdr(t, bucket, link)->ver[slot], seg_fin_ver);
+    }
   }
   kv_stamp(tr, 6);
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the table reads above precede the write-backs below
-  // ---- 4. final state of each simple segment, written once by its head.  The lock word belongs to the one
-  // segment of the bucket that carries lock ops (fin_la / fin_lb differ from la0 / lb0 only there).
+  // ---- 4b. the rest of each simple segment's final state, written once by its head.  The lock word belongs to the one
+  // segment of the bucket that carries lock ops (fin_la / fin_lb differ from la0 / lb0 only there).  Segments that
+  // insert / delete apply their net effect to the chain here, behind a fence (rare: the branch is wave-uniform).
+  if (__ballot(leader && structural)) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the table reads above precede the chain operations below
   if (leader) {
     const uint32_t found0 = found & 1u, exists1 = structural ? (found >> 1) & 1u : found0;
     const bool redo = structural && found0 && exists1 && ((found >> 2) & 1u);  // deleted and inserted again
     if (found0 && exists1 && !redo) {  // the row stays where it is: value / version of the last writer
-      if (fin_src >= 0) {
+      if (structural && fin_src >= 0) {
         kv_copy_words(row, rep + dint_view_off(V, fin_idx, F::MSG) + F::VAL, F::VS);
         KV_ST(uint32_t, &kv_entry_hdr(t, bucket, link)->ver[slot], fin_ver);
       }
@@ -1895,14 +1957,11 @@ struct kvr_lds {
   uint2 chs[KVR_F];            // chunks: [first, last) record in rec[]
   uint32_t nch;
 };
-static_assert(sizeof(kvr_lds) <= sizeof(kvb_lds), "the coarse-bin split shares the big path's LDS buffer");
 
 template <int WL, uint32_t NT>
 __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev *kv, uint32_t coarse, uint8_t *lds_raw,
                                             uint2 *Sbig /* [KVR_F] {offset in ovf, records} of the bin's big subs */,
-                                            uint32_t cnt, const uint4 &r0, const uint4 &r1, uint64_t *tr,
-                                            const uint32_t (&pf_head)[2], const uint8_t *const (&pf_entries)[2],
-                                            const uint64_t (&pf_stride)[2], const uint64_t (&pf_nlocal)[2], uint32_t &pf_sink) {
+                                            uint32_t cnt, const uint4 &r0, const uint4 &r1, uint64_t *tr) {
   kvr_lds &L = *(kvr_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const kv_cut &cut = A.cut;
@@ -1984,10 +2043,6 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     if (bo == KV_NONE) L.rec[L.off[sub] + pos] = r;
     else A.ovf[bo + pos] = ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull));  // the big path's record: group / (64 C) | idx | payload
   });
-  // second stage of the prefetch: the headers are here by now; chains that start in an overflow entry
-#pragma unroll
-  for (int j = 0; j < 2; j++)
-    if (pf_head[j] >= 2u) pf_sink += KV_LD(uint32_t, pf_entries[j] + (pf_nlocal[j] + (uint64_t)(pf_head[j] - 2u)) * pf_stride[j] + KV_VALID_OFF);
   __syncthreads();
   if (tr && t == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
   // ---- the chunks, one wave each: sort by (group / C, key hash, idx) in registers -- groups commute, so any order that
@@ -2020,15 +2075,16 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
 // The launch carries the big path's footprint (~73 KB of LDS, 128 VGPRs): two workgroups = 16 waves per CU.  The big
 // path is a function of its own (noinline), so that its register pressure -- it spills at 128 VGPRs -- stays out of the
 // chunk path's allocation (the chunk path alone needs 89 VGPRs and no scratch).
-// LATE = the big subs are not resolved here but listed for k_kv_big, a launch of its own behind this one: the chunk
-// workgroups then carry 19 KB of LDS and ~100 VGPRs without scratch, and the big path is compiled on its own.
-// NT = threads per workgroup (512: two workgroups = 16 waves per CU; 256 with bins half the size: five = 20 waves).
-template <int WL, bool LATE, uint32_t NT>
-__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 5) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
+// The big subs (hot keys) are not resolved here but listed for k_kv_big, a launch of its own behind this one: the chunk
+// workgroups then carry 19 KB of LDS and ~115 VGPRs without scratch, and the big path -- compiled on its own, at 256
+// VGPRs -- does not spill either (r03's one kernel for both: 62 spilled VGPRs).  Measured against
+// resolving them in place, behind the bin's chunks (r04a): NOTEBOOK.md section 1.
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
+  constexpr uint32_t NT = KVB_T;
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
-  __shared__ __attribute__((aligned(16))) uint8_t Lraw[LATE ? sizeof(kvr_lds) : sizeof(kvb_lds)];
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvr_lds)];
   __shared__ uint2 Sbig[KVR_F];
-  static_assert(LATE || NT == KVB_T, "the big path is written for KVB_T threads");
   uint32_t e = 0, b = blockIdx.x;
   while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
   const kv_pass_args &A = M.e[e];
@@ -2058,58 +2114,22 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 5) k_kv_resolve(kv_multi_a
   }
   __syncthreads();
   if (tr && t == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
-  // PREFETCH: the bucket header of every record this thread holds, now -- the chunk that will need it is ~6 us of LDS
-  // work away (count, lay out, place, sort), and a header that has reached this XCD's L2 by then costs a fraction of
-  // the HBM round trip.  The 16 bytes with the chain head come back into registers: a bucket whose chain starts in an
-  // overflow entry gets that entry's header prefetched too, after the split (kv_locate would find it another round trip
-  // later).  smallbank: also the sector with the values and the counters.
-  uint32_t pf_head[2] = {KV_NULL, KV_NULL}, pf_sink = 0;
-  const uint8_t *pf_entries[2] = {nullptr, nullptr};
-  uint64_t pf_stride[2] = {0, 0}, pf_nlocal[2] = {0, 0};
-  if (!(A.force_flags & 4)) {
-    const uint32_t n_in = min(cnt, A.cap);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const uint4 &r = j ? r1 : r0;
-      if (t + (uint32_t)j * NT < n_in) {
-        const uint32_t gk = kv_cut_gk((uint32_t)(u4_meta(r) >> (16 + A.cut.ibits)), b, A.cut);
-        const kv_tab &tb = Skv.tab[kv_table_of(&Skv, gk)];
-        const uint8_t *ie = tb.entries + (uint64_t)(gk - Skv.gk_base[kv_table_of(&Skv, gk)]) * tb.stride;
-        pf_head[j] = KV_LD(uint32_t, ie + KV_VALID_OFF + 8);  // kv_hdr::head
-        pf_entries[j] = tb.entries; pf_stride[j] = tb.stride; pf_nlocal[j] = tb.n_local;
-        if (WL == DINT_WL_SMALLBANK) pf_sink += KV_LD(uint32_t, ie + KV_SB_LOCK_OFF);
-      }
-    }
+  // (r04b also prefetched every record's bucket header here, ~6 us of LDS work ahead of the chunk that needs it: the
+  // header round trip of the chunk fell from 2.4 to 1.6 us and the bench lost 3 % -- the prefetch is one more transaction
+  // per request on a memory system that is the bottleneck once three engines run side by side.  Removed.)
+  kv_coarse_bin<WL, NT>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr);
+  if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big
+    const uint2 bs = Sbig[t];
+    const uint64_t m = __ballot(bs.y != 0);
+    uint32_t base = 0;
+    if (t == 0 && m) base = atomicAdd(&A.big[3], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (bs.y) A.bigq[base + (uint32_t)__popcll(m & lanemask_lt())] = make_uint4(b + A.cut.P * t, bs.x, bs.y, 0u);
   }
-  kv_coarse_bin<WL, NT>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr, pf_head, pf_entries, pf_stride, pf_nlocal, pf_sink);
-  asm volatile("" ::"v"(pf_sink));  // (the prefetched words are "used")
-  if (LATE) {
-    if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big
-      const uint2 bs = Sbig[t];
-      const uint64_t m = __ballot(bs.y != 0);
-      uint32_t base = 0;
-      if (t == 0 && m) base = atomicAdd(&A.big[3], (uint32_t)__popcll(m));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (bs.y) A.bigq[base + (uint32_t)__popcll(m & lanemask_lt())] = make_uint4(b + A.cut.P * t, bs.x, bs.y, 0u);
-    }
-    if (tr && t == 0) { tr[11] = tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
-  } else {
-    // ---- the bin's big subs (hot keys), one after the other, by the whole workgroup
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __syncthreads();
-    if (tr && t == 0) tr[11] = __builtin_amdgcn_s_memrealtime();
-    kv_cut cut2 = A.cut;
-    cut2.P = A.cut.P * KVR_F;
-    for (uint32_t sub = 0; sub < KVR_F; sub++) {
-      const uint2 bs = Sbig[sub];  // workgroup-uniform
-      if (bs.y == 0) continue;
-      kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, b + A.cut.P * sub, A.ovf + bs.x, bs.y, A.stats, A.force_flags, A.V, Lraw);
-    }
-    if (tr && t == 0) { tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
-  }
+  if (tr && t == 0) { tr[11] = tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
 }
 
-// LATE: the pass's big subs, KVB_GRID workgroups per engine taking them in turn (longest job of a pass: a hot key)
+// the pass's big subs, KVB_GRID workgroups per engine taking them in turn (the longest job of a pass: a hot key)
 // (one workgroup per CU: a pass has a few hundred big subs at most, and at 256 VGPRs the stretch machinery does not spill)
 template <int WL>
 __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
@@ -2142,15 +2162,12 @@ static uint32_t kv_env(const char *name, uint32_t dflt) {
   return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
-// threads per resolve workgroup (DINT_KV_WG = 256 | 512) and the records per coarse bin that go with them
-static inline uint32_t kv_resolve_threads() { return kv_env("DINT_KV_LATE_BIG", 1) && kv_env("DINT_KV_WG", 512) == 256 ? 256u : 512u; }
-
 static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log,
                          const dint_scratch &s, int load_mode, const dint_view &view, uint32_t rpt) {
   // tuning / test knobs, read at every launch (a getenv is noise next to a launch): DINT_KV_COARSE_LOAD = records per
   // coarse bin, DINT_KV_CAP = records a coarse bin holds in place (small values exercise the overflow list),
   // DINT_KV_LCAP = records of a bin's small subs resolved from LDS (small values exercise the all-big fallback)
-  const uint32_t load = std::min(8192u, std::max(64u, kv_env("DINT_KV_COARSE_LOAD", kv_resolve_threads())));
+  const uint32_t load = std::min(8192u, std::max(64u, kv_env("DINT_KV_COARSE_LOAD", KVB_T)));
   const uint32_t C = kv_pick_coarse(n, load);
   const uint32_t mean = (n + C - 1) / C;
   uint32_t cap = 2 * mean + 64;
@@ -2164,7 +2181,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.stats = s.stats;
   A.bigq = s.bigq;
   A.load_mode = load_mode;
-  A.force_flags = kv.force_rounds | (kv_env("DINT_KV_NO_PREFETCH", 0) ? 4 : 0) | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
+  A.force_flags = kv.force_rounds | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
   A.has_log = kv.workload != DINT_WL_STORE;
   A.trace = kv.d_trace;
   A.V = view;
@@ -2172,7 +2189,6 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
 
 template <int WL>
 static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_t st, hipEvent_t *ev) {
-  const uint32_t nt = kv_resolve_threads();
   uint32_t max_tiles = 0, sum_c = 0;
   for (uint32_t k = 0; k < n_eng; k++) {
     max_tiles = std::max(max_tiles, M.e[k].n_tiles);
@@ -2183,13 +2199,8 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   else if (rpt == 2) hipLaunchKernelGGL((k_kv_part<WL, 2>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   else hipLaunchKernelGGL((k_kv_part<WL, 4>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   if (ev) hipEventRecord(ev[1], st);
-  if (kv_env("DINT_KV_LATE_BIG", 1)) {
-    if (nt == 256) hipLaunchKernelGGL((k_kv_resolve<WL, true, 256>), dim3(sum_c), dim3(256), 0, st, M, n_eng);
-    else hipLaunchKernelGGL((k_kv_resolve<WL, true, 512>), dim3(sum_c), dim3(512), 0, st, M, n_eng);
-    hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
-  } else {
-    hipLaunchKernelGGL((k_kv_resolve<WL, false, 512>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
-  }
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+  hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
   if (ev) hipEventRecord(ev[2], st);
 }
 

@@ -299,6 +299,11 @@ int dint_bench_rand64(int32_t device, uint64_t bytes, uint64_t n_access, int wri
  * vectors (*out_aps = vectors per second).  Indices come from the engines' own hash + magic-multiply modulo. */
 int dint_bench_access(int32_t device, uint64_t bytes, uint64_t n_access, uint32_t mode, uint32_t width,
                       uint32_t blocks_per_cu, double *out_aps, double *out_s);
+
+/* Device primitives against their portable forms, on `device` (-1 = current): 0 = equal; bit 0 = the wave sort network
+ * built from DPP / permlane exchanges differs from the ds_bpermute network, bit 1 = a single lane exchange differs;
+ * negative = error.  (tests/test_gpu_locks.py; a diagnostic, not a hot-path call.) */
+int dint_selftest(int32_t device);
 /* Per-kernel launch time of the most recent dint_submit_device micro-batch sequence, measured
  * with HIP events on the stream the kernels ran on.  Call dint_timing_enable(e,1) first. */
 int dint_timing_enable(dint_engine_t *e, int on);

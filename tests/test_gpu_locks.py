@@ -218,3 +218,11 @@ def test_2pl_client_trace_vs_oracle():
     assert eng2.submit(req).tobytes() == rep.tobytes()
     ex, sh = eng2.read_locks()
     assert (ex == o.num_ex).all() and (sh == o.num_sh).all()
+
+
+def test_device_primitives_match_their_portable_forms():
+    """dint_selftest: the wave sort network built from DPP / v_permlane*_swap exchanges (dint_device.h) against the
+    ds_bpermute network, and every single lane exchange against __shfl_xor."""
+    from dint_amd import _lib
+
+    assert _lib.load().dint_selftest(-1) == 0
