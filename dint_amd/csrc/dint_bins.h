@@ -153,22 +153,43 @@ __device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, 
   return cnt;
 }
 
+// the value of lane (lane ^ j), j a wave-uniform power of two below 64 (DPP / permlane exchanges, dint_device.h)
+__device__ __forceinline__ static uint32_t lane_xor_rt(uint32_t v, uint32_t j) {
+  switch (j) {
+    case 1: return lane_xor_u32<1>(v);
+    case 2: return lane_xor_u32<2>(v);
+    case 4: return lane_xor_u32<4>(v);
+    case 8: return lane_xor_u32<8>(v);
+    case 16: return lane_xor_u32<16>(v);
+    default: return lane_xor_u32<32>(v);
+  }
+}
+__device__ __forceinline__ static uint64_t lane_xor_rt(uint64_t v, uint32_t j) {
+  return ((uint64_t)lane_xor_rt((uint32_t)(v >> 32), j) << 32) | lane_xor_rt((uint32_t)v, j);
+}
 // Bitonic sort of KVB_T * R keys held R per thread (thread t owns positions R*t .. R*t + R - 1): the steps with a
-// partner inside the thread run in registers, those inside the wave by shuffle, and only the few with a partner in
-// another wave go through LDS (the key array itself is the staging area -- every key is in a register by then --
-// laid out [r][t] so the exchange is conflict-free).
-template <int R>
-__device__ __attribute__((noinline)) static void kvb_sort_blocked(uint64_t *Sk) {
-  uint64_t *X = Sk;
+// partner inside the thread run in registers, those inside the wave by lane exchange, and only the few with a
+// partner in another wave go through LDS (the key array itself is the staging area -- every key is in a register by then --
+// laid out [r][t] so the exchange is conflict-free).  KVB_SORT_INLINE (k_kv.hip's big-sub kernel): inlined -- as a function
+// of its own it takes the LDS array as a generic pointer (flat instructions); the lock kernels, at their register limit,
+// keep the call.
+#ifdef KVB_SORT_INLINE
+#define KVB_SORT_ATTR __forceinline__
+#else
+#define KVB_SORT_ATTR __attribute__((noinline))
+#endif
+template <int R, class K>
+__device__ KVB_SORT_ATTR static void kvb_sort_blocked_t(K *Sk, uint32_t N) {  // N: power of two, 64 R <= N <= KVB_T R; positions >= N hold the maximum
+  K *X = Sk;
   const uint32_t t = threadIdx.x;
-  uint64_t v[R];
+  K v[R];
 #pragma unroll
   for (int r = 0; r < R; r++) v[r] = Sk[R * t + r];
-  auto cmpx = [](uint64_t &a, uint64_t &b, bool up) {  // up: a <= b afterwards
-    const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+  auto cmpx = [](K &a, K &b, bool up) {  // up: a <= b afterwards
+    const K lo = a < b ? a : b, hi = a < b ? b : a;
     a = up ? lo : hi; b = up ? hi : lo;
   };
-  for (uint32_t k = 2; k <= KVB_T * R; k <<= 1) {
+  for (uint32_t k = 2; k <= N; k <<= 1) {
     for (uint32_t j = k >> 1; j >= (uint32_t)R; j >>= 1) {  // partner in thread t ^ (j / R), same register
       const uint32_t tj = j / R;
       const bool low = (t & tj) == 0;
@@ -180,13 +201,7 @@ __device__ __attribute__((noinline)) static void kvb_sort_blocked(uint64_t *Sk) 
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        uint64_t o;
-        if (tj < 64) {
-          const uint32_t lo = __shfl_xor((uint32_t)v[r], (int)tj, 64), hi = __shfl_xor((uint32_t)(v[r] >> 32), (int)tj, 64);
-          o = ((uint64_t)hi << 32) | lo;
-        } else {
-          o = X[r * KVB_T + (t ^ tj)];
-        }
+        const K o = tj < 64 ? lane_xor_rt(v[r], tj) : X[r * KVB_T + (t ^ tj)];
         const bool up = ((R * t + r) & k) == 0;
         v[r] = (low == up) ? (v[r] < o ? v[r] : o) : (v[r] < o ? o : v[r]);
       }
@@ -205,6 +220,10 @@ __device__ __attribute__((noinline)) static void kvb_sort_blocked(uint64_t *Sk) 
   for (int r = 0; r < R; r++) Sk[R * t + r] = v[r];
   __syncthreads();
 }
+template <int R>
+__device__ __forceinline__ static void kvb_sort_blocked(uint64_t *Sk, uint32_t N = KVB_T * R) { kvb_sort_blocked_t<R, uint64_t>(Sk, N); }
+template <int R>
+__device__ __forceinline__ static void kvb_sort_blocked_u32(uint32_t *Sk, uint32_t N = KVB_T * R) { kvb_sort_blocked_t<R, uint32_t>(Sk, N); }
 
 // sort Sk[0, m) ascending (m <= KVB_NMAX; the slots up to the next power of two are filled with ~0 and sort last).
 // <= 512 keys: one per thread, in-wave steps by shuffle, the wide ones through LDS; more: 2 / 4 / 8 keys per thread.
@@ -215,25 +234,7 @@ __device__ static inline void kvb_sort_stretch(uint64_t *Sk, uint32_t m) {
   for (uint32_t k = m + t; k < max(N, KVB_T); k += KVB_T) Sk[k] = ~0ull;  // empty slots sort last
   __syncthreads();
   if (N <= KVB_T) {
-    uint64_t v = Sk[t];
-    for (uint32_t k = 2; k <= N; k <<= 1) {
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        uint64_t o;
-        if (j < 64) {
-          const uint32_t lo = __shfl_xor((uint32_t)v, (int)j, 64), hi = __shfl_xor((uint32_t)(v >> 32), (int)j, 64);
-          o = ((uint64_t)hi << 32) | lo;
-        } else {
-          Sk[t] = v;
-          __syncthreads();
-          o = Sk[t ^ j];
-          __syncthreads();
-        }
-        const bool up = (t & k) == 0, low = (t & j) == 0;
-        v = (low == up) ? (v < o ? v : o) : (v < o ? o : v);
-      }
-    }
-    Sk[t] = v;
-    __syncthreads();
+    kvb_sort_blocked<1>(Sk, N);  // (slots N .. KVB_T - 1 hold ~0: they stay last)
   } else if (N == 2 * KVB_T) {
     kvb_sort_blocked<2>(Sk);
   } else if (N == 4 * KVB_T) {

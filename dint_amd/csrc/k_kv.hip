@@ -37,6 +37,7 @@
 
 #include "../../include/dint_abi.h"
 #include "dint_kv.h"
+#define KVB_SORT_INLINE
 #include "dint_bins.h"
 
 // ---- wire formats ------------------------------------------------------------------------------------
@@ -1110,7 +1111,8 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     uint32_t m = Swn;
     __syncthreads();  // Swn is reset at the top of the next stretch
     if (m == 0) continue;  // workgroup-uniform
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    bool tiny = m <= 64;  // what one wave resolves in registers (kv_chunk): below, also for what a dominant key leaves behind
+    if (!tiny) {
 
     // ---- the stretch's DOMINANT KEY (a hot row: most of a big bin is one key) is answered without sorting the stretch.
     // Only the requests that change what a later request sees -- writers and lock ops, a few hundred of the thousands
@@ -1158,7 +1160,8 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
         if (t < 16) Hs[t] = 0;  // [0] bad, [1] ordering ops
         __syncthreads();
         uint32_t bad = 0, nord = 0;
-        for (uint32_t p = t; p < m; p += KVB_T) {
+#pragma unroll 8
+        for (uint32_t p = t; p < m; p += KVB_T) {  // (unrolled: the key gathers of a thread's <= 8 records in flight together)
           const uint64_t cur = Sk[p];
           const uint32_t type = k_type(cur);
           if ((cur >> sh_k) == hpf) {
@@ -1193,21 +1196,17 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           }
           // (sorting M with kvb_sort_stretch -- registers / shuffles instead of an LDS step per barrier -- was measured:
           // the list sort itself is faster, the bench 1.3 % slower on the same box; the kernel is code-size sensitive)
-          uint32_t N2 = 64;
-          while (N2 < nM) N2 <<= 1;
+          // (r02-r03 sorted M with one LDS compare-exchange step per barrier -- 55 barriers for 1,024 words, 13 of the hot
+          // key's 54 us -- because the register / shuffle sort made the shared resolve kernel 1.3 % slower by its code size;
+          // the big path is a kernel of its own now)
           __syncthreads();
-          for (uint32_t k = nM + t; k < N2; k += KVB_T) Mk[k] = 0xFFFFFFFFu;
+          for (uint32_t k = nM + t; k < KVB_MMAX; k += KVB_T) Mk[k] = 0xFFFFFFFFu;  // empty slots sort last
           __syncthreads();
-          for (uint32_t k = 2; k <= N2 && nM > 1; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-              for (uint32_t a = t; a < N2 / 2; a += KVB_T) {  // compare-exchange pair number a
-                const uint32_t i0 = ((a & ~(j - 1)) << 1) | (a & (j - 1)), i1 = i0 | j;
-                const uint32_t x0 = Mk[i0], x1 = Mk[i1];
-                const bool up = (i0 & k) == 0;
-                if ((x0 > x1) == up) { Mk[i0] = x1; Mk[i1] = x0; }
-              }
-              __syncthreads();
-            }
+          {
+            uint32_t N2 = 64;
+            while (N2 < nM) N2 <<= 1;
+            if (nM > KVB_T) kvb_sort_blocked_u32<2>(Mk, max(N2, 128u));
+            else if (nM > 1) kvb_sort_blocked_u32<1>(Mk, N2);
           }
           // prefix tables over M (nM + 1 rows: what precedes op j; row nM = the totals): thread t owns ops 2t, 2t + 1
           {
@@ -1253,10 +1252,21 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           const uint64_t hbucket = (uint64_t)(hgk - kv->gk_base[htable]);
           const kv_tab htb = kv->tab[htable];
           uint8_t *hrow = kv_entry_ptr(htb, hbucket, link) + KV_VAL_OFF + slot * F::VS;  // meaningful when found
-          // 5. every request of the key, 512 at a time: no table dependency between them
-          for (uint32_t p = t; p < m; p += KVB_T) {
-            const uint64_t cur = Sk[p];
-            if ((cur >> sh_k) != hpf) continue;
+          // 5. every request of the key: no table dependency between them.  A thread's <= 8 requests are answered in two
+          // sweeps -- outcomes and value loads of all of them, then the stores -- so the loads ride on one round trip
+          // (as a loop of load / store pairs every request waited for its own: 10 of the hot key's 54 us)
+          constexpr uint32_t NP = 4, NWD = F::VS / 4;  // (four at a time: eight value buffers do not fit the register file)
+          static_assert(KVB_NMAX / KVB_T == 2 * NP, "two sweeps of NP requests per thread");
+          for (uint32_t j0 = 0; j0 < 2 * NP && j0 * KVB_T < m; j0 += NP) {
+          uint32_t a_code[NP], a_ver[NP], a_idx[NP], a_w[NP][NWD];
+          bool a_on[NP], a_get[NP];
+#pragma unroll
+          for (uint32_t j = 0; j < NP; j++) {
+            const uint32_t p = t + (j0 + j) * KVB_T;
+            const uint64_t cur = p < m ? Sk[p] : 0;
+            a_on[j] = p < m && (cur >> sh_k) == hpf;
+            a_get[j] = false; a_code[j] = 0; a_ver[j] = 0; a_idx[j] = 0;
+            if (!a_on[j]) continue;
             const uint32_t type = k_type(cur), idx = k_idx(cur);
             uint32_t lo = 0, hi = nM;  // ops of M with a smaller request index
             const uint32_t key32 = idx << 12;
@@ -1264,7 +1274,6 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
               const uint32_t mid = (lo + hi) >> 1;
               if (Mk[mid] < key32) lo = mid + 1; else hi = mid;
             }
-            const uint32_t my_ver = ver0 + (found ? Mwc[lo] : 0u);
             const int lw = found ? (int)Mlw[lo] : -1, ll = (int)Mll[lo];
             uint32_t code, get = 0;
             if (WL == DINT_WL_STORE) {
@@ -1280,13 +1289,24 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
                 default: code = 16; break;  // 13 kCommitBck
               }
             }
-            uint8_t *msg = rep + dint_view_off(V, idx, F::MSG);
+            a_code[j] = code; a_ver[j] = ver0 + (found ? Mwc[lo] : 0u); a_idx[j] = idx; a_get[j] = get != 0;
             if (get) {
               const uint8_t *from = lw >= 0 ? rep + dint_view_off(V, k_idx(Sk[Mk[lw] & 4095u]), F::MSG) + F::VAL : hrow;
-              kv_copy_words(msg + F::VAL, from, F::VS);
-              st_u32(msg + F::VER, my_ver);
+#pragma unroll
+              for (uint32_t k = 0; k < NWD; k++) a_w[j][k] = ld_u32(from + 4 * k);
             }
-            msg[F::TYPE] = (uint8_t)code;
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < NP; j++) {
+            if (!a_on[j]) continue;
+            uint8_t *msg = rep + dint_view_off(V, a_idx[j], F::MSG);
+            if (a_get[j]) {
+#pragma unroll
+              for (uint32_t k = 0; k < NWD; k++) st_u32(msg + F::VAL + 4 * k, a_w[j][k]);
+              st_u32(msg + F::VER, a_ver[j]);
+            }
+            msg[F::TYPE] = (uint8_t)a_code[j];
+          }
           }
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __syncthreads();  // every read of the row precedes its write-back
@@ -1322,10 +1342,27 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           m = Hs[2];
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __syncthreads();
-          if (tr && t == 0) tr[13] += 1u << 16;  // stretches that took the dominant-key path
           if (m == 0) continue;  // workgroup-uniform
+          tiny = m <= 64;
         }
       }
+    }
+    }
+    if (tiny) {
+      // <= 64 records left (a big sub is its hot key and a handful of neighbours; the all-big fallback of a crowded coarse bin
+      // hands over subs of any size): one wave, as a chunk of the resolve kernel -- not ~25 barriers of stretch machinery
+      if (wave == 0) {
+        const bool valid = lane < m;
+        uint64_t wv = valid ? Sk[lane] : ~0ull;  // group / P | key-hash bits | idx | type, quadrant: the chunk's sort word
+        wv = wave_sort_u64(wv);
+        const uint32_t idx = valid ? k_idx(wv) : 0, gk = kv_cut_gk((uint32_t)(wv >> sh_g), bin, cut);
+        const uint64_t key = valid ? ld_u64(rep + dint_view_off(V, idx, F::MSG) + F::KEY) : 0;
+        kv_chunk<WL>(rep, valid, idx, gk, (uint32_t)(wv >> sh_k) & 511u, k_type(wv), valid ? kv_table_of(kv, gk) : 0, k_q(wv), key, kv,
+                     stats, force_rounds, true, V);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __syncthreads();
+      continue;
     }
     kvb_sort_stretch(Sk, m);
     const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
@@ -2143,9 +2180,12 @@ __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __syncthreads();
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
+  uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 8 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;  // {in, out, records, sub} of the first sub it takes
   for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
     const uint4 d = A.bigq[i];
+    if (tr && t == 0 && i == blockIdx.x) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = d.z; tr[3] = d.x; }
     kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + d.y, d.z, A.stats, A.force_flags, A.V, Lraw);
+    if (tr && t == 0 && i == blockIdx.x) tr[1] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -45,7 +45,14 @@ n = float(np.mean([rp.counts[e][0] for e in range(E)]))
 out = {"clients": C, "theta": theta, "requests_per_pass": round(n), "wall_us_per_pass": round(wall, 1),
        "Mreq_s_alone": round(n / wall, 1), "kernels_us": {k: round(v["avg_us"], 2) for k, v in eng.timing_read().items()}}
 if os.environ.get("DINT_KV_TRACE"):
-    tr = eng.kv_trace().astype(np.int64)
+    tr, big = eng.kv_trace(workgroups=True)
+    tr, big = tr.astype(np.int64), big.astype(np.int64)
+    big = big[big[:, 0] > 0]
+    if len(big):
+        du = (big[:, 1] - big[:, 0]) / 100.0
+        top = np.argsort(-du)[:8]
+        out["big_subs"] = {"n": int(len(big)), "us_mean": round(float(du.mean()), 1), "us_max": round(float(du.max()), 1),
+                           "longest": [[int(big[i, 2]), round(float(du[i]), 1)] for i in top]}
     tr = tr[tr[:, 0] > 0]
     t0 = tr[:, 0].min()
     names = ["in", "loaded", "counted", "laid_out", "placed", "sorted", "masks", "located", "replied", "written", "rounds", "chunks_done", "bigs_done"]
