@@ -153,17 +153,11 @@ __device__ static inline uint32_t kvb_range_popc(const uint64_t *M, uint32_t a, 
   return cnt;
 }
 
-// the value of lane (lane ^ j), j a wave-uniform power of two below 64 (DPP / permlane exchanges, dint_device.h)
-__device__ __forceinline__ static uint32_t lane_xor_rt(uint32_t v, uint32_t j) {
-  switch (j) {
-    case 1: return lane_xor_u32<1>(v);
-    case 2: return lane_xor_u32<2>(v);
-    case 4: return lane_xor_u32<4>(v);
-    case 8: return lane_xor_u32<8>(v);
-    case 16: return lane_xor_u32<16>(v);
-    default: return lane_xor_u32<32>(v);
-  }
-}
+// the value of lane (lane ^ j), j a wave-uniform run-time value below 64: ds_bpermute.  (r04 tried the DPP / permlane
+// exchanges of dint_device.h here behind a switch on j: the stretch sort of 4,096 keys went from 40 to ~120 us and
+// lock_fasst lost 9 % -- six-way branches inside the unrolled register loops.  The compile-time network of one wave,
+// wave_sort_u64, keeps them.)
+__device__ __forceinline__ static uint32_t lane_xor_rt(uint32_t v, uint32_t j) { return (uint32_t)__shfl_xor((int)v, (int)j, 64); }
 __device__ __forceinline__ static uint64_t lane_xor_rt(uint64_t v, uint32_t j) {
   return ((uint64_t)lane_xor_rt((uint32_t)(v >> 32), j) << 32) | lane_xor_rt((uint32_t)v, j);
 }

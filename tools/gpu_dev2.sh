@@ -5,12 +5,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 mkdir -p gpurun_out/dev
 P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d.get("kernels_us"), d.get("value_repeats"), d.get("latency_us"), "pf", d.get("parity_failures"))'
-ST=$(python -c "from dint_amd import _lib; print(_lib.load().dint_selftest(-1))" 2>&1 | tail -1)
-echo "== selftest: $ST"
-echo "== kv + lock tests"; timeout 900 python -m pytest tests/test_gpu_kv.py tests/test_gpu_locks.py tests/test_gpu_async.py tests/test_ebpf_golden.py tests/test_ebpf_surface.py tests/test_long_traces.py tests/test_fasst_24m.py -m gpu -x -q --timeout 300 2>&1 | tail -4
+echo "== hot-key tests first (a hang must show early)"; timeout 200 python -m pytest tests/test_gpu_kv.py -m gpu -x -q --timeout 60 -k "million or hot or partition" 2>&1 | tail -4
+echo "== kv + lock tests"; timeout 900 python -m pytest tests/test_gpu_kv.py tests/test_gpu_locks.py tests/test_gpu_async.py tests/test_ebpf_golden.py tests/test_ebpf_surface.py tests/test_long_traces.py tests/test_gpu_gdriver.py tests/test_gpu_route.py -m gpu -x -q --timeout 300 2>&1 | tail -4
 for th in 0.8; do
-  echo "== trace theta $th"; DINT_KV_TRACE=1 timeout 300 python tools/exp_pass.py 524288 $th 2>&1 | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print(d['kernels_us'], d.get('big_subs'), d['wgs_with_big_subs'])"
   echo "== plain theta $th"; timeout 300 python tools/exp_pass.py 524288 $th 2>&1 | tail -1
 done
 ARGS="--no-cpu-baseline --no-rand64 --no-host-path --no-closed-loop --no-other-workloads --no-shim"
@@ -22,5 +19,3 @@ for w in store smallbank fasst; do
   echo "== $w base"; (cd gpurun_tmp/base && timeout 300 python bench.py --workload $w $ARGS 2>/dev/null | python -c "$P")
   echo "== $w work"; timeout 300 python bench.py --workload $w $ARGS 2>gpurun_out/dev/e3 | python -c "$P" || tail -5 gpurun_out/dev/e3
 done
-echo "== smallbank trace"; DINT_KV_TRACE=1 timeout 300 python tools/exp_pass.py 524288 0.99 smallbank 2>&1 | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print(d['kernels_us'], d.get('big_subs'), d['wgs_with_big_subs'], d['requests_per_pass'])"
