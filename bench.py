@@ -989,15 +989,17 @@ def bench_txn(args, world, rank, dev, transport, kind):
         avg = {k: float(np.mean([t[k]["avg_us"] for t in tims])) for k in names}
         extra["kernels_us"] = {k: round(v, 3) for k, v in avg.items()}
         # A pass = k_kv_part (every request is classified, hashed and put into its coarse bin; log requests are finished
-        # there) and k_kv_resolve (every coarse bin of the pass, one launch: the table requests).  The dominant kernel is
-        # the one the most time goes to; its algorithmic bytes are those of the requests it serves.
+        # there), k_kv_resolve (every coarse bin of the pass: the table requests but those of the hot keys) and k_kv_big
+        # (the hot keys).  The dominant kernel is the one the most time goes to; its algorithmic bytes are those of the
+        # requests it serves.
         hist, launches = type_histogram(rp, 0, n_t, 1)
         tab_b = sum(b * int(hist[c]) for c, b in alg_tab.items() if c not in log_types)
         log_b = sum(b * int(hist[c]) for c, b in alg_tab.items() if c in log_types)
         n_tab = sum(int(hist[c]) for c in alg_tab if c not in log_types)
         f_big = big_req / max(1, n_tab)
-        cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b),
-                "k_kv_part": (avg.get("k_kv_part", 0.0), tab_b + log_b)}
+        cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b * (1.0 - f_big)),
+                "k_kv_part": (avg.get("k_kv_part", 0.0), tab_b + log_b),
+                "k_kv_big": (avg.get("k_kv_big", 0.0), tab_b * f_big)}
         dom = max(cand, key=lambda k: cand[k][0])
         dom_us, alg = cand[dom][0], cand[dom][1] / max(1, launches)
         achieved = alg / (dom_us * 1e-6) / 1e9

@@ -193,7 +193,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
   if (int rc = order_stream(e, st)) return rc;
   static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_count", "k_log_write"};
-  static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve"};
+  static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve", "k_kv_big"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
@@ -214,7 +214,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 2, kv_names), view);
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 3, kv_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;

@@ -30,7 +30,6 @@
 // partial-sector scatter per request in the count kernel, a key gather per request and half-empty waves in the resolve
 // kernel.  NOTEBOOK.md section 1.)
 #include <algorithm>
-#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -187,15 +186,11 @@ struct kv_pass_args {
   uint32_t lcap;         // records of a coarse bin's small subs that are resolved from LDS (<= KVR_LCAP)
   uint32_t *bin_cnt;     // [C] records per coarse bin (the resolve workgroups leave them zero)
   uint4 *kbins;          // [C][cap] records
-  // control words of the pass (two sets, used alternately; the resolve kernel zeroes the next pass's): [0] records handed to the
-  // big-sub path (bump pointer into ovf), [1] overflow-list entries, [2] tiles handed out, [5] coarse bins whose split is
-  // done, [6] hot subs listed for the workers, [7] hot subs taken by a worker
-  uint32_t *big, *big_next;
+  uint32_t *big, *big_next;  // {[0] records handed to the big-sub path (bump pointer into ovf), [1] overflow-list entries, [2] tiles handed out}
   uint32_t *blk_pub, *blk_pub_next;
   uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
   uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
-  uint4 *bigq;           // the pass's HOT subs {bin, offset in ovf, records, pass tag} for the worker workgroups
-  uint32_t pass_tag;     // marks the entries of bigq written in this pass (bit 31 set, never the stale value of an earlier pass)
+  uint4 *bigq;           // the pass's big subs {bin, offset in ovf, records, -} for k_kv_big; big[3] = how many
   dint_dev_stats *stats;
   int load_mode, force_flags;
   uint32_t has_log;
@@ -962,15 +957,6 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 }
 
 
-// kv_chunk as a function of its own, for the big path's tiny stretches: a second inlined copy would share -- and blow --
-// the register budget of the kernel's hot chunk path (the pointers arrive generic here: flat instructions, on a rare path)
-template <int WL>
-__device__ __attribute__((noinline)) static void
-kv_chunk_call(uint8_t *rep, bool valid, uint32_t idx, uint32_t gk, uint32_t kh, uint32_t type, uint32_t table, uint32_t q,
-              uint64_t key, const kv_dev *kv, dint_dev_stats *stats, int force_rounds, const dint_view *V) {
-  kv_chunk<WL>(rep, valid, idx, gk, kh, type, table, q, key, kv, stats, force_rounds, true, *V);
-}
-
 // ---- LDS of the big path: one struct, so that the coarse-bin split (kvr_lds) can share the buffer ---------------------
 struct kvb_lds {
   uint64_t Sk[KVB_NMAX];           // the stretch: group / P | key-hash bits | idx | type, quadrant
@@ -1059,10 +1045,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
   };
   __syncthreads();  // the LDS buffer is free (the chunk path, or the previous big sub, is done with it)
   uint64_t *const tr = nullptr;
-  // (agent-scope loads: a hot sub's records were written by another workgroup of this launch, with agent-scope stores)
-  auto rec_at = [&](uint32_t k) -> uint64_t {
-    return __hip_atomic_load((const unsigned long long *)recs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
+  auto rec_at = [&](uint32_t k) -> uint64_t { return recs[k]; };
 
   uint32_t nwin = 1;
   if (c > KVB_NMAX) {
@@ -1272,9 +1255,9 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           // 5. every request of the key: no table dependency between them.  A thread's <= 8 requests are answered in two
           // sweeps -- outcomes and value loads of all of them, then the stores -- so the loads ride on one round trip
           // (as a loop of load / store pairs every request waited for its own: 10 of the hot key's 54 us)
-          constexpr uint32_t NP = 2, NWD = F::VS / 4;  // (two at a time: the kernel shares the chunk path's 128 registers)
-          static_assert((KVB_NMAX / KVB_T) % NP == 0, "sweeps of NP requests per thread");
-          for (uint32_t j0 = 0; j0 < KVB_NMAX / KVB_T && j0 * KVB_T < m; j0 += NP) {
+          constexpr uint32_t NP = 4, NWD = F::VS / 4;  // (four at a time: eight value buffers do not fit the register file)
+          static_assert(KVB_NMAX / KVB_T == 2 * NP, "two sweeps of NP requests per thread");
+          for (uint32_t j0 = 0; j0 < 2 * NP && j0 * KVB_T < m; j0 += NP) {
           uint32_t a_code[NP], a_ver[NP], a_idx[NP], a_w[NP][NWD];
           bool a_on[NP], a_get[NP];
 #pragma unroll
@@ -1374,8 +1357,8 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
         wv = wave_sort_u64(wv);
         const uint32_t idx = valid ? k_idx(wv) : 0, gk = kv_cut_gk((uint32_t)(wv >> sh_g), bin, cut);
         const uint64_t key = valid ? ld_u64(rep + dint_view_off(V, idx, F::MSG) + F::KEY) : 0;
-        kv_chunk_call<WL>(rep, valid, idx, gk, (uint32_t)(wv >> sh_k) & 511u, k_type(wv), valid ? kv_table_of(kv, gk) : 0, k_q(wv), key,
-                          kv, stats, force_rounds, &V);
+        kv_chunk<WL>(rep, valid, idx, gk, (uint32_t)(wv >> sh_k) & 511u, k_type(wv), valid ? kv_table_of(kv, gk) : 0, k_q(wv), key, kv,
+                     stats, force_rounds, true, V);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __syncthreads();
@@ -2002,8 +1985,6 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
 // path's stretch machinery (kvb_lds); the two never live at the same time and share one buffer.
 #define KVR_LCAP 1024u   // records of a coarse bin's small subs that fit the LDS split (the average bin holds ~512)
 #define KVR_F 64u        // subs per coarse bin = lanes of the wave that lays them out
-#define KVR_HOT 768u     // a sub of at least this many records is resolved by a worker workgroup, beside the chunks
-#define KVR_NBW 16u      // worker workgroups per engine and launch (2 per XCD: they wait, and must never fill an XCD's slots)
 struct kvr_lds {
   uint4 rec[KVR_LCAP];         // records of the small subs, sub after sub
   uint32_t hist[KVR_F];        // records per sub
@@ -2024,6 +2005,7 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   const uint32_t C = cut.P, cap = A.cap, sh = 16 + cut.ibits;
   const uint32_t idx_mask = (uint32_t)((1ull << cut.ibits) - 1ull);
   const uint4 *__restrict__ recs = A.kbins + (size_t)coarse * cap;
+  if (cnt == 0) return;  // workgroup-uniform
   const uint32_t n_in = min(cnt, cap);
   const uint32_t novl = cnt > cap ? A.big[1] : 0u;  // my records beyond `cap` are somewhere in the pass's overflow list
   // (the first two records of every thread -- r0, r1, loaded by the kernel together with the counter -- stay in
@@ -2096,37 +2078,8 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     const uint32_t sub = (uint32_t)(m >> sh) & (KVR_F - 1);
     const uint32_t pos = atomicAdd(&L.cur[sub], 1u), bo = L.bigoff[sub];
     if (bo == KV_NONE) L.rec[L.off[sub] + pos] = r;
-    else  // the big path's record: group / (64 C) | idx | payload; written through (agent scope): a worker workgroup may read it
-      __hip_atomic_store((unsigned long long *)A.ovf + bo + pos, ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull)), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+    else A.ovf[bo + pos] = ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull));  // the big path's record: group / (64 C) | idx | payload
   });
-  __syncthreads();  // (a release at workgroup scope: every wave has waited for its stores)
-  // ---- the bin's HOT subs go to the worker workgroups of this launch, which start on them at once -- while this
-  // workgroup and the other ~C resolve their chunks: the longest job of a pass (a hot row: thousands of requests, tens of
-  // microseconds in ONE workgroup) runs beside the bulk instead of behind it.  An entry is complete when its tag is there.
-  if (wave == 0) {
-    const uint2 bs = Sbig[lane];
-    const bool hot = bs.y >= KVR_HOT;
-    const uint64_t hm = __ballot(hot);
-    if (hm) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&A.big[6], (uint32_t)__popcll(hm));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      uint32_t *q = (uint32_t *)(A.bigq + base + (uint32_t)__popcll(hm & lanemask_lt()));
-      if (hot) {
-        __hip_atomic_store(q + 0, coarse + C * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 1, bs.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(q + 2, bs.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (hot) {
-        __hip_atomic_store(q + 3, A.pass_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Sbig[lane] = make_uint2(0u, 0u);  // not mine any more
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (lane == 0) atomicAdd(&A.big[5], 1u);  // this bin's split is done: it lists nothing more
-  }
   __syncthreads();
   if (tr && t == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
   // ---- the chunks, one wave each: sort by (group / C, key hash, idx) in registers -- groups commute, so any order that
@@ -2159,41 +2112,30 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
 // The launch carries the big path's footprint (~73 KB of LDS, 128 VGPRs): two workgroups = 16 waves per CU.  The big
 // path is a function of its own (noinline), so that its register pressure -- it spills at 128 VGPRs -- stays out of the
 // chunk path's allocation (the chunk path alone needs 89 VGPRs and no scratch).
-// Workgroups [0, sum_c) of the launch take a coarse bin each: the split, the chunks, then the bin's medium subs (65 ..
-// KVR_HOT - 1 records) by the whole workgroup, in place.  The last KVR_NBW workgroups per engine are WORKERS: they take the
-// hot subs as the coarse-bin workgroups list them (a ticket each; an entry is there when it carries this pass's tag) and
-// leave when every bin's split is done and no listed sub is left.  A worker waits -- so there are few of them (two per
-// XCD): whatever else runs on the GPU, they can never hold all of an XCD's workgroup slots while a coarse-bin workgroup
-// of this launch still waits for one, and a coarse-bin workgroup never waits for anything.
-// (r04a resolved every big sub behind its bin's chunks, r04b in a launch of its own behind this one (k_kv_big, at 256 VGPRs
-// without spills): the hot row then ran ALONE for ~55 us per pass -- resolve 49 + big 56 us where r03's single launch took
-// 100.  This form costs the big path its spill-free registers again (one kernel, 128 VGPRs) and wins the overlap back.)
+// The big subs (hot keys) are not resolved here but listed for k_kv_big, a launch of its own behind this one: the chunk
+// workgroups then carry 19 KB of LDS and ~115 VGPRs without scratch, and the big path -- compiled on its own, at 256
+// VGPRs -- does not spill either (r03's one kernel for both: 62 spilled VGPRs).  Measured against
+// (a) resolving them in place, behind the bin's chunks, and (c) handing the hot ones to worker workgroups at the end of
+// THIS launch, which take them as they are listed (agent-scope stores, a ticket per worker: parity-green, no hang) -- the
+// overlap that costs the big path its registers again (one kernel, 128 VGPRs, ~100 spilled): TATP 1,750 against 2,170
+// Mtxn/s, store 2,370 against 3,290.  NOTEBOOK.md section 1.
 template <int WL>
-__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng, uint32_t sum_c) {
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
   constexpr uint32_t NT = KVB_T;
   __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
-  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvr_lds)];
   __shared__ uint2 Sbig[KVR_F];
-  __shared__ uint32_t Sq[4];
-  static_assert(sizeof(kvr_lds) <= sizeof(kvb_lds), "the coarse-bin split shares the big path's LDS buffer");
-  static_assert(sizeof(kv_dev) / 4 <= NT, "one word of the table descriptors per thread");
-  const uint32_t t = threadIdx.x;
-  const bool worker = blockIdx.x >= sum_c;  // (workgroup-uniform)
   uint32_t e = 0, b = blockIdx.x;
-  if (worker) {
-    e = (blockIdx.x - sum_c) / KVR_NBW;
-    b = 0;
-  } else {
-    while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
-  }
+  while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
   const kv_pass_args &A = M.e[e];
-  uint64_t *tr = (A.trace && !worker) ? A.trace + 32 * (size_t)blockIdx.x : nullptr;
-  if (!worker) {
+  const uint32_t t = threadIdx.x;
+  uint64_t *tr = A.trace ? A.trace + 32 * (size_t)blockIdx.x : nullptr;
   if (tr && t == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
   // everything the workgroup needs from memory before its LDS phases, in flight together: the table descriptors, the
   // bin's record count and -- without waiting for the count: the bin's region always exists -- its first 2 x NT records
   // (the counter is loaded LAST: the compiler makes it a scalar at once -- a wait -- and the loads issued before it ride
   // on the same round trip)
+  static_assert(sizeof(kv_dev) / 4 <= NT, "one word of the table descriptors per thread");
   const uint4 *__restrict__ recs = A.kbins + (size_t)b * A.cap;
   const uint4 r0 = t < A.cap ? recs[t] : make_uint4(0, 0, 0, 0);
   const uint4 r1 = t + NT < A.cap ? recs[t + NT] : make_uint4(0, 0, 0, 0);
@@ -2206,7 +2148,7 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
     L.hist[t] = 0; L.cur[t] = 0;
   }
   if (b == 0) {  // what the next pass will find: its counters zero, the log tail current
-    if (t < 16) A.big_next[t] = 0;
+    if (t < 4) A.big_next[t] = 0;
     for (uint32_t k = t; k < 1024; k += NT) A.blk_pub_next[k] = 0;
     if (t == 0 && A.has_log) A.log.tail[0] = A.log.tail[1];
   }
@@ -2215,57 +2157,39 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
   // (r04b also prefetched every record's bucket header here, ~6 us of LDS work ahead of the chunk that needs it: the
   // header round trip of the chunk fell from 2.4 to 1.6 us and the bench lost 3 % -- the prefetch is one more transaction
   // per request on a memory system that is the bottleneck once three engines run side by side.  Removed.)
-  if (cnt == 0) {  // (workgroup-uniform) an empty bin's split is done
-    if (t == 0) atomicAdd(&A.big[5], 1u);
-    return;
-  }
   kv_coarse_bin<WL, NT>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr);
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  } else {
-    if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = ((const uint32_t *)A.kv)[t];
+  if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big
+    const uint2 bs = Sbig[t];
+    const uint64_t m = __ballot(bs.y != 0);
+    uint32_t base = 0;
+    if (t == 0 && m) base = atomicAdd(&A.big[3], (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (bs.y) A.bigq[base + (uint32_t)__popcll(m & lanemask_lt())] = make_uint4(b + A.cut.P * t, bs.x, bs.y, 0u);
   }
+  if (tr && t == 0) { tr[11] = tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
+}
+
+// the pass's big subs, KVB_GRID workgroups per engine taking them in turn (the longest job of a pass: a hot key)
+// (one workgroup per CU: a pass has a few hundred big subs at most, and at 256 VGPRs the stretch machinery does not spill)
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
+  __shared__ kv_dev Skv;
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
+  const kv_pass_args &A = M.e[blockIdx.y];
+  const uint32_t nq = A.big[3];
+  if (blockIdx.x >= nq) return;
+  const uint32_t t = threadIdx.x;
+  if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = ((const uint32_t *)A.kv)[t];
   __syncthreads();
-  if (tr && t == 0) tr[11] = __builtin_amdgcn_s_memrealtime();
-  // ---- big subs, one after the other, by the whole workgroup: a coarse-bin workgroup takes its bin's medium subs (Sbig),
-  // a worker the pass's hot subs as they are listed (a ticket each; an entry is there when it carries this pass's tag) until
-  // every bin's split is done and no listed sub is left
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
-  for (uint32_t sub = 0;;) {
-    uint32_t bin = 0, off = 0, c = 0;
-    if (!worker) {
-      while (sub < KVR_F && Sbig[sub].y == 0) sub++;  // workgroup-uniform
-      if (sub == KVR_F) break;
-      bin = b + A.cut.P * sub; off = Sbig[sub].x; c = Sbig[sub].y;
-      sub++;
-    } else {
-      __syncthreads();  // Sq is free
-      if (t == 0) {
-        const uint32_t i = atomicAdd(&A.big[7], 1u);  // my ticket: the i-th hot sub of the pass, if there will be one
-        const uint32_t *q = (const uint32_t *)(A.bigq + i);
-        uint32_t ok = 0;
-        for (uint32_t spin = 0; spin < (1u << 22); spin++) {  // (bounded, ~2 s: a worker must never be what hangs a GPU)
-          if (__hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.pass_tag) { ok = 1; break; }
-          // every bin has listed what it had (a bin bumps [5] after its listing) and mine is not among it
-          if (__hip_atomic_load(&A.big[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.cut.P) {
-            if (__hip_atomic_load(&A.big[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= i) break;
-          }
-          __builtin_amdgcn_s_sleep(20);
-        }
-        Sq[0] = ok;
-        if (ok) {
-          Sq[1] = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          Sq[2] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          Sq[3] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      __syncthreads();
-      if (!Sq[0]) break;  // workgroup-uniform
-      bin = Sq[1]; off = Sq[2]; c = Sq[3];
-    }
-    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, bin, A.ovf + off, c, A.stats, A.force_flags, A.V, Lraw);
+  uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 8 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;  // {in, out, records, sub} of the first sub it takes
+  for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
+    const uint4 d = A.bigq[i];
+    if (tr && t == 0 && i == blockIdx.x) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = d.z; tr[3] = d.x; }
+    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + d.y, d.z, A.stats, A.force_flags, A.V, Lraw);
+    if (tr && t == 0 && i == blockIdx.x) tr[1] = __builtin_amdgcn_s_memrealtime();
   }
-  if (tr && t == 0) { tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
 }
 
 // ---- launch -------------------------------------------------------------------------------------------
@@ -2299,8 +2223,6 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.bin_cnt = s.bin_cnt; A.kbins = s.kbins; A.big = s.big; A.big_next = s.big_next;
   A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.stats = s.stats;
   A.bigq = s.bigq;
-  static std::atomic<uint32_t> pass_seq{1};
-  A.pass_tag = 0x80000000u | pass_seq.fetch_add(1, std::memory_order_relaxed);
   A.load_mode = load_mode;
   A.force_flags = kv.force_rounds | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
   A.has_log = kv.workload != DINT_WL_STORE;
@@ -2320,8 +2242,10 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   else if (rpt == 2) hipLaunchKernelGGL((k_kv_part<WL, 2>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   else hipLaunchKernelGGL((k_kv_part<WL, 4>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c + KVR_NBW * n_eng), dim3(KVB_T), 0, st, M, n_eng, sum_c);
+  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
   if (ev) hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
+  if (ev) hipEventRecord(ev[3], st);
 }
 
 // requests per thread of k_kv_part: longer tiles = fewer, longer runs per (tile, coarse bin), but a pass must still
