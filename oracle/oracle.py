@@ -311,16 +311,22 @@ def ebpf_available(workload: str) -> bool:
     return os.access(os.path.join(REF_DIR, EBPF_BIN[workload]), os.X_OK)
 
 
-def ebpf_replay(workload: str, msgs: np.ndarray, timeout: float = 3600):
+def ebpf_replay(workload: str, msgs: np.ndarray, timeout: float = 3600, hold: int = 0, hold_every: int = 1):
     """Run the unmodified reference eBPF server of `workload` (XDP program -> user-space fallback -> TC program,
     oracle/ref_harness/ebpf) over `msgs`, one request at a time.  Returns (replies, stats); a request the server
-    never answers comes back unchanged and is counted in stats["unanswered"]."""
+    never answers comes back unchanged and is counted in stats["unanswered"].
+    hold: during every `hold_every`-th request the emulator holds the spin lock of every cache entry (bit 0) / lock unit
+    (bit 1) the XDP program looks up, as a concurrent packet would -- what the program answers then are the back-pressure
+    replies a serial replay never sees (REJECT_READ / REJECT_COMMIT / REJECT_SET / RETRY ...)."""
     exe = os.path.join(REF_DIR, EBPF_BIN[workload])
     msgs = np.ascontiguousarray(msgs)
     with tempfile.TemporaryDirectory(prefix="dint_ebpf_") as td:
         tp, rp = os.path.join(td, "trace.bin"), os.path.join(td, "replies.bin")
         msgs.tofile(tp)
-        res = subprocess.run([exe, tp, rp], capture_output=True, text=True, timeout=timeout)
+        env = dict(os.environ)
+        if hold:
+            env.update(EMU_HOLD=str(hold), EMU_HOLD_EVERY=str(hold_every))
+        res = subprocess.run([exe, tp, rp], capture_output=True, text=True, timeout=timeout, env=env)
         if res.returncode != 0:
             raise RuntimeError(f"{exe} failed rc={res.returncode}: {res.stderr[-2000:]}")
         return np.fromfile(rp, dtype=msgs.dtype), json.loads(res.stdout.strip().splitlines()[-1])

@@ -9,6 +9,11 @@ int emu_tc(void *pkt, uint32_t *len);    /* egress hook; *len may shrink (bpf_sk
 size_t emu_msg_size(void);               /* sizeof(struct message) / sizeof(struct ext_message) of the included source */
 size_t emu_ext_size(void);
 int emu_dump_maps(const char *path);     /* every touched map entry: name-less, in definition order */
+/* hold mode: while g_emu_hold is set, every cache entry (bit 0) / lock unit (bit 1) the XDP program looks up has its spin
+ * lock taken by "another packet"; emu_release() gives them back.  EMU_HOLD=<bits> EMU_HOLD_EVERY=<k> in the environment of
+ * a replay holds during every k-th request (emu_main.c). */
+extern int g_emu_hold;
+void emu_release(void);
 /* emu_user.c: the reference's user-space fallback (its kvs + server_handler thread) */
 void emu_user_start(void);
 /* emu_main.c: the sockets the user thread thinks it has */

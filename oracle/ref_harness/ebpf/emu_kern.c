@@ -1,5 +1,6 @@
 /* emu_kern.c -- compiles ONE unmodified reference *_kern.c (named by -DEMU_KERN_SRC, found through -I$(REF)/<wl>/ebpf)
  * against stub/linux/tools/lib/bpf/bpf_helpers.h and exposes its two programs.  TEST INFRASTRUCTURE ONLY. */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/mman.h>
@@ -13,6 +14,17 @@
 #define EMU_MAX_MAPS 64
 static struct { const void *def; unsigned char *mem; size_t vsz, n; } g_maps[EMU_MAX_MAPS];
 static int g_nmaps;
+
+int g_emu_hold;  /* bit 0: the cache entries' lock words, bit 1: the lock units' */
+static uint64_t *g_held[16];
+static int g_nheld;
+static void emu_hold_word(uint64_t *w) {
+  if (*w == 0 && g_nheld < 16) { *w = 1; g_held[g_nheld++] = w; }
+}
+void emu_release(void) {
+  for (int i = 0; i < g_nheld; i++) *g_held[i] = 0;
+  g_nheld = 0;
+}
 
 void *emu_map_lookup(const void *map, size_t value_size, size_t max_entries, const void *key) {
   int i;
@@ -28,7 +40,18 @@ void *emu_map_lookup(const void *map, size_t value_size, size_t max_entries, con
   }
   uint32_t k = *(const uint32_t *)key;  /* BPF_MAP_TYPE_ARRAY / PERCPU_ARRAY (one CPU): u32 index */
   if (k >= g_maps[i].n) return NULL;
-  return g_maps[i].mem + (size_t)k * g_maps[i].vsz;
+  unsigned char *p = g_maps[i].mem + (size_t)k * g_maps[i].vsz;
+  /* HOLD MODE (emu.h): "another packet holds this entry's spin lock" -- the one concurrency artefact a serial replay
+   * never produces (REJECT_READ / REJECT_COMMIT / REJECT_SET / RETRY ..., e.g. tatp/ebpf/shard_kern.c:173-178).  The
+   * emulator owns the map memory: it sets the lock word of every cache entry / lock unit the program looks up during
+   * this request and clears it again when the program is back; the UNMODIFIED program answers what it answers. */
+#ifndef EMU_NO_TC
+  if ((g_emu_hold & 1) && value_size == sizeof(struct cache_entry)) emu_hold_word((uint64_t *)(p + offsetof(struct cache_entry, lock)));
+#endif
+#ifdef EMU_HAS_LOCK_UNIT
+  if ((g_emu_hold & 2) && value_size == sizeof(struct lock_unit)) emu_hold_word((uint64_t *)(p + offsetof(struct lock_unit, lock)));
+#endif
+  return p;
 }
 
 int emu_xdp(void *pkt, uint32_t *len) {

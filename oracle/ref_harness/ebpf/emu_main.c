@@ -14,7 +14,8 @@
  * Serial, one thread each: the serial semantics of the eBPF flavour, the pin for the codes that only it has
  * (REJECT_LOCK_SAME_KEY, WARMUP_READ, store INSERT).
  *
- * usage: ref_ebpf_<wl> <trace.bin> <replies.bin> [maps_dump.bin]      (records = packed `struct message`)
+ * usage: [EMU_HOLD=<1|2|3> [EMU_HOLD_EVERY=<k>]] ref_ebpf_<wl> <trace.bin> <replies.bin> [maps_dump.bin]
+ *        (records = packed `struct message`; EMU_HOLD: see emu.h -- the back-pressure replies of a contended entry)
  * stdout: one JSON line {"n":..., "tx":..., "pass":..., "seconds":...}
  */
 #define _GNU_SOURCE
@@ -112,13 +113,18 @@ int main(int argc, char **argv) {
   g_user_on = 1;
 #endif
   size_t n_tx = 0, n_pass = 0, n_other = 0;
+  const int hold_bits = getenv("EMU_HOLD") ? atoi(getenv("EMU_HOLD")) : 0;
+  const size_t hold_every = getenv("EMU_HOLD_EVERY") ? (size_t)atol(getenv("EMU_HOLD_EVERY")) : (hold_bits ? 1 : 0);
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (size_t i = 0; i < n; i++) {
     fill_headers(pkt, msg, 0);
     memcpy(pkt + HDR, trace + i * msg, msg);
     uint32_t len = (uint32_t)(HDR + msg);
+    g_emu_hold = (hold_every && i % hold_every == hold_every - 1) ? hold_bits : 0;
     const int rc = emu_xdp(pkt, &len);
+    emu_release();  /* the "other packet" is done before the user side / the TC program see this one */
+    g_emu_hold = 0;
     if (rc == XDP_TX) {
       n_tx++;
       memcpy(replies + i * msg, pkt + HDR, msg);

@@ -208,7 +208,51 @@ def gen_tatp():
                           "delete_acks_val_masked": int(isdel.sum()), "user_path": est["pass"]}))
 
 
-GEN = {"micro": gen_micro, "tatp_lock": gen_tatp_lock, "smallbank": gen_smallbank, "store": gen_store, "tatp": gen_tatp}
+def gen_backpressure():
+    """The replies of a CONTENDED entry: REJECT_READ / REJECT_COMMIT / REJECT_SET / REJECT_INSERT /
+    RETRY come from a failed CAS on the spin lock of a cache entry or lock unit (tatp/ebpf/shard_kern.c:173-178,371-376,
+    store/ebpf/store_kern.c:57-66,140-150,226-236, lock_2pl/ebpf/ls_kern.c:59-64, smallbank/ebpf/shard_kern.c:122-152):
+    another packet holds it.  A serial replay never fails that CAS -- so the emulator, which owns the map memory, holds
+    the lock words itself during the request (EMU_HOLD) and records what the UNMODIFIED programs answer.  Every request
+    type of every server, on existing and on missing keys; dint_refuse / rt_refuse are held to these bytes."""
+    out, meta = {}, {}
+    rng = np.random.default_rng(77)
+
+    def stream(dt, types, keyf, n_each=24, table=None):
+        m = np.zeros(len(types) * n_each, dt)
+        m["type" if "type" in dt.names and dt is not wire.TPL_MSG else "action"] = np.repeat(types, n_each)
+        keyf(m)
+        if "val" in dt.names:
+            m["val"] = rng.integers(0, 256, m["val"].shape, dtype=np.uint8)
+        if "ver" in dt.names:
+            m["ver"] = rng.integers(0, 1 << 31, len(m))
+        if table is not None:
+            m["table"] = rng.integers(0, table, len(m))
+        return m
+
+    T, S, B = wire.Tatp, wire.Store, wire.Sb
+    cases = {
+        "lock_2pl": (stream(wire.TPL_MSG, [0, 1], lambda m: (m.__setitem__("lid", rng.integers(0, 1000, len(m))),
+                                                            m.__setitem__("type", rng.integers(0, 2, len(m))))), 2),
+        "store": (stream(wire.STORE_MSG, [S.READ, S.SET, S.INSERT], lambda m: m.__setitem__("key", rng.integers(0, 1 << 40, len(m)))), 1),
+        "tatp": (stream(wire.TATP_MSG, [T.READ, T.ACQUIRE_LOCK, T.ABORT, T.COMMIT_PRIM, T.COMMIT_BCK, T.COMMIT_LOG, T.INSERT_PRIM,
+                                        T.INSERT_BCK, T.DELETE_PRIM, T.DELETE_BCK, T.DELETE_LOG],
+                        lambda m: m.__setitem__("key", rng.integers(0, 1 << 40, len(m))), table=5), 1),
+        "smallbank": (stream(wire.SB_MSG, [0, 1, 2, 3, 4, 5, 6, 17], lambda m: m.__setitem__("key", rng.integers(0, 5000, len(m))), table=2), 3),
+    }
+    for wl, (req, hold) in cases.items():
+        free, _ = orc.ebpf_replay(wl, req)               # the same requests with nothing held: the serial answers
+        rep, st = orc.ebpf_replay(wl, req, hold=hold)    # ... and with the entries' locks held by "another packet"
+        f = "action" if wl == "lock_2pl" else "type"
+        out[wl + "_req"], out[wl + "_rep"], out[wl + "_free"] = raw(req), raw(rep), raw(free)
+        meta[wl] = {"hold_bits": hold, "n": len(req),
+                    "held_reply_types": {str(k): int(v) for k, v in enumerate(np.bincount(rep[f], minlength=32)) if v},
+                    "free_reply_types": {str(k): int(v) for k, v in enumerate(np.bincount(free[f], minlength=32)) if v}}
+        print(wl, meta[wl])
+    save("ebpf_backpressure", meta=json.dumps(meta), **out)
+
+
+GEN = {"backpressure": gen_backpressure, "micro": gen_micro, "tatp_lock": gen_tatp_lock, "smallbank": gen_smallbank, "store": gen_store, "tatp": gen_tatp}
 
 if __name__ == "__main__":
     orc.build()

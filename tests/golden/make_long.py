@@ -33,16 +33,26 @@ def main():
     out = json.load(open(path)) if os.path.exists(path) else {}
     for wl in sys.argv[1:] or list(lt.TRACES):
         t = time.time()
-        req, rep = lt.TRACES[wl](lt.oracle_servers(wl))  # closed loop / stream against the CPU oracle
-        ref = orc.ref_replay(lt.REF_NAME[wl], req, dump=wl in ("lock_2pl", "log_server"))
+        servers = lt.oracle_servers(wl)
+        req, rep = lt.TRACES[wl](servers)  # closed loop / stream against the CPU oracle
+        ref = orc.ref_replay(lt.REF_NAME[wl], req, dump=True)
         ref_rep = ref[0]
         if wl in ("store", "smallbank", "tatp"):  # rows the trace never wrote still hold the reference's populate-time stack bytes
             a, b = orc.mask_populate_garbage(wl, ref_rep.copy()), orc.mask_populate_garbage(wl, rep.copy())
         else:
             a, b = ref_rep, rep
         assert a.tobytes() == b.tobytes(), f"{wl}: the restatement and the unmodified reference disagree"
+        if wl in lt.VS:  # ... and the state the N requests leave behind (a fresh oracle server: the closed loops ran past N)
+            del servers
+            srv = lt.fresh_oracle(wl)
+            assert srv.submit(req).tobytes() == rep.tobytes()
+            assert lt.digest_of_oracle(wl, srv.o, lt.n_log_appends(wl, rep)) == lt.digest_of_reference_dump(wl, ref[2]), f"{wl}: final states differ"
+            del srv
         out[wl] = {"n_requests": len(req), "req_sha256": sha(req), "rep_sha256": sha(b), "rep_prefix_1m_sha256": sha(b[:1 << 20]),
-                   "dump_sha256": sha(ref[2]) if len(ref) > 2 else None, "reference_ops_per_s": ref[1].get("ops_per_s"),
+                   # the state the reference is left in: the raw dump of the lock table / the ring; for the kv servers its
+                   # canonical form (long_traces.digest_of_reference_dump: rows in bucket / chain order, lock words, log ring)
+                   "dump_sha256": lt.digest_of_reference_dump(wl, ref[2]) if wl in lt.VS else sha(ref[2]),
+                   "reference_ops_per_s": ref[1].get("ops_per_s"),
                    "reply_types": lt.reply_types(wl, b), "params": lt.PARAMS[wl]}
         print(wl, f"{time.time() - t:.0f}s", json.dumps(out[wl])[:300])
         with open(path, "w") as f:

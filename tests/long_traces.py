@@ -27,6 +27,19 @@ class _Oracle:
         return self.o.replay(r) if len(r) else r
 
 
+def fresh_oracle(wl):
+    """one CPU oracle server of the workload, populated like the reference (state digests: the closed-loop generators run
+    their last epoch past request N, so the state of exactly the first N requests comes from a replay on a fresh server)"""
+    from oracle import oracle as orc
+
+    if wl == "store":
+        n = PARAMS[wl]["subscribers"]
+        return _Oracle(orc.StoreOracle(n * 18 // 4, n))
+    if wl == "tatp":
+        return _Oracle(orc.TatpOracle(PARAMS[wl]["subscribers"], log_entries=PARAMS[wl]["log_entries"]))
+    return _Oracle(orc.SmallbankOracle(PARAMS[wl]["accounts"]))
+
+
 def oracle_servers(wl):
     from oracle import oracle as orc
 
@@ -116,3 +129,102 @@ def reply_types(wl, rep):
     f = "action" if wl == "lock_2pl" else "type"
     c = np.bincount(rep[f], minlength=32)
     return {str(k): int(v) for k, v in enumerate(c) if v}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Final-state digests of the kv workloads: one canonical byte stream per workload, built the same way
+# from the unmodified reference's dump file (oracle/ref_harness/*: rows in bucket / chain order, lock words, log ring), from
+# the CPU oracle and from a GPU engine, and hashed.  Canonical = what the reference defines: the value bytes of a row
+# nobody wrote since the populate (ver == 0) are cut down to the bytes the populate assigns (the reference copies
+# partially initialised stack structs there, tatp/udp/tatp.h:291-307), and a DELETE_LOG record's val bytes are dropped
+# (the reference leaves them as they were, tatp/udp/server_shard.cc:196-207).
+import hashlib
+
+VS = {"store": 40, "tatp": 40, "smallbank": 8}
+N_TABLES = {"store": 1, "tatp": 5, "smallbank": 2}
+
+
+def _rows_canon(wl, t, keys, vers, vals):
+    from oracle import oracle as orc
+
+    vals = np.array(vals, "u1", copy=True).reshape(len(keys), VS[wl])
+    cols = orc.STORE_ASSIGNED if wl == "store" else orc.TATP_ASSIGNED.get(t) if wl == "tatp" else None
+    if cols is not None:
+        keep = np.zeros(VS[wl], bool)
+        keep[cols] = True
+        vals[np.ix_(np.asarray(vers) == 0, ~keep)] = 0
+    rec = np.zeros(len(keys), np.dtype([("key", "<u8"), ("ver", "<u4"), ("val", "u1", (VS[wl],))]))
+    rec["key"], rec["ver"], rec["val"] = keys, vers, vals
+    return rec.tobytes()
+
+
+def _log_canon(tail, recs):
+    recs = np.array(recs, "u1", copy=True).reshape(-1, 64)
+    recs[recs[:, 52] == 1, 8:48] = 0  # DELETE_LOG
+    recs[:, 54:] = 0
+    return np.array([tail, len(recs)], "<u4").tobytes() + recs.tobytes()
+
+
+def digest_of_reference_dump(wl, dump: bytes) -> str:
+    """the state dump the replay harness writes after the trace (ref_harness/kvs_dump.h, ref_tatp.cc, ref_smallbank.cc)"""
+    h, off, row = hashlib.sha256(), 0, 12 + VS[wl]
+    for t in range(N_TABLES[wl]):
+        n = int(np.frombuffer(dump, "<u8", 1, off)[0]); off += 8
+        r = np.frombuffer(dump, np.dtype([("key", "<u8"), ("ver", "<u4"), ("val", "u1", (VS[wl],))]), n, off); off += n * row
+        h.update(_rows_canon(wl, t, r["key"], r["ver"], r["val"]))
+    if wl == "tatp":
+        for t in range(5):
+            cnt = int(np.frombuffer(dump, "<u4", 1, off)[0]); off += 4
+            h.update(np.frombuffer(dump, "<u4", cnt, off).tobytes()); off += 4 * cnt
+        tail, n = (int(x) for x in np.frombuffer(dump, "<u4", 2, off)); off += 8
+        h.update(_log_canon(tail, np.frombuffer(dump, "u1", n * 64, off))); off += n * 64
+    elif wl == "smallbank":
+        for t in range(2):
+            cnt = int(np.frombuffer(dump, "<u4", 1, off)[0]); off += 4
+            h.update(np.frombuffer(dump, "<u4", 3 * cnt, off).tobytes()); off += 12 * cnt
+    assert off == len(dump), (off, len(dump))
+    return h.hexdigest()
+
+
+def digest_of_oracle(wl, o, n_log: int = 0) -> str:
+    h = hashlib.sha256()
+    for t in range(N_TABLES[wl]):
+        k, v, x = o.dump() if wl == "store" else o.dump(t)
+        h.update(_rows_canon(wl, t, k, v, x))
+    if wl == "tatp":
+        for t in range(5):
+            h.update(np.nonzero(o.locks(t))[0].astype("<u4").tobytes())
+        h.update(_log_canon(o.tail, o.ring[:min(n_log, o.cap)]))
+    elif wl == "smallbank":
+        for t in range(2):
+            ex, sh = o.num_ex(t), o.num_sh(t)
+            nz = np.nonzero(ex | sh)[0]
+            h.update(np.stack([nz.astype("<u4"), ex[nz], sh[nz]], 1).astype("<u4").tobytes())
+    return h.hexdigest()
+
+
+def digest_of_engine(wl, eng, n_log: int = 0) -> str:
+    h = hashlib.sha256()
+    for t in range(N_TABLES[wl]):
+        k, v, x = eng.dump_rows(t)
+        h.update(_rows_canon(wl, t, k, v, x))
+    if wl == "tatp":
+        for t in range(5):
+            a, _ = eng.read_locks(t)
+            h.update(np.nonzero(a)[0].astype("<u4").tobytes())
+        cap = PARAMS["tatp"]["log_entries"]
+        ring, tail = eng.read_log(cap)
+        h.update(_log_canon(tail, np.frombuffer(ring.tobytes(), "u1").reshape(-1, 64)[:min(n_log, cap)]))
+    elif wl == "smallbank":
+        for t in range(2):
+            ex, sh = eng.read_locks(t)
+            nz = np.nonzero(ex | sh)[0]
+            h.update(np.stack([nz.astype("<u4"), ex[nz], sh[nz]], 1).astype("<u4").tobytes())
+    return h.hexdigest()
+
+
+def n_log_appends(wl, rep) -> int:
+    """log records the trace appended (= replies of the log ack types): how much of the ring belongs to the state"""
+    if wl == "tatp":
+        return int(np.isin(rep["type"], (17, 27)).sum())
+    return 0

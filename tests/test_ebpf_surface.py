@@ -42,6 +42,43 @@ def test_refusal_codes_follow_the_ebpf_servers():
     assert refuse(W.FASST, f)["type"].tolist() == [0, wire.Fasst.REJECT_LOCK, 2, 3]
 
 
+def test_refusal_codes_match_the_unmodified_ebpf_programs_under_contention():
+    """tests/golden/ebpf_backpressure.npz (make_golden_ebpf.py backpressure): the reference's own XDP programs, run under the
+    emulator while it holds the spin lock of every cache entry / lock unit they look up -- the failed CAS of
+    tatp/ebpf/shard_kern.c:173-178,371-376, store/ebpf/store_kern.c:57-66, lock_2pl/ebpf/ls_kern.c:59-64,
+    smallbank/ebpf/shard_kern.c:122-152.  Where they answer a back-pressure code, dint_refuse (and through
+    tests/test_gpu_route.py its device twin rt_refuse) must produce the same BYTES; a request they answer as always
+    (tatp ACQUIRE_LOCK / ABORT and the log appends touch no spin lock) is one dint_refuse leaves in the batch -- but for
+    tatp ACQUIRE_LOCK, which it refuses with the answer of a taken LOCK WORD, REJECT_LOCK (shard_kern.c:289-293): the one
+    "not now" of that request type, pinned by every serial fixture."""
+    import json
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ebpf_backpressure.npz"))
+    meta = json.loads(str(z["meta"]))
+    T = wire.Tatp
+    back = {"lock_2pl": {wire.Tpl.RETRY}, "store": {wire.Store.REJECT_READ, wire.Store.REJECT_SET, wire.Store.REJECT_INSERT},
+            "tatp": {T.REJECT_READ, T.REJECT_COMMIT}, "smallbank": {wire.Sb.RETRY}}
+    for wl, dt, w in (("lock_2pl", wire.TPL_MSG, W.TPL), ("store", wire.STORE_MSG, W.STORE), ("tatp", wire.TATP_MSG, W.TATP),
+                      ("smallbank", wire.SB_MSG, W.SMALLBANK)):
+        req = np.frombuffer(z[wl + "_req"].tobytes(), dt)
+        held = np.frombuffer(z[wl + "_rep"].tobytes(), dt)
+        free = np.frombuffer(z[wl + "_free"].tobytes(), dt)
+        f = "action" if wl == "lock_2pl" else "type"
+        got = refuse(w, req)
+        is_back = np.isin(held[f], list(back[wl]))
+        assert is_back.sum() >= 48 and meta[wl]["n"] == len(req)
+        assert got[is_back].tobytes() == held[is_back].tobytes(), wl      # the refusal, byte for byte
+        assert (free[f][is_back] != held[f][is_back]).all()                 # ... which a serial replay never produces
+        rest = ~is_back
+        if wl == "tatp":
+            acq = req["type"] == T.ACQUIRE_LOCK
+            assert (got["type"][acq] == T.REJECT_LOCK).all() and (held["type"][acq] == T.GRANT_LOCK).all()
+            rest &= ~acq
+        assert got[rest].tobytes() == req[rest].tobytes(), wl               # not refusable: stays in the batch
+        assert held[rest].tobytes() == free[rest].tobytes(), wl             # ... the eBPF program answers it as always
+
+
 def test_oracle_same_key_and_warmup_semantics():
     T = wire.Tatp
     o = orc.TatpOracle(300, log_entries=1000)
