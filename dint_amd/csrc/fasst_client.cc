@@ -176,6 +176,20 @@ int dint_fasst_client_consume(dint_fasst_client_t *c, const void *replies) {
   return 0;
 }
 
+// the transaction worker `worker` is running: its sorted read set (all keys) and its write set, as one transaction of the
+// reference's trace files lists them (trace_init.sh:20-27).  For the pin against the unmodified reference client, which
+// reads its transactions from such a file (tests/golden/make_golden_clients_micro.py).
+int dint_fasst_client_peek(const dint_fasst_client_t *c, uint32_t worker, uint32_t *keys, uint32_t *n_keys, uint32_t *wkeys,
+                           uint32_t *n_wkeys) {
+  if (!c || !keys || !n_keys || !wkeys || !n_wkeys || worker >= c->w.size()) return DINT_EINVAL;
+  const Worker &x = c->w[worker];
+  *n_keys = x.nk;
+  *n_wkeys = x.nw;
+  memcpy(keys, x.keys, sizeof(uint32_t) * x.nk);
+  memcpy(wkeys, x.wkeys, sizeof(uint32_t) * x.nw);
+  return 0;
+}
+
 int dint_fasst_client_get_stats(const dint_fasst_client_t *c, dint_fasst_client_stats *out) {
   if (!c || !out) return DINT_EINVAL;
   *out = c->st;

@@ -225,6 +225,15 @@ class FasstClient:
         replies = np.ascontiguousarray(replies)
         _lib.check(self._L.dint_fasst_client_consume(self._h, replies.ctypes.data))
 
+    def peek(self, worker: int = 0):
+        """(read set, write set) of the transaction `worker` is running"""
+        k, w = (C.c_uint32 * 10)(), (C.c_uint32 * 10)()
+        nk, nw = C.c_uint32(), C.c_uint32()
+        self._L.dint_fasst_client_peek.restype = C.c_int
+        self._L.dint_fasst_client_peek.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.check(self._L.dint_fasst_client_peek(self._h, worker, k, C.byref(nk), w, C.byref(nw)))
+        return list(k[:nk.value]), list(w[:nw.value])
+
     def stats(self) -> dict:
         s = FasstClientStats()
         _lib.check(self._L.dint_fasst_client_get_stats(self._h, C.byref(s)))

@@ -118,6 +118,10 @@ void dint_fasst_client_destroy(dint_fasst_client_t *c);
 const void *dint_fasst_client_next(dint_fasst_client_t *c);
 int dint_fasst_client_consume(dint_fasst_client_t *c, const void *replies);
 int dint_fasst_client_get_stats(const dint_fasst_client_t *c, dint_fasst_client_stats *out);
+/* the transaction `worker` is running: keys[0 .. *n_keys) = its sorted read set, wkeys[0 .. *n_wkeys) = its write set (room
+ * for 10 each) -- one transaction of lock_fasst/caladan/trace_init.sh's trace files */
+int dint_fasst_client_peek(const dint_fasst_client_t *c, uint32_t worker, uint32_t *keys, uint32_t *n_keys, uint32_t *wkeys,
+                           uint32_t *n_wkeys);
 
 #ifdef __cplusplus
 }

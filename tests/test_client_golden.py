@@ -61,3 +61,37 @@ def test_restated_clients_send_what_the_reference_clients_send(wl):
         assert sum(cur) > 0.99 * meta["runs"][f"{wl}_{gid}"]["messages"]
         assert all(c > 0 for c in st["by_type"][:nt]) and st["committed"] < st["txns"]  # every transaction type, aborts too
         assert meta["runs"][f"{wl}_{gid}"]["locks_refused"] > 100
+
+
+def test_restated_micro_clients_send_what_the_reference_load_generators_send():
+    """tests/golden/clients_micro.npz (make_golden_clients_micro.py): one worker each of the UNMODIFIED
+    lock_fasst/caladan/client.cc and lock_2pl/caladan/client.cc, replaying the transactions the restated clients draw for
+    their worker 0, against a CPU oracle lock server, with one ACQUIRE in five refused by the harness (aborts, releases,
+    restarts, validation).  dint_amd/csrc/fasst_client.cc and dint_amd/driver.py::TplClient, fed the recorded replies one by
+    one, must send the recorded requests -- the "fixed 24M-op trace" of tests/test_fasst_24m.py is made by this client."""
+    from dint_amd.driver import FasstClient, TplClient
+
+    z = np.load(os.path.join(G, "clients_micro.npz"))
+    meta = json.loads(str(z["meta"]))
+    req = np.frombuffer(z["fasst_req"].tobytes(), wire.FASST_MSG)
+    rep = np.frombuffer(z["fasst_rep"].tobytes(), wire.FASST_MSG)
+    c = FasstClient(1, meta["fasst"]["key_space"], zipf_theta=None)
+    for i in range(len(req)):
+        out = c.next()
+        # (the reference's requests carry ver = 0: `message msg = {type, lid, 0}`, client.cc:199,216,225,237,248,258)
+        assert out.tobytes() == req[i:i + 1].tobytes(), ("lock_fasst", i, out, req[i])
+        c.consume(rep[i:i + 1].copy())
+    st = c.stats()
+    assert st["protocol_errors"] == 0 and st["rejects"] > 300 and st["committed"] > 500 and st["rollbacks"] == 0
+    assert len(req) == meta["fasst"]["messages"] and set(rep["type"].tolist()) == {4, 5, 6, 7, 8}
+
+    req = np.frombuffer(z["tpl_req"].tobytes(), wire.TPL_MSG)
+    rep = np.frombuffer(z["tpl_rep"].tobytes(), wire.TPL_MSG)
+    t = TplClient(1, meta["tpl"]["key_space"], zipf_theta=None, seed=meta["tpl"]["seed"])
+    for i in range(len(req)):
+        out = t.next()
+        assert out.tobytes() == req[i:i + 1].tobytes(), ("lock_2pl", i, out, req[i])
+        t.consume(rep[i:i + 1].copy())
+    st = t.stats()
+    assert st["protocol_errors"] == 0 and st["rejects"] > 1000 and st["committed"] > 500
+    assert len(req) == meta["tpl"]["messages"] and set(rep["action"].tolist()) == {2, 3, 5}
