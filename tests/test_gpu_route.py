@@ -434,3 +434,117 @@ def test_router_over_rccl_world_size_one():
     p.join(120)
     assert p.exitcode == 0
     assert ok and overflow == 0 and committed > 0
+
+
+# ------------------------------------------------------------------------- BASELINE configs[4] in its stated shape
+def _row_checksum(keys, vers, vals):
+    """order-independent checksum of a table share: the sum (mod 2^64) of a 64-bit mix of every row -- the shares of the
+    ranks add up to the unsharded table's"""
+    k = np.asarray(keys, "<u8").astype(np.uint64)
+    h = k * np.uint64(0x9E3779B97F4A7C15) ^ (np.asarray(vers, "<u4").astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F))
+    v = np.ascontiguousarray(vals, "u1").reshape(len(k), -1)
+    for c in range(0, v.shape[1], 8):
+        w = np.zeros(len(k), np.uint64)
+        blk = v[:, c:c + 8]
+        for b in range(blk.shape[1]):
+            w |= blk[:, b].astype(np.uint64) << np.uint64(8 * b)
+        h = (h ^ (w + np.uint64(c + 1))) * np.uint64(0xFF51AFD7ED558CCD)
+        h ^= h >> np.uint64(33)
+    return int(h.sum(dtype=np.uint64)), int(len(k))
+
+
+def _lock_summary(eng, wl):
+    out = []
+    for t in e_tables(wl):
+        a, b = eng.read_locks(t)
+        out.append((int(np.count_nonzero(a)), int(a.sum(dtype=np.uint64)), int(np.count_nonzero(b)), int(b.sum(dtype=np.uint64))))
+    return out
+
+
+def _rank_big(rank, world, port, wl, n_rows, clients, epochs, zipf, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dint_amd.driver import Driver
+    from dint_amd.replay import ShardGroup
+
+    torch.cuda.set_device(0)
+    grp = ShardGroup(wl, n_rows, device=0, rank=rank, world=world, log_entries=200_000, n_max=1 << 16)
+    d = Driver(wl, clients, n_rows, first_client=rank * clients, zipf_theta=zipf)
+    trace = []
+    for _ in range(epochs):
+        req = d.next()
+        rep = grp.submit(req)
+        d.consume(rep)
+        trace.append(([r.tobytes() for r in req], [r.tobytes() for r in rep]))
+    sums = [[_row_checksum(*e.dump_rows(t)) for t in e_tables(wl)] for e in grp.engines]
+    locks = [_lock_summary(e, wl) for e in grp.engines]
+    local = [[int(e.hash_size(t)) for t in e_tables(wl)] for e in grp.engines[:1]]
+    q.put((rank, trace, sums, locks, [e.stats() for e in grp.engines], d.stats(), local))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("wl,n_rows,clients,zipf,epochs", [(int(W.SMALLBANK), 80_000_000, 24_000, 0.99 - 1e-9, 6),
+                                                           (int(W.TATP), 1_000_001, 16_000, 0.8, 8)])
+def test_eight_ranks_at_the_baseline_shape_equal_one_unsharded_server(wl, n_rows, clients, zipf, epochs):
+    """BASELINE configs[4] as stated -- SmallBank, 80M accounts hash-sharded over EIGHT ranks (10M accounts each: 3,750,000
+    local buckets per table and logical server), accounts ~ Zipf-0.99, closed-loop clients on every rank -- with the eight
+    ranks sharing the one GPU of the box (gloo / host transport; the kernels, capacities and orders are those of the 8-GPU
+    run).  Every reply byte of every rank must equal what ONE unsharded engine group of 80M accounts answers to the
+    rank-major concatenation of the batches (smallbank/udp/smallbank.h:10,16-18, server_shard.cc:75-76), and the ranks'
+    table shares must add up to its tables (order-independent row checksums, lock-counter sums).  The TATP case runs the
+    same eight ranks at configs[3]'s size + 1: 937,500 and 1,406,251 buckets -- the latter not divisible by 8, so the ranks'
+    local tables are ceil-divided and the last rank's share is short (tatp/udp/server_shard.cc:75-79)."""
+    import torch.multiprocessing as mp
+    from dint_amd.replay import ShardGroup
+
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_big, args=(r, world, port, wl, n_rows, clients, epochs, zipf, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    one = ShardGroup(wl, n_rows, device=0, log_entries=200_000)  # the unsharded servers, populated while the ranks start up
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=1200)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    dtype = wire.MSG_DTYPE[wire.Workload(wl)]
+    total = 0
+    for e in range(epochs):
+        for s in range(3):
+            parts = [np.frombuffer(res[r][0][e][0][s], dtype) for r in range(world)]
+            want = one.engines[s].submit(np.concatenate(parts))  # the serial order: rank-major concatenation
+            lo = 0
+            for r in range(world):
+                n = len(parts[r])
+                assert res[r][0][e][1][s] == want[lo:lo + n].tobytes(), (e, s, r)
+                lo += n
+                total += n
+    assert total > world * clients
+    for s in range(3):
+        for ti, t in enumerate(e_tables(wl)):
+            cs = sum(res[r][1][s][ti][0] for r in range(world)) % (1 << 64)
+            n = sum(res[r][1][s][ti][1] for r in range(world))
+            assert (cs, n) == _row_checksum(*one.engines[s].dump_rows(t)), (s, t)
+        want_l = _lock_summary(one.engines[s], wl)
+        for ti in range(len(want_l)):
+            got_l = tuple(sum(res[r][2][s][ti][k] for r in range(world)) for k in range(4))
+            assert got_l == want_l[ti], (s, ti)
+    for r in range(world):
+        for st in res[r][3]:
+            assert st["foreign_requests"] == 0 and st["route_overflow"] == 0 and st["bad_requests"] == 0 and st["pool_exhausted"] == 0
+        assert res[r][4]["committed"] > 0
+    for st in (e.stats() for e in one.engines):
+        assert st["bad_requests"] == 0 and st["pool_exhausted"] == 0
+    if wire.Workload(wl) == W.TATP:
+        assert any(h % world for h in res[0][5][0]), res[0][5]  # a bucket count the ranks cannot divide evenly

@@ -31,16 +31,28 @@ def _check(wl, req, rep):
     assert lt.reply_types(wl, rep) == f["reply_types"]
 
 
+def _check_state(wl, digest):
+    """the state the 3M requests leave behind, in canonical form (long_traces.digest_of_*: rows in bucket / chain order, lock
+    words, log ring) -- the unmodified reference's dump hashed the same way when the fixture was made"""
+    assert digest == FIX[wl]["dump_sha256"], f"{wl}: the final state differs from the unmodified reference's"
+
+
 @pytest.mark.parametrize("wl", ["lock_2pl", "log_server", "store"])
 def test_oracle_long_trace(wl):
-    req, rep = lt.TRACES[wl](lt.oracle_servers(wl))
+    servers = lt.oracle_servers(wl)
+    req, rep = lt.TRACES[wl](servers)
     _check(wl, req, rep)
+    if wl == "store":
+        _check_state(wl, lt.digest_of_oracle(wl, servers[0].o))
 
 
 @pytest.mark.slow
 def test_oracle_long_trace_smallbank():
     req, rep = lt.TRACES["smallbank"](lt.oracle_servers("smallbank"))
     _check("smallbank", req, rep)
+    srv = lt.fresh_oracle("smallbank")  # (the closed loop ran its last epoch past request N)
+    srv.submit(req)
+    _check_state("smallbank", lt.digest_of_oracle("smallbank", srv.o))
 
 
 @pytest.mark.slow
@@ -49,6 +61,9 @@ def test_oracle_long_trace_smallbank():
 def test_oracle_long_trace_tatp():
     req, rep = lt.TRACES["tatp"](lt.oracle_servers("tatp"))
     _check("tatp", req, rep)
+    srv = lt.fresh_oracle("tatp")
+    srv.submit(req)
+    _check_state("tatp", lt.digest_of_oracle("tatp", srv.o, lt.n_log_appends("tatp", rep)))
 
 
 # ------------------------------------------------------------------------------------------------- GPU
@@ -98,6 +113,7 @@ def test_gpu_long_trace_store():
         else:
             rep = _replay(eng, req, batch)
         _check("store", req, rep)
+        _check_state("store", lt.digest_of_engine("store", eng))
 
 
 @pytest.mark.gpu
@@ -117,6 +133,7 @@ def test_gpu_long_trace_smallbank():
     e2 = Engine(W.SMALLBANK, n_rows=n)
     e2.populate(n)
     _check("smallbank", req, _replay(e2, req, 1 << 20))
+    _check_state("smallbank", lt.digest_of_engine("smallbank", e2))
 
 
 @pytest.mark.gpu
@@ -141,4 +158,6 @@ def test_gpu_long_trace_tatp():
     st = engs[p["server"]].stats()
     assert st["bad_requests"] == 0
     del engs
-    _check("tatp", req, _replay(mk(), req, 1 << 20))
+    e2 = mk()
+    _check("tatp", req, _replay(e2, req, 1 << 20))
+    _check_state("tatp", lt.digest_of_engine("tatp", e2, lt.n_log_appends("tatp", rep)))
