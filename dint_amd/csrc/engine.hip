@@ -187,12 +187,12 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
   return p;
 }
 
-// one micro-batch (n <= DINT_MICRO) on device buffers
+// one pass (n <= pass_max) on device buffers
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0,
              const dint_view &view = dint_flat_view()) {
   if (int rc = order_stream(e, st)) return rc;
   static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve"};
-  static const char *const log_names[] = {"k_log_count", "k_log_write"};
+  static const char *const log_names[] = {"k_log_append"};
   static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve", "k_kv_big"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
@@ -209,7 +209,8 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
       break;
     case DINT_WL_LOG:
       if (view.seg_cap) return fail(DINT_ESTATE, "the log workload is not sharded by key");
-      dint_launch_log(d_req, d_rep, n, e->log, e->scratch, st, timer_events(e, 2, log_names));
+      dint_launch_log(d_req, d_rep, n, e->log, e->scratch, st, timer_events(e, 1, log_names));
+      std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);  // the tile counts alternate between passes
       break;
     case DINT_WL_STORE:
     case DINT_WL_TATP:
@@ -300,10 +301,10 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   }
   const uint32_t wl = cfg->workload;
   const bool is_kv = wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK;
-  // requests per kernel pass: the request index must fit the batch record (20 bits; the log append 16)
-  e->pass_max = wl == DINT_WL_LOG ? DINT_MICRO : DINT_KV_PASS;
+  // requests per kernel pass: the request index must fit the batch record (20 bits)
+  e->pass_max = DINT_KV_PASS;
   if (cfg->max_pass) e->pass_max = std::min<uint32_t>(e->pass_max, std::max<uint32_t>(cfg->max_pass, 64u));
-  if (wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
+  if (wl == DINT_WL_LOG || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
     // a pass never laps the log ring, so a DELETE_LOG record keeps the val bytes of the record it overwrites
     // exactly as in the serial reference
     const uint32_t cap = cfg->log_entries ? cfg->log_entries : 1000000u;
@@ -332,7 +333,8 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
       e->scratch.lock_trace = e->kv.d_trace;
     }
   } else {  // the log append has no bins: per-block counts of its scan only
-    TRY(dev_alloc((void **)&e->scratch.blk_cnt, 256 * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.blk_pub, 2 * (1024 + 16) * sizeof(uint32_t)));  // per tile: valid requests; + ticket, finished
+    e->scratch.blk_pub_next = e->scratch.blk_pub + (1024 + 16);
   }
   TRY(slot_alloc(e, 0));
   if (hipHostMalloc((void **)&e->h_pinned, (size_t)e->pass_max * e->msg_size + 64, hipHostMallocDefault) != hipSuccess ||

@@ -83,8 +83,9 @@ enum {
 };
 
 /* The largest request count one kernel pass handles: dint_submit splits larger
- * arrays into consecutive passes (correct by the serial-order contract).  LOG engines take
- * DINT_MICRO_BATCH, every other workload DINT_KV_PASS_MAX (see max_pass). */
+ * arrays into consecutive passes (correct by the serial-order contract).  DINT_KV_PASS_MAX for every
+ * workload (see max_pass), never more than the log ring holds (log_server, tatp, smallbank); DINT_MICRO_BATCH was the
+ * log_server limit until r03 and remains as the batch size of BASELINE's micro configs. */
 #define DINT_MICRO_BATCH 65536u
 #define DINT_KV_PASS_MAX 1048576u
 
