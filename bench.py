@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="tatp: skip the compact legs of the other BASELINE configs (lock_fasst, lock_2pl, log, store, smallbank)")
     ap.add_argument("--no-shim", action="store_true", help="skip the UDP shim loopback leg")
+    ap.add_argument("--no-as-shipped", action="store_true", help="skip the as-shipped tatp/udp deployment leg (three reference "
+                    "server processes, ~27 GB of host memory)")
     ap.add_argument("--sweep-clients", action="store_true",
                     help="tatp / smallbank: abort rate and Mtxn/s at 4096 / 32768 / 131072 / 524288 closed-loop clients")
     return ap.parse_args()
@@ -266,6 +268,35 @@ def cpu_baseline_micro(kind, sample: np.ndarray, size: int, want: bytes):
     out["host_cpu"] = host_cpu()
     out["oracle_parity"] = {"requests": len(sample), "ok": rep.tobytes() == want}
     return out
+
+
+def cpu_as_shipped_tatp(shipped, trace, ops_per_txn, args):
+    """BASELINE.md 3(2) / configs[3] "compare ... vs tatp/udp CPU server": the reference's as-shipped deployment -- three
+    unmodified `tatp/udp/server_shard <id> 8` processes (exp/run_tatp.sh; their own main(), populate at 7M subscribers,
+    thread pinning, kernel UDP sockets; bind() redirected 10.10.1.N -> 127.0.1.N) -- each driven closed-loop over loopback
+    with ITS stream of the recorded 7M-subscriber epochs, all three at once.  The closed-loop client replays requests out of
+    transaction context and wraps around, so the requests the udp server panics on out of context are left out (a COMMIT /
+    DELETE of a CALL_FORWARDING row that is not there: tatp/udp/kvs.h:91,152; INSERTs, which would grow the table with every
+    lap): READ, ACQUIRE_LOCK, ABORT, the log appends and the commits of the three static tables remain (~97 % of the stream)."""
+    try:
+        if not shipped.wait_populated(args.ref_timeout):
+            return {"error": f"the as-shipped servers were not populated within {args.ref_timeout:.0f} s"}
+        streams, kept, total = [], 0, 0
+        for sv in range(3):
+            m = np.concatenate([trace[e][0][sv] for e in range(len(trace))])
+            safe = np.isin(m["type"], (0, 1, 2, 14, 24)) | (np.isin(m["type"], (12, 13)) & (m["table"] < 4))
+            kept, total = kept + int(safe.sum()), total + len(m)
+            streams.append(m[safe].copy())
+        cores = os.cpu_count() or 8
+        r = shipped.run(streams, client_threads=min(16, max(2, cores // 8)), window=32, warmup_s=1.0, measure_s=4.0)
+    except Exception as ex:
+        return {"error": f"{type(ex).__name__}: {ex}"}
+    return {"value": round(r["ops_per_s"] / ops_per_txn / 1e6, 4), "unit": "Mtxn/s", "cores": 3 * r["server_threads"], "kind": "reference",
+            "path": "as shipped: three unmodified tatp/udp/server_shard.cc processes (8 worker threads each) over loopback UDP",
+            "ops_per_s": round(r["ops_per_s"]), "ops_per_txn": round(ops_per_txn, 3), "lost": r["lost"], "populate_s": r["populate_s"],
+            "servers": r["servers"], "host_cpu": host_cpu(),
+            "sample": f"{kept} of {total} requests of the three servers' streams of {len(trace)} closed-loop epochs at 7,000,000 "
+                      f"subscribers, replayed closed-loop for 4 s (16 client threads x 32 outstanding per server)"}
 
 
 def cpu_as_shipped_fasst(sample: np.ndarray):
@@ -609,7 +640,7 @@ def bench_log(args, world, rank, dev, transport):
 STORE_ALG = {0: 158, 1: 162}  # READ 53 + 53 + 52, SET 53 + 53 + 12 + 44
 
 
-def store_stream(n, n_sub, theta, seed):
+def store_stream(n, n_sub, theta, seed, p_set=0.05):
     """store/caladan/client_udp.cc:135-147 key shape {s_id, sf_type 1..4, start_time 0/8/16}, s_id ~ Zipf(theta) over
     the populated subscribers, 95 % READ / 5 % SET (BASELINE configs[2]); SET value {end_time, 0x5a} (:56-66)"""
     from dint_amd import wire, workloads
@@ -620,7 +651,7 @@ def store_stream(n, n_sub, theta, seed):
     s_id = z.sample(n).astype(np.uint64)
     m["key"] = s_id | (rng.integers(1, 5, n).astype(np.uint64) << np.uint64(32)) | (
         (rng.integers(0, 3, n) * 8).astype(np.uint64) << np.uint64(40))
-    m["type"] = (rng.random(n) < 0.05).astype(np.uint8)
+    m["type"] = (rng.random(n) < p_set).astype(np.uint8)
     m["val"][:, 0] = rng.integers(0, 24, n)
     m["val"][:, 1] = 0x5A
     return m
@@ -641,6 +672,7 @@ def bench_store(args, world, rank, dev, transport):
     t_setup = time.perf_counter()
     eng.populate(n_sub)
     eng.sync()
+    eng.snapshot()  # (the mixes leg starts from the populated table again)
     t_setup = time.perf_counter() - t_setup
     n_batches = (K + W) * B
     stream = store_stream(NB * n_batches, n_sub, theta, 77 + rank)
@@ -702,6 +734,7 @@ def bench_store(args, world, rank, dev, transport):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, alg), 3)
     value = world * K * B * NB / dt / 1e6
+    mixes = {}
     if rank != 0:
         return None
     if not args.no_rand64 and rt is None:
@@ -721,11 +754,33 @@ def bench_store(args, world, rank, dev, transport):
         cpu = {"value": round(n_s / dtc / 1e6, 4), "unit": "Mtxn/s", "cores": 1, "kind": "port", "host_cpu": host_cpu(),
                "sample": f"the first {n_s} requests of the bench stream, oracle/dint_oracle.c ({n_sub * 12} keys), 1 thread",
                "oracle_parity": {"requests": n_s, "ok": rep.tobytes() == got.tobytes()[:n_s * msg]}}
+    # ---- the reference client's other two mixes (store/caladan/client_udp.cc:56-66: `parallel` = 100 % READ, `contention` =
+    # 50 % READ / 50 % SET), same table size and key distribution, 16 batches each.  From a known state -- the populated
+    # table + the first n_s requests of the bench stream, where the oracle above stands -- so every reply is checked.
+    if rt is None:
+        n_s = min(len(stream), 8 * NB)
+        eng.restore()
+        eng.submit_device(d_req.data_ptr(), n_s, d_rep.data_ptr(), 0)
+        sync()
+        for name, p_set in (("100/0", 0.0), ("50/50", 0.5)):
+            ms = store_stream(NB * 16, n_sub, theta, 991 + rank, p_set)
+            dq = torch.from_numpy(np.frombuffer(ms.tobytes(), np.uint8).copy()).cuda()
+            dp = torch.empty_like(dq)
+            sync()
+            tm = time.perf_counter()
+            for b in range(16):
+                eng.submit_device(dq.data_ptr() + b * NB * msg, NB, dp.data_ptr() + b * NB * msg, 0)
+            sync()
+            tm = time.perf_counter() - tm
+            mixes[name] = {"value": round(16 * NB / tm / 1e6, 3), "unit": "Mtxn/s", "read_write": name, "batches": 16}
+            if cpu is not None:
+                mixes[name]["oracle_parity"] = {"requests": len(ms), "ok": o.replay(ms.copy()).tobytes() == dp.cpu().numpy().tobytes()}
+            del dq, dp
     return {
         "metric": "Mtxn/s (store: 1 txn = 1 request) + p50/p99 batch latency",
         "value": round(value, 3), "unit": "Mtxn/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
+        "dtype": "u64", "data": "synthetic", "mixes": mixes or None,
         "config": {"workload": f"store KV on {world} MI355X: {n_sub * 12} keys x 40-B values, 95/5 read/write, "
                                f"s_id ~ Zipf-{theta}, {NB}-request batches; 1 step = {B} batches", "keys": n_sub * 12, "batch": NB,
                    "batches_per_step": B, "parallelism": f"hash-shard x{world}", "transport": transport},
@@ -793,7 +848,7 @@ def cpu_baseline_txn(kind, rp, done, n_rows, lo, hi):
 REF_TATP_SUBSCRIBERS = 7_000_000  # tatp/udp/tatp.h:28 (constexpr: the unmodified server has no other size)
 
 
-def cpu_reference_tatp(ref, args, dev, C, zipf, n_epochs=12):
+def cpu_reference_tatp(ref, args, dev, C, zipf, n_epochs=12, shipped=None, extra=None):
     """BASELINE.md 3(1) for the headline workload: the UNMODIFIED tatp/udp/server_shard.cc (oracle/_ref/ref_tatp,
     sockets interposed, 1 thread) against the engines on the configuration the reference is compiled for -- 7M
     subscribers on both sides.  A second shard group is populated at 7M rows, the closed loop runs `n_epochs` epochs
@@ -829,6 +884,8 @@ def cpu_reference_tatp(ref, args, dev, C, zipf, n_epochs=12):
     req = np.concatenate([trace[e][0][0] for e in range(n_epochs)])
     want = np.concatenate([trace[e][1][0] for e in range(n_epochs)])
     ops_per_txn = sum(sum(len(r) for r in trace[e][0]) for e in range(n_epochs)) / max(1, sum(done))
+    if shipped is not None and extra is not None:
+        extra["cpu_as_shipped_tatp"] = cpu_as_shipped_tatp(shipped, trace, ops_per_txn, args)
     del grp, rp
     if not ref.wait_populated(args.ref_timeout):
         return {"error": f"reference server not populated within {args.ref_timeout:.0f} s of the GPU legs ending"}
@@ -973,12 +1030,17 @@ def bench_txn(args, world, rank, dev, transport, kind):
     dt = max_over_ranks(time.perf_counter() - t0, world, transport)
     rp.check(0, E1)  # parity with the recorded closed-loop run, every reply byte
     overflow = grp.router.overflow() if grp.router is not None else 0
-    ref = None
+    ref = shipped = None
     compact = getattr(args, "compact", False)
     if kind == "tatp" and world == 1 and not (args.no_cpu_baseline or args.no_cpu_reference or compact):
         from oracle import oracle as orc  # cpu_baseline leg only: the reference populates (minutes, one host core)
         if orc.ref_available("tatp"):     # while the remaining GPU legs run; the headline region above is over
             ref = orc.RefServer("tatp")
+        if orc.loopback_tatp_available() and not args.no_as_shipped:  # ... and the as-shipped deployment: three servers
+            try:
+                shipped = orc.TatpAsShipped(server_threads=8)  # `server_shard <id> 8`, exp/run_tatp.sh
+            except Exception:
+                shipped = None
 
     txns = sum_over_ranks(sum(done[E0:E1]), world, transport)
     ops = sum_over_ranks(rp.ops(E0, E1), world, transport)
@@ -1133,16 +1195,20 @@ def bench_txn(args, world, rank, dev, transport, kind):
         cpu = cpu_baseline_txn(kind, rp, done, n_rows, E0, min(E1, E0 + (12 if compact else 60)))
         if ref is not None:
             try:
-                r = cpu_reference_tatp(ref, args, dev, C, zipf)
+                r = cpu_reference_tatp(ref, args, dev, C, zipf, shipped=shipped, extra=extra)
             except Exception as ex:  # the reported baseline falls back to the port, with the reason
                 r = {"error": f"{type(ex).__name__}: {ex}"}
             finally:
                 ref.close()
+                if shipped is not None:
+                    shipped.close()
             if "error" in r:
                 cpu["reference"] = r
             else:
                 r["port_on_bench_config"] = cpu
                 cpu = r
+        if shipped is not None:
+            shipped.close()
         if kind == "tatp" and not args.no_cpu_reference and not compact:
             # the reference's as-shipped per-packet path on this host (its lock_fasst server: the one udp/ server
             # that starts in under a second; tatp's shard server spends minutes populating before it binds) -- and
@@ -1225,10 +1291,12 @@ def other_workloads(args, world, rank, dev, transport):
     import gc
 
     out = {}
-    for wl in ("fasst", "2pl", "log", "store", "smallbank"):
+    for wl in ("fasst", "fasst_36m", "2pl", "log", "store", "smallbank"):
         a = copy.copy(args)
         a.workload, a.compact, a.steps, a.warmup, a.per_step, a.theta = wl, True, 8, 2, (4 if wl in ("store", "smallbank") else 16), None
         a.no_rand64 = a.no_closed_loop = a.no_host_path = True
+        if wl == "fasst_36m":  # the reference's own table size: 288 MB, HBM-resident -- configs[1]'s 1M slots (8 MB) live in L2
+            a.workload, a.slots, a.no_cpu_baseline = "fasst", 36_000_000, True
         try:
             r = run_workload(a, world, rank, dev, transport)
         except Exception as ex:  # one leg failing must not take the headline down; it fails the run at the end
@@ -1244,6 +1312,9 @@ def other_workloads(args, world, rank, dev, transport):
                    "kernels_us": r.get("kernels_us"), "latency_us": r.get("latency_us"),
                    "replay_equals_recorded": r.get("replay_equals_recorded"), "abort_rate": r.get("abort_rate"),
                    "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None, "oracle_parity": par}
+        for k in ("pass_1m", "mixes"):  # log_server: 1M-request passes; store: the 100/0 and 50/50 read/write mixes
+            if r.get(k) is not None:
+                out[wl][k] = r[k]
     return out
 
 

@@ -8,7 +8,7 @@
  * was recorded from that logic, and any request is legal for the server in any state).  A request whose reply does
  * not arrive within 20 ms is counted lost and its window slot is reused (UDP may drop under overload).
  *
- * usage: udp_loop_client <requests.bin> <msg_size> <port> <threads> <window> <warmup_s> <measure_s>
+ * usage: udp_loop_client <requests.bin> <msg_size> <port> <threads> <window> <warmup_s> <measure_s> [server ip = 127.0.0.1]
  * stdout: one JSON line {"replies":..., "seconds":..., "ops_per_s":..., "lost":..., "threads":..., "window":...}
  */
 #define _GNU_SOURCE
@@ -32,6 +32,7 @@
 static unsigned char *g_req;
 static size_t g_n, g_msg;
 static int g_port, g_threads, g_window;
+static uint32_t g_host = 0x7F000001u; /* 127.0.0.1 */
 static volatile int g_phase; /* 0 warm-up, 1 measured, 2 stop */
 
 typedef struct { pthread_t th; int id; uint64_t replies, lost; } worker;
@@ -49,7 +50,7 @@ static void *run(void *arg) {
   memset(&srv, 0, sizeof srv);
   srv.sin_family = AF_INET;
   srv.sin_port = htons((uint16_t)g_port);
-  srv.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+  srv.sin_addr.s_addr = htonl(g_host);
   if (fd < 0 || connect(fd, (struct sockaddr *)&srv, sizeof srv) < 0) { perror("client socket"); return NULL; }
   int sz = 4 << 20;
   setsockopt(fd, SOL_SOCKET, SO_RCVBUF, &sz, sizeof sz);
@@ -96,7 +97,12 @@ static void *run(void *arg) {
 }
 
 int main(int argc, char **argv) {
-  if (argc != 8) { fprintf(stderr, "usage: %s <requests.bin> <msg_size> <port> <threads> <window> <warmup_s> <measure_s>\n", argv[0]); return 2; }
+  if (argc != 8 && argc != 9) { fprintf(stderr, "usage: %s <requests.bin> <msg_size> <port> <threads> <window> <warmup_s> <measure_s> [server ip]\n", argv[0]); return 2; }
+  if (argc == 9) {
+    struct in_addr ia;
+    if (inet_pton(AF_INET, argv[8], &ia) != 1) { fprintf(stderr, "bad server ip %s\n", argv[8]); return 2; }
+    g_host = ntohl(ia.s_addr);
+  }
   g_msg = (size_t)atoi(argv[2]); g_port = atoi(argv[3]); g_threads = atoi(argv[4]); g_window = atoi(argv[5]);
   double warm = atof(argv[6]), meas = atof(argv[7]);
   if (g_msg == 0 || g_msg > MAXMSG || g_threads < 1 || g_window < 1) return 2;

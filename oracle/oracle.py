@@ -407,6 +407,69 @@ def ref_loopback_fasst(msgs: np.ndarray, server_threads: int = 8, client_threads
     return out
 
 
+class TatpAsShipped:
+    """BASELINE.md 3(2) for the headline workload: the reference's as-shipped deployment -- three `tatp/udp/server_shard <id>
+    <T>` processes (unmodified server_shard.cc, its own main(), populate and thread pinning; only bind() is redirected:
+    10.10.1.N -> 127.0.1.N, ref_harness/bind_lo.c).  Started ahead of its traffic (each populates 7M subscribers for tens of
+    seconds); `run` drives each over loopback UDP with a closed-loop client replaying `streams[id - 1]`
+    (udp_loop_client.c), all three at once, and returns the summed reply rate and the per-server lines."""
+
+    def __init__(self, server_threads: int = 8):
+        self.server_threads, self.t0, self.populate_s = server_threads, time.perf_counter(), None
+        env = dict(os.environ, BIND_LO_MAP="1")
+        self.procs = [subprocess.Popen([os.path.join(REF_DIR, "udp_tatp_server"), str(sid), str(server_threads)], env=env,
+                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for sid in (1, 2, 3)]
+
+    def wait_populated(self, timeout: float = 240.0) -> bool:
+        import select
+
+        for p in self.procs:  # "finish initialization" = populated (server_shard.cc:294)
+            while True:
+                left = timeout - (time.perf_counter() - self.t0)
+                if left <= 0 or not select.select([p.stdout], [], [], left)[0]:
+                    return False
+                line = p.stdout.readline()
+                if not line:
+                    raise RuntimeError(f"reference tatp server exited rc={p.poll()} (port 20230 on 127.0.1.N busy?)")
+                if "finish initialization" in line:
+                    break
+        self.populate_s = round(time.perf_counter() - self.t0, 1)
+        time.sleep(0.5)  # the worker threads bind their sockets
+        return True
+
+    def run(self, streams, client_threads: int = 16, window: int = 32, warmup_s: float = 1.0, measure_s: float = 4.0) -> dict:
+        out = {"servers": []}
+        with tempfile.TemporaryDirectory(prefix="dint_ref_") as td:
+            for sid in (1, 2, 3):
+                np.ascontiguousarray(streams[sid - 1]).tofile(os.path.join(td, f"req{sid}.bin"))
+            cl = [subprocess.Popen([os.path.join(REF_DIR, "udp_loop_client"), os.path.join(td, f"req{sid}.bin"),
+                                    str(streams[sid - 1].dtype.itemsize), "20230", str(client_threads), str(window), str(warmup_s),
+                                    str(measure_s), f"127.0.1.{sid}"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                  for sid in (1, 2, 3)]
+            for c in cl:
+                so, se = c.communicate(timeout=warmup_s + measure_s + 60)
+                if c.returncode != 0:
+                    raise RuntimeError(f"udp_loop_client failed rc={c.returncode}: {se[-300:]}")
+                out["servers"].append(json.loads(so.strip().splitlines()[-1]))
+        if any(p.poll() is not None for p in self.procs):
+            raise RuntimeError("a reference tatp server exited during the run (a request it panics on?)")
+        out["ops_per_s"] = sum(x["ops_per_s"] for x in out["servers"])
+        out["lost"] = sum(x["lost"] for x in out["servers"])
+        out["server_threads"], out["populate_s"] = self.server_threads, self.populate_s
+        return out
+
+    def close(self):
+        for p in self.procs:  # the exact processes started above
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+        self.procs = []
+
+
+def loopback_tatp_available() -> bool:
+    return os.access(os.path.join(REF_DIR, "udp_tatp_server"), os.X_OK) and os.access(os.path.join(REF_DIR, "udp_loop_client"), os.X_OK)
+
+
 # ---------------------------------------------------------------------------- populate-time garbage
 _STORE_GRANT_READ = 3  # store/udp/net.h:22 kGrantRead
 _TATP_GRANT_READ = 4  # tatp/udp/net.h:23 kGrantRead
