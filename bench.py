@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--slots", type=int, default=1 << 20, help="lock_fasst table slots (BASELINE configs[1]: 1M; reference 36000000)")
     ap.add_argument("--theta", type=float, default=None,
                     help="Zipf skew of the key stream (default 0.8; smallbank 0.99); 0 = the reference's own distribution")
-    ap.add_argument("--subscribers", type=int, default=1_000_000, help="tatp subscribers (BASELINE configs[3]: 1M)")
+    ap.add_argument("--subscribers", type=int, default=1_000_000, help="tatp subscribers PER GPU (BASELINE configs[3]: 1M on one GPU)")
     ap.add_argument("--accounts", type=int, default=0,
                     help="smallbank accounts in total over all GPUs (default 10M per GPU: BASELINE configs[4] = 80M on 8)")
     ap.add_argument("--keys", type=int, default=16_777_216, help="store keys (BASELINE configs[2]: 16M)")
@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="tatp: skip the compact legs of the other BASELINE configs (lock_fasst, lock_2pl, log, store, smallbank)")
     ap.add_argument("--no-shim", action="store_true", help="skip the UDP shim loopback leg")
+    ap.add_argument("--no-exchange-leg", action="store_true", help="skip the compact --force-exchange leg of the default line")
     ap.add_argument("--no-as-shipped", action="store_true", help="skip the as-shipped tatp/udp deployment leg (three reference "
                     "server processes, ~27 GB of host memory)")
     ap.add_argument("--sweep-clients", action="store_true",
@@ -997,7 +998,10 @@ def bench_txn(args, world, rank, dev, transport, kind):
     K, W, B = args.steps, args.warmup, args.per_step
     C = args.clients
     if kind == "tatp":
-        wl, n_rows, theta = wire.Workload.TATP, args.subscribers, (0.8 if args.theta is None else args.theta)
+        # weak scaling: every GPU brings its clients AND its subscribers (--subscribers is per GPU), so the contention per
+        # key -- and the load of the hot key's home rank -- does not grow with N (4.2M lock-step clients on
+        # 1M subscribers at 8 GPUs would be neither weak scaling nor BASELINE's configuration)
+        wl, n_rows, theta = wire.Workload.TATP, args.subscribers * world, (0.8 if args.theta is None else args.theta)
         alg_tab, log_types, dtype = TATP_ALG, TATP_LOG_TYPES, "u64"
     else:
         wl, theta = wire.Workload.SMALLBANK, (0.99 if args.theta is None else args.theta)
@@ -1224,7 +1228,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
                 extra["shim_loopback"] = shim_loopback(probe, dev)
     if kind == "tatp":
         dist_name = f"Zipf-{theta}" if zipf else "tatp_nurand (reference)"
-        what = (f"TATP full txn mix (35/35/10/2/14/2/2) on {world} MI355X: {n_rows} subscribers, 3 replicated "
+        what = (f"TATP full txn mix (35/35/10/2/14/2/2) on {world} MI355X: {n_rows} subscribers ({n_rows // world} per GPU), 3 replicated "
                 f"shard servers per GPU group, {C} closed-loop clients per GPU, s_id ~ {dist_name}; "
                 f"1 step = {B} epochs = {3 * B} request batches")
         metric = "Mtxn/s + p50/p99 batch latency, TATP"
@@ -1365,6 +1369,26 @@ def main():
         ow = other_workloads(args, world, rank, dev, transport)
         if out is not None:
             out["other_workloads"] = ow
+    if args.workload == "tatp" and world == 1 and not args.no_exchange_leg and not args.force_exchange:
+        # the multi-GPU machinery on this one GPU (pack -> "all-to-all" = a device copy -> segments -> back -> unpack), compact:
+        # what a rank of an N-GPU run does per epoch besides the engines' passes
+        import copy
+
+        a = copy.copy(args)
+        a.force_exchange, a.compact, a.steps, a.warmup = True, True, 8, 2
+        a.no_rand64 = a.no_closed_loop = a.no_host_path = a.no_cpu_baseline = True
+        try:
+            r = run_workload(a, world, rank, dev, transport)
+            ex = {k: r.get(k) for k in ("value", "unit", "ms_per_step", "ms_per_epoch", "host_issue_ms_per_step", "route_overflow",
+                                        "latency_us", "replay_equals_recorded")}
+            ex["what"] = "--force-exchange on one GPU: the routing kernels and both exchange legs (device copies) around the same passes"
+            if out is not None and out.get("value"):
+                ex["ratio_to_value"] = round(r["value"] / out["value"], 3)
+        except Exception as e_:
+            ex = {"error": f"{type(e_).__name__}: {e_}"}
+        gc.collect()
+        if out is not None:
+            out["exchange"] = ex
     bad = []
     if rank == 0:
         bad = parity_failures(out)

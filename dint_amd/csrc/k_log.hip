@@ -8,7 +8,7 @@
 // -- an exclusive scan over the batch, so ring contents are deterministic and identical to the
 // serial order (an atomicAdd per request would give an arbitrary order).  One launch per pass of up to 2^20 requests
 // (never more than the ring holds, so a pass does not lap it):
-//   k_log_append : 1024 requests per 1024-thread workgroup, tiles handed out by ticket.  The tile's 53-byte messages come
+//   k_log_append : 1024 (256 for small passes) requests per workgroup of as many threads, tiles handed out by ticket.  The tile's 53-byte messages come
 //                  in as 16-byte vectors, whole lines, through LDS (a thread reading its own packed struct from HBM
 //                  touches two sectors for 53 bytes and shares each with its neighbours' loads); every thread takes its
 //                  message out of LDS, the tile publishes its count of valid requests at once and reads the counts of
@@ -23,19 +23,23 @@
 // own work is done.)
 #include "dint_kernels.h"
 
-#define LOG_TB 1024u
 #define LOG_MSG 53u  // log_server/udp/net.h:23-30: {u8 type; u64 key; u8 val[40]; u32 ver}, packed
-#define LOG_TILE_VEC (LOG_TB * LOG_MSG / 16u)  // 3392 16-byte vectors per full tile
-static_assert(LOG_TB * LOG_MSG % 16u == 0, "tiles start on a 16-byte boundary");
+// requests per workgroup (= threads): 1024 for the passes that fill the GPU anyway, 256 for the small ones -- a 64k-request
+// batch is 64 tiles of 1024, a quarter of the CUs; as 256 tiles of 256 it reaches all of them (17 -> ~10 us per batch)
+#define LOG_TB_BIG 1024u
+#define LOG_TB_SMALL 256u
+#define LOG_SMALL_MAX (LOG_TB_SMALL * 1024u)  // a tile's look-back reads at most 1024 counts
 
 __device__ static inline uint32_t lds_u32(const uint8_t *p) {  // (packed: byte-aligned in LDS)
   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
 // pub: [0, 1024) valid requests per tile (bit 31 = published), [1024] tiles handed out, [1025] tiles finished
+template <uint32_t LOG_TB>
 __global__ void __launch_bounds__(LOG_TB)
 k_log_append(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, uint32_t n_tiles, dint_log log, uint32_t *pub,
              uint32_t *__restrict__ pub_next, dint_dev_stats *__restrict__ stats) {
+  static_assert(LOG_TB * LOG_MSG % 16u == 0, "tiles start on a 16-byte boundary");
   __shared__ __attribute__((aligned(16))) uint8_t Sm[LOG_TB * LOG_MSG];
   __shared__ uint32_t Stile, Swc[LOG_TB / 64], Swp[LOG_TB / 64];
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -74,10 +78,10 @@ k_log_append(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, uint32_t
   if (valid) Sm[t * LOG_MSG] = 1;  // kAck
   // ---- the tiles before mine (they were handed out earlier, so they run or are done): one count per thread
   uint32_t part = 0;
-  if (t < tile) {
+  for (uint32_t k = t; k < tile; k += LOG_TB) {
     uint32_t v;
-    do { v = __hip_atomic_load(&pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 31));
-    part = v & 0x7FFFFFFFu;
+    do { v = __hip_atomic_load(&pub[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (!(v >> 31));
+    part += v & 0x7FFFFFFFu;
   }
   uint32_t tot;
   wave_excl_scan_u32(part, &tot);
@@ -111,9 +115,15 @@ k_log_append(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, uint32_t
 void dint_launch_log(const void *d_req, void *d_rep, uint32_t n, dint_log log, dint_scratch s, hipStream_t st,
                      hipEvent_t *ev) {
   if (n == 0) return;
-  const uint32_t nt = (n + LOG_TB - 1) / LOG_TB;  // <= 1024 tiles for n <= 2^20
   if (ev) hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_log_append, dim3(nt), dim3(LOG_TB), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, nt, log,
-                     s.blk_pub, s.blk_pub_next, s.stats);
+  if (n <= LOG_SMALL_MAX) {
+    const uint32_t nt = (n + LOG_TB_SMALL - 1) / LOG_TB_SMALL;  // <= 1024 tiles
+    hipLaunchKernelGGL((k_log_append<LOG_TB_SMALL>), dim3(nt), dim3(LOG_TB_SMALL), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, nt,
+                       log, s.blk_pub, s.blk_pub_next, s.stats);
+  } else {
+    const uint32_t nt = (n + LOG_TB_BIG - 1) / LOG_TB_BIG;  // <= 1024 tiles for n <= 2^20
+    hipLaunchKernelGGL((k_log_append<LOG_TB_BIG>), dim3(nt), dim3(LOG_TB_BIG), 0, st, (const uint8_t *)d_req, (uint8_t *)d_rep, n, nt,
+                       log, s.blk_pub, s.blk_pub_next, s.stats);
+  }
   if (ev) hipEventRecord(ev[1], st);
 }

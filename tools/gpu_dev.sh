@@ -21,7 +21,7 @@ if has pass; then
     echo "== exp_pass $a: work"; timeout 300 python tools/exp_pass.py $a 2>&1 | tail -1
   done
 fi
-ARGS="--no-cpu-baseline --no-rand64 --no-host-path --no-closed-loop --no-other-workloads --no-shim"
+ARGS="--no-cpu-baseline --no-rand64 --no-host-path --no-closed-loop --no-other-workloads --no-shim --no-exchange-leg --no-as-shipped"
 if has ab; then
   for i in 1 2; do
     echo "== tatp base #$i"; (cd gpurun_tmp/base && timeout 300 python bench.py $ARGS 2>/dev/null | python -c "$P")

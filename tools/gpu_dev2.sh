@@ -10,7 +10,7 @@ echo "== kv + lock tests"; timeout 900 python -m pytest tests/test_gpu_kv.py tes
 for th in 0.8; do
   echo "== plain theta $th"; timeout 300 python tools/exp_pass.py 524288 $th 2>&1 | tail -1
 done
-ARGS="--no-cpu-baseline --no-rand64 --no-host-path --no-closed-loop --no-other-workloads --no-shim"
+ARGS="--no-cpu-baseline --no-rand64 --no-host-path --no-closed-loop --no-other-workloads --no-shim --no-exchange-leg --no-as-shipped"
 for i in 1 2; do
 echo "== tatp base"; (cd gpurun_tmp/base && timeout 300 python bench.py $ARGS 2>/dev/null | python -c "$P")
 echo "== tatp work"; timeout 300 python bench.py $ARGS 2>gpurun_out/dev/e1 | python -c "$P" || tail -5 gpurun_out/dev/e1

@@ -35,13 +35,13 @@ fi
 if has bench; then
   echo "== bench (default line, as the driver runs it)"; timeout 900 python bench.py > "$OUT/bench_tatp.json" 2> "$OUT/bench_tatp.err"; line "$OUT/bench_tatp.json"
   for w in fasst 2pl log store smallbank; do
-    echo "== bench $w"; timeout 900 python bench.py --workload $w --no-other-workloads --no-shim > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; line "$OUT/bench_$w.json"
+    echo "== bench $w"; timeout 900 python bench.py --workload $w --no-other-workloads --no-shim --no-exchange-leg --no-as-shipped > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; line "$OUT/bench_$w.json"
   done
 fi
 if has extra; then
   echo "== driver-style"; timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_tatp_driver_style.json" 2> /dev/null; line "$OUT/bench_tatp_driver_style.json"
-  echo "== nurand"; timeout 600 python bench.py --theta 0 --no-other-workloads --no-shim --no-cpu-baseline > "$OUT/bench_tatp_nurand.json" 2>/dev/null; line "$OUT/bench_tatp_nurand.json"
-  echo "== force-exchange"; timeout 600 python bench.py --force-exchange --no-cpu-baseline --no-rand64 --no-other-workloads --no-shim > "$OUT/bench_tatp_force_exchange.json" 2>/dev/null; line "$OUT/bench_tatp_force_exchange.json"
-  echo "== client sweep"; timeout 900 python bench.py --sweep-clients --no-other-workloads --no-shim --no-cpu-baseline > "$OUT/bench_tatp_sweep_clients.json" 2>/dev/null; line "$OUT/bench_tatp_sweep_clients.json"
+  echo "== nurand"; timeout 600 python bench.py --theta 0 --no-other-workloads --no-shim --no-exchange-leg --no-as-shipped --no-cpu-baseline > "$OUT/bench_tatp_nurand.json" 2>/dev/null; line "$OUT/bench_tatp_nurand.json"
+  echo "== force-exchange"; timeout 600 python bench.py --force-exchange --no-cpu-baseline --no-rand64 --no-other-workloads --no-shim --no-exchange-leg --no-as-shipped > "$OUT/bench_tatp_force_exchange.json" 2>/dev/null; line "$OUT/bench_tatp_force_exchange.json"
+  echo "== client sweep"; timeout 900 python bench.py --sweep-clients --no-other-workloads --no-shim --no-exchange-leg --no-as-shipped --no-cpu-baseline > "$OUT/bench_tatp_sweep_clients.json" 2>/dev/null; line "$OUT/bench_tatp_sweep_clients.json"
 fi
 du -sh gpurun_out
