@@ -30,6 +30,7 @@ struct dint_scratch {
   uint32_t *bin_off;   // [DINT_KV_PMAX] start of a big bin's records DINT_KV_BINCAP.. in `ovf`
   uint4 *ovl;          // [pass_max] overflow records as counted: {record lo, record hi, bin, position in bin}
   uint64_t *ovf;       // [pass_max] overflow records grouped by bin
+  uint64_t *ovf2;      // [pass_max] kv: a big sub's records again, grouped by stretch (kv_big_bin's one-time partition)
   // ---- kv workloads (k_kv.hip): the coarse bins of the two-level partition; their overflow list is `ovl` with two
   // uint4 per entry, the 8-byte records of the big subs go to `ovf`
   uint4 *kbins = nullptr;          // [C][cap] 16-byte records {key, group / C | idx | payload}

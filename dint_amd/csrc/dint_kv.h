@@ -71,9 +71,10 @@ dint_kv_fmt dint_kv_format(uint32_t workload);
 // ---- multi-GPU routing (k_route.hip) --------------------------------------------------------------------------
 #define DINT_ROUTE_MAXW 64u        // ranks a batch can be routed to
 #define DINT_ROUTE_MAXN 1048576u   // requests per dint_route_pack call
+#define DINT_ROUTE_BLK_WORDS (1024u * DINT_ROUTE_MAXW + 64u)  // one copy of the pack kernel's scratch
 struct dint_route_scratch {
-  uint8_t *home;   // [DINT_ROUTE_MAXN] home rank of each request
-  uint32_t *blk;   // [4096][world] requests per destination and 256-request block, then their exclusive scan
+  uint32_t *blk;       // [1024 tiles][world] requests per tile and destination, then {ticket, words published}: all zero between calls
+  uint32_t *blk_next;  // the copy the NEXT call uses (this call zeroes it; the engine swaps the two after every call)
 };
 // stable partition of n contiguous requests by home rank into `shard.count` slots of `cap` messages, slot w at
 // d_send + w * stride, its live count (u32) at d_cnt + w * cnt_stride; d_slot[i] = home * cap + position (or ~0u)

@@ -82,7 +82,7 @@ struct dint_engine {
   // first waits for it (dint_submit_device with a caller stream)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev_order = nullptr;
-  // ... the routing kernels have scratch of their own (route.home / route.blk) and touch neither tables nor pass
+  // ... the routing kernels have scratch of their own (route.blk) and touch neither tables nor pass
   // scratch: they are ordered among themselves only, so a pack for the next step overlaps the pass of this one
   hipStream_t route_last_stream = nullptr;
   hipEvent_t ev_route_order = nullptr;
@@ -294,7 +294,11 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     return fail(DINT_EINVAL, "shard %u of %u", cfg->shard_index, cfg->shard_count);
   }
   // (the copy streams of the host path exist only with DINT_FLAG_COPY_STREAMS, and are created on first use)
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+  // (a high-priority engine stream beside the wide routing kernels of a sharded step was measured: --force-exchange 1,310 ->
+  // 804 Mtxn/s; DINT_ENGINE_PRIORITY keeps the knob)
+  const char *pe = getenv("DINT_ENGINE_PRIORITY");
+  const int prio = pe ? atoi(pe) : 0;
+  if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio) != hipSuccess ||
       hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) != hipSuccess) {
     dint_engine_destroy(e);
     return fail(DINT_EHIP, "hipStreamCreate");
@@ -328,6 +332,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4) * (is_kv ? 2 : 1), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
+    if (is_kv) TRY(dev_alloc((void **)&e->scratch.ovf2, (size_t)e->pass_max * sizeof(uint64_t), false));
     if ((e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL) && getenv("DINT_KV_TRACE")) {
       TRY(dev_alloc((void **)&e->kv.d_trace, (size_t)DINT_KV_TRACE_WORDS * 8, true));
       e->scratch.lock_trace = e->kv.d_trace;
@@ -393,6 +398,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bin_off);
   hipFree(e->scratch.ovl);
   hipFree(e->scratch.ovf);
+  hipFree(e->scratch.ovf2);
   if (e->scratch.lock_trace) { hipFree(e->scratch.lock_trace); e->kv.d_trace = nullptr; }
   for (auto &sl : e->slot) {
     hipFree(sl.d_req);
@@ -401,8 +407,7 @@ void dint_engine_destroy(dint_engine_t *e) {
     if (sl.comp) hipEventDestroy(sl.comp);
     if (sl.done) hipEventDestroy(sl.done);
   }
-  hipFree(e->route.home);
-  hipFree(e->route.blk);
+  hipFree(std::min(e->route.blk, e->route.blk_next));
   if (e->h_pinned) hipHostFree(e->h_pinned);
   if (e->h_pool) hipHostFree(e->h_pool);
   if (e->ev_order) hipEventDestroy(e->ev_order);
@@ -616,9 +621,9 @@ int route_job(const dint_route_item &it, bool pack, uint64_t cnt_stride, hipStre
   HIP_TRY(hipSetDevice(e->device));
   if (!st) st = stream ? (hipStream_t)stream : e->stream;
   if (pack) {
-    if (!e->route.home) {
-      if (int rc = dev_alloc((void **)&e->route.home, DINT_ROUTE_MAXN, false)) return rc;
-      if (int rc = dev_alloc((void **)&e->route.blk, (size_t)(DINT_ROUTE_MAXN / 256) * DINT_ROUTE_MAXW * 4)) return rc;
+    if (!e->route.blk) {
+      if (int rc = dev_alloc((void **)&e->route.blk, (size_t)2 * DINT_ROUTE_BLK_WORDS * 4)) return rc;
+      e->route.blk_next = e->route.blk + DINT_ROUTE_BLK_WORDS;
       HIP_TRY(hipDeviceSynchronize());  // the zero-fill ran on the null stream, which a caller's non-blocking stream does not wait for
     }
     if (int rc = order_route_stream(e, st)) return rc;  // the routing scratch is per engine, and only the routing kernels use it
@@ -663,13 +668,17 @@ int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64
   hipStream_t st = nullptr;
   std::vector<std::unique_lock<std::mutex>> locks;
   if (int rc = lock_engines(items, n_items, locks)) return rc;  // held across the launch: two threads packing with
+  if (locks.size() != n_items) return fail(DINT_EINVAL, "an engine routes one batch per call (its routing scratch is one batch's)");
   for (uint32_t k = 0; k < n_items; k++)                        // one engine launch in the order order_route_stream recorded
     if (int rc = route_job(items[k], true, cnt_stride, st, stream, &jobs[k])) return rc;
   dint_launch_route_pack(jobs, n_items, seg_stride, st);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
-  for (uint32_t k = 0; k < n_items; k++)
-    if (int rc = mark_route_stream(items[k].engine, st)) return rc;
+  for (uint32_t k = 0; k < n_items; k++) {
+    dint_engine *e = items[k].engine;
+    std::swap(e->route.blk, e->route.blk_next);  // the launch left the other copy of the scratch zeroed for the next call
+    if (int rc = mark_route_stream(e, st)) return rc;
+  }
   return 0;
 }
 

@@ -190,6 +190,7 @@ struct kv_pass_args {
   uint32_t *blk_pub, *blk_pub_next;
   uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
   uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
+  uint64_t *ovf2;        // ... and the same ranges again: a sub of several stretches is regrouped by stretch once
   uint4 *bigq;           // the pass's big subs {bin, offset in ovf, records, -} for k_kv_big; big[3] = how many
   dint_dev_stats *stats;
   int load_mode, force_flags;
@@ -958,6 +959,10 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 
 
 // ---- LDS of the big path: one struct, so that the coarse-bin split (kvr_lds) can share the buffer ---------------------
+// the index-bitmap ordering of a one- or two-key stretch (kv_big_bin): bitmap words, their popcount table, the ordered copy
+constexpr uint32_t KVB_BM_W = 4096, KVB_BM_OT = 1024, KVB_BM_MIN = 1024;
+constexpr uint32_t KVB_BM_BYTES = KVB_BM_W * 8 + KVB_BM_W * 2 + KVB_NMAX * 8;
+
 struct kvb_lds {
   uint64_t Sk[KVB_NMAX];           // the stretch: group / P | key-hash bits | idx | type, quadrant
   uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
@@ -971,6 +976,7 @@ struct kvb_lds {
   __attribute__((aligned(8))) uint8_t CarryCrow[KVB_T * (sizeof(kv_rowst) > sizeof(kvb_carry) ? sizeof(kv_rowst) : sizeof(kvb_carry))];
   uint16_t HeadPos[KVB_T];         // sorted position of each segment's head
   uint32_t Sany, Swn;
+  uint32_t Wst[KVB_T + 1], Wcur[KVB_T];  // a sub of several stretches: where each stretch's records start in the regrouped copy
   uint32_t Sred[KVB_W];
   uint32_t Hs[16];                 // dominant-key path: candidate counts, flags, the row's location
   int Hc[2][KVB_W];                // ... wave carries of its prefix tables
@@ -995,7 +1001,8 @@ struct kvb_lds {
 template <int WL>
 __device__ __forceinline__ static void
 kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_t bin, const uint64_t *__restrict__ recs,
-           uint32_t c, dint_dev_stats *__restrict__ stats, int force_flags, const dint_view V, uint8_t *lds_raw) {
+           uint64_t *__restrict__ recs2, uint32_t c, dint_dev_stats *__restrict__ stats, int force_flags, const dint_view V, uint8_t *lds_raw,
+           uint8_t *lds_bm, uint64_t *wtr) {
   using F = Fmt<WL>;
   const int force_rounds = force_flags & 1, no_hot = force_flags & 2;
   const uint32_t hot_min = (uint32_t)force_flags >> 8 ? (uint32_t)force_flags >> 8 : KVB_HOT_MIN;
@@ -1007,12 +1014,15 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
   auto &Ehead = LB.Ehead; auto &Ebh = LB.Ebh; auto &Ewr = LB.Ewr; auto &Elk = LB.Elk;
   auto &Mbail = LB.Mbail; auto &Lead = LB.Lead; auto &CarryCrow = LB.CarryCrow; auto &HeadPos = LB.HeadPos; auto &Phead = LB.Phead;
   auto &Sany = LB.Sany; auto &Swn = LB.Swn; auto &Sred = LB.Sred; auto &Hs = LB.Hs; auto &Hc = LB.Hc;
+  auto &Wst = LB.Wst; auto &Wcur = LB.Wcur;
   // smallbank walks its counters through Carry[segment], store / tatp the row machine of segments with an INSERT /
   // DELETE through Crow[segment]: never both in one instantiation, so they share one buffer
   kvb_carry *Carry = (kvb_carry *)CarryCrow;
   kv_rowst *Crow = (kv_rowst *)CarryCrow;
-  uint64_t *const trace = nullptr;  // (the per-phase stamps of r02 / r03 tuning runs: compiled out)
-  const uint32_t bi = 0, first = 0;
+  // DINT_KV_TRACE: phase stamps of one stretch (the second of a sub cut into several -- the first one pays the cold misses)
+  // into the workgroup's trace words: [4] stretch in, [5] gathered, [6] in order, [7] heads / op classes, [8] keys
+  // checked, [9] masks, [10] rows located and lock grants walked, [11] tiles, [12] written back, [13] out (after the rounds)
+#define KVB_STAMP(k) do { if (wtr && t == 0 && win == stamp_win) wtr[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // idx buckets for the stretches of a bin with more than KVB_NMAX records: 2^bs requests per bucket, <= KVB_NBK buckets
   const uint32_t nbits = n > 1 ? 32u - (uint32_t)__clz(n - 1) : 0u, bs = nbits > 11 ? nbits - 11 : 0u;
@@ -1044,10 +1054,10 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     return kind;
   };
   __syncthreads();  // the LDS buffer is free (the chunk path, or the previous big sub, is done with it)
-  uint64_t *const tr = nullptr;
   auto rec_at = [&](uint32_t k) -> uint64_t { return recs[k]; };
 
   uint32_t nwin = 1;
+  bool regrouped = false;
   if (c > KVB_NMAX) {
     for (uint32_t w = t; w < KVB_NBK / 2; w += KVB_T) Bcnt[w] = 0;
     __syncthreads();
@@ -1067,18 +1077,59 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     if (lane == 0) Sred[wave] = tot;
     __syncthreads();
     for (uint32_t w = 0; w < wave; w++) base += Sred[w];
+    nwin = (c - 1) / wcap + 1;  // upper bound: the last one may be empty
+    // a sub of three stretches or more is regrouped by stretch ONCE (recs2): each stretch then reads its own ~4,000
+    // records instead of looking through all of them (r03: 13 us per stretch of smallbank's 35,000-request account)
+    regrouped = recs2 != nullptr && nwin >= 3 && nwin <= KVB_T;
+    if (regrouped) {
+      for (uint32_t w = t; w <= KVB_T; w += KVB_T) Wst[w] = c;
+      Wst[t] = c; Wcur[t] = 0;
+    }
+    __syncthreads();
+    uint32_t prevcnt = t ? Bcnt[2 * t - 1] >> 16 : 0u;
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) {
-      Bwin[4 * t + j] = (uint16_t)(base / wcap);
-      base += (cw[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
+      const uint32_t wb = base / wcap, cntb = (cw[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
+      Bwin[4 * t + j] = (uint16_t)wb;
+      if (regrouped && (4 * t + j == 0 || (base - prevcnt) / wcap != wb)) Wst[wb] = base;  // the stretch's first bucket
+      prevcnt = cntb;
+      base += cntb;
     }
-    nwin = (c - 1) / wcap + 1;  // upper bound: the last one may be empty
+    __syncthreads();
+    if (regrouped) {
+      for (uint32_t k0 = 0; k0 < c; k0 += 4 * KVB_T) {
+        uint64_t r4[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+          const uint32_t k = k0 + j * KVB_T + t;
+          r4[j] = k < c ? rec_at(k) : 0;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+          const uint32_t k = k0 + j * KVB_T + t;
+          const uint32_t w = k < c ? Bwin[kv_rec_idx(r4[j], cut) >> bs] : 0xFFFFFFFFu;
+          for (uint64_t todo = __ballot(k < c); todo;) {  // one LDS atomic per wave and stretch (records arrive nearly in request order)
+            const int l = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+            const uint64_t mm = __ballot(w == w0);
+            uint32_t at = 0;
+            if ((int)lane == l) at = atomicAdd(&Wcur[w0], (uint32_t)__popcll(mm));
+            at = (uint32_t)__builtin_amdgcn_readlane((int)at, l);
+            if (w == w0) recs2[Wst[w0] + at + (uint32_t)__popcll(mm & lanemask_lt())] = r4[j];
+            todo &= ~mm;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
   }
   __syncthreads();
 
+  const uint32_t stamp_win = nwin > 1 ? 1u : 0u;
   for (uint32_t win = 0; win < nwin; win++) {
     if (t == 0) Swn = 0;
     __syncthreads();
+    KVB_STAMP(4);
     // ---- gather the stretch (any order) as sort keys
     auto sort_key = [&](uint64_t r) -> uint64_t {
       return kv_sort_key(r, cut);
@@ -1086,6 +1137,15 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     if (c <= KVB_NMAX) {  // the whole bin
       for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = sort_key(rec_at(k));
       if (t == 0) Swn = c;
+    } else if (regrouped) {
+      const uint32_t a = Wst[win], b = max(a, Wst[win + 1]);  // (an empty stretch between two others keeps the end mark c)
+      uint64_t r8[KVB_NMAX / KVB_T];  // (all loads first: a loop of load / LDS store pairs waits for every load on its own)
+#pragma unroll
+      for (uint32_t j = 0; j < KVB_NMAX / KVB_T; j++) r8[j] = a + j * KVB_T + t < b ? recs2[a + j * KVB_T + t] : 0;
+#pragma unroll
+      for (uint32_t j = 0; j < KVB_NMAX / KVB_T; j++)
+        if (a + j * KVB_T + t < b) Sk[j * KVB_T + t] = sort_key(r8[j]);
+      if (t == 0) Swn = b - a;
     } else {
       for (uint32_t k0 = 0; k0 < c; k0 += 4 * KVB_T) {  // four records per thread in flight; one slot reservation per wave and step
         uint64_t r4[4];
@@ -1110,6 +1170,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     __syncthreads();
     uint32_t m = Swn;
     __syncthreads();  // Swn is reset at the top of the next stretch
+    KVB_STAMP(5);
     if (m == 0) continue;  // workgroup-uniform
     bool tiny = m <= 64;  // what one wave resolves in registers (kv_chunk): below, also for what a dominant key leaves behind
     if (!tiny) {
@@ -1364,9 +1425,159 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
       __syncthreads();
       continue;
     }
-    kvb_sort_stretch(Sk, m);
+    // ---- a stretch that is (nearly) one or two keys -- smallbank's hot account, its savings and its checking row -- is put
+    // in order WITHOUT the LDS sort (40 us for 4,096 words, five stretches a pass: the largest part of the hot pass in
+    // r03).  Request indices are distinct, so the sorted position of a record among those of its key is the number of
+    // set bits below its own in a bitmap over the stretch's index span: one LDS atomic to set the bit, one popcount
+    // table, one popcount.  The few records of other keys are sorted on their own (<= 1,024) and the runs spliced by
+    // comparing key prefixes.  Falls through to the sort when the span or the other keys do not fit.
+    bool ordered = false;
+    if (WL == DINT_WL_SMALLBANK && lds_bm != nullptr && !(force_flags & 4) && m >= KVB_BM_MIN) {  // (store / tatp: the dominant-key path above)
+      uint64_t *Bm = (uint64_t *)lds_bm;              // [KVB_BM_W] bit (idx - lo) of the class in hand
+      uint16_t *Wp = (uint16_t *)(Bm + KVB_BM_W);      // [KVB_BM_W] bits set below each word
+      uint64_t *Sk2 = (uint64_t *)(Wp + KVB_BM_W);     // [KVB_NMAX] the stretch in order
+      uint64_t *Ot = (uint64_t *)Lead;                 // [KVB_BM_OT] records of other keys
+      static_assert(sizeof(LB.Lead) >= KVB_BM_OT * 8, "the other keys' list lives where the segment leaders will");
+      uint64_t cand[8];
+      uint32_t cc[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) { cand[k] = Sk[(uint32_t)(((uint64_t)m * k) >> 3)] >> sh_k; cc[k] = 0; }
+      if (t < 16) Hs[t] = 0;
+      __syncthreads();
+      for (uint32_t p = t; p < m; p += KVB_T) {
+        const uint64_t pfx = Sk[p] >> sh_k;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) cc[k] += pfx == cand[k];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) {
+        uint32_t v = cc[k];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0 && v) atomicAdd(&Hs[k], v);
+      }
+      __syncthreads();
+      uint32_t b0 = 0, b1 = 8;
+#pragma unroll
+      for (uint32_t k = 1; k < 8; k++) b0 = Hs[k] > Hs[b0] ? k : b0;
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++)
+        if (cand[k] != cand[b0] && (b1 == 8 || Hs[k] > Hs[b1])) b1 = k;
+      const uint64_t pf0 = cand[b0];
+      const uint32_t n0 = Hs[b0];
+      uint32_t n1 = b1 < 8 ? Hs[b1] : 0;
+      if (8 * n1 < m) n1 = 0;  // a second class only when it is worth a bitmap of its own
+      const uint64_t pf1 = n1 ? cand[b1] : ~0ull;  // (no prefix equals ~0: sh_k > 0)
+      const uint32_t m_o = m - n0 - n1;
+      __syncthreads();
+      if (m_o <= KVB_BM_OT) {  // workgroup-uniform
+        if (t < 16) Hs[t] = (t == 0 || t == 2) ? 0xFFFFFFFFu : 0u;  // lo0 hi0 lo1 hi1 | others placed, below pf0, below pf1
+        for (uint32_t k = t; k < KVB_BM_OT; k += KVB_T) Ot[k] = ~0ull;
+        __syncthreads();
+        uint32_t lo0 = 0xFFFFFFFFu, hi0 = 0, lo1 = 0xFFFFFFFFu, hi1 = 0, l0 = 0, l1 = 0;
+        for (uint32_t p0 = 0; p0 < m; p0 += KVB_T) {
+          const uint32_t p = p0 + t;
+          const uint64_t cur = p < m ? Sk[p] : 0;
+          const uint64_t pfx = cur >> sh_k;
+          const uint32_t idx = k_idx(cur);
+          const bool c0 = p < m && pfx == pf0, c1 = p < m && pfx == pf1, oth = p < m && !c0 && !c1;
+          if (c0) { lo0 = min(lo0, idx); hi0 = max(hi0, idx); }
+          if (c1) { lo1 = min(lo1, idx); hi1 = max(hi1, idx); }
+          const uint64_t om = __ballot(oth);
+          uint32_t base = 0;
+          if (lane == 0 && om) base = atomicAdd(&Hs[4], (uint32_t)__popcll(om));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (oth) {
+            Ot[base + (uint32_t)__popcll(om & lanemask_lt())] = cur;
+            l0 += pfx < pf0;
+            l1 += pfx < pf1;
+          }
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+          lo0 = min(lo0, (uint32_t)__shfl_xor(lo0, d, 64)); hi0 = max(hi0, (uint32_t)__shfl_xor(hi0, d, 64));
+          lo1 = min(lo1, (uint32_t)__shfl_xor(lo1, d, 64)); hi1 = max(hi1, (uint32_t)__shfl_xor(hi1, d, 64));
+          l0 += __shfl_xor(l0, d, 64); l1 += __shfl_xor(l1, d, 64);
+        }
+        if (lane == 0) {
+          atomicMin(&Hs[0], lo0); atomicMax(&Hs[1], hi0); atomicMin(&Hs[2], lo1); atomicMax(&Hs[3], hi1);
+          if (l0) atomicAdd(&Hs[5], l0);
+          if (l1) atomicAdd(&Hs[6], l1);
+        }
+        __syncthreads();
+        const uint32_t glo0 = Hs[0], glo1 = Hs[2];
+        const uint32_t span0 = n0 ? Hs[1] - glo0 + 1 : 0, span1 = n1 ? Hs[3] - glo1 + 1 : 0;
+        const uint32_t less0 = Hs[5], less1 = Hs[6];
+        __syncthreads();
+        if (span0 <= KVB_BM_W * 64 && span1 <= KVB_BM_W * 64) {  // workgroup-uniform
+          if (m_o > KVB_T) kvb_sort_blocked<2>(Ot, KVB_BM_OT);
+          else if (m_o > 64) kvb_sort_blocked<1>(Ot, KVB_T);
+          else if (m_o > 1) {  // a handful of neighbours of the hot account: one wave, in registers
+            if (wave == 0) Ot[lane] = wave_sort_u64(Ot[lane]);
+            __syncthreads();
+          }
+#pragma unroll 1
+          for (uint32_t cls = 0; cls < 2; cls++) {
+            const uint32_t nk = cls ? n1 : n0;
+            if (nk == 0) continue;
+            const uint64_t pfc = cls ? pf1 : pf0;
+            const uint32_t glo = cls ? glo1 : glo0, nw = ((cls ? span1 : span0) + 63) >> 6;
+            // where the class starts: the other class and the other keys that sort below it
+            const uint32_t cbase = (cls ? (pf0 < pf1 ? n0 : 0u) : (pf1 < pf0 ? n1 : 0u)) + (cls ? less1 : less0);
+            for (uint32_t w = t; w < nw; w += KVB_T) Bm[w] = 0;
+            __syncthreads();
+            for (uint32_t p = t; p < m; p += KVB_T) {
+              const uint64_t cur = Sk[p];
+              if ((cur >> sh_k) == pfc) {
+                const uint32_t b = k_idx(cur) - glo;
+                atomicOr((unsigned long long *)&Bm[b >> 6], 1ull << (b & 63));
+              }
+            }
+            __syncthreads();
+            {  // bits below each word: thread t owns words 8t .. 8t + 7
+              uint32_t pc[8], run = 0;
+#pragma unroll
+              for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t w = 8 * t + j;
+                pc[j] = w < nw ? (uint32_t)__popcll(Bm[w]) : 0u;
+                run += pc[j];
+              }
+              uint32_t tot, base = wave_excl_scan_u32(run, &tot);
+              if (lane == 0) Sred[wave] = tot;
+              __syncthreads();
+              for (uint32_t w = 0; w < wave; w++) base += Sred[w];
+#pragma unroll
+              for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t w = 8 * t + j;
+                if (w < nw) Wp[w] = (uint16_t)base;
+                base += pc[j];
+              }
+            }
+            __syncthreads();
+            for (uint32_t p = t; p < m; p += KVB_T) {
+              const uint64_t cur = Sk[p];
+              if ((cur >> sh_k) == pfc) {
+                const uint32_t b = k_idx(cur) - glo;
+                Sk2[cbase + Wp[b >> 6] + (uint32_t)__popcll(Bm[b >> 6] & ((1ull << (b & 63)) - 1ull))] = cur;
+              }
+            }
+            __syncthreads();
+          }
+          for (uint32_t j = t; j < m_o; j += KVB_T) {
+            const uint64_t o = Ot[j];
+            const uint64_t pfx = o >> sh_k;
+            Sk2[j + (pf0 < pfx ? n0 : 0u) + (pf1 < pfx ? n1 : 0u)] = o;
+          }
+          __syncthreads();
+          uint32_t N = 64;
+          while (N < m) N <<= 1;
+          for (uint32_t k = t; k < max(N, KVB_T); k += KVB_T) Sk[k] = k < m ? Sk2[k] : ~0ull;  // (as the sort leaves it)
+          __syncthreads();
+          ordered = true;
+        }
+      }
+    }
+    if (!ordered) kvb_sort_stretch(Sk, m);
     const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    KVB_STAMP(6);
 
     // ---- pass A: segment heads (key hash changes), bucket-run heads (group changes), op classes
     for (uint32_t j = 0; j < ntile; j++) {
@@ -1394,7 +1605,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     if (wave == 4) kvb_build_pop(Mhead, Phead);
     __syncthreads();
     const uint32_t nseg = Phead.below[KVB_NW];
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 4] = __builtin_amdgcn_s_memrealtime();
+    KVB_STAMP(7);
     // ---- pass B: a segment must be one key (9 hash bits can collide) and carry only ops the closed form knows;
     // list the segment heads
     for (uint32_t j = 0; j < ntile; j++) {
@@ -1413,7 +1624,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     }
     __syncthreads();
     if (wave == 0) kvb_build_pop(Mbad, Pbad);
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+    KVB_STAMP(8);
     // ---- pass C, one thread per key segment: segments that carry lock ops, per lock quadrant (smallbank: two on one
     // lock word make the bucket run non-simple); segments that insert / delete
     const bool closed = !force_rounds && nseg <= KVB_T;  // else: every request of the stretch runs on its own, in rounds
@@ -1464,7 +1675,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     if (wave == 1) kvb_build_edge(Mwr, Ewr);
     if (wave == 2) kvb_build_edge(Mlk, Elk);
     __syncthreads();
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+    KVB_STAMP(9);
 
     // ---- leaders: one thread per simple key segment loads the bucket's inline header (+ smallbank counters) and
     // locates the row; every segment of the stretch at once
@@ -1608,7 +1819,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     // ---- tiles: outcomes and replies of the simple segments, 512 requests at a time.  Nothing a tile reads from
     // the table is written before the last tile is done, so the tiles' loads and stores stream back to back.
     const bool walks = WL != DINT_WL_SMALLBANK && Sany;  // workgroup-uniform
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+    KVB_STAMP(10);
     struct kvb_out { uint8_t *msg; const uint8_t *from; uint32_t ver, code; bool simple, get; };
     auto outcome = [&](uint32_t j, kvb_out &o) {  // tile j: what each request answers, and where a read finds its value
       const uint32_t lo = j * KVB_T, hi = min(lo + KVB_T, m), p = lo + t;
@@ -1761,7 +1972,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();  // every table read of the stretch precedes the write-backs
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 8] = __builtin_amdgcn_s_memrealtime();
+    KVB_STAMP(11);
 
     // ---- write-back: one thread per simple key segment
     if (mine) {
@@ -1861,7 +2072,11 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
       if (WL == DINT_WL_TATP && type == 2) return 2u;
       return 3u;
     };
-    if (tr && t == 0 && win == 0 && bi == first) trace[(size_t)DINT_KV_PMAX * 16 + 16 * blockIdx.x + 9] = __builtin_amdgcn_s_memrealtime();
+    KVB_STAMP(12);
+    bool ns = false;  // anything left for the rounds? (a hot account's stretch: nothing)
+    for (uint32_t j = 0; j < ntile; j++) ns |= j * KVB_T + t < m && !kvb_bit(Msimple, j * KVB_T + t);
+    uint32_t nrounds = 0;
+    if (__syncthreads_or((int)ns)) {
     for (uint32_t k = t; k < KVB_RMAX / 32; k += KVB_T) Rbits[k] = 0;
     uint32_t mylen = 0, tot;
     for (uint32_t j = 0; j < ntile; j++) {  // runs of several key segments: every request counts its predecessors
@@ -1955,7 +2170,6 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
       tot = 0;
       for (uint32_t w = 0; w < KVB_W; w++) tot = max(tot, Sred[w]);
     }
-    uint32_t nrounds = 0;
     for (uint32_t rw = 0; rw * 32 < tot; rw++) {
       for (uint32_t bits = Rbits[rw]; bits; bits &= bits - 1) {  // the same word for every thread
         const uint32_t r = rw * 32 + (uint32_t)__ffs((int)bits) - 1;
@@ -1973,11 +2187,13 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
         __syncthreads();
       }
     }
-    if (tr && t == 0) { tr[12] += nrounds; tr[13] += 1; }
+    }
+    if (wtr && t == 0) { wtr[14] += nrounds; wtr[15] += 1; }  // rounds of the request-by-request fallback; stretches
+    KVB_STAMP(13);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();  // the next stretch sees this stretch's stores; LDS arrays are free again
   }
-  if (tr && t == 0) tr[9] = __builtin_amdgcn_s_memrealtime();
+#undef KVB_STAMP
 }
 
 // ---- k_kv_resolve: one workgroup per coarse bin -------------------------------------------------------------------
@@ -2175,6 +2391,7 @@ template <int WL>
 __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __shared__ kv_dev Skv;
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
+  __shared__ __attribute__((aligned(16))) uint8_t Lbm[WL == DINT_WL_SMALLBANK ? KVB_BM_BYTES : 16];  // (one workgroup per CU either way: 8 waves of 256 VGPRs)
   const kv_pass_args &A = M.e[blockIdx.y];
   const uint32_t nq = A.big[3];
   if (blockIdx.x >= nq) return;
@@ -2183,11 +2400,12 @@ __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __syncthreads();
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
-  uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 8 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;  // {in, out, records, sub} of the first sub it takes
+  // DINT_KV_TRACE: 16 words per workgroup -- {in, out, records, sub} of the first sub it takes, then kv_big_bin's stamps
+  uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 16 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;
   for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
     const uint4 d = A.bigq[i];
     if (tr && t == 0 && i == blockIdx.x) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = d.z; tr[3] = d.x; }
-    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + d.y, d.z, A.stats, A.force_flags, A.V, Lraw);
+    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + d.y, A.ovf2 + d.y, d.z, A.stats, A.force_flags, A.V, Lraw, Lbm, i == blockIdx.x ? tr : nullptr);
     if (tr && t == 0 && i == blockIdx.x) tr[1] = __builtin_amdgcn_s_memrealtime();
   }
 }
@@ -2224,7 +2442,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.stats = s.stats;
   A.bigq = s.bigq;
   A.load_mode = load_mode;
-  A.force_flags = kv.force_rounds | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
+  A.force_flags = kv.force_rounds | (kv_env("DINT_KV_NO_BM", 0) ? 4 : 0) | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
   A.has_log = kv.workload != DINT_WL_STORE;
   A.trace = kv.d_trace;
   A.V = view;

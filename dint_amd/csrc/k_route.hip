@@ -5,14 +5,15 @@
 // ingested the request: home = global slot / bucket % world -- the hash and modulus the engines use -- and the
 // batch crosses xGMI once each way (one all-to-all of fixed-size slots; the collective itself is RCCL's).
 //
-//   k_route_count   : home rank of every request (kept in scratch) + requests per destination of each
-//                     1024-request block
-//   k_route_scan    : exclusive scan of those counts over the blocks, per destination (one workgroup); writes the
-//                     slot headers (live count per destination, clamped to the slot capacity)
-//   k_route_scatter : STABLE partition -- request i goes to position (requests of the same home before i) of its
-//                     destination's slot, so every destination receives this rank's requests in index order and
-//                     the order at the home engine is (source rank, index): the serial order of the rank-major
-//                     concatenation of all ingest batches, whatever the number of GPUs
+//   k_route_pack    : ONE pass over the batch -- home rank of every request, STABLE partition into the destinations' slots,
+//                     slot headers.  A tile of 1,024 requests is read once into LDS; its requests per destination
+//                     are published, and the tile adds up what the tiles before it published (tiles are numbered
+//                     by a ticket, so every predecessor is running: the wait cannot deadlock).  Request i goes to
+//                     position (requests of the same home before i) of its destination's slot, so every destination
+//                     receives this rank's requests in index order and the order at the home engine is (source
+//                     rank, index): the serial order of the rank-major concatenation of all ingest batches, whatever
+//                     the number of GPUs.  (r01-r03: three kernels -- count, scan, scatter -- that read the batch
+//                     twice and kept a home[] array between them.)
 //   k_route_unpack  : replies[i] = the slot message request i was sent in, after the inverse all-to-all
 //
 // A slot is `cap` messages; what a destination cannot take is answered "not now, send again" by the sender's own
@@ -23,9 +24,9 @@
 #include "../../include/dint_abi.h"
 #include "dint_kv.h"
 
-#define RT_TB 256u    // requests per workgroup of the count / scatter / unpack kernels (>= 1000 workgroups per 256k batch)
-#define RS_TB 1024u   // threads of the one scan workgroup
-#define RS_PER 4u     // blocks per scan thread: RS_TB * RS_PER = DINT_ROUTE_MAXN / RT_TB
+#define RT_TB 256u    // requests per workgroup of the unpack kernel (>= 1000 workgroups per 256k batch)
+#define RP_TB 1024u   // requests (= threads) per tile of the pack kernel: <= 1,024 tiles per batch, each adds up its predecessors
+#define RP_FLAG 0x80000000u
 #define RT_NONE 0xFFFFFFFFu
 
 struct rt_params {
@@ -49,8 +50,8 @@ struct rt_item {
   uint8_t *cnt;          // its u32 live count of peer 0 (peer w at + w * cnt_stride)
   uint64_t cnt_stride;
   uint32_t *slot;        // [n] where each request went
-  uint8_t *home;         // [n] scratch: home rank
-  uint32_t *blk;         // [blocks][world] scratch: counts, then exclusive prefixes
+  uint32_t *blk;         // [tiles][world] scratch: requests per tile and destination (RP_FLAG = published) | ticket, extent
+  uint32_t *blk_next;    // the other copy (the next call's): zeroed by this one
   dint_dev_stats *stats;
   rt_params p;
 };
@@ -111,114 +112,6 @@ __device__ static inline void rt_copy_msg(uint8_t *dst, const uint8_t *src, uint
   for (uint32_t k = nd * 4; k < msg; k++) dst[k] = tail[k - nd * 4];
 }
 
-__global__ void __launch_bounds__(RT_TB)
-k_route_count(rt_items I) {
-  const rt_item &it = I.it[blockIdx.y];
-  const uint32_t n = rt_n(it);
-  if (blockIdx.x * RT_TB >= n) return;  // the grid is as wide as the largest item
-  const uint8_t *__restrict__ req = it.req;
-  uint8_t *__restrict__ home = it.home;
-  uint32_t *__restrict__ blk = it.blk;
-  const rt_params &p = it.p;
-  __shared__ uint32_t H[DINT_ROUTE_MAXW];
-  const uint32_t t = threadIdx.x, i = blockIdx.x * RT_TB + t;
-  if (t < p.world) H[t] = 0;
-  __syncthreads();
-  const bool valid = i < n;
-  uint32_t h = 0;
-  if (valid) {
-    h = rt_home(req + (size_t)i * p.msg, p);
-    home[i] = (uint8_t)h;
-  }
-  for (uint64_t todo = __ballot(valid); todo;) {  // one LDS atomic per wave and destination
-    const int l = __ffsll((unsigned long long)todo) - 1;
-    const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane(h, l);
-    const uint64_t m = __ballot(valid && h == hh);
-    if ((int)lane_id() == l) atomicAdd(&H[hh], (uint32_t)__popcll(m));
-    todo &= ~m;
-  }
-  __syncthreads();
-  if (t < p.world) blk[(size_t)blockIdx.x * p.world + t] = H[t];
-}
-
-__global__ void __launch_bounds__(RS_TB)
-k_route_scan(rt_items I) {  // one workgroup per item
-  const rt_item &it = I.it[blockIdx.x];
-  const uint32_t nb = (rt_n(it) + RT_TB - 1) / RT_TB, world = it.p.world, cap = it.cap;
-  uint32_t *__restrict__ blk = it.blk;
-  uint8_t *cnt = it.cnt;
-  const uint64_t cnt_stride = it.cnt_stride;
-  dint_dev_stats *__restrict__ stats = it.stats;
-  __shared__ uint32_t Sw[RS_TB / 64];
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (uint32_t w = 0; w < world; w++) {
-    uint32_t c[RS_PER], sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < RS_PER; j++) {
-      const uint32_t b = t * RS_PER + j;
-      c[j] = b < nb ? blk[(size_t)b * world + w] : 0;
-      sum += c[j];
-    }
-    uint32_t tot, x = wave_excl_scan_u32(sum, &tot);
-    __syncthreads();
-    if (lane == 0) Sw[wave] = tot;
-    __syncthreads();
-    uint32_t total = 0;
-    for (uint32_t k = 0; k < RS_TB / 64; k++) {
-      if (k < wave) x += Sw[k];
-      total += Sw[k];
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < RS_PER; j++) {
-      const uint32_t b = t * RS_PER + j;
-      if (b < nb) blk[(size_t)b * world + w] = x;
-      x += c[j];
-    }
-    if (t == 0) {
-      *(uint32_t *)(cnt + (size_t)w * cnt_stride) = min(total, cap);
-      if (total > cap) atomicAdd(&stats->route_overflow, (unsigned long long)(total - cap));
-    }
-  }
-}
-
-__global__ void __launch_bounds__(RT_TB)
-k_route_scatter_simple(rt_items I) {
-  const rt_item &it = I.it[blockIdx.y];
-  const uint32_t n = rt_n(it), msg = it.p.msg, world = it.p.world, cap = it.cap;
-  if (blockIdx.x * RT_TB >= n) return;
-  const uint8_t *__restrict__ req = it.req;
-  const uint8_t *__restrict__ home = it.home;
-  const uint32_t *__restrict__ blk = it.blk;
-  uint8_t *send = it.send;
-  const uint64_t stride = I.stride;
-  uint32_t *__restrict__ slot = it.slot;
-  __shared__ uint32_t Wc[RT_TB / 64][DINT_ROUTE_MAXW];
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, i = blockIdx.x * RT_TB + t;
-  for (uint32_t k = t; k < (RT_TB / 64) * DINT_ROUTE_MAXW; k += RT_TB) (&Wc[0][0])[k] = 0;
-  __syncthreads();
-  const bool valid = i < n;
-  const uint32_t h = valid ? home[i] : 0;
-  uint32_t rank = 0;  // requests of my home before me inside my wave
-  for (uint64_t todo = __ballot(valid); todo;) {
-    const int l = __ffsll((unsigned long long)todo) - 1;
-    const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane(h, l);
-    const uint64_t m = __ballot(valid && h == hh);
-    if (valid && h == hh) rank = (uint32_t)__popcll(m & lanemask_lt());
-    if ((int)lane == l) Wc[wave][hh] = (uint32_t)__popcll(m);
-    todo &= ~m;
-  }
-  __syncthreads();
-  if (!valid) return;
-  uint32_t pos = blk[(size_t)blockIdx.x * world + h] + rank;
-  for (uint32_t k = 0; k < wave; k++) pos += Wc[k][h];
-  if (pos < cap) {
-    rt_copy_msg(send + (size_t)h * stride + (size_t)pos * msg, req + (size_t)i * msg, msg);
-    slot[i] = h * cap + pos;
-  } else {
-    slot[i] = RT_NONE;
-  }
-}
-
 __global__ void __launch_bounds__(256)
 k_route_unpack_simple(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
@@ -260,17 +153,19 @@ __device__ static inline void rt_lds_store_tile(uint8_t *g, const uint8_t *L, ui
 }
 // A run of nb bytes between global memory g and LDS L, where L was placed with g's 16-byte phase ((L - Lb) & 15 ==
 // g & 15, Lb 16-byte aligned): head bytes up to the first 16-byte boundary, 16-byte vectors, tail bytes.
+template <uint32_t TB = RT_TB>
 __device__ static inline void rt_run_store(uint8_t *g, const uint8_t *L, uint32_t nb) {
   const uint32_t t = threadIdx.x, hb = min(nb, (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u), nv = (nb - hb) >> 4;
   if (t < hb) g[t] = L[t];
-  for (uint32_t k = t; k < nv; k += RT_TB) ((uint4 *)(g + hb))[k] = ((const uint4 *)(L + hb))[k];
+  for (uint32_t k = t; k < nv; k += TB) ((uint4 *)(g + hb))[k] = ((const uint4 *)(L + hb))[k];
   const uint32_t done = hb + (nv << 4);
   if (t < nb - done) g[done + t] = L[done + t];
 }
+template <uint32_t TB = RT_TB>
 __device__ static inline void rt_run_load(uint8_t *L, const uint8_t *g, uint32_t nb) {
   const uint32_t t = threadIdx.x, hb = min(nb, (16u - (uint32_t)((uintptr_t)g & 15u)) & 15u), nv = (nb - hb) >> 4;
   if (t < hb) L[t] = g[t];
-  for (uint32_t k = t; k < nv; k += RT_TB) ((uint4 *)(L + hb))[k] = ((const uint4 *)(g + hb))[k];
+  for (uint32_t k = t; k < nv; k += TB) ((uint4 *)(L + hb))[k] = ((const uint4 *)(g + hb))[k];
   const uint32_t done = hb + (nv << 4);
   if (t < nb - done) L[done + t] = g[done + t];
 }
@@ -291,29 +186,47 @@ template <uint32_t MSG> __device__ static inline void rt_put(uint8_t *L, const r
   for (uint32_t k = 0; k < MSG % 4; k++) L[(MSG / 4) * 4 + k] = r.tail[k];
 }
 
+#define RP_LDS_BYTES (RP_TB * 55u + 32u * DINT_ROUTE_MAXW + 16u)  // the tile at its 16-byte phase; then every run at its own
+#define RP_CTL (DINT_ROUTE_BLK_WORDS - 4u)                         // [0] ticket, [1] aggregate words this call published
+
 template <uint32_t MSG>
-__global__ void __launch_bounds__(RT_TB)
-k_route_scatter(rt_items I) {
+__global__ void __launch_bounds__(RP_TB)
+k_route_pack(rt_items I) {
   const rt_item &it = I.it[blockIdx.y];
   constexpr uint32_t msg = MSG;
   const uint32_t n = rt_n(it), world = it.p.world, cap = it.cap;
-  if (blockIdx.x * RT_TB >= n) return;
+  const uint32_t ntiles = (n + RP_TB - 1) / RP_TB;
   const uint8_t *__restrict__ req = it.req;
-  const uint8_t *__restrict__ home = it.home;
-  const uint32_t *__restrict__ blk = it.blk;
+  uint32_t *blk = it.blk;
   uint8_t *send = it.send;
   const uint64_t stride = I.stride;
   uint32_t *__restrict__ slot = it.slot;
-  __shared__ __attribute__((aligned(16))) uint8_t Lb[RT_LDS_BYTES];
-  __shared__ uint32_t Wc[RT_TB / 64][DINT_ROUTE_MAXW];
-  __shared__ uint32_t Cnt[DINT_ROUTE_MAXW], Loff[DINT_ROUTE_MAXW];  // messages of the tile per destination; LDS byte offset of its run
-  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, i = blockIdx.x * RT_TB + t;
-  const uint32_t tile_n = min(RT_TB, n - blockIdx.x * RT_TB);
-  for (uint32_t k = t; k < (RT_TB / 64) * DINT_ROUTE_MAXW; k += RT_TB) (&Wc[0][0])[k] = 0;
-  rt_lds_load_tile(Lb, req + (size_t)blockIdx.x * RT_TB * msg, tile_n * msg);
+  __shared__ __attribute__((aligned(16))) uint8_t Lb[RP_LDS_BYTES];
+  __shared__ uint32_t Wc[RP_TB / 64][DINT_ROUTE_MAXW];
+  __shared__ uint32_t Cnt[DINT_ROUTE_MAXW], Loff[DINT_ROUTE_MAXW], Base[DINT_ROUTE_MAXW];  // of the tile per destination: messages, LDS byte offset of the run, messages of earlier tiles
+  __shared__ uint32_t Sb;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) Sb = atomicAdd(&blk[RP_CTL], 1u);  // tiles in the order the workgroups start
+  for (uint32_t k = t; k < (RP_TB / 64) * DINT_ROUTE_MAXW; k += RP_TB) (&Wc[0][0])[k] = 0;
+  if (t < DINT_ROUTE_MAXW) Base[t] = 0;
   __syncthreads();
-  const bool valid = i < n;
-  const uint32_t h = valid ? home[i] : 0;
+  const uint32_t b = Sb;
+  if (b == 0) {  // housekeeping: the other copy of the scratch, which the next call uses, goes back to zero
+    uint32_t *nx = it.blk_next;
+    const uint32_t ext = nx[RP_CTL + 1];
+    for (uint32_t k = t; k < ext; k += RP_TB) nx[k] = 0;
+    if (t < 2) nx[RP_CTL + t] = 0;
+    if (t == 0) blk[RP_CTL + 1] = ntiles * world;
+    if (ntiles == 0 && t < world) *(uint32_t *)(it.cnt + (size_t)t * it.cnt_stride) = 0;  // an empty batch still writes its headers
+  }
+  if (b >= ntiles) return;  // (workgroup-uniform; the grid is as wide as the largest item's upper bound)
+  const uint32_t tile_n = min(RP_TB, n - b * RP_TB), i = b * RP_TB + t;
+  const uint8_t *g0 = req + (size_t)b * RP_TB * msg;
+  uint8_t *Lt = Lb + (uint32_t)((uintptr_t)g0 & 15u);  // the tile keeps its 16-byte phase (request arrays at any address)
+  rt_run_load<RP_TB>(Lt, g0, tile_n * msg);
+  __syncthreads();
+  const bool valid = t < tile_n;
+  const uint32_t h = valid ? rt_home(Lt + t * msg, it.p) : 0;
   uint32_t rank = 0;  // requests of my home before me inside my wave
   for (uint64_t todo = __ballot(valid); todo;) {
     const int l = __ffsll((unsigned long long)todo) - 1;
@@ -324,18 +237,31 @@ k_route_scatter(rt_items I) {
     todo &= ~m;
   }
   rt_regs<MSG> r;
-  if (valid) rt_get<MSG>(r, Lb + t * msg);
+  if (valid) rt_get<MSG>(r, Lt + t * msg);
   __syncthreads();  // every message is in registers: the buffer can be rewritten destination-major
   if (t < world) {
     uint32_t c = 0;
-    for (uint32_t k = 0; k < RT_TB / 64; k++) c += Wc[k][t];
+    for (uint32_t k = 0; k < RP_TB / 64; k++) c += Wc[k][t];
     Cnt[t] = c;
+    __hip_atomic_store(&blk[(size_t)b * world + t], c | RP_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {  // what the tiles before mine hold, per destination: thread t adds up words t, t + per, ... (all of destination t % world)
+    const uint32_t per = (RP_TB / world) * world, tot = b * world;
+    if (t < per) {
+      uint32_t acc = 0;
+      for (uint32_t k = t; k < tot; k += per) {
+        uint32_t v;
+        while (!((v = __hip_atomic_load(&blk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & RP_FLAG)) __builtin_amdgcn_s_sleep(1);
+        acc += v & ~RP_FLAG;
+      }
+      if (acc) atomicAdd(&Base[t % world], acc);
+    }
   }
   __syncthreads();
   if (t == 0) {  // every destination's run gets the 16-byte phase of where it goes in memory
     uint32_t o = 0;
     for (uint32_t w = 0; w < world; w++) {
-      const uint8_t *g = send + (size_t)w * stride + (size_t)blk[(size_t)blockIdx.x * world + w] * msg;
+      const uint8_t *g = send + (size_t)w * stride + (size_t)Base[w] * msg;
       o = ((o + 15u) & ~15u) + (uint32_t)((uintptr_t)g & 15u);
       Loff[w] = o;
       o += Cnt[w] * msg;
@@ -346,15 +272,19 @@ k_route_scatter(rt_items I) {
   for (uint32_t k = 0; k < wave; k++) lrank += Wc[k][h];
   if (valid) {
     rt_put<MSG>(Lb + Loff[h] + lrank * msg, r);
-    const uint32_t pos = blk[(size_t)blockIdx.x * world + h] + lrank;
+    const uint32_t pos = Base[h] + lrank;
     slot[i] = pos < cap ? h * cap + pos : RT_NONE;
   }
   __syncthreads();
   for (uint32_t w = 0; w < world; w++) {  // every destination's run of this tile: one contiguous stream
-    const uint32_t base = blk[(size_t)blockIdx.x * world + w];
+    const uint32_t base = Base[w];
     const uint32_t cnt = base < cap ? min(Cnt[w], cap - base) : 0;
-    const uint32_t nb = cnt * msg;
-    rt_run_store(send + (size_t)w * stride + (size_t)base * msg, Lb + Loff[w], cnt * msg);
+    rt_run_store<RP_TB>(send + (size_t)w * stride + (size_t)base * msg, Lb + Loff[w], cnt * msg);
+  }
+  if (b == ntiles - 1 && t < world) {  // the last tile knows the totals: slot headers (live count, clamped to the slot capacity)
+    const uint32_t total = Base[t] + Cnt[t];
+    *(uint32_t *)(it.cnt + (size_t)t * it.cnt_stride) = min(total, cap);
+    if (total > cap) atomicAdd(&it.stats->route_overflow, (unsigned long long)(total - cap));
   }
 }
 
@@ -436,12 +366,24 @@ static rt_params make_params(uint32_t workload, uint32_t msg, dint_mod slots, co
   return p;
 }
 
-// items[k] routed with engine k's parameters; every kernel once, grid.y = item
+// items[k] routed with engine k's parameters; one launch, grid.y = item (batches of different wire formats: one launch each)
+template <uint32_t MSG> static void launch_pack(const rt_items &I, uint32_t tiles, uint32_t n_items, hipStream_t st) {
+  hipLaunchKernelGGL(k_route_pack<MSG>, dim3(std::max(tiles, 1u), n_items), dim3(RP_TB), 0, st, I);
+}
+static void launch_pack_msg(uint32_t msg, const rt_items &I, uint32_t tiles, uint32_t n_items, hipStream_t st) {
+  switch (msg) {
+    case 6: launch_pack<6>(I, tiles, n_items, st); break;
+    case 9: launch_pack<9>(I, tiles, n_items, st); break;
+    case 23: launch_pack<23>(I, tiles, n_items, st); break;
+    case 53: launch_pack<53>(I, tiles, n_items, st); break;
+    default: launch_pack<55>(I, tiles, n_items, st); break;  // (the engines' wire formats: 6, 9, 23, 53, 55)
+  }
+}
 void dint_launch_route_pack(const dint_route_job *jobs, uint32_t n_jobs, uint64_t stride, hipStream_t st) {
   rt_items I;
   I.stride = stride;
-  uint32_t nb_max = 0;
-  bool aligned = true;
+  uint32_t tiles = 0;
+  bool one_fmt = true;
   for (uint32_t k = 0; k < n_jobs; k++) {
     const dint_route_job &j = jobs[k];
     rt_item &it = I.it[k];
@@ -454,31 +396,23 @@ void dint_launch_route_pack(const dint_route_job *jobs, uint32_t n_jobs, uint64_
     it.cnt = (uint8_t *)j.d_cnt;
     it.cnt_stride = j.cnt_stride;
     it.slot = j.d_slot;
-    it.home = j.rs.home;
     it.blk = j.rs.blk;
+    it.blk_next = j.rs.blk_next;
     it.stats = j.stats;
     it.p = make_params(j.workload, j.msg, j.slots, j.kv, j.shard);
-    nb_max = std::max(nb_max, (j.n + RT_TB - 1) / RT_TB);  // <= DINT_ROUTE_MAXN / RT_TB = 4096
-    aligned = aligned && ((uintptr_t)j.d_req & 15) == 0;
+    tiles = std::max(tiles, (j.n + RP_TB - 1) / RP_TB);  // <= DINT_ROUTE_MAXN / RP_TB = 1024
+    one_fmt = one_fmt && j.msg == jobs[0].msg;
   }
-  if (nb_max) hipLaunchKernelGGL(k_route_count, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
-  hipLaunchKernelGGL(k_route_scan, dim3(n_jobs), dim3(RS_TB), 0, st, I);  // 0 blocks still writes the headers
-  bool staged = nb_max && aligned;
-  for (uint32_t k = 1; k < n_jobs; k++) staged = staged && jobs[k].msg == jobs[0].msg;  // one instantiation per launch
-  if (staged) {
-    const dim3 g(nb_max, n_jobs), b(RT_TB);
-    switch (jobs[0].msg) {
-      case 6: hipLaunchKernelGGL(k_route_scatter<6>, g, b, 0, st, I); break;
-      case 9: hipLaunchKernelGGL(k_route_scatter<9>, g, b, 0, st, I); break;
-      case 23: hipLaunchKernelGGL(k_route_scatter<23>, g, b, 0, st, I); break;
-      case 53: hipLaunchKernelGGL(k_route_scatter<53>, g, b, 0, st, I); break;
-      case 55: hipLaunchKernelGGL(k_route_scatter<55>, g, b, 0, st, I); break;
-      default: staged = false;
-    }
+  if (one_fmt) {
+    launch_pack_msg(jobs[0].msg, I, tiles, n_jobs, st);
+    return;
   }
-  if (staged) return;
-  if (nb_max)
-    hipLaunchKernelGGL(k_route_scatter_simple, dim3(nb_max, n_jobs), dim3(RT_TB), 0, st, I);
+  for (uint32_t k = 0; k < n_jobs; k++) {
+    rt_items J;
+    J.stride = stride;
+    J.it[0] = I.it[k];
+    launch_pack_msg(jobs[k].msg, J, (jobs[k].n + RP_TB - 1) / RP_TB, 1, st);
+  }
 }
 
 void dint_launch_route_unpack(const dint_route_job *jobs, uint32_t n_jobs, uint64_t stride, hipStream_t st) {
@@ -520,4 +454,4 @@ void dint_launch_route_unpack(const dint_route_job *jobs, uint32_t n_jobs, uint6
     hipLaunchKernelGGL(k_route_unpack_simple, dim3((n_max + 255) / 256, n_jobs), dim3(256), 0, st, I);
 }
 
-static_assert(RS_TB * RS_PER * RT_TB == DINT_ROUTE_MAXN, "the scan workgroup covers every block of the largest batch");
+static_assert((DINT_ROUTE_MAXN / RP_TB) * DINT_ROUTE_MAXW <= RP_CTL, "aggregates of the largest batch to the widest world, then the control words");

@@ -530,6 +530,23 @@ def test_store_dominant_key_vs_oracle():
     assert _same_rows(eng.dump_rows(0), o.dump())
 
 
+@pytest.mark.parametrize("no_bitmap", ["0", "1"])
+@pytest.mark.parametrize("n,touch", [(60_000, 1), (90_000, 3), (30_000, 40)])
+def test_smallbank_hot_accounts_bitmap_order_and_sort_agree(n, touch, no_bitmap, monkeypatch):
+    """A stretch that is one account (its savings and its checking row: one or two key classes) is put in order by an
+    index bitmap instead of the LDS sort, and a sub of several stretches is regrouped by stretch once
+    (kv_big_bin); DINT_KV_NO_BM=1 keeps the sort.  Both against the oracle, in two passes so the second starts from
+    counters the first one left."""
+    monkeypatch.setenv("DINT_KV_NO_BM", no_bitmap)
+    req = tracegen.sb_random(n, seed=n + touch, n_acct_touch=touch)
+    eng = _engine(W.SMALLBANK, n_rows=10_000)
+    eng.populate(max(touch, 8))
+    o = orc.SmallbankOracle(10_000, populate_n=max(touch, 8))
+    got = np.concatenate([eng.submit(req[:n // 2 + 7]), eng.submit(req[n // 2 + 7:])])
+    assert got.tobytes() == o.replay(req).tobytes()
+    _sb_state(eng, o)
+
+
 # ---------------------------------------------------------------- the two-level partition's own corners
 @pytest.mark.parametrize("knob", [("DINT_KV_CAP", "24"), ("DINT_KV_LCAP", "96"), ("DINT_KV_RPT", "1"), ("DINT_KV_RPT", "2"),
                                   ("DINT_KV_RPT", "4"), ("DINT_KV_COARSE_LOAD", "4096"), ("DINT_KV_COARSE_LOAD", "64")])

@@ -53,6 +53,11 @@ if os.environ.get("DINT_KV_TRACE"):
         top = np.argsort(-du)[:8]
         out["big_subs"] = {"n": int(len(big)), "us_mean": round(float(du.mean()), 1), "us_max": round(float(du.max()), 1),
                            "longest": [[int(big[i, 2]), round(float(du[i]), 1)] for i in top]}
+        # the stamped stretch of the longest sub (kv_big_bin: [4] in .. [13] out)
+        bn = ["gathered", "ordered", "heads", "keys", "masks", "located_granted", "tiles", "written", "out"]
+        i = int(top[0])
+        out["big_subs"]["stretch_us"] = {bn[k - 5]: round(float(big[i, k] - big[i, k - 1]) / 100.0, 2) for k in range(5, 14) if big[i, k] > 0 and big[i, k - 1] > 0}
+        out["big_subs"]["stretches_rounds"] = [int(big[i, 15]), int(big[i, 14])]
     tr = tr[tr[:, 0] > 0]
     t0 = tr[:, 0].min()
     names = ["in", "loaded", "counted", "laid_out", "placed", "sorted", "masks", "located", "replied", "written", "rounds", "chunks_done", "bigs_done"]
