@@ -963,6 +963,10 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 constexpr uint32_t KVB_BM_W = 4096, KVB_BM_OT = 1024, KVB_BM_MIN = 1024;
 constexpr uint32_t KVB_BM_BYTES = KVB_BM_W * 8 + KVB_BM_W * 2 + KVB_NMAX * 8;
 
+constexpr bool KV_HOT_BM = true;           // dominant-key path: order the key's writers + lock ops by an index bitmap (else: LDS sort + binary search)
+constexpr uint32_t KV_HOT_BM_W = 8192;     // ... bitmap words: request-index spans of up to 512k
+constexpr uint32_t KV_MMAX = 2048;  // dominant-key path: writers + lock ops of the key it puts in order (a tatp subscriber of 4,000 requests: ~1,100)
+
 struct kvb_lds {
   uint64_t Sk[KVB_NMAX];           // the stretch: group / P | key-hash bits | idx | type, quadrant
   uint32_t Bcnt[KVB_NBK / 2];      // records per idx bucket, 16 bits each (a bucket spans <= 512 requests)
@@ -973,7 +977,9 @@ struct kvb_lds {
   kvb_edge Ehead, Ebh, Ewr, Elk;
   uint64_t Mbail[KVB_W];           // tile-local
   __attribute__((aligned(8))) kvb_lead Lead[KVB_T];  // by key segment number (a stretch with more segments runs request by request)
-  __attribute__((aligned(8))) uint8_t CarryCrow[KVB_T * (sizeof(kv_rowst) > sizeof(kvb_carry) ? sizeof(kv_rowst) : sizeof(kvb_carry))];
+  static constexpr uint32_t CC_ROWS = KVB_T * (sizeof(kv_rowst) > sizeof(kvb_carry) ? sizeof(kv_rowst) : sizeof(kvb_carry));
+  static constexpr uint32_t CC_TABS = 3 * (KV_MMAX + 8) * 2;  // ... or the dominant-key path's three prefix tables
+  __attribute__((aligned(8))) uint8_t CarryCrow[(CC_ROWS > CC_TABS ? CC_ROWS : CC_TABS) + 7 & ~7u];
   uint16_t HeadPos[KVB_T];         // sorted position of each segment's head
   uint32_t Sany, Swn;
   uint32_t Wst[KVB_T + 1], Wcur[KVB_T];  // a sub of several stretches: where each stretch's records start in the regrouped copy
@@ -1021,7 +1027,9 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
   kv_rowst *Crow = (kv_rowst *)CarryCrow;
   // DINT_KV_TRACE: phase stamps of one stretch (the second of a sub cut into several -- the first one pays the cold misses)
   // into the workgroup's trace words: [4] stretch in, [5] gathered, [6] in order, [7] heads / op classes, [8] keys
-  // checked, [9] masks, [10] rows located and lock grants walked, [11] tiles, [12] written back, [13] out (after the rounds)
+  // checked, [9] masks, [10] rows located and lock grants walked, [11] tiles, [12] written back, [13] out (after the rounds);
+  // the dominant-key path (first time round): [16] in, [17] sampled, [18] checked, [19] ordering ops sorted, [20] row located,
+  // [21] answered, [22] remainder compacted; [23] a check failed, [24] ordering ops, [25] requests of the key, [26] of the stretch
 #define KVB_STAMP(k) do { if (wtr && t == 0 && win == stamp_win) wtr[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // idx buckets for the stretches of a bin with more than KVB_NMAX records: 2^bs requests per bucket, <= KVB_NBK buckets
@@ -1126,6 +1134,8 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
   __syncthreads();
 
   const uint32_t stamp_win = nwin > 1 ? 1u : 0u;
+  bool pf = false;      // the next stretch's records are already in LDS (smallbank: the ordered-copy buffer, free by then)
+  uint32_t pf_m = 0;
   for (uint32_t win = 0; win < nwin; win++) {
     if (t == 0) Swn = 0;
     __syncthreads();
@@ -1137,6 +1147,13 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     if (c <= KVB_NMAX) {  // the whole bin
       for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = sort_key(rec_at(k));
       if (t == 0) Swn = c;
+    } else if (regrouped && pf) {
+      if (wtr && t == 0 && win == stamp_win) wtr[27] = 1;
+#pragma unroll
+      for (uint32_t j = 0; j < KVB_NMAX / KVB_T; j++)
+        if (j * KVB_T + t < pf_m) Sk[j * KVB_T + t] = ((const uint64_t *)(lds_bm + KVB_BM_W * 10))[j * KVB_T + t];
+      if (t == 0) Swn = pf_m;
+      pf = false;
     } else if (regrouped) {
       const uint32_t a = Wst[win], b = max(a, Wst[win + 1]);  // (an empty stretch between two others keeps the end mark c)
       uint64_t r8[KVB_NMAX / KVB_T];  // (all loads first: a loop of load / LDS store pairs waits for every load on its own)
@@ -1167,6 +1184,8 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
         }
       }
     }
+    KVB_STAMP(31);
+    if (wtr && t == 0 && win == stamp_win) { wtr[28] = regrouped; wtr[29] = nwin; }
     __syncthreads();
     uint32_t m = Swn;
     __syncthreads();  // Swn is reset at the top of the next stretch
@@ -1182,11 +1201,16 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     // of the last writer before me, lock = what the last lock op before me left.  The closed forms are those of
     // kv_chunk; anything they do not cover (another key of the same bucket on the same lock byte, inserts / deletes,
     // a key-hash collision, > 1024 ordering ops) leaves the whole stretch to the general path below.
-    if (WL != DINT_WL_SMALLBANK && !force_rounds && !no_hot && m >= hot_min) {
+    // (repeated while what is left still has a dominant key: a sub with TWO hot keys -- tatp's hottest subscriber and a
+    // neighbour -- used to send the second one, ~1,000 requests, through the whole stretch machinery: 43 us behind the 50)
+    bool again = WL != DINT_WL_SMALLBANK && !force_rounds && !no_hot;
+    for (uint32_t hot_pass = 0; again && !tiny && m >= hot_min && hot_pass < 4; hot_pass++) {
+      again = false;
+      if (hot_pass == 0) KVB_STAMP(16);
       uint32_t *Mk = (uint32_t *)Lead;                 // [1024] idx << 12 | position in Sk, ascending
       uint16_t *Mwc = (uint16_t *)Carry;                // [j] writers among the first j ops of M
-      int16_t *Mlw = (int16_t *)(Mwc + KVB_MMAX + 8);   // [j] last writer among the first j (index into Mk), -1: none
-      int16_t *Mll = Mlw + KVB_MMAX + 8;                // [j] last lock op among the first j
+      int16_t *Mlw = (int16_t *)(Mwc + KV_MMAX + 8);   // [j] last writer among the first j (index into Mk), -1: none
+      int16_t *Mll = Mlw + KV_MMAX + 8;                // [j] last lock op among the first j
       // 1. the most frequent (bucket group, key hash) among eight samples
       uint64_t cand[8];
       uint32_t cc[8];
@@ -1213,14 +1237,15 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
       const uint64_t hpf = cand[best];
       const uint32_t hsp = (uint32_t)(((uint64_t)m * best) >> 3);  // a position that holds the hot key
       __syncthreads();
+      if (hot_pass == 0) KVB_STAMP(17);
       if (hot_n >= hot_min && 2 * hot_n >= m) {  // workgroup-uniform
         // 2. everything the closed form needs to hold, checked before anything is written
         const uint64_t hcur = Sk[hsp];
         const uint32_t hq = k_q(hcur);
         const uint64_t hkey = ld_u64(rep + dint_view_off(V, k_idx(hcur), F::MSG) + F::KEY);
-        if (t < 16) Hs[t] = 0;  // [0] bad, [1] ordering ops
+        if (t < 16) Hs[t] = t == 3 ? 0xFFFFFFFFu : 0u;  // [0] bad, [1] ordering ops, [3] / [4] their lowest / highest request index
         __syncthreads();
-        uint32_t bad = 0, nord = 0;
+        uint32_t bad = 0, nord = 0, olo = 0xFFFFFFFFu, ohi = 0;
 #pragma unroll 8
         for (uint32_t p = t; p < m; p += KVB_T) {  // (unrolled: the key gathers of a thread's <= 8 records in flight together)
           const uint64_t cur = Sk[p];
@@ -1228,20 +1253,75 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           if ((cur >> sh_k) == hpf) {
             bad |= !kv_simple_op<WL>(type);
             bad |= ld_u64(rep + dint_view_off(V, k_idx(cur), F::MSG) + F::KEY) != hkey;  // 9 hash bits can collide
-            nord += is_writer(type) || kv_lock_op<WL>(type);
+            if (is_writer(type) || kv_lock_op<WL>(type)) { nord++; olo = min(olo, k_idx(cur)); ohi = max(ohi, k_idx(cur)); }
           } else if ((cur >> sh_g) == (hpf >> 9)) {  // another key of the hot bucket: must not touch my lock byte or the chain
             bad |= kv_struct_op<WL>(type) || (kv_lock_op<WL>(type) && k_q(cur) == hq);
           }
         }
-        for (int d = 32; d > 0; d >>= 1) nord += __shfl_xor(nord, d, 64);
-        if (lane == 0 && nord) atomicAdd(&Hs[1], nord);
+        for (int d = 32; d > 0; d >>= 1) {
+          nord += __shfl_xor(nord, d, 64);
+          olo = min(olo, (uint32_t)__shfl_xor(olo, d, 64)); ohi = max(ohi, (uint32_t)__shfl_xor(ohi, d, 64));
+        }
+        if (lane == 0 && nord) { atomicAdd(&Hs[1], nord); atomicMin(&Hs[3], olo); atomicMax(&Hs[4], ohi); }
         if (bad) Hs[0] = 1;
         __syncthreads();
         const uint32_t nM = Hs[1];
-        const bool hot_ok = !Hs[0] && nM <= KVB_MMAX;
+        olo = Hs[3];
+        const uint32_t ospan = nM ? Hs[4] - olo + 1 : 0;
+        const bool hot_ok = !Hs[0] && nM <= KV_MMAX;
         __syncthreads();
+        if (hot_pass == 0) KVB_STAMP(18);
+        if (wtr && t == 0 && win == stamp_win && hot_pass == 0) { wtr[23] = Hs[0]; wtr[24] = nM; wtr[25] = hot_n; wtr[26] = m; }
         if (hot_ok) {
-          // 3. M = the key's writers and lock ops, sorted by request index
+          // 3. M = the key's writers and lock ops, sorted by request index.  Request indices are distinct, so when their span
+          // fits the index bitmap (a pass of up to 512k requests) an op's place in M is the number of set bits below its
+          // own -- and every request of the key later finds "ops before me" the same way, not by binary search.
+          // (r03: compaction + LDS sort of M, 15 us for the 1,075 ops of tatp's hottest subscriber; 11-step searches.)
+          const bool by_bitmap = KV_HOT_BM && lds_bm != nullptr && ospan <= KV_HOT_BM_W * 64;  // workgroup-uniform
+          uint64_t *Bm = (uint64_t *)lds_bm;                  // [KV_HOT_BM_W]
+          uint16_t *Wp = (uint16_t *)(Bm + KV_HOT_BM_W);       // [KV_HOT_BM_W] bits set below each word
+          auto ops_below = [&](uint32_t idx) -> uint32_t {     // ordering ops with a smaller request index
+            if (idx <= olo) return 0u;
+            const uint32_t b = idx - olo;
+            if (b >= ospan) return nM;
+            return Wp[b >> 6] + (uint32_t)__popcll(Bm[b >> 6] & ((1ull << (b & 63)) - 1ull));
+          };
+          if (by_bitmap) {
+            const uint32_t nw = (ospan + 63) >> 6;
+            for (uint32_t w = t; w < nw; w += KVB_T) Bm[w] = 0;
+            __syncthreads();
+            for (uint32_t p = t; p < m; p += KVB_T) {
+              const uint64_t cur = Sk[p];
+              const uint32_t type = k_type(cur);
+              if ((cur >> sh_k) == hpf && (is_writer(type) || kv_lock_op<WL>(type))) {
+                const uint32_t b = k_idx(cur) - olo;
+                atomicOr((unsigned long long *)&Bm[b >> 6], 1ull << (b & 63));
+              }
+            }
+            __syncthreads();
+            {  // thread t owns words PW t .. PW t + PW - 1
+              constexpr uint32_t PW = KV_HOT_BM_W / KVB_T;
+              uint32_t run = 0;
+#pragma unroll 4
+              for (uint32_t j = 0; j < PW; j++) run += PW * t + j < nw ? (uint32_t)__popcll(Bm[PW * t + j]) : 0u;
+              uint32_t tot, base = wave_excl_scan_u32(run, &tot);
+              if (lane == 0) Sred[wave] = tot;
+              __syncthreads();
+              for (uint32_t w = 0; w < wave; w++) base += Sred[w];
+#pragma unroll 4
+              for (uint32_t j = 0; j < PW; j++) {  // (the words are read again: sixteen counts per thread do not fit the register file here)
+                const uint32_t w = PW * t + j;
+                if (w < nw) { Wp[w] = (uint16_t)base; base += (uint32_t)__popcll(Bm[w]); }
+              }
+            }
+            __syncthreads();
+            for (uint32_t p = t; p < m; p += KVB_T) {
+              const uint64_t cur = Sk[p];
+              const uint32_t type = k_type(cur);
+              if ((cur >> sh_k) == hpf && (is_writer(type) || kv_lock_op<WL>(type))) Mk[ops_below(k_idx(cur))] = (k_idx(cur) << 12) | p;
+            }
+            __syncthreads();
+          } else {
           if (t == 0) Hs[2] = 0;
           __syncthreads();
           for (uint32_t p0 = 0; p0 < m; p0 += KVB_T) {
@@ -1261,38 +1341,50 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           // key's 54 us -- because the register / shuffle sort made the shared resolve kernel 1.3 % slower by its code size;
           // the big path is a kernel of its own now)
           __syncthreads();
-          for (uint32_t k = nM + t; k < KVB_MMAX; k += KVB_T) Mk[k] = 0xFFFFFFFFu;  // empty slots sort last
+          for (uint32_t k = nM + t; k < KV_MMAX; k += KVB_T) Mk[k] = 0xFFFFFFFFu;  // empty slots sort last
           __syncthreads();
           {
             uint32_t N2 = 64;
             while (N2 < nM) N2 <<= 1;
-            if (nM > KVB_T) kvb_sort_blocked_u32<2>(Mk, max(N2, 128u));
-            else if (nM > 1) kvb_sort_blocked_u32<1>(Mk, N2);
+            if (nM > 1) kvb_sort_blocked_u32<4>(Mk, max(N2, 256u));  // (the fallback of passes beyond 512k requests: one instantiation)
           }
-          // prefix tables over M (nM + 1 rows: what precedes op j; row nM = the totals): thread t owns ops 2t, 2t + 1
+          }
+          if (hot_pass == 0) KVB_STAMP(19);
+          // prefix tables over M (nM + 1 rows: what precedes op j; row nM = the totals): thread t owns ops PER t .. PER t + PER - 1
           {
-            const uint32_t j0 = 2 * t, j1 = 2 * t + 1;
-            const uint32_t ty0 = j0 < nM ? k_type(Sk[Mk[j0] & 4095u]) : 0xFFu, ty1 = j1 < nM ? k_type(Sk[Mk[j1] & 4095u]) : 0xFFu;
-            const bool w0 = j0 < nM && is_writer(ty0), w1 = j1 < nM && is_writer(ty1);
-            const bool l0 = j0 < nM && kv_lock_op<WL>(ty0), l1 = j1 < nM && kv_lock_op<WL>(ty1);
-            uint32_t wt, wx = wave_excl_scan_u32((uint32_t)w0 + (uint32_t)w1, &wt);
-            int iw = w1 ? (int)j1 : (w0 ? (int)j0 : -1), il = l1 ? (int)j1 : (l0 ? (int)j0 : -1);  // last of my pair
+            constexpr uint32_t PER = KV_MMAX / KVB_T;
+            bool wv[PER], lv[PER];
+            uint32_t nwr = 0;
+            int iw = -1, il = -1;  // last writer / lock op among my ops
+#pragma unroll
+            for (uint32_t r = 0; r < PER; r++) {
+              const uint32_t j = PER * t + r;
+              const uint32_t ty = j < nM ? k_type(Sk[Mk[j] & 4095u]) : 0xFFu;
+              wv[r] = j < nM && is_writer(ty);
+              lv[r] = j < nM && kv_lock_op<WL>(ty);
+              nwr += wv[r];
+              if (wv[r]) iw = (int)j;
+              if (lv[r]) il = (int)j;
+            }
+            uint32_t wt, wx = wave_excl_scan_u32(nwr, &wt);
             for (int d = 1; d < 64; d <<= 1) {  // inclusive running maxima over the wave
               const int a2 = __shfl_up(iw, d, 64), b2 = __shfl_up(il, d, 64);
               if ((int)lane >= d) { iw = max(iw, a2); il = max(il, b2); }
             }
             if (lane == 63) { Sred[wave] = wt; Hc[0][wave] = iw; Hc[1][wave] = il; }
-            int ew = __shfl_up(iw, 1, 64), el = __shfl_up(il, 1, 64);  // exclusive: what precedes my pair inside the wave
+            int ew = __shfl_up(iw, 1, 64), el = __shfl_up(il, 1, 64);  // exclusive: what precedes my ops inside the wave
             if (lane == 0) { ew = -1; el = -1; }
             __syncthreads();
             for (uint32_t w = 0; w < wave; w++) { wx += Sred[w]; ew = max(ew, Hc[0][w]); el = max(el, Hc[1][w]); }
-            if (j0 <= nM) { Mwc[j0] = (uint16_t)wx; Mlw[j0] = (int16_t)ew; Mll[j0] = (int16_t)el; }
-            const uint32_t wx1 = wx + (uint32_t)w0;
-            const int ew1 = w0 ? (int)j0 : ew, el1 = l0 ? (int)j0 : el;
-            if (j1 <= nM) { Mwc[j1] = (uint16_t)wx1; Mlw[j1] = (int16_t)ew1; Mll[j1] = (int16_t)el1; }
-            if (j1 + 1 == nM) {  // my pair ends M: the totals
-              Mwc[nM] = (uint16_t)(wx1 + (uint32_t)w1); Mlw[nM] = (int16_t)(w1 ? (int)j1 : ew1); Mll[nM] = (int16_t)(l1 ? (int)j1 : el1);
+#pragma unroll
+            for (uint32_t r = 0; r < PER; r++) {
+              const uint32_t j = PER * t + r;
+              if (j <= nM) { Mwc[j] = (uint16_t)wx; Mlw[j] = (int16_t)ew; Mll[j] = (int16_t)el; }
+              wx += wv[r];
+              if (wv[r]) ew = (int)j;
+              if (lv[r]) el = (int)j;
             }
+            if (PER * t + PER == nM) { Mwc[nM] = (uint16_t)wx; Mlw[nM] = (int16_t)ew; Mll[nM] = (int16_t)el; }  // my ops end M: the totals
           }
           __syncthreads();
           // 4. the row: one thread probes the bucket
@@ -1308,6 +1400,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
             Hs[12] = WL == DINT_WL_TATP ? (H.lockw >> (8 * hq)) & 0xFFu : 0;
           }
           __syncthreads();
+          if (hot_pass == 0) KVB_STAMP(20);
           const uint32_t found = Hs[8], link = Hs[9], slot = Hs[10], ver0 = Hs[11], la0 = Hs[12];
           const uint32_t hgk = kv_cut_gk((uint32_t)(hcur >> sh_g), bin, cut), htable = kv_table_of(kv, hgk);
           const uint64_t hbucket = (uint64_t)(hgk - kv->gk_base[htable]);
@@ -1330,10 +1423,14 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
             if (!a_on[j]) continue;
             const uint32_t type = k_type(cur), idx = k_idx(cur);
             uint32_t lo = 0, hi = nM;  // ops of M with a smaller request index
-            const uint32_t key32 = idx << 12;
-            while (lo < hi) {
-              const uint32_t mid = (lo + hi) >> 1;
-              if (Mk[mid] < key32) lo = mid + 1; else hi = mid;
+            if (by_bitmap) {
+              lo = ops_below(idx);
+            } else {
+              const uint32_t key32 = idx << 12;
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (Mk[mid] < key32) lo = mid + 1; else hi = mid;
+              }
             }
             const int lw = found ? (int)Mlw[lo] : -1, ll = (int)Mll[lo];
             uint32_t code, get = 0;
@@ -1371,6 +1468,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           }
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __syncthreads();  // every read of the row precedes its write-back
+          if (hot_pass == 0) KVB_STAMP(21);
           // 6. final state, written once
           if (t == 0) {
             const uint32_t nw = Mwc[nM];
@@ -1403,12 +1501,14 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
           m = Hs[2];
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __syncthreads();
-          if (m == 0) continue;  // workgroup-uniform
           tiny = m <= 64;
+          again = true;
+          if (hot_pass == 0) KVB_STAMP(22);
         }
       }
     }
     }
+    if (m == 0) continue;  // workgroup-uniform: the dominant keys were all of it
     if (tiny) {
       // <= 64 records left (a big sub is its hot key and a handful of neighbours; the all-big fallback of a crowded coarse bin
       // hands over subs of any size): one wave, as a chunk of the resolve kernel -- not ~25 barriers of stretch machinery
@@ -1576,6 +1676,23 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
       }
     }
     if (!ordered) kvb_sort_stretch(Sk, m);
+    // The replies of a stretch are thousands of scattered byte and word stores; a wave's next LOAD returns only after its
+    // older stores have (one counter for both on gfx9): the first global load of the following stretch used to wait ~13 us
+    // for them.  The next stretch's records are therefore fetched HERE, before this stretch's stores are issued, into the
+    // ordered-copy buffer (free from now on); the stores then drain under the next stretch's ordering phase, which works
+    // in LDS only.
+    if (WL == DINT_WL_SMALLBANK && lds_bm != nullptr && regrouped && win + 1 < nwin) {
+      uint64_t *Nx = (uint64_t *)(lds_bm + KVB_BM_W * 10);
+      const uint32_t a2 = Wst[win + 1], b2 = max(a2, Wst[min(win + 2, KVB_T)]);
+      uint64_t r8[KVB_NMAX / KVB_T];
+#pragma unroll
+      for (uint32_t j = 0; j < KVB_NMAX / KVB_T; j++) r8[j] = a2 + j * KVB_T + t < b2 ? recs2[a2 + j * KVB_T + t] : 0;
+#pragma unroll
+      for (uint32_t j = 0; j < KVB_NMAX / KVB_T; j++)
+        if (a2 + j * KVB_T + t < b2) Nx[j * KVB_T + t] = kv_sort_key(r8[j], cut);
+      pf = true;
+      pf_m = b2 - a2;
+    }
     const uint32_t ntile = (m + KVB_T - 1) / KVB_T;
     KVB_STAMP(6);
 
@@ -2391,7 +2508,7 @@ template <int WL>
 __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __shared__ kv_dev Skv;
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
-  __shared__ __attribute__((aligned(16))) uint8_t Lbm[WL == DINT_WL_SMALLBANK ? KVB_BM_BYTES : 16];  // (one workgroup per CU either way: 8 waves of 256 VGPRs)
+  __shared__ __attribute__((aligned(16))) uint8_t Lbm[WL == DINT_WL_SMALLBANK ? KVB_BM_BYTES : KV_HOT_BM ? KV_HOT_BM_W * 10 : 16];  // (one workgroup per CU either way: 8 waves of 256 VGPRs)
   const kv_pass_args &A = M.e[blockIdx.y];
   const uint32_t nq = A.big[3];
   if (blockIdx.x >= nq) return;
@@ -2400,12 +2517,12 @@ __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __syncthreads();
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
-  // DINT_KV_TRACE: 16 words per workgroup -- {in, out, records, sub} of the first sub it takes, then kv_big_bin's stamps
-  uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 16 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;
+  // DINT_KV_TRACE: 32 words per workgroup -- {in, out, records, sub} of the first sub it takes, then kv_big_bin's stamps
+  uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 32 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;
   for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
     const uint4 d = A.bigq[i];
     if (tr && t == 0 && i == blockIdx.x) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = d.z; tr[3] = d.x; }
-    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + d.y, A.ovf2 + d.y, d.z, A.stats, A.force_flags, A.V, Lraw, Lbm, i == blockIdx.x ? tr : nullptr);
+    kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + d.y, A.ovf2 ? A.ovf2 + d.y : nullptr, d.z, A.stats, A.force_flags, A.V, Lraw, Lbm, i == blockIdx.x ? tr : nullptr);
     if (tr && t == 0 && i == blockIdx.x) tr[1] = __builtin_amdgcn_s_memrealtime();
   }
 }
@@ -2439,7 +2556,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.kv = kv.d_dev; A.log = log; A.cut = kv_make_cut(C, n); A.cap = cap;
   A.lcap = std::min(KVR_LCAP, kv_env("DINT_KV_LCAP", KVR_LCAP));
   A.bin_cnt = s.bin_cnt; A.kbins = s.kbins; A.big = s.big; A.big_next = s.big_next;
-  A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.stats = s.stats;
+  A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.ovf2 = s.ovf2; A.stats = s.stats;
   A.bigq = s.bigq;
   A.load_mode = load_mode;
   A.force_flags = kv.force_rounds | (kv_env("DINT_KV_NO_BM", 0) ? 4 : 0) | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);

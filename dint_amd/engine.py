@@ -203,9 +203,9 @@ class Engine:
             # stamps (run / segment masks, rows located, replies, write-backs, rounds), [11] chunks done, [12] big subs
             # done, [13] coarse bin, [14] records, [15] records in big subs, [16] chunks
             wg = out[:2048 * 32].reshape(2048, 32)
-            # ... and 16 words per k_kv_big workgroup: {in, out, records, sub} of the first big sub it resolved, then the
-            # phase stamps of one of its stretches ([4] in .. [12] written back: kv_big_bin)
-            return (wg, out[2048 * 32:2048 * 32 + 4 * 512 * 16].reshape(2048, 16)) if workgroups else wg
+            # ... and 32 words per k_kv_big workgroup: {in, out, records, sub} of the first big sub it resolved, then the
+            # phase stamps of one of its stretches ([4] in .. [13] out, [16] .. [22] its dominant-key path: kv_big_bin)
+            return (wg, out[2048 * 32:2048 * 32 + 4 * 512 * 32].reshape(2048, 32)) if workgroups else wg
         bins = out[:32768 * 16].reshape(32768, 16)
         return (bins, out[32768 * 16:].reshape(8192, 16)) if workgroups else bins
 

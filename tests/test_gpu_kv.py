@@ -489,7 +489,8 @@ def _hot_tatp(n, p_hot, mix, seed, hot_key=(0, 7), existing=None, n_noise_sub=20
 @pytest.mark.parametrize("p_hot,mix,hot_key", [
     (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (0, 7)),           # reads + a few hundred lock ops / writers
     (0.9, {0: 99, 13: 1}, (0, 7)),                               # almost only reads
-    (0.5, {0: 30, 1: 30, 2: 20, 12: 10, 13: 10}, (0, 7)),        # > 1024 ordering ops in a stretch: general path
+    (0.5, {0: 30, 1: 30, 2: 20, 12: 10, 13: 10}, (0, 7)),        # > 1024 ordering ops in a stretch: four per thread
+    (0.9, {0: 20, 1: 30, 2: 20, 12: 15, 13: 15}, (0, 7)),        # > 2048 ordering ops in a stretch: general path
     (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (0, 5_000_000)),   # the hot row does not exist
     (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (4, 7 | (1 << 32))),  # a CALL_FORWARDING row: inserts / deletes around it
     # the hot CALL_FORWARDING row itself inserted (also when it exists: duplicate rows) and deleted: its runs go request
@@ -528,6 +529,47 @@ def test_store_dominant_key_vs_oracle():
         got, want = eng.submit(req), o.replay(req)
         assert got.tobytes() == want.tobytes()
     assert _same_rows(eng.dump_rows(0), o.dump())
+
+
+@pytest.mark.parametrize("same_quadrant", [False, True])
+def test_tatp_two_hot_rows_in_one_bucket(same_quadrant):
+    """Two hot subscribers whose rows share a bucket land in one sub: the dominant-key path answers the hotter one, is run
+    again on what is left and answers the second (other lock quadrant) -- or, when they share the lock byte, leaves the
+    stretch to the general path.  Either way byte for byte the oracle's replies and state."""
+    import struct
+
+    n_sub = 3000
+    o = orc.TatpOracle(n_sub, populate_n=n_sub, log_entries=400_000)
+    hs = o.hash_size(0)
+    by_bucket = {}
+    for s_id in range(n_sub):
+        h = orc.fasthash64(struct.pack("<Q", s_id))
+        by_bucket.setdefault(h % hs, []).append((s_id, (h % (4 * hs)) // hs))
+    pair = None
+    for g in by_bucket.values():
+        for a in g:
+            for b in g:
+                if a[0] < b[0] and (a[1] == b[1]) == same_quadrant:
+                    pair = pair or (a[0], b[0])
+    assert pair is not None
+    existing = [o.dump(t)[0] for t in range(5)]
+    eng = _engine(W.TATP, n_rows=n_sub, log_entries=400_000)
+    eng.populate(n_sub)
+    rng = np.random.default_rng(5)
+    T = wire.Tatp
+    for k, n in enumerate((9000, 60_000)):
+        req = tracegen.tatp_random(n, existing, seed=31 + k, n_sub_touch=n_sub)
+        u = rng.random(n)
+        for key, lo, hi in ((pair[0], 0.0, 0.55), (pair[1], 0.55, 0.85)):
+            hot = (u >= lo) & (u < hi)
+            req["table"][hot] = 0
+            req["key"][hot] = key
+            req["type"][hot] = rng.choice([T.READ, T.ACQUIRE_LOCK, T.ABORT, T.COMMIT_PRIM, T.COMMIT_BCK], int(hot.sum()), p=[0.7, 0.1, 0.04, 0.08, 0.08])
+        got, want = eng.submit(req), o.replay(req)
+        assert got.tobytes() == want.tobytes(), k
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+    _tatp_locks(eng, o)
 
 
 @pytest.mark.parametrize("no_bitmap", ["0", "1"])

@@ -58,6 +58,10 @@ if os.environ.get("DINT_KV_TRACE"):
         i = int(top[0])
         out["big_subs"]["stretch_us"] = {bn[k - 5]: round(float(big[i, k] - big[i, k - 1]) / 100.0, 2) for k in range(5, 14) if big[i, k] > 0 and big[i, k - 1] > 0}
         out["big_subs"]["stretches_rounds"] = [int(big[i, 15]), int(big[i, 14])]
+        hn = ["sampled", "checked", "ops_sorted", "row_located", "answered", "compacted"]
+        out["big_subs"]["pf_regrouped_nwin_t0gather_us"] = [int(big[i, 27]), int(big[i, 28]), int(big[i, 29]), round(float(big[i, 31] - big[i, 4]) / 100.0, 2)]
+        out["big_subs"]["dominant_key_bad_ops_hot_m"] = [int(big[i, k]) for k in range(23, 27)]
+        out["big_subs"]["dominant_key_us"] = {hn[k - 17]: round(float(big[i, k] - big[i, k - 1]) / 100.0, 2) for k in range(17, 23) if big[i, k] > 0 and big[i, k - 1] > 0}
     tr = tr[tr[:, 0] > 0]
     t0 = tr[:, 0].min()
     names = ["in", "loaded", "counted", "laid_out", "placed", "sorted", "masks", "located", "replied", "written", "rounds", "chunks_done", "bigs_done"]
