@@ -52,7 +52,8 @@ def main():
     tag = sys.argv[1]
     rest = sys.argv[2:]
     sq = "--sq" in rest  # also the SQ (instruction mix / wave cycle) counters, two more passes
-    rest = [a for a in rest if a != "--sq"]
+    fast = "--fast" in rest  # without the TCC hit / miss pass
+    rest = [a for a in rest if a not in ("--sq", "--fast")]
     wl = rest[rest.index("--workload") + 1] if "--workload" in rest else "tatp"
     out_dir = os.path.join(ROOT, "gpurun_out", f"{tag}_{wl}")
     os.makedirs(out_dir, exist_ok=True)
@@ -69,6 +70,8 @@ def main():
               ("EA", ["--pmc", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "--kernel-trace"])]
     SQ1 = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"]
     SQ2 = ["SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_SCA", "GRBM_GUI_ACTIVE"]
+    if fast:
+        passes = [p for p in passes if p[0] != "TCC"]
     if sq:
         passes = passes[:1] + [("SQ1", ["--pmc"] + SQ1 + ["--kernel-trace"]), ("SQ2", ["--pmc"] + SQ2 + ["--kernel-trace"])]
     merged, lines = {}, []
