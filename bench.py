@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="tatp: skip the compact legs of the other BASELINE configs (lock_fasst, lock_2pl, log, store, smallbank)")
     ap.add_argument("--no-shim", action="store_true", help="skip the UDP shim loopback leg")
+    ap.add_argument("--no-mixes", action="store_true", help="store: skip the 100/0 and 50/50 legs (profile runs)")
     ap.add_argument("--no-exchange-leg", action="store_true", help="skip the compact --force-exchange leg of the default line")
     ap.add_argument("--no-as-shipped", action="store_true", help="skip the as-shipped tatp/udp deployment leg (three reference "
                     "server processes, ~27 GB of host memory)")
@@ -758,7 +759,7 @@ def bench_store(args, world, rank, dev, transport):
     # ---- the reference client's other two mixes (store/caladan/client_udp.cc:56-66: `parallel` = 100 % READ, `contention` =
     # 50 % READ / 50 % SET), same table size and key distribution, 16 batches each.  From a known state -- the populated
     # table + the first n_s requests of the bench stream, where the oracle above stands -- so every reply is checked.
-    if rt is None:
+    if rt is None and not args.no_mixes:
         n_s = min(len(stream), 8 * NB)
         eng.restore()
         eng.submit_device(d_req.data_ptr(), n_s, d_rep.data_ptr(), 0)

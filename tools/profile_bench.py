@@ -62,7 +62,7 @@ def main():
     last = engines * 190  # ... of which the last 190 per engine are averaged here
     base = [sys.executable, os.path.join(ROOT, "bench.py")] + rest + ["--steps", str(steps), "--warmup", str(warm), "--per-step", str(per_step),
                                                                        "--no-cpu-baseline", "--no-rand64", "--no-host-path", "--no-closed-loop",
-                                                                       "--no-other-workloads", "--no-shim", "--no-exchange-leg", "--no-as-shipped"]
+                                                                       "--no-other-workloads", "--no-shim", "--no-exchange-leg", "--no-as-shipped", "--no-mixes"]
     env = dict(os.environ, TMPDIR="/tmp")
     passes = [("trace", ["--kernel-trace", "--stats"]), ("FETCH_SIZE", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
               ("WRITE_SIZE", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
@@ -81,7 +81,8 @@ def main():
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
         lines.append(f"# pass {name}: rc {r.returncode}: {' '.join(cmd[:6])} ... -- bench.py {' '.join(rest)}")
         if r.returncode != 0:
-            lines.append(r.stderr[-1500:])
+            err = [l for l in r.stderr.splitlines() if "simple_timer" not in l and "generateRocpd" not in l and "tool.cpp" not in l]
+            lines.append("\n".join(err)[-1500:] + "\n# stdout tail: " + r.stdout[-300:])
             print(lines[-2], lines[-1], flush=True)
             continue
         if r.stdout and "parity" in r.stdout[-2000:]:
