@@ -137,7 +137,17 @@ class Replay:
         for e in range(lo, hi):
             for s in range(N_SHARDS):
                 if not torch.equal(self.d_rep[e][s], self.d_want[e][s]):
-                    raise AssertionError(f"replay diverged from the recorded run at epoch {e}, shard {s}")
+                    got = self.d_rep[e][s].cpu().numpy().reshape(-1, self.msg)
+                    want = self.d_want[e][s].cpu().numpy().reshape(-1, self.msg)
+                    req = self.d_req[e][s].cpu().numpy().reshape(-1, self.msg)
+                    bad = np.nonzero((got != want).any(axis=1))[0]
+                    if os.environ.get("DINT_DUMP_DIVERGENCE"):  # the whole batch, for tools/ analysis against the CPU oracle
+                        np.savez_compressed(os.environ["DINT_DUMP_DIVERGENCE"], req=req, got=got, want=want, epoch=e, shard=s)
+                    i = int(bad[0])
+                    raise AssertionError(f"replay diverged from the recorded run at epoch {e}, shard {s}: {len(bad)} of {len(got)} "
+                                         f"messages differ, first at {i} (last at {int(bad[-1])}): request {req[i].tobytes().hex()} "
+                                         f"got {got[i].tobytes().hex()} want {want[i].tobytes().hex()}; differing indices "
+                                         f"{bad[:12].tolist()}")
 
     def ops(self, lo: int, hi: int) -> int:
         return sum(sum(c) for c in self.counts[lo:hi])

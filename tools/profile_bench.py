@@ -78,7 +78,15 @@ def main():
     for name, flags in passes:
         d = os.path.join(out_dir, name)
         cmd = ["rocprofv3"] + flags + ["-d", d, "-o", name, "--"] + base
-        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
+        # (r04: under rocprofv3 about every second smallbank run fails bench.py's own replay-equals-recording check -- a tail of
+        # one staging chunk of a pageable host <-> device copy of the RECORDING is stale; the device replay equals the CPU
+        # oracle.  NOTEBOOK.md.  A failed pass is run again, and the summary says how often.)
+        for attempt in range(4):
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
+            if r.returncode == 0:
+                break
+            shutil.rmtree(d, ignore_errors=True)
+            lines.append(f"# pass {name}: attempt {attempt + 1} failed (rc {r.returncode}): " + " ".join(l for l in r.stderr.splitlines() if "AssertionError" in l)[-300:])
         lines.append(f"# pass {name}: rc {r.returncode}: {' '.join(cmd[:6])} ... -- bench.py {' '.join(rest)}")
         if r.returncode != 0:
             err = [l for l in r.stderr.splitlines() if "simple_timer" not in l and "generateRocpd" not in l and "tool.cpp" not in l]
