@@ -141,7 +141,7 @@ class Replay:
                     want = self.d_want[e][s].cpu().numpy().reshape(-1, self.msg)
                     req = self.d_req[e][s].cpu().numpy().reshape(-1, self.msg)
                     bad = np.nonzero((got != want).any(axis=1))[0]
-                    if os.environ.get("DINT_DUMP_DIVERGENCE"):  # the whole batch, for tools/ analysis against the CPU oracle
+                    if os.environ.get("DINT_DUMP_DIVERGENCE"):  # the whole batch, for offline analysis (tools/gpu_bisect.sh)
                         np.savez_compressed(os.environ["DINT_DUMP_DIVERGENCE"], req=req, got=got, want=want, epoch=e, shard=s)
                     i = int(bad[0])
                     raise AssertionError(f"replay diverged from the recorded run at epoch {e}, shard {s}: {len(bad)} of {len(got)} "

@@ -110,7 +110,7 @@ typedef struct dint_config {
   uint32_t shard_index;
   uint32_t shard_count;
   /* requests per kernel pass; longer submissions run as several passes.  0 = the engine's maximum
-   * (LOG 65,536; every other workload 1,048,576 -- TATP / SMALLBANK never more than log_entries). */
+   * (1,048,576 -- LOG / TATP / SMALLBANK never more than log_entries; LOG was 65,536 until r03). */
   uint32_t max_pass;
   /* STORE / TATP / SMALLBANK: overflow entries per table (a bucket whose 4 inline slots are taken chains 4-slot
    * entries from this pool; the reference `new`s them without bound, store/udp/kvs.h:95-102).  0 = local buckets / 4
