@@ -1103,7 +1103,15 @@ def bench_txn(args, world, rank, dev, transport, kind):
         cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b * (1.0 - f_big)),
                 "k_kv_part": (avg.get("k_kv_part", 0.0), tab_b + log_b),
                 "k_kv_big": (avg.get("k_kv_big", 0.0), tab_b * f_big)}
-        dom = max(cand, key=lambda k: cand[k][0])
+        # ... when the two resolve-stage kernels are a near tie in time (tatp: 60 against 53 us) the one that serves more
+        # algorithmic bytes is priced, not whichever took a few us longer in this run: "the longest" flipped from box to box
+        # (r04: frac 0.064 on one box, 0.004 on the next, same kernels).  The other one is reported under `roofline.other`
+        t_res, t_big = cand["k_kv_resolve"][0], cand["k_kv_big"][0]
+        if min(t_res, t_big) >= 0.75 * max(t_res, t_big):  # a near tie: the one with more bytes
+            stage = "k_kv_resolve" if cand["k_kv_resolve"][1] >= cand["k_kv_big"][1] else "k_kv_big"
+        else:
+            stage = "k_kv_resolve" if t_res >= t_big else "k_kv_big"
+        dom = "k_kv_part" if cand["k_kv_part"][0] > max(t_res, t_big) else stage
         dom_us, alg = cand[dom][0], cand[dom][1] / max(1, launches)
         achieved = alg / (dom_us * 1e-6) / 1e9
         # `traffic` is not measured inside this run (rocprofv3 cannot attach to itself): null here; the PMC figures of
@@ -1117,6 +1125,13 @@ def bench_txn(args, world, rank, dev, transport, kind):
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, alg), 3)
+        oth = "k_kv_big" if stage == "k_kv_resolve" else "k_kv_resolve"
+        if cand[oth][0] > 0:
+            o_alg = cand[oth][1] / max(1, launches)
+            o_ach = o_alg / (cand[oth][0] * 1e-6) / 1e9
+            roof["other"] = {"kernel": oth, "kernel_avg_us": round(cand[oth][0], 3), "alg_bytes_per_launch": int(o_alg),
+                             "achieved": round(o_ach, 2), "frac": round(o_ach / HBM_PEAK_GBS, 5),
+                             "what": "the pass's other resolve-stage kernel (the hot keys, or the bulk), priced the same way"}
 
     # ---- the closed loop itself, resident on the GPU: the same clients as device code emit the same
     # stream (tests/test_gpu_gdriver.py), the engines read the batch sizes on the device, nothing crosses PCIe
