@@ -72,6 +72,14 @@ struct dint_engine {
     uint8_t *d_req = nullptr, *d_rep = nullptr;
     hipEvent_t h2d = nullptr, comp = nullptr, done = nullptr;
     uint64_t seq = 0;  // sequence number of the chunk that used the slot last (0 = never)
+    // Pageable callers (a plain malloc / numpy buffer): hipMemcpyAsync never sees their memory.  The chunk is staged through
+    // these page-locked buffers of the engine -- a host memcpy in on submission, a host memcpy out once the chunk has left
+    // the GPU (at dint_wait, or when the slot is taken again).  r04: under rocprofv3 a pageable D2H / H2D of the HIP runtime
+    // left the tail of a 4 KB page of one reply batch holding bytes of another (NOTEBOOK.md); the boundary contract
+    // (lock_fasst/udp/net.h:33-48: the caller owns plain buffers) must not depend on the runtime's pageable path.
+    uint8_t *h_req = nullptr, *h_rep = nullptr;
+    uint8_t *deliver_to = nullptr;  // replies of the slot's chunk still to be copied from h_rep to the caller
+    size_t deliver_bytes = 0;
   } slot[kNSlot];
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;
   uint64_t next_seq = 1;
@@ -403,6 +411,8 @@ void dint_engine_destroy(dint_engine_t *e) {
   for (auto &sl : e->slot) {
     hipFree(sl.d_req);
     hipFree(sl.d_rep);
+    if (sl.h_req) hipHostFree(sl.h_req);
+    if (sl.h_rep) hipHostFree(sl.h_rep);
     if (sl.h2d) hipEventDestroy(sl.h2d);
     if (sl.comp) hipEventDestroy(sl.comp);
     if (sl.done) hipEventDestroy(sl.done);
@@ -520,7 +530,38 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
 // ---- host buffers: pipelined H2D / kernels / D2H ---------------------------------------------------------------
 namespace {
 // enqueue chunk [off, off + m) of a host submission; returns its sequence number in *seq
-int enqueue_chunk(dint_engine *e, const uint8_t *rq, uint8_t *rp, uint32_t m, uint64_t *seq) {
+// is [p, p + bytes) page-locked memory the HIP runtime knows (dint_alloc_pinned, hipHostMalloc, hipHostRegister)?
+bool host_range_pinned(const void *p, size_t bytes) {
+  if (bytes == 0) return true;
+  static const bool no_bounce = getenv("DINT_NO_BOUNCE") != nullptr;  // diagnostic (tools/stress_pageable.py): r04's direct copies
+  if (no_bounce) return true;
+  const uint8_t *ends[2] = {(const uint8_t *)p, (const uint8_t *)p + bytes - 1};
+  for (const uint8_t *q : ends) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+      (void)hipGetLastError();  // an unregistered pointer is an error to older runtimes: not ours
+      return false;
+    }
+    if (a.type != hipMemoryTypeHost) return false;  // hipMemoryTypeUnregistered (plain memory), or not host memory at all
+  }
+  return true;
+}
+// copy a delivered chunk's replies out of the slot's bounce buffer (the chunk has left the GPU: sl.done was waited for)
+void slot_deliver(dint_engine::Slot &sl) {
+  if (sl.deliver_to) memcpy(sl.deliver_to, sl.h_rep, sl.deliver_bytes);
+  sl.deliver_to = nullptr;
+  sl.deliver_bytes = 0;
+}
+int slot_bounce_alloc(dint_engine *e, dint_engine::Slot &sl, bool req, bool rep) {
+  const size_t bytes = (size_t)e->pass_max * e->msg_size + 64;
+  if (req && !sl.h_req && hipHostMalloc((void **)&sl.h_req, bytes, hipHostMallocDefault) != hipSuccess)
+    return fail(DINT_ENOMEM, "hipHostMalloc(%zu) for the staging of a pageable request buffer", bytes);
+  if (rep && !sl.h_rep && hipHostMalloc((void **)&sl.h_rep, bytes, hipHostMallocDefault) != hipSuccess)
+    return fail(DINT_ENOMEM, "hipHostMalloc(%zu) for the staging of a pageable reply buffer", bytes);
+  return 0;
+}
+int enqueue_chunk(dint_engine *e, const uint8_t *rq, uint8_t *rp, uint32_t m, uint64_t *seq, bool rq_pinned, bool rp_pinned) {
   const uint64_t sq = e->next_seq;
   const int k = (int)(sq % dint_engine::kNSlot);
   if (int rc = slot_alloc(e, k)) return rc;
@@ -538,13 +579,24 @@ int enqueue_chunk(dint_engine *e, const uint8_t *rq, uint8_t *rp, uint32_t m, ui
   }
   dint_engine::Slot &sl = e->slot[k];
   if (sl.seq) HIP_TRY(hipEventSynchronize(sl.done));  // the slot's previous chunk has left the GPU
+  slot_deliver(sl);                                    // ... and, for a pageable caller, reaches its reply buffer now
   const size_t bytes = (size_t)m * e->msg_size;
+  if (int rc = slot_bounce_alloc(e, sl, !rq_pinned, !rp_pinned)) return rc;
+  if (!rq_pinned) {
+    memcpy(sl.h_req, rq, bytes);
+    rq = sl.h_req;
+  }
   HIP_TRY(hipMemcpyAsync(sl.d_req, rq, bytes, hipMemcpyHostToDevice, e->s_h2d));
   HIP_TRY(hipEventRecord(sl.h2d, e->s_h2d));
   HIP_TRY(hipStreamWaitEvent(e->stream, sl.h2d, 0));
   if (int rc = run_pass(e, sl.d_req, m, sl.d_rep, e->stream)) return rc;
   HIP_TRY(hipEventRecord(sl.comp, e->stream));
   HIP_TRY(hipStreamWaitEvent(e->s_d2h, sl.comp, 0));
+  if (!rp_pinned) {
+    sl.deliver_to = rp;
+    sl.deliver_bytes = bytes;
+    rp = sl.h_rep;
+  }
   HIP_TRY(hipMemcpyAsync(rp, sl.d_rep, bytes, hipMemcpyDeviceToHost, e->s_d2h));
   if (e->kv.n_tables)  // the overflow-pool counter travels with the replies (see dint_wait)
     HIP_TRY(hipMemcpyAsync(e->h_pool, &e->scratch.stats->pool_exhausted, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->s_d2h));
@@ -558,6 +610,13 @@ int wait_seq(dint_engine *e, uint64_t seq) {
   if (seq == 0 || seq >= e->next_seq) return fail(DINT_EINVAL, "unknown ticket");
   dint_engine::Slot &sl = e->slot[seq % dint_engine::kNSlot];
   if (sl.seq == seq) HIP_TRY(hipEventSynchronize(sl.done));  // else: the slot was reused, so the chunk finished long ago
+  // replies of `seq` and of every earlier chunk are complete: the ones that went through a bounce buffer reach the
+  // caller's memory here (chunks are enqueued, and leave the GPU, in sequence order)
+  for (auto &o : e->slot)
+    if (o.deliver_to && o.seq <= seq) {
+      if (o.seq != seq) HIP_TRY(hipEventSynchronize(o.done));
+      slot_deliver(o);
+    }
   if (*e->h_pool > e->pool_seen) {
     const unsigned long long lost = *e->h_pool - e->pool_seen;
     e->pool_seen = *e->h_pool;
@@ -575,9 +634,10 @@ int dint_submit_async(dint_engine_t *e, const void *reqs, uint32_t n, void *repl
   const uint8_t *rq = (const uint8_t *)reqs;
   uint8_t *rp = (uint8_t *)replies;
   uint64_t seq = e->next_seq - 1;  // n == 0: the ticket of whatever was submitted last
+  const bool rq_pinned = host_range_pinned(rq, (size_t)n * e->msg_size), rp_pinned = host_range_pinned(rp, (size_t)n * e->msg_size);
   for (uint32_t off = 0; off < n; off += e->pass_max) {
     const uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
-    if (int rc = enqueue_chunk(e, rq + (size_t)off * e->msg_size, rp + (size_t)off * e->msg_size, m, &seq)) return rc;
+    if (int rc = enqueue_chunk(e, rq + (size_t)off * e->msg_size, rp + (size_t)off * e->msg_size, m, &seq, rq_pinned, rp_pinned)) return rc;
   }
   *ticket = seq;
   return 0;
@@ -673,7 +733,18 @@ int dint_route_pack_multi(const dint_route_item *items, uint32_t n_items, uint64
     if (int rc = route_job(items[k], true, cnt_stride, st, stream, &jobs[k])) return rc;
   dint_launch_route_pack(jobs, n_items, seg_stride, st);
   hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  if (err != hipSuccess) {
+    // some of the per-format launches may be queued already: their tickets and tile words would be left dirty in a
+    // copy the engines still point at.  Drain the stream and hand every engine two clean copies again.
+    hipStreamSynchronize(st);
+    for (uint32_t k = 0; k < n_items; k++) {
+      dint_engine *e = items[k].engine;
+      hipMemset(std::min(e->route.blk, e->route.blk_next), 0, (size_t)2 * DINT_ROUTE_BLK_WORDS * 4);
+      mark_route_stream(e, st);
+    }
+    hipDeviceSynchronize();
+    return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
+  }
   for (uint32_t k = 0; k < n_items; k++) {
     dint_engine *e = items[k].engine;
     std::swap(e->route.blk, e->route.blk_next);  // the launch left the other copy of the scratch zeroed for the next call

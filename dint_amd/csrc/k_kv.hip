@@ -7,8 +7,8 @@
 // Every request touches exactly one bucket of one table (lock_hash % hash_size == kvs bucket), or only
 // the log ring.  Requests on different buckets commute; requests on one bucket apply in request order.
 //
-// One pass (n <= 2^20 requests) = two kernels, a TWO-LEVEL partition; the passes of several engines share one set of
-// launches (grid.y / grid ranges = engine, dint_launch_kv_multi):
+// One pass (n <= 2^20 requests) = three kernels (k_kv_part, k_kv_resolve, k_kv_big), a TWO-LEVEL partition; the passes of
+// several engines share one set of launches (grid.y / grid ranges = engine, dint_launch_kv_multi):
 //   k_kv_part    : KV_TB * RPT requests per workgroup -- copy the messages to the reply array, classify, hash, count the
 //                  records per COARSE bin (coarse = group % C, C ~ n / 512, any number: kv_cut) in LDS, reserve each run
 //                  with one device atomic per (workgroup, coarse bin) and store the 16-byte records {key, group / C |
@@ -19,9 +19,11 @@
 //   k_kv_resolve : one 512-thread workgroup per coarse bin.  It splits the bin's records by sub = (group / C) % 64 in
 //                  LDS and packs neighbouring subs into chunks of <= 64 records; every chunk is one wave: sorted by
 //                  (bucket group, key hash, idx) in registers and resolved at once (kv_chunk).  A sub of more than 64
-//                  records (a hot key) is resolved by the whole workgroup afterwards: sorted in LDS, ballot masks over
-//                  the whole sorted stretch with O(1) range tables, then leaders / 512-request tiles / write-back
-//                  (kv_big_bin).  Inside a chunk or stretch, several requests on ONE key are resolved in closed form
+//                  records (a hot key) is listed for k_kv_big.
+//   k_kv_big     : one 512-thread workgroup per big sub: sorted in LDS, ballot masks over the whole sorted stretch with
+//                  O(1) range tables, then leaders / 512-request tiles / write-back (kv_big_bin); the hottest key of a
+//                  pass is cut into pieces that several workgroups answer at once (kv_hot_piece).
+//                  Inside a chunk or stretch, several requests on ONE key are resolved in closed form
 //                  (version = v0 + #writers below, value = message of the last writer below, lock = last lock op
 //                  below); what the closed forms do not cover runs in rounds (k-th request of a bucket run in round k,
 //                  workgroup fence between rounds), so every request sees the table exactly as the serial reference
@@ -2442,12 +2444,10 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   }
 }
 
-// The launch carries the big path's footprint (~73 KB of LDS, 128 VGPRs): two workgroups = 16 waves per CU.  The big
-// path is a function of its own (noinline), so that its register pressure -- it spills at 128 VGPRs -- stays out of the
-// chunk path's allocation (the chunk path alone needs 89 VGPRs and no scratch).
 // The big subs (hot keys) are not resolved here but listed for k_kv_big, a launch of its own behind this one: the chunk
-// workgroups then carry 19 KB of LDS and ~115 VGPRs without scratch, and the big path -- compiled on its own, at 256
-// VGPRs -- does not spill either (r03's one kernel for both: 62 spilled VGPRs).  Measured against
+// workgroups then carry 19 KB of LDS and ~115 VGPRs without scratch (two workgroups = 16 waves per CU), and the big path
+// -- compiled on its own at 256 VGPRs -- spills 3 .. 40 dwords per lane instead of r03's 62 in the shared kernel
+// (profiles/r05_kernel_resources.txt).  Measured against
 // (a) resolving them in place, behind the bin's chunks, and (c) handing the hot ones to worker workgroups at the end of
 // THIS launch, which take them as they are listed (agent-scope stores, a ticket per worker: parity-green, no hang) -- the
 // overlap that costs the big path its registers again (one kernel, 128 VGPRs, ~100 spilled): TATP 1,750 against 2,170
@@ -2462,7 +2462,7 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
   while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
   const kv_pass_args &A = M.e[e];
   const uint32_t t = threadIdx.x;
-  uint64_t *tr = A.trace ? A.trace + 32 * (size_t)blockIdx.x : nullptr;
+  uint64_t *tr = A.trace ? A.trace + 32 * (size_t)b : nullptr;  // per engine (its own trace buffer), by ITS bin: < 2048 * 32, where k_kv_big's rows start
   if (tr && t == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
   // everything the workgroup needs from memory before its LDS phases, in flight together: the table descriptors, the
   // bin's record count and -- without waiting for the count: the bin's region always exists -- its first 2 x NT records
@@ -2503,7 +2503,10 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
 }
 
 // the pass's big subs, KVB_GRID workgroups per engine taking them in turn (the longest job of a pass: a hot key)
-// (one workgroup per CU: a pass has a few hundred big subs at most, and at 256 VGPRs the stretch machinery does not spill)
+// One workgroup per CU: its 8 waves are 2 per SIMD (the second launch bound is waves per SIMD, not workgroups per CU) at
+// the full 256 VGPRs, and its LDS (static_assert below) leaves no room for a second one.
+static_assert(sizeof(kvb_lds) + KVB_BM_BYTES + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
+static_assert(sizeof(kvb_lds) + KV_HOT_BM_W * 10 + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
 template <int WL>
 __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __shared__ kv_dev Skv;
@@ -2579,7 +2582,8 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
   if (ev) hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
+  // (DINT_EXP_SKIP_BIG=1, tools/exp_chain.py only: the chain without its last kernel -- the hot keys stay unanswered)
+  if (!kv_env("DINT_EXP_SKIP_BIG", 0)) hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
   if (ev) hipEventRecord(ev[3], st);
 }
 

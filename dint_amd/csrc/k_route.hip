@@ -204,16 +204,21 @@ k_route_pack(rt_items I) {
   __shared__ __attribute__((aligned(16))) uint8_t Lb[RP_LDS_BYTES];
   __shared__ uint32_t Wc[RP_TB / 64][DINT_ROUTE_MAXW];
   __shared__ uint32_t Cnt[DINT_ROUTE_MAXW], Loff[DINT_ROUTE_MAXW], Base[DINT_ROUTE_MAXW];  // of the tile per destination: messages, LDS byte offset of the run, messages of earlier tiles
-  __shared__ uint32_t Sb;
+  __shared__ uint32_t Sb, Sext;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) Sb = atomicAdd(&blk[RP_CTL], 1u);  // tiles in the order the workgroups start
+  if (t == 0) {
+    Sb = atomicAdd(&blk[RP_CTL], 1u);  // tiles in the order the workgroups start
+    // (read by ONE thread, before the barrier: the housekeeping below clears this word, and a wave that loaded it after
+    // wave 0's store would see 0 and skip its share of the zeroing -- ADVICE r04)
+    Sext = Sb == 0 ? it.blk_next[RP_CTL + 1] : 0u;
+  }
   for (uint32_t k = t; k < (RP_TB / 64) * DINT_ROUTE_MAXW; k += RP_TB) (&Wc[0][0])[k] = 0;
   if (t < DINT_ROUTE_MAXW) Base[t] = 0;
   __syncthreads();
   const uint32_t b = Sb;
   if (b == 0) {  // housekeeping: the other copy of the scratch, which the next call uses, goes back to zero
     uint32_t *nx = it.blk_next;
-    const uint32_t ext = nx[RP_CTL + 1];
+    const uint32_t ext = min(Sext, RP_CTL);
     for (uint32_t k = t; k < ext; k += RP_TB) nx[k] = 0;
     if (t < 2) nx[RP_CTL + t] = 0;
     if (t == 0) blk[RP_CTL + 1] = ntiles * world;

@@ -98,7 +98,15 @@ class Replay:
             self.append(req, rep)
 
     def append(self, req, rep) -> None:
-        up = lambda a: torch.from_numpy(np.frombuffer(a.tobytes(), np.uint8).copy()).cuda()  # noqa: E731
+        def up(a):  # through page-locked staging: torch / HIP never copy pageable memory here (r04: a stale page tail of a
+            b = np.frombuffer(a.tobytes(), np.uint8)  # pageable copy under rocprofv3 made every second smallbank profile run fail)
+            if len(b) == 0:
+                return torch.empty(0, dtype=torch.uint8, device="cuda")
+            h = torch.empty(len(b), dtype=torch.uint8).pin_memory()
+            h.numpy()[:] = b
+            d = h.cuda(non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return d
         self.counts.append([len(req[s]) for s in range(N_SHARDS)])
         self.d_req.append([up(req[s]) for s in range(N_SHARDS)])
         self.d_want.append([up(rep[s]) for s in range(N_SHARDS)])

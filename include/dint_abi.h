@@ -154,8 +154,11 @@ int dint_submit(dint_engine_t *e, const void *reqs, uint32_t n, void *replies);
  * into passes of max_pass requests; pass k+1's host-to-device copy and pass k-1's device-to-host copy overlap pass
  * k's kernels (DINT_FLAG_COPY_STREAMS: three HIP streams; three staging slots), and successive submissions pipeline the same way -- as long
  * as reqs / replies are page-locked (dint_alloc_pinned, or the caller's own hipHostMalloc / hipHostRegister
- * memory); pageable buffers work but every copy then blocks the calling thread.  Buffers must stay untouched until
- * dint_wait(ticket) returns.  Submissions are applied in call order (one serial history per engine). */
+ * memory).  Pageable buffers (plain malloc memory, as the reference's stack `message` of lock_fasst/udp/net.h:33-48) work
+ * too: the engine stages them through page-locked buffers of its own -- one host memcpy on submission, and the replies
+ * reach the caller's buffer inside dint_wait -- so the HIP runtime is never handed pageable memory.  Buffers must stay
+ * untouched until dint_wait(ticket) returns; replies are valid only then.  Submissions are applied in call order (one
+ * serial history per engine). */
 typedef uint64_t dint_ticket;
 int dint_submit_async(dint_engine_t *e, const void *reqs, uint32_t n, void *replies, dint_ticket *ticket);
 /* replies of `ticket` (and of every earlier ticket) are complete.  DINT_ENOMEM if INSERTs were refused since the

@@ -44,6 +44,46 @@ def test_async_pageable_buffers_and_in_place():
     assert buf.tobytes() == o.replay(req).tobytes()
 
 
+def test_pageable_callers_three_engines_back_to_back():
+    """The host boundary with plain (pageable) buffers, as the reference's stack `message` (lock_fasst/udp/net.h:33-48): three
+    engines in one process, many batches back to back of sizes that end inside a 4 KB page and at odd alignments, several
+    passes per batch, mixed with page-locked submissions.  Every reply byte must equal the oracle's -- r04 saw the tail of a
+    page of one reply batch hold another batch's bytes when the HIP runtime copied pageable memory under a profiler; the
+    engine stages pageable callers through its own page-locked buffers now."""
+    rng = np.random.default_rng(41)
+    n_eng, rounds = 3, 40
+    orcs = [orc.SmallbankOracle(20_000, log_entries=50_000) for _ in range(n_eng)]
+    engs = [Engine(W.SMALLBANK, n_rows=20_000, log_entries=50_000, max_pass=4096) for _ in range(n_eng)]
+    for e in engs:
+        e.populate(20_000)
+    msg = wire.SB_MSG.itemsize
+    pend = []
+    for r in range(rounds):
+        for k, e in enumerate(engs):
+            n = int(rng.integers(150, 9000))
+            req = tracegen.sb_random(n, seed=1000 * r + k, n_acct_touch=200)
+            want = orcs[k].replay(req)
+            # a reply buffer at an odd offset inside a larger pageable allocation, pre-filled with a pattern
+            off = int(rng.integers(0, 4096))
+            raw = np.full(n * msg + 8192, 0xA5, np.uint8)
+            out = raw[off:off + n * msg]
+            if r % 5 == 4:  # every fifth round through page-locked memory: both kinds share the staging slots
+                pi, po = Pinned(n * msg), Pinned(n * msg)
+                pi.array[:] = np.frombuffer(req.tobytes(), np.uint8)
+                t = e.submit_async(pi.ptr, n, po.ptr)
+                pend.append((e, t, po.array, want, raw, None, (pi, po)))
+            else:
+                t = e.submit_async(req, n, out.ctypes.data)
+                pend.append((e, t, out, want, raw, (off, n * msg), req))
+        if r % 4 == 3 or r == rounds - 1:  # several batches per engine in flight before the first wait
+            for e, t, out, want, raw, span, _keep in pend:
+                e.wait(t)
+                assert out.tobytes() == want.tobytes()
+                if span:  # nothing outside the reply range was touched
+                    assert (raw[:span[0]] == 0xA5).all() and (raw[span[0] + span[1]:] == 0xA5).all()
+            pend = []
+
+
 def test_submit_device_on_alternating_caller_streams_is_serial():
     """consecutive passes on different streams share the engine's scratch: the engine must order them itself"""
     n, steps = 60_000, 12
