@@ -78,9 +78,18 @@ def parse():
     ap.add_argument("--no-exchange-leg", action="store_true", help="skip the compact --force-exchange leg of the default line")
     ap.add_argument("--no-as-shipped", action="store_true", help="skip the as-shipped tatp/udp deployment leg (three reference "
                     "server processes, ~27 GB of host memory)")
+    ap.add_argument("--legs", default="all", choices=["all", "gpu", "headline"],
+                    help="one switch over the --no-* flags: all = every leg (the driver's run); gpu = no CPU leg (cpu baseline, "
+                         "reference, as-shipped servers, UDP shim); headline = the timed region, its kernel times and roofline "
+                         "only (what tools/profile_bench.py runs under rocprofv3)")
     ap.add_argument("--sweep-clients", action="store_true",
                     help="tatp / smallbank: abort rate and Mtxn/s at 4096 / 32768 / 131072 / 524288 closed-loop clients")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.legs in ("gpu", "headline"):
+        args.no_cpu_baseline = args.no_cpu_reference = args.no_shim = args.no_as_shipped = True
+    if args.legs == "headline":
+        args.no_closed_loop = args.no_rand64 = args.no_host_path = args.no_other_workloads = args.no_mixes = args.no_exchange_leg = True
+    return args
 
 
 # --------------------------------------------------------------------------------------------- launch / dist
@@ -724,8 +733,11 @@ def bench_store(args, world, rank, dev, transport):
         tim = eng.timing_read()
         eng.timing_enable(False)
         extra["kernels_us"] = {k: round(v["avg_us"], 3) for k, v in tim.items()}
-        alg = NB * (STORE_ALG[0] * float((ty == 0).mean()) + STORE_ALG[1] * float((ty == 1).mean()))
-        # the table requests are answered by k_kv_resolve and -- the hot keys -- by k_kv_big behind it: priced together
+        alg_all = NB * (STORE_ALG[0] * float((ty == 0).mean()) + STORE_ALG[1] * float((ty == 1).mean()))
+        # the table requests are answered by k_kv_resolve and -- the hot keys -- by k_kv_big behind it: priced together, as
+        # for tatp / smallbank; the 53 request bytes of every request are k_kv_part's, which reads them (bench_txn)
+        part_b, alg = NB * float(msg), alg_all - NB * float(msg)
+        t_part = tim.get("k_kv_part", {"avg_us": 0.0})["avg_us"]
         us = tim["k_kv_resolve"]["avg_us"] + tim.get("k_kv_big", {"avg_us": 0.0})["avg_us"]
         ach = alg / (us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": "k_kv_resolve+k_kv_big", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -735,6 +747,14 @@ def bench_store(args, world, rank, dev, transport):
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, alg), 3)
+        roof["kernels"] = [{"kernel": k, "kernel_avg_us": round(tim[k]["avg_us"], 3)} for k in tim]
+        roof["kernels"][0].update({"alg_bytes_per_launch": int(part_b), "frac": round(part_b / max(t_part, 1e-9) / 1e3 / HBM_PEAK_GBS, 5)})
+        roof["pass"] = {"alg_bytes": int(alg_all), "chain_us": round(t_part + us, 3),
+                        "frac": round(alg_all / max(t_part + us, 1e-9) / 1e3 / HBM_PEAK_GBS, 5),
+                        "what": "the pass: algorithmic bytes of all its requests / (part + resolve + big)"}
+        roof["gpu"] = {"alg_bytes_per_request": round(alg_all / NB, 1), "achieved": round(K * B * NB / dt * alg_all / NB / 1e9, 2),
+                       "frac": round(K * B * NB / dt * alg_all / NB / 1e9 / HBM_PEAK_GBS, 5),
+                       "what": "requests/s of the timed region x mean algorithmic bytes per request / 8 TB/s"}
     value = world * K * B * NB / dt / 1e6
     mixes = {}
     if rank != 0:
@@ -1091,47 +1111,53 @@ def bench_txn(args, world, rank, dev, transport, kind):
         names = list(tims[0].keys())
         avg = {k: float(np.mean([t[k]["avg_us"] for t in tims])) for k in names}
         extra["kernels_us"] = {k: round(v, 3) for k, v in avg.items()}
-        # A pass = k_kv_part (every request is classified, hashed and put into its coarse bin; log requests are finished
-        # there), k_kv_resolve (every coarse bin of the pass: the table requests but those of the hot keys) and k_kv_big
-        # (the hot keys).  The dominant kernel is the one the most time goes to; its algorithmic bytes are those of the
-        # requests it serves.
+        # A pass = k_kv_part (every request is read, classified, hashed and put into its coarse bin; log requests are finished
+        # there) -> the RESOLVE STAGE = k_kv_resolve (every coarse bin: the table requests but those of the hot keys) +
+        # k_kv_big (the hot keys), two launches that answer the table requests between them.  Every kv workload is priced
+        # the same way (store always was): `roofline` = the resolve stage, both kernels' time against the bytes of the
+        # table requests -- it is the longest piece of the chain on every box, so the line's meaning does not move with a
+        # few microseconds (r04 picked "the longer kernel" and flipped between 0.064 and 0.004).
+        # Algorithmic bytes are credited to the kernel that must move them: the 55 / 23 request bytes of
+        # EVERY request to k_kv_part, which reads them (+ reply and ring record of the log requests it finishes); the reply
+        # and the row / lock bytes of a table request to the resolve stage.
         hist, launches = type_histogram(rp, 0, n_t, 1)
-        tab_b = sum(b * int(hist[c]) for c, b in alg_tab.items() if c not in log_types)
-        log_b = sum(b * int(hist[c]) for c, b in alg_tab.items() if c in log_types)
+        msgb = rp.msg
+        n_all = sum(int(hist[c]) for c in alg_tab)
         n_tab = sum(int(hist[c]) for c in alg_tab if c not in log_types)
+        tab_b = sum((b - msgb) * int(hist[c]) for c, b in alg_tab.items() if c not in log_types)  # reply + row / lock bytes
+        part_b = msgb * n_all + sum((b - msgb) * int(hist[c]) for c, b in alg_tab.items() if c in log_types)
         f_big = big_req / max(1, n_tab)
-        cand = {"k_kv_resolve": (avg.get("k_kv_resolve", 0.0), tab_b * (1.0 - f_big)),
-                "k_kv_part": (avg.get("k_kv_part", 0.0), tab_b + log_b),
-                "k_kv_big": (avg.get("k_kv_big", 0.0), tab_b * f_big)}
-        # ... when the two resolve-stage kernels are a near tie in time (tatp: 60 against 53 us) the one that serves more
-        # algorithmic bytes is priced, not whichever took a few us longer in this run: "the longest" flipped from box to box
-        # (r04: frac 0.064 on one box, 0.004 on the next, same kernels).  The other one is reported under `roofline.other`
-        t_res, t_big = cand["k_kv_resolve"][0], cand["k_kv_big"][0]
-        if min(t_res, t_big) >= 0.75 * max(t_res, t_big):  # a near tie: the one with more bytes
-            stage = "k_kv_resolve" if cand["k_kv_resolve"][1] >= cand["k_kv_big"][1] else "k_kv_big"
-        else:
-            stage = "k_kv_resolve" if t_res >= t_big else "k_kv_big"
-        dom = "k_kv_part" if cand["k_kv_part"][0] > max(t_res, t_big) else stage
-        dom_us, alg = cand[dom][0], cand[dom][1] / max(1, launches)
-        achieved = alg / (dom_us * 1e-6) / 1e9
+        L = max(1, launches)
+        t_part, t_res, t_big = avg.get("k_kv_part", 0.0), avg.get("k_kv_resolve", 0.0), avg.get("k_kv_big", 0.0)
+
+        def priced(name, us, nbytes):
+            ach = nbytes / L / max(us, 1e-9) / 1e3  # bytes per launch / us -> GB/s
+            return {"kernel": name, "kernel_avg_us": round(us, 3), "alg_bytes_per_launch": int(nbytes / L),
+                    "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
+
+        stage = priced("k_kv_resolve+k_kv_big", t_res + t_big, tab_b)
         # `traffic` is not measured inside this run (rocprofv3 cannot attach to itself): null here; the PMC figures of
         # the same command live in profiles/ and are quoted under from_profile only for the same kernel sources
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "alg_bytes_per_launch": int(alg), "kernel_avg_us": round(dom_us, 3),
+        roof = {"bound": "hbm", **stage, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "requests_in_big_bins": round(f_big, 4),
-                "from_profile": profile_counters(kind, dom.split("+"))}
+                "from_profile": profile_counters(kind, ["k_kv_resolve", "k_kv_big"])}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
-            roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, alg), 3)
-        oth = "k_kv_big" if stage == "k_kv_resolve" else "k_kv_resolve"
-        if cand[oth][0] > 0:
-            o_alg = cand[oth][1] / max(1, launches)
-            o_ach = o_alg / (cand[oth][0] * 1e-6) / 1e9
-            roof["other"] = {"kernel": oth, "kernel_avg_us": round(cand[oth][0], 3), "alg_bytes_per_launch": int(o_alg),
-                             "achieved": round(o_ach, 2), "frac": round(o_ach / HBM_PEAK_GBS, 5),
-                             "what": "the pass's other resolve-stage kernel (the hot keys, or the bulk), priced the same way"}
+            roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, tab_b / L), 3)
+        roof["kernels"] = [priced("k_kv_part", t_part, part_b), priced("k_kv_resolve", t_res, tab_b * (1.0 - f_big)),
+                           priced("k_kv_big", t_big, tab_b * f_big)]
+        # the whole pass of one engine: all its algorithmic bytes over the serial chain of its three kernels (events on the
+        # engine's stream, launch gaps included) -- what bounds a step, which is one engine's chain
+        chain = t_part + t_res + t_big
+        roof["pass"] = {"alg_bytes": int((part_b + tab_b) / L), "chain_us": round(chain, 3),
+                        "frac": round((part_b + tab_b) / L / max(chain, 1e-9) / 1e3 / HBM_PEAK_GBS, 5),
+                        "what": "one engine's pass: algorithmic bytes of all its requests / (part + resolve + big)"}
+        # ... and the GPU as a whole in the timed region: three engines' chains side by side
+        alg_all = sum(b * int(hist[c]) for c, b in alg_tab.items()) / max(1, n_all)  # mean algorithmic bytes per request
+        roof["gpu"] = {"alg_bytes_per_request": round(alg_all, 1), "achieved": round(ops / dt * alg_all / 1e9, 2),
+                       "frac": round(ops / dt * alg_all / 1e9 / HBM_PEAK_GBS, 5),
+                       "what": "requests/s of the timed region x mean algorithmic bytes per request / 8 TB/s"}
 
     # ---- the closed loop itself, resident on the GPU: the same clients as device code emit the same
     # stream (tests/test_gpu_gdriver.py), the engines read the batch sizes on the device, nothing crosses PCIe
@@ -1265,6 +1291,9 @@ def bench_txn(args, world, rank, dev, transport, kind):
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": what, rows_key: n_rows, "clients_per_gpu": C, "epochs_per_step": B,
+                   f"{rows_key}_per_gpu": n_rows // world,
+                   "scaling_rule": ("--subscribers is PER GPU since r04 (rows = subscribers x N: weak scaling of clients and rows)"
+                                    if kind == "tatp" else "--accounts is the TOTAL over all GPUs (default 10M per GPU = configs[4]'s 80M on 8)"),
                    "requests_per_step": round(ops / K / world), "parallelism": f"3 shard servers x hash-shard x{world}",
                    "transport": transport, "exchange_slot_caps": caps},
         "Mops_s": round(ops / dt / 1e6, 3), "ops_per_txn": round(ops / max(1.0, txns), 3), "ms_per_epoch": round(dt / (E1 - E0) * 1e3, 5),
@@ -1311,12 +1340,14 @@ def other_workloads(args, world, rank, dev, transport):
     import gc
 
     out = {}
-    for wl in ("fasst", "fasst_36m", "2pl", "log", "store", "smallbank"):
+    for wl in ("tatp_nurand", "fasst", "fasst_36m", "2pl", "log", "store", "smallbank"):
         a = copy.copy(args)
-        a.workload, a.compact, a.steps, a.warmup, a.per_step, a.theta = wl, True, 8, 2, (4 if wl in ("store", "smallbank") else 16), None
+        a.workload, a.compact, a.steps, a.warmup, a.per_step, a.theta = wl, True, 8, 2, (4 if wl in ("store", "smallbank", "tatp_nurand") else 16), None
         a.no_rand64 = a.no_closed_loop = a.no_host_path = True
         if wl == "fasst_36m":  # the reference's own table size: 288 MB, HBM-resident -- configs[1]'s 1M slots (8 MB) live in L2
             a.workload, a.slots, a.no_cpu_baseline = "fasst", 36_000_000, True
+        if wl == "tatp_nurand":  # the headline workload with the reference's OWN key distribution (tatp_nurand, tatp/udp/tatp.h:40-43:
+            a.workload, a.theta = "tatp", 0.0  # no hot subscriber), same tables, same clients, oracle parity on its stream
         try:
             r = run_workload(a, world, rank, dev, transport)
         except Exception as ex:  # one leg failing must not take the headline down; it fails the run at the end

@@ -195,6 +195,17 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
   return p;
 }
 
+// kv passes: the tag of what the pieces of a hot key publish to each other in hotpub (k_kv.hip, kvh_word: 30 bits, never 0).
+// When the counter wraps, the words are cleared on the pass's stream first, so a word left by the pass that carried the
+// same tag 2^30 passes ago cannot be taken for this pass's.
+int next_pass_seq(dint_engine *e, hipStream_t st) {
+  if (++e->scratch.pass_seq >= 0x3FFFFFFFu) {
+    if (e->scratch.hotpub) HIP_TRY(hipMemsetAsync(e->scratch.hotpub, 0, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long), st));
+    e->scratch.pass_seq = 1;
+  }
+  return 0;
+}
+
 // one pass (n <= pass_max) on device buffers
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0,
              const dint_view &view = dint_flat_view()) {
@@ -223,6 +234,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_STORE:
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
+      if (int rc = next_pass_seq(e, st)) return rc;  // tags what the pieces of a hot key publish in this pass
       dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 3, kv_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
@@ -329,7 +341,8 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     if (is_kv) {  // coarse bins of 16-byte records: C * cap = C * (2 ceil(n / C) + 64) <= 2 n + 66 C
       e->scratch.kbins_slots = 2ull * e->pass_max + 66ull * DINT_KV_CMAX;
       TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
-      TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_CMAX * 64 * sizeof(uint4), false));
+      TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_BIGQ_MAX * 2 * sizeof(uint4), false));
+      TRY(dev_alloc((void **)&e->scratch.hotpub, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long)));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
     }
@@ -399,6 +412,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bins);
   hipFree(e->scratch.kbins);
   hipFree(e->scratch.bigq);
+  hipFree(e->scratch.hotpub);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
   hipFree(std::min(e->scratch.blk_pub, e->scratch.blk_pub_next));
@@ -509,6 +523,7 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
     const dint_segments_item &it = items[k];
     dint_engine *e = it.engine;
     if (int rc = order_stream(e, st)) return rc;
+    if (int rc = next_pass_seq(e, st)) return rc;
     pass[k].d_req = it.d_base; pass[k].d_rep = it.d_base; pass[k].n = it.n_seg * it.seg_cap;
     pass[k].kv = &e->kv; pass[k].log = e->log; pass[k].s = e->scratch;
     pass[k].view = dint_seg_view(it.n_seg, it.seg_cap, it.seg_stride, it.d_cnt, it.cnt_stride);

@@ -572,6 +572,111 @@ def test_tatp_two_hot_rows_in_one_bucket(same_quadrant):
     _tatp_locks(eng, o)
 
 
+# ---------------------------------------------------------------- a hot key in pieces, several workgroups at once (r05)
+SPLIT_KNOBS = [{"DINT_KV_SPLIT_MIN": "65", "DINT_KV_SPLIT_TARGET": "16"},    # 16 pieces of a few dozen requests
+               {"DINT_KV_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "100"},
+               {},                                                          # the defaults: subs of >= 768 records, ~384 per piece
+               {"DINT_KV_NO_SPLIT": "1"}]                                   # r04: one workgroup per hot key
+
+
+@pytest.mark.parametrize("knobs", SPLIT_KNOBS, ids=lambda k: "+".join(f"{a[8:]}={b}" for a, b in k.items()) or "default")
+@pytest.mark.parametrize("p_hot,mix,hot_key", [
+    (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (0, 7)),           # reads, lock ops and writers in every piece
+    (0.9, {0: 99, 13: 1}, (0, 7)),                               # almost only reads: a writer in one piece or another
+    (0.7, {0: 20, 1: 30, 2: 20, 12: 15, 13: 15}, (0, 7)),        # mostly ordering ops
+    (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (0, 5_000_000)),   # the hot row does not exist (NOT_EXIST, missing_keys)
+    (0.6, {0: 70, 1: 10, 2: 4, 12: 8, 13: 8}, (4, 7 | (1 << 32))),  # a CALL_FORWARDING row: the remainder inserts / deletes around it
+    (0.5, {0: 85, 1: 10, 2: 2, 18: 1.5, 22: 1.5}, (4, 7 | (1 << 32))),  # the hot row itself inserted / deleted: not in closed form, piece 0 takes the sub
+])
+def test_tatp_hot_key_in_pieces(p_hot, mix, hot_key, knobs, monkeypatch):
+    """k_kv_resolve cuts a sub that is one key into pieces by request-index range and k_kv_big answers every piece with a
+    workgroup of its own (kv_hot_item): version / value / lock byte seen by a request come from its piece and from one word
+    per earlier piece.  Small thresholds force the path on small passes; every variant -- and r04's single workgroup -- must
+    give the oracle's bytes, rows and lock words, pass after pass on one engine (the words are tagged per pass)."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    n_sub = 3000
+    o = orc.TatpOracle(n_sub, log_entries=400_000)
+    existing = [o.dump(t)[0] for t in range(5)]
+    eng = _engine(W.TATP, n_rows=n_sub, log_entries=400_000)
+    eng.populate(n_sub)
+    miss0 = 0
+    for k, n in enumerate((900, 3000, 6000, 9000, 2500, 14_000)):
+        req = _hot_tatp(n, p_hot, mix, seed=17 * k + 5, hot_key=hot_key, existing=existing, n_noise_sub=n_sub)
+        got, want = eng.submit(req), o.replay(req)
+        assert got.tobytes() == want.tobytes(), (k, np.nonzero(np.frombuffer(got.tobytes(), "u1") != np.frombuffer(want.tobytes(), "u1"))[0][:5] // 55)
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+        lk, _ = eng.read_locks(t)
+        assert (lk == o.locks(t)).all()
+    st = eng.stats()
+    assert st["bad_requests"] == 0 and st["big_bin_requests"] > 0
+    if hot_key == (0, 5_000_000):
+        assert st["missing_keys"] > 100  # every COMMIT of the missing hot row is counted (tatp/udp/kvs.h:91)
+
+
+@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3], ids=["t16", "t100", "default"])
+def test_store_hot_key_in_pieces(knobs, monkeypatch):
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    n_sub = 5000
+    o = orc.StoreOracle(n_sub * 18 // 4, n_sub)
+    eng = _engine(W.STORE, n_rows=n_sub)
+    eng.populate(n_sub)
+    rng = np.random.default_rng(4)
+    for n, key in ((1500, tracegen.store_key(11, 2, 8)), (5000, tracegen.store_key(11, 2, 8)), (8000, tracegen.store_key(4999, 4, 16)),
+                   (6000, tracegen.store_key(77_777, 1, 0))):  # the last one is not in the table: NOT_EXIST for READ and SET
+        req = tracegen.store_random(n, seed=n, n_sub_touch=n_sub, p_set=0.3, p_missing=0.05)
+        hot = rng.random(n) < 0.7
+        req["key"][hot] = key
+        got, want = eng.submit(req), o.replay(req)
+        assert got.tobytes() == want.tobytes(), n
+    assert _same_rows(eng.dump_rows(0), o.dump())
+
+
+@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3], ids=["t16", "t100", "default"])
+@pytest.mark.parametrize("same_quadrant", [False, True])
+def test_tatp_hot_key_in_pieces_beside_a_neighbour_in_its_bucket(same_quadrant, knobs, monkeypatch):
+    """The sub's other keys (the remainder) are resolved beside the pieces -- unless one of the hot BUCKET uses the hot key's
+    lock byte (same quadrant) or restructures the chain: then the remainder says so and the whole sub goes the old way."""
+    import struct
+
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    n_sub = 3000
+    o = orc.TatpOracle(n_sub, populate_n=n_sub, log_entries=400_000)
+    hs = o.hash_size(0)
+    by_bucket = {}
+    for s_id in range(n_sub):
+        h = orc.fasthash64(struct.pack("<Q", s_id))
+        by_bucket.setdefault(h % hs, []).append((s_id, (h % (4 * hs)) // hs))
+    pair = None
+    for g in by_bucket.values():
+        for a in g:
+            for b in g:
+                if a[0] < b[0] and (a[1] == b[1]) == same_quadrant:
+                    pair = pair or (a[0], b[0])
+    assert pair is not None
+    existing = [o.dump(t)[0] for t in range(5)]
+    eng = _engine(W.TATP, n_rows=n_sub, log_entries=400_000)
+    eng.populate(n_sub)
+    rng = np.random.default_rng(5)
+    T = wire.Tatp
+    for k, n in enumerate((2500, 7000, 4000)):
+        req = tracegen.tatp_random(n, existing, seed=31 + k, n_sub_touch=n_sub)
+        u = rng.random(n)
+        for key, lo, hi in ((pair[0], 0.0, 0.70), (pair[1], 0.70, 0.76)):  # the neighbour: a few dozen requests, well under a quarter
+            hot = (u >= lo) & (u < hi)
+            req["table"][hot] = 0
+            req["key"][hot] = key
+            req["type"][hot] = rng.choice([T.READ, T.ACQUIRE_LOCK, T.ABORT, T.COMMIT_PRIM, T.COMMIT_BCK], int(hot.sum()), p=[0.6, 0.15, 0.05, 0.1, 0.1])
+        got, want = eng.submit(req), o.replay(req)
+        assert got.tobytes() == want.tobytes(), k
+    for t in range(5):
+        assert _same_rows(eng.dump_rows(t), o.dump(t)), t
+    _tatp_locks(eng, o)
+
+
 @pytest.mark.parametrize("no_bitmap", ["0", "1"])
 @pytest.mark.parametrize("n,touch", [(60_000, 1), (90_000, 3), (30_000, 40)])
 def test_smallbank_hot_accounts_bitmap_order_and_sort_agree(n, touch, no_bitmap, monkeypatch):

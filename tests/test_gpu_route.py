@@ -511,6 +511,31 @@ def test_eight_ranks_at_the_baseline_shape_equal_one_unsharded_server(wl, n_rows
     for p in procs:
         p.start()
     one = ShardGroup(wl, n_rows, device=0, log_entries=200_000)  # the unsharded servers, populated while the ranks start up
+    # ... and the CPU oracle at the SAME table sizes, so that the unsharded engine the ranks are compared with is itself held
+    # to the serial restatement at configs[4]'s size.  tatp (1,000,001 subscribers): the whole tables.
+    # smallbank (80M accounts = 30,000,000 buckets per table, smallbank/udp/server_shard.cc:75-76): the oracle is sized for
+    # 80M accounts but holds only the rows of one bucket in 64 (bucket % 64 == 0: 1.25M accounts per table, loaded with
+    # the population's values, smallbank/udp/smallbank.h:105-127); it replays every request that touches those buckets --
+    # a request touches one bucket, and its lock slot lock_hash % hash_size is that bucket -- plus every log append.
+    SAMPLE = 64
+    if wire.Workload(wl) == W.TATP:
+        oracles = [orc.TatpOracle(n_rows, log_entries=200_000) for _ in range(3)]
+        hs = None
+    else:
+        oracles = [orc.SmallbankOracle(n_rows, log_entries=200_000, populate_n=0) for _ in range(3)]
+        hs = np.uint64(oracles[0].hash_size(0))
+        assert int(hs) == n_rows * 3 // 2 // 4 == 30_000_000
+        assert int(sd.fasthash_key(np.zeros(1, np.uint64))[0]) == 0x16C38EE185750EBC
+        acct = np.arange(n_rows, dtype=np.uint64)
+        mine = acct[(sd.fasthash_key(acct) % hs) % np.uint64(SAMPLE) == 0]
+        assert 0.9 * n_rows / SAMPLE < len(mine) < 1.1 * n_rows / SAMPLE
+        bal = np.frombuffer(np.float32(1e9).tobytes(), np.uint8)
+        for t, magic in ((0, 97), (1, 98)):
+            vals = np.zeros((len(mine), 8), np.uint8)
+            vals[:, 0], vals[:, 4:] = magic, bal
+            for o in oracles:
+                o.load(t, mine, np.zeros(len(mine), np.uint32), vals)
+        del acct
     res = {}
     for _ in range(world):
         r = q.get(timeout=1200)
@@ -519,11 +544,20 @@ def test_eight_ranks_at_the_baseline_shape_equal_one_unsharded_server(wl, n_rows
         p.join(180)
         assert p.exitcode == 0
     dtype = wire.MSG_DTYPE[wire.Workload(wl)]
-    total = 0
+    total = checked_by_oracle = sampled_table_reqs = 0
     for e in range(epochs):
         for s in range(3):
             parts = [np.frombuffer(res[r][0][e][0][s], dtype) for r in range(world)]
-            want = one.engines[s].submit(np.concatenate(parts))  # the serial order: rank-major concatenation
+            allreq = np.concatenate(parts)
+            want = one.engines[s].submit(allreq)  # the serial order: rank-major concatenation
+            if hs is None:
+                assert oracles[s].replay(allreq).tobytes() == want.tobytes(), ("oracle", e, s)
+                checked_by_oracle += len(allreq)
+            else:
+                pick = (allreq["type"] == 6) | ((sd.fasthash_key(allreq["key"]) % hs) % np.uint64(SAMPLE) == 0)
+                assert oracles[s].replay(allreq[pick].copy()).tobytes() == want[pick].tobytes(), ("oracle", e, s)
+                checked_by_oracle += int(pick.sum())
+                sampled_table_reqs += int((pick & (allreq["type"] != 6)).sum())
             lo = 0
             for r in range(world):
                 n = len(parts[r])
@@ -531,6 +565,9 @@ def test_eight_ranks_at_the_baseline_shape_equal_one_unsharded_server(wl, n_rows
                 lo += n
                 total += n
     assert total > world * clients
+    # the oracle saw a real share: all of tatp; of smallbank ~1/64 of the cold traffic -- and whatever hot account falls into
+    # the sampled buckets -- with table requests among it
+    assert checked_by_oracle == total if hs is None else (checked_by_oracle > total // 200 and sampled_table_reqs > 200)
     for s in range(3):
         for ti, t in enumerate(e_tables(wl)):
             cs = sum(res[r][1][s][ti][0] for r in range(world)) % (1 << 64)

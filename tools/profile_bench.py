@@ -61,8 +61,7 @@ def main():
     engines = 3 if wl in ("tatp", "smallbank") else 1
     last = engines * 190  # ... of which the last 190 per engine are averaged here
     base = [sys.executable, os.path.join(ROOT, "bench.py")] + rest + ["--steps", str(steps), "--warmup", str(warm), "--per-step", str(per_step),
-                                                                       "--no-cpu-baseline", "--no-rand64", "--no-host-path", "--no-closed-loop",
-                                                                       "--no-other-workloads", "--no-shim", "--no-exchange-leg", "--no-as-shipped", "--no-mixes"]
+                                                                       "--legs", "headline"]
     env = dict(os.environ, TMPDIR="/tmp")
     passes = [("trace", ["--kernel-trace", "--stats"]), ("FETCH_SIZE", ["--pmc", "FETCH_SIZE", "--kernel-trace"]),
               ("WRITE_SIZE", ["--pmc", "WRITE_SIZE", "--kernel-trace"]),
