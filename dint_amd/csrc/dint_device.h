@@ -14,7 +14,7 @@
 #define DINT_KV_PMAX 32768u        // ... and max bins per pass
 #define DINT_KV_BINCAP 64u         // lock tables: records a bin holds in place; the rest goes to the pass's overflow area
 #define DINT_KV_CMAX 2048u         // kv workloads: coarse bins per pass at most (k_kv.hip: a two-level partition)
-#define DINT_KV_BIGQ_MAX (DINT_KV_CMAX * 128u)  // ... work items of k_kv_big at most: 64 big subs per coarse bin + the pieces of <= 4 split ones
+#define DINT_KV_BIGQ_MAX (DINT_KV_CMAX * 128u)  // ... work items of k_kv_big at most: pass / 8 hot-key pieces + 2 per big sub (k_kv.hip, kv_hot_item)
 
 // ---- fasthash64 ------------------------------------------------------------------------
 __host__ __device__ static inline uint64_t dint_mix(uint64_t h) {

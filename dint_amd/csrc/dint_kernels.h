@@ -35,7 +35,7 @@ struct dint_scratch {
   // uint4 per entry, the 8-byte records of the big subs go to `ovf`
   uint4 *kbins = nullptr;          // [C][cap] 16-byte records {key, group / C | idx | payload}
   uint64_t kbins_slots = 0;        // records `kbins` holds: C * cap never exceeds it
-  uint4 *bigq = nullptr;           // [DINT_KV_BIGQ_MAX][2] the pass's big subs and hot-key pieces (work items of k_kv_big)
+  uint4 *bigq = nullptr;           // [DINT_KV_BIGQ_MAX][3] the pass's big subs and hot-key pieces (work items of k_kv_big)
   unsigned long long *hotpub = nullptr;  // [DINT_KV_BIGQ_MAX] what the pieces of a hot key tell each other (tagged with pass_seq)
   uint32_t pass_seq = 0;           // host side: passes launched so far (never 0 in a launch)
   uint64_t *lock_trace = nullptr;  // DINT_KV_TRACE=1 on a lock engine: per big-bin workgroup 16 s_memrealtime stamps

@@ -341,7 +341,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
     if (is_kv) {  // coarse bins of 16-byte records: C * cap = C * (2 ceil(n / C) + 64) <= 2 n + 66 C
       e->scratch.kbins_slots = 2ull * e->pass_max + 66ull * DINT_KV_CMAX;
       TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
-      TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_BIGQ_MAX * 2 * sizeof(uint4), false));
+      TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_BIGQ_MAX * 3 * sizeof(uint4), false));  // KVQ_W uint4 per work item (k_kv.hip)
       TRY(dev_alloc((void **)&e->scratch.hotpub, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long)));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));

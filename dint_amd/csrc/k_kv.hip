@@ -2325,7 +2325,6 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
 // path's stretch machinery (kvb_lds); the two never live at the same time and share one buffer.
 #define KVR_LCAP 1024u   // records of a coarse bin's small subs that fit the LDS split (the average bin holds ~512)
 #define KVR_F 64u        // subs per coarse bin = lanes of the wave that lays them out
-#define KVR_NSPLIT 4u     // big subs of one coarse bin that can be cut into hot-key pieces (a pass has a dozen in all)
 #define KVR_NPMAX 16u     // pieces of one hot key at most
 struct kvr_lds {
   uint4 rec[KVR_LCAP];         // records of the small subs, sub after sub
@@ -2335,25 +2334,22 @@ struct kvr_lds {
   uint32_t bigoff[KVR_F];      // start of each big sub's 8-byte records in ovf[], KV_NONE for a small sub
   uint2 chs[KVR_F];            // chunks: [first, last) record in rec[]
   uint32_t nch;
-  // hot keys (kv_hot_item): the split subs of this coarse bin
-  uint32_t nsplit;
-  uint32_t sps[KVR_F];                          // split slot of a sub, KV_NONE: not split
-  uint32_t csub[KVR_NSPLIT], np[KVR_NSPLIT], sok[KVR_NSPLIT], cflag[KVR_NSPLIT];
-  uint64_t ckey[KVR_NSPLIT], hrec[KVR_NSPLIT];   // the key; one of its 8-byte records (its bucket group, lock quadrant)
-  uint32_t pc[KVR_NSPLIT][KVR_NPMAX + 1];       // records per piece; [np] = the sub's other keys (the remainder)
-  uint32_t po[KVR_NSPLIT][KVR_NPMAX + 2];       // ... where each piece starts inside the sub's range of ovf[]
-  uint32_t pcur[KVR_NSPLIT][KVR_NPMAX + 1];     // ... placed so far
+  // hot keys (kv_hot_item): per sub, the key of one of its records -- of a sub that is one hot key, almost surely that key --
+  // and that record in the big path's form (bucket group, key-hash bits, lock quadrant)
+  uint32_t cflag[KVR_F];
+  uint64_t ckey[KVR_F], hrec[KVR_F];
 };
 // which piece a request index belongs to: monotone in idx (a piece is a range of request indices), ~n / np indices each
 __device__ static inline uint32_t kv_piece_of(uint32_t idx, uint32_t np, uint32_t inv_n) {
   const uint32_t p = (uint32_t)(((uint64_t)idx * np * inv_n) >> 32);
   return p < np ? p : np - 1;
 }
-// work items of k_kv_big (bigq): two uint4 each
-//   [0] = {bin = coarse bin + C * sub, offset in ovf, records, kind | piece << 2 | pieces << 7 | has_remainder << 12}
-//   [1] = kind 0: unused.  kind 1 (piece of a hot key): {key lo, key hi, item index of piece 0, records of the whole sub}.
-//         kind 2 (remainder: the sub's other keys): {a record of the hot key lo, hi, item index of piece 0, records of the sub}
-enum : uint32_t { KVQ_SUB = 0, KVQ_PIECE = 1, KVQ_REM = 2 };
+// work items of k_kv_big (bigq): KVQ_W uint4 each
+//   [0] = {bin = coarse bin + C * sub, offset of the sub in ovf, records of the sub, kind | piece << 2 | pieces << 7}
+//   [1] = kind 0: unused.  Else {hot key lo, hi, item index of the sub's first item, -}
+//   [2] = kind 0: unused.  Else {one record of the hot key (big path's form) lo, hi, -, -}
+#define KVQ_W 3u
+enum : uint32_t { KVQ_SUB = 0, KVQ_PIECE = 1, KVQ_REM = 2, KVQ_SOLO = 3 };
 
 template <int WL, uint32_t NT>
 __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev *kv, uint32_t coarse, uint8_t *lds_raw,
@@ -2378,8 +2374,15 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     for (uint32_t k = t; k < novl; k += NT)
       if (A.ovl[2 * (size_t)k + 1].x == coarse) f(A.ovl[2 * (size_t)k]);
   };
-  // ---- phase A: records per sub
-  for_each_record([&](const uint4 &r) { atomicAdd(&L.hist[(uint32_t)(u4_meta(r) >> sh) & (KVR_F - 1)], 1u); });
+  // ---- phase A: records per sub; and per sub the key of whichever record comes first (a sub of hundreds of records is one
+  // hot key's: k_kv_big cuts it into pieces around that key, kv_hot_item)
+  auto big_rec = [&](uint64_t m) -> uint64_t { return ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull)); };  // group / (64 C) | idx | payload
+  for_each_record([&](const uint4 &r) {
+    const uint64_t m = u4_meta(r);
+    const uint32_t sub = (uint32_t)(m >> sh) & (KVR_F - 1);
+    atomicAdd(&L.hist[sub], 1u);
+    if (L.cflag[sub] == 0 && atomicCAS(&L.cflag[sub], 0u, 1u) == 0u) { L.ckey[sub] = u4_key(r); L.hrec[sub] = big_rec(m); }
+  });
   __syncthreads();
   if (tr && t == 0) tr[2] = __builtin_amdgcn_s_memrealtime();
   // ---- layout (one wave, a lane per sub): small subs get a range of rec[], big subs a range of ovf[]; neighbouring
@@ -2404,18 +2407,6 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     if (lane == 63) L.off[KVR_F] = stot;
     L.bigoff[lane] = big ? gbase + boff : KV_NONE;
     Sbig[lane] = make_uint2(big ? gbase + boff : 0u, big ? h : 0u);
-    {  // hot keys: the first KVR_NSPLIT subs of at least split_min records are candidates for pieces (checked below)
-      const bool cand = big && h >= A.split_min;
-      const uint64_t cm = __ballot(cand);
-      const uint32_t sl = (uint32_t)__popcll(cm & lanemask_lt());
-      const bool take = cand && sl < KVR_NSPLIT;
-      L.sps[lane] = take ? sl : KV_NONE;
-      if (take) {
-        L.csub[sl] = lane; L.sok[sl] = 0; L.cflag[sl] = 0;
-        L.np[sl] = min(KVR_NPMAX, (h + A.split_target - 1) / A.split_target);
-      }
-      if (lane == 0) L.nsplit = min((uint32_t)__popcll(cm), KVR_NSPLIT);
-    }
     // next[l] = the sub after the chunk that starts at sub l: the largest e in (l, 64] with off[e] - off[l] <= 64
     // (a small sub alone always fits).  Binary search over the lanes' registers, the same trip count for every lane.
     uint32_t lo = lane + 1, hi = KVR_F;
@@ -2444,54 +2435,13 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   }
   __syncthreads();
   if (tr && t == 0) tr[3] = __builtin_amdgcn_s_memrealtime();
-  // ---- hot keys (rare, workgroup-uniform): a sub of thousands of records is one key's -- the hottest subscriber draws
-  // 4,000 of a 240k-request pass -- and one workgroup of k_kv_big answering it alone is what the pass waits for.  The
-  // key's records are laid out in `np` pieces by request-index range (kv_piece_of), the sub's other keys behind them;
-  // k_kv_big gives every piece a workgroup (kv_hot_item).  The key is compared in full (the record carries it), so a
-  // piece holds ONE key's requests by construction.
-  auto big_rec = [&](uint64_t m) -> uint64_t { return ((m >> (sh + 6)) << sh) | (m & ((1ull << sh) - 1ull)); };
-  const uint32_t nsplit = L.nsplit;
-  if (nsplit) {
-    for (uint32_t k = t; k < KVR_NSPLIT * (KVR_NPMAX + 1); k += NT) { (&L.pc[0][0])[k] = 0; (&L.pcur[0][0])[k] = 0; }
-    for_each_record([&](const uint4 &r) {  // the candidate: the key of whichever record of the sub comes first
-      const uint32_t sl = L.sps[(uint32_t)(u4_meta(r) >> sh) & (KVR_F - 1)];
-      if (sl != KV_NONE && L.cflag[sl] == 0 && atomicCAS(&L.cflag[sl], 0u, 1u) == 0u) L.ckey[sl] = u4_key(r);
-    });
-    __syncthreads();
-    for_each_record([&](const uint4 &r) {
-      const uint64_t m = u4_meta(r);
-      const uint32_t sl = L.sps[(uint32_t)(m >> sh) & (KVR_F - 1)];
-      if (sl == KV_NONE) return;
-      const uint32_t np = L.np[sl];
-      const bool hot = u4_key(r) == L.ckey[sl];
-      atomicAdd(&L.pc[sl][hot ? kv_piece_of((uint32_t)(m >> 16) & idx_mask, np, A.inv_n) : np], 1u);
-      if (hot && L.cflag[sl] == 1 && atomicCAS(&L.cflag[sl], 1u, 2u) == 1u) L.hrec[sl] = big_rec(m);
-    });
-    __syncthreads();
-    if (t < nsplit) {  // every piece fits a workgroup (one request per thread), and the key really dominates the sub
-      const uint32_t np = L.np[t], h = L.hist[L.csub[t]];
-      uint32_t o = 0, mx = 0;
-      for (uint32_t p = 0; p < np; p++) { const uint32_t c = L.pc[t][p]; L.po[t][p] = o; o += c; mx = max(mx, c); }
-      L.po[t][np] = o;
-      L.po[t][np + 1] = o + L.pc[t][np];
-      L.sok[t] = (mx <= KVB_T && 4 * o >= 3 * h && o + L.pc[t][np] == h) ? 1u : 0u;
-    }
-    __syncthreads();
-  }
   // ---- phase B: every record to its sub's range
   for_each_record([&](const uint4 &r) {
     const uint64_t m = u4_meta(r);
     const uint32_t sub = (uint32_t)(m >> sh) & (KVR_F - 1);
-    uint32_t pos = atomicAdd(&L.cur[sub], 1u);
-    const uint32_t bo = L.bigoff[sub];
-    if (bo == KV_NONE) { L.rec[L.off[sub] + pos] = r; return; }
-    const uint32_t sl = nsplit ? L.sps[sub] : KV_NONE;
-    if (sl != KV_NONE && L.sok[sl]) {  // a split sub: piece by piece, then the other keys
-      const uint32_t np = L.np[sl];
-      const uint32_t p = u4_key(r) == L.ckey[sl] ? kv_piece_of((uint32_t)(m >> 16) & idx_mask, np, A.inv_n) : np;
-      pos = L.po[sl][p] + atomicAdd(&L.pcur[sl][p], 1u);
-    }
-    A.ovf[bo + pos] = big_rec(m);  // the big path's record: group / (64 C) | idx | payload
+    const uint32_t pos = atomicAdd(&L.cur[sub], 1u), bo = L.bigoff[sub];
+    if (bo == KV_NONE) L.rec[L.off[sub] + pos] = r;
+    else A.ovf[bo + pos] = big_rec(m);  // the big path's record
   });
   __syncthreads();
   if (tr && t == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
@@ -2556,7 +2506,7 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
   if (t < KVR_F) {
     Sbig[t] = make_uint2(0u, 0u);
     kvr_lds &L = *(kvr_lds *)Lraw;
-    L.hist[t] = 0; L.cur[t] = 0;
+    L.hist[t] = 0; L.cur[t] = 0; L.cflag[t] = 0;
   }
   if (b == 0) {  // what the next pass will find: its counters zero ([4] = k_kv_big's ticket), the log tail current
     if (t < 8) A.big_next[t] = 0;
@@ -2569,58 +2519,57 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
   // header round trip of the chunk fell from 2.4 to 1.6 us and the bench lost 3 % -- the prefetch is one more transaction
   // per request on a memory system that is the bottleneck once three engines run side by side.  Removed.)
   kv_coarse_bin<WL, NT>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr);
-  if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big -- a split one as its pieces (+ its remainder), side by side
+  if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big
+    // A sub of at least split_min records is listed as `np` hot-key PIECES (ranges of the request index) + its REMAINDER (the
+    // other keys), side by side -- or, when one piece is enough, as one SOLO item (kv_hot_item); every item names the whole sub.
     const uint2 bs = Sbig[t];
     const kvr_lds &L = *(const kvr_lds *)Lraw;
-    uint32_t sl = KV_NONE, np = 0, rem = 0;
-    if (bs.y && cnt) {
-      sl = L.nsplit ? L.sps[t] : KV_NONE;
-      if (sl != KV_NONE && !L.sok[sl]) sl = KV_NONE;
-      if (sl != KV_NONE) { np = L.np[sl]; rem = L.pc[sl][np]; }
-    }
-    const uint32_t nent = bs.y ? (sl != KV_NONE ? np + (rem ? 1u : 0u) : 1u) : 0u;
+    const bool hot = bs.y >= A.split_min;
+    const uint32_t np = hot ? min(KVR_NPMAX, (bs.y + A.split_target - 1) / A.split_target) : 0u;
+    const uint32_t nent = bs.y ? (np > 1 ? np + 1 : 1u) : 0u;
     uint32_t tot, at = wave_excl_scan_u32(nent, &tot);
     uint32_t base = 0;
     if (t == 0 && tot) base = atomicAdd(&A.big[3], tot);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     at += base;
     const uint32_t bin = b + A.cut.P * t;
-    if (nent && sl == KV_NONE) {
-      A.bigq[2 * (size_t)at] = make_uint4(bin, bs.x, bs.y, KVQ_SUB);
+    if (nent && !hot) {
+      A.bigq[KVQ_W * (size_t)at] = make_uint4(bin, bs.x, bs.y, KVQ_SUB);
     } else if (nent) {
-      const uint64_t hk = L.ckey[sl], hr = L.hrec[sl];
-      const uint32_t fl = (np << 7) | ((rem ? 1u : 0u) << 12);
-      for (uint32_t p = 0; p < np; p++) {
-        A.bigq[2 * (size_t)(at + p)] = make_uint4(bin, bs.x + L.po[sl][p], L.pc[sl][p], KVQ_PIECE | (p << 2) | fl);
-        A.bigq[2 * (size_t)(at + p) + 1] = make_uint4((uint32_t)hk, (uint32_t)(hk >> 32), at, bs.y);
-      }
-      if (rem) {
-        A.bigq[2 * (size_t)(at + np)] = make_uint4(bin, bs.x + L.po[sl][np], rem, KVQ_REM | (np << 2) | fl);
-        A.bigq[2 * (size_t)(at + np) + 1] = make_uint4((uint32_t)hr, (uint32_t)(hr >> 32), at, bs.y);
+      const uint64_t hk = L.ckey[t], hr = L.hrec[t];
+      for (uint32_t p = 0; p < nent; p++) {
+        const uint32_t kind = np == 1 ? KVQ_SOLO : (p < np ? KVQ_PIECE : KVQ_REM);
+        uint4 *q = A.bigq + KVQ_W * (size_t)(at + p);
+        q[0] = make_uint4(bin, bs.x, bs.y, kind | (p << 2) | (np << 7));
+        q[1] = make_uint4((uint32_t)hk, (uint32_t)(hk >> 32), at, 0u);
+        q[2] = make_uint4((uint32_t)hr, (uint32_t)(hr >> 32), 0u, 0u);
       }
     }
   }
   if (tr && t == 0) { tr[11] = tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
 }
 
-// ---- hot keys: one key's thousands of requests, several workgroups at once --------------------------------------------
-// A sub that is (nearly) one key -- tatp's hottest subscribers at Zipf-0.8: 1,500 .. 4,000 requests of a 240k-request pass,
-// a dozen such keys per pass -- used to be ONE workgroup's job for 30 .. 50 us while the pass waited ("several
-// workgroups per hot key").  k_kv_resolve now lays the key's records out in `np` PIECES by request-index range (every request of
-// piece j precedes every request of piece j + 1; <= KVB_T requests, one per thread) and lists every piece as a work item of its
-// own, the sub's other keys as one more (the REMAINDER).  The closed forms of kv_chunk hold across pieces because what a request
-// sees of its predecessors is tiny:
+// ---- hot keys: one key's hundreds or thousands of requests, in closed form, several workgroups at once ---------------------
+// A big sub is (nearly) one key -- tatp's hot subscribers at Zipf-0.8: 100 .. 4,000 requests of a 240k-request pass each, a
+// hundred such subs per pass -- and kv_big_bin's stretch machinery took 20 .. 50 us for it on ONE workgroup while the pass
+// waited ("several workgroups per hot key"; r05 measured 42 % of an epoch behind k_kv_big).  k_kv_resolve
+// names a candidate key per sub (a record's, compared in full here) and lists a sub of `split_min` records or more as `np`
+// PIECES -- piece j = the key's requests whose index falls into the j-th of np ranges (kv_piece_of), <= KVB_T of them, one
+// per thread -- and a REMAINDER (every record of another (bucket group, key hash)); np = 1: one SOLO item for both.  The
+// closed forms of kv_chunk hold across pieces because what a request sees of its predecessors is tiny:
 //     version seen   = v0 + writers before me        value seen = message of the last writer before me (else the row)
 //     lock byte seen = what the last lock op before me left (ACQUIRE: 1, ABORT / COMMIT_PRIM: 0; else the stored byte)
 // so a piece needs from the pieces before it only {writers, index of the last writer, what the last lock op left}: one 64-bit
-// word per piece (kvh_word), published with an agent-scope store as soon as the piece has its requests in order and read by all
-// its siblings (work items are handed out by ticket, siblings sit side by side in the list: whoever waits, waits for workgroups
-// that are running or will be started before any later item).  ALL OR NOTHING: a piece that holds an op outside the closed form
-// (INSERT / DELETE of the row), or a remainder in which another key of the hot bucket restructures the chain or uses the hot
-// key's lock byte, says so in its word, and then piece 0 resolves the whole sub the old way (kv_big_bin over the sub's range,
-// which is contiguous: pieces, then remainder) while its siblings do nothing -- nothing has touched the table by then.  Otherwise
-// every piece answers its requests at once, the piece that holds the pass's last writer stores row and version, the one with the
-// last lock op the lock byte, and the remainder (other buckets, or other rows of the bucket) goes through kv_big_bin beside them.
+// word per item (kvh_word), published with an agent-scope store once the piece has its requests in order and read by all its
+// siblings (items are handed out by ticket and siblings sit side by side in the list: whoever waits, waits for workgroups
+// that are running or that draw the very next tickets).  Every piece reads the bucket header and the row BEFORE it publishes,
+// and stores to the table only after it has seen every sibling's word: no write-back overtakes a sibling's read.
+// ALL OR NOTHING: a piece that finds an op outside the closed form (INSERT / DELETE of the row), more than KVB_T requests, or a
+// different key behind the candidate's hash bits -- or a remainder in which another key of the hot BUCKET restructures the
+// chain or uses the hot key's lock byte -- says so in its word; then item 0 resolves the whole sub the old way (kv_big_bin
+// over the sub's records, which nobody has touched) and its siblings do nothing.  Otherwise every piece answers its requests
+// at once, the piece with the pass's last writer stores row and version, the one with the last lock op the lock byte, and the
+// remainder goes through kv_big_bin beside them (its records compacted into ovf2).
 // Semantics per op: tatp/udp/server_shard.cc:116-168, store/udp/server.cc:75-97 (as kv_do_request).
 //   kvh_word: [1:0] last lock op {left the byte set, there is one} | [21:2] request index of the last writer | [22] there is one |
 //             [32:23] writers | [33] ok | [63:34] the pass's tag
@@ -2629,101 +2578,87 @@ __device__ static inline unsigned long long kvh_word(uint32_t seq, bool ok, uint
          (lw_idx >= 0 ? (1ull << 22) | ((unsigned long long)(uint32_t)lw_idx << 2) : 0ull) | (ll_acq >= 0 ? 2ull | (unsigned long long)(ll_acq & 1) : 0ull);
 }
 struct kvh_lds {
-  uint32_t key[KVB_T];            // idx << 9 | thread that loaded the record: sorted = the piece in request order
+  uint32_t key[KVB_T];            // idx << 9 | slot of the record: sorted = the piece in request order
   uint32_t idx[KVB_T];            // request index at each sorted position
-  uint8_t typ[KVB_T];             // request type by loading thread
+  uint8_t typ[KVB_T];             // request type by slot
   uint64_t Bw[KVB_W], Bl[KVB_W], Ba[KVB_W];  // per wave of sorted positions: writers, lock ops, ACQUIREs
   unsigned long long pub[KVR_NPMAX + 1];     // the siblings' words
-  uint32_t bad, timeout;
+  uint32_t bad, timeout, nhot, nrem;
   uint32_t found, link, slot, ver0, la0, table;
-  uint32_t rowv[10];              // the row's value before the pass (read BEFORE this piece publishes: see below)
+  uint32_t rowv[10];              // the row's value before the pass
 };
-// returns 0: the item is done (or not this workgroup's to do); 1: run kv_big_bin over ovf[*off, *off + *cnt)
+// returns 0: the item is done (or not this workgroup's to do); 1: run kv_big_bin over recs[*src][*off, *off + *cnt), src 0 = ovf, 1 = ovf2
 template <int WL>
-__device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut2, const kv_dev *kv, const uint4 d, const uint4 x,
-                                                  const uint64_t *__restrict__ ovf, unsigned long long *hotpub, uint32_t seq,
-                                                  dint_dev_stats *__restrict__ stats, const dint_view V, uint8_t *lds_raw,
-                                                  uint32_t *off, uint32_t *cnt) {
+__device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut2, const kv_dev *kv, const uint4 d, const uint4 x, const uint4 y,
+                                                  const uint64_t *__restrict__ ovf, uint64_t *__restrict__ ovf2, unsigned long long *hotpub,
+                                                  uint32_t seq, uint32_t inv_n, dint_dev_stats *__restrict__ stats, const dint_view V,
+                                                  uint8_t *lds_raw, uint32_t *src, uint32_t *off, uint32_t *cnt) {
   using F = Fmt<WL>;
   kvh_lds &H = *(kvh_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 31u, np = (d.w >> 7) & 31u, has_rem = (d.w >> 12) & 1u;
-  const uint32_t nsib = np + has_rem, first = x.z, c = d.z;
+  const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 31u, np = (d.w >> 7) & 31u;
+  const uint32_t nsib = np > 1 ? np + 1 : 1, first = x.z, h = d.z;
   const uint32_t sh_g = 16 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
+  const uint64_t hkey = ((uint64_t)x.y << 32) | x.x, hrec = ((uint64_t)y.y << 32) | y.x;
+  const uint32_t hq = pay_q(kv_rec_pay(hrec)), hkh = pay_kh(kv_rec_pay(hrec));
+  const bool do_piece = kind != KVQ_REM, do_rem = kind != KVQ_PIECE;
   unsigned long long *pub = hotpub + first;
   auto is_writer = [](uint32_t type) -> bool { return WL == DINT_WL_STORE ? type == 1 : (type == 12 || type == 13); };
-  auto wait_siblings = [&]() -> bool {  // every sibling's word into H.pub[]; false: one of them says "not in closed form"
-    if (t < nsib) {
-      unsigned long long w = 0;
-      uint32_t spins = 0;
-      for (;;) {
-        w = __hip_atomic_load(&pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(w >> 34) == (seq & 0x3FFFFFFFu)) break;
-        // (siblings are running or about to be started -- see above; a bound nevertheless: a hung GPU is worse than a trap)
-        if (++spins > (1u << 22)) { H.timeout = 1; break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-      H.pub[t] = w;
-    }
-    __syncthreads();
-    if (H.timeout) __builtin_trap();
-    bool ok = true;
-    for (uint32_t k = 0; k < nsib; k++) ok = ok && ((H.pub[k] >> 33) & 1ull);
-    return ok;
-  };
   __syncthreads();  // the LDS buffer is free (the previous item is done with it)
-  if (t == 0) { H.bad = 0; H.timeout = 0; }
+  H.key[t] = 0xFFFFFFFFu;
+  if (t == 0) { H.bad = 0; H.timeout = 0; H.nhot = 0; H.nrem = 0; }
   __syncthreads();
 
-  if (kind == KVQ_REM) {
-    // the sub's other keys: fine beside the pieces unless one of the hot BUCKET restructures its chain or uses the hot key's
-    // lock byte (the same conditions the dominant-key path of kv_big_bin checks)
-    const uint64_t hrec = ((uint64_t)x.y << 32) | x.x;
-    const uint32_t hq = pay_q(kv_rec_pay(hrec));
-    bool bad = false;
-    for (uint32_t k = t; k < c; k += KVB_T) {
-      const uint64_t r = ovf[d.y + k];
-      const uint32_t type = pay_type(kv_rec_pay(r));
-      if ((r >> sh_g) == (hrec >> sh_g)) bad |= kv_struct_op<WL>(type) || (kv_lock_op<WL>(type) && pay_q(kv_rec_pay(r)) == hq);
+  // ---- one pass over the sub's records: mine are the hot key's of my index range (a piece) / everything else (the remainder)
+  for (uint32_t k0 = 0; k0 < h; k0 += KVB_T) {
+    const uint32_t k = k0 + t;
+    const uint64_t r = k < h ? ovf[d.y + k] : 0;
+    const uint32_t pay = kv_rec_pay(r), ridx = (uint32_t)(r >> 16) & idx_mask, type = pay_type(pay);
+    const bool same_g = k < h && (r >> sh_g) == (hrec >> sh_g), same = same_g && pay_kh(pay) == hkh;
+    if (do_piece) {
+      const bool mine = same && (np == 1 || kv_piece_of(ridx, np, inv_n) == j);
+      // behind the candidate's hash bits there may be another key (9 bits): the closed form is not for it
+      const bool really = mine && ld_u64(rep + dint_view_off(V, ridx, F::MSG) + F::KEY) == hkey;
+      if (mine && !really) H.bad = 1;
+      const uint64_t mm = __ballot(really);
+      uint32_t at = 0;
+      if (lane == 0 && mm) at = atomicAdd(&H.nhot, (uint32_t)__popcll(mm));
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
+      if (really && at < KVB_T) { H.key[at] = (ridx << 9) | at; H.typ[at] = (uint8_t)(type & 0xFFu); }
     }
-    if (bad) H.bad = 1;
-    __syncthreads();
-    if (t == 0) __hip_atomic_store(&pub[np], kvh_word(seq, !H.bad, 0, -1, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!wait_siblings()) return 0;  // piece 0 takes the whole sub
-    *off = d.y; *cnt = c;
-    return 1;
+    if (do_rem) {
+      // another key of the hot BUCKET must not restructure the chain or use the hot key's lock byte
+      if (same_g && !same && (kv_struct_op<WL>(type) || (kv_lock_op<WL>(type) && pay_q(pay) == hq))) H.bad = 1;
+      const bool other = k < h && !same;
+      const uint64_t mm = __ballot(other);
+      uint32_t at = 0;
+      if (lane == 0 && mm) at = atomicAdd(&H.nrem, (uint32_t)__popcll(mm));
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
+      if (other) ovf2[d.y + at] = r;  // the remainder, compacted (ovf itself stays as it is: the old way needs it whole)
+    }
   }
-
-  // ---- a piece: its requests in request order, one per thread
-  const uint64_t hkey = ((uint64_t)x.y << 32) | x.x;
-  const bool has = t < c;
-  const uint64_t r = has ? ovf[d.y + t] : 0;
-  const uint32_t ridx = (uint32_t)(r >> 16) & idx_mask, rpay = kv_rec_pay(r);
-  H.key[t] = has ? (ridx << 9) | t : 0xFFFFFFFFu;
-  H.typ[t] = (uint8_t)(pay_type(rpay) & 0xFFu);
-  // the row: one thread loads the bucket's header now (the round trip overlaps the sort) and, behind the sort, locates the
-  // row and reads its value into LDS.  EVERY piece has header and value in hand before it publishes its word, and nobody
-  // stores to the row or the lock byte before it has seen every sibling's word: the write-backs at the end cannot overtake
-  // a sibling's reads (the pieces run on different CUs, different XCDs; there is no other order between them).
+  __syncthreads();
+  const uint32_t c = do_piece ? H.nhot : 0u, c_rem = do_rem ? H.nrem : 0u;
+  if (t == 0 && c > KVB_T) H.bad = 1;  // more of the key's requests in this range than a workgroup has threads
+  // ---- the bucket's header now (the round trip overlaps the sort), the row behind the sort
   kv_hdr Hd;
   kv_tab tb0;
   uint64_t bucket0 = 0;
-  uint32_t q0 = 0, table0 = 0;
+  uint32_t table0 = 0;
   const bool locator = t == 0 && c != 0;  // (an empty piece answers nothing and stores nothing: it only says so)
   if (locator) {
-    const uint32_t gk = kv_cut_gk((uint32_t)(r >> sh_g), d.x, cut2);  // my record: every record of the piece is the hot key's
-    q0 = pay_q(rpay);
+    const uint32_t gk = kv_cut_gk((uint32_t)(hrec >> sh_g), d.x, cut2);
     table0 = kv_table_of(kv, gk);
     tb0 = kv->tab[table0];
     bucket0 = (uint64_t)(gk - kv->gk_base[table0]);
     kv_hdr_load(Hd, kv_entry_ptr(tb0, bucket0, KV_INLINE));
   }
   __syncthreads();
-  kvb_sort_blocked_u32<1>(H.key, KVB_T);
+  if (do_piece) kvb_sort_blocked_u32<1>(H.key, KVB_T);
   if (locator) {
     const kv_where w = kv_locate(tb0, bucket0, Hd, hkey);
     H.found = w.found; H.link = w.link; H.slot = w.slot; H.ver0 = w.ver; H.table = table0;
-    H.la0 = WL == DINT_WL_TATP ? (Hd.lockw >> (8 * q0)) & 0xFFu : 0u;
+    H.la0 = WL == DINT_WL_TATP ? (Hd.lockw >> (8 * hq)) & 0xFFu : 0u;
     if (w.found) {
       const uint8_t *rv = kv_entry_ptr(tb0, bucket0, w.link) + KV_VAL_OFF + w.slot * F::VS;
 #pragma unroll
@@ -2731,7 +2666,7 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
     }
   }
   const uint32_t sk = H.key[t];
-  const bool v = sk != 0xFFFFFFFFu;
+  const bool v = do_piece && sk != 0xFFFFFFFFu;
   const uint32_t my_idx = sk >> 9, my_type = v ? H.typ[sk & 511u] : 0xFFu;
   if (v && !kv_simple_op<WL>(my_type)) H.bad = 1;
   const bool wr = v && is_writer(my_type), lk = v && kv_lock_op<WL>(my_type), aq = v && WL == DINT_WL_TATP && my_type == 1;
@@ -2753,75 +2688,99 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
     if (ml) ll_tot = (int)(w * 64 + 63 - __clzll((long long)ml));
   }
   auto acq_at = [&](int p) -> int { return (int)((H.Ba[p >> 6] >> (p & 63)) & 1ull); };
-  if (t == 0)
-    __hip_atomic_store(&pub[j], kvh_word(seq, !H.bad, wr_tot, lw_tot >= 0 ? (int)H.idx[lw_tot] : -1, ll_tot >= 0 ? acq_at(ll_tot) : -1),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!wait_siblings()) {  // not in closed form: the whole sub the old way, by piece 0
+  const unsigned long long mine_w = kvh_word(seq, !H.bad, wr_tot, lw_tot >= 0 ? (int)H.idx[lw_tot] : -1, ll_tot >= 0 ? acq_at(ll_tot) : -1);
+  bool all_ok = !H.bad;
+  if (nsib > 1) {  // tell the siblings, hear from them
+    if (t == 0) __hip_atomic_store(&pub[j], mine_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < nsib) {
+      unsigned long long w = 0;
+      uint32_t spins = 0;
+      for (;;) {
+        w = __hip_atomic_load(&pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(w >> 34) == (seq & 0x3FFFFFFFu)) break;
+        // (siblings are running or about to be started -- see above; a bound nevertheless: a hung GPU is worse than a trap)
+        if (++spins > (1u << 22)) { H.timeout = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      H.pub[t] = w;
+    }
+    __syncthreads();
+    if (H.timeout) __builtin_trap();
+    for (uint32_t k = 0; k < nsib; k++) all_ok = all_ok && ((H.pub[k] >> 33) & 1ull);
+  } else if (t == 0) {
+    H.pub[0] = mine_w;
+  }
+  if (nsib == 1) __syncthreads();
+  if (!all_ok) {  // not in closed form: the whole sub the old way, by the sub's first item
     if (j != 0) return 0;
-    *off = d.y; *cnt = x.w;  // piece 0 starts the sub's range
+    *src = 0; *off = d.y; *cnt = h;
     return 1;
   }
-  if (c == 0) return 0;
-  // ---- what the pieces before mine leave me, and who stores the row / the lock byte at the end
-  uint32_t nw_before = 0, nw_all = 0;
-  int lw_before = -1, la_before = -1, jw = -1, jl = -1, la_fin = -1;
-  for (uint32_t k = 0; k < np; k++) {
-    const unsigned long long w = H.pub[k];
-    const uint32_t nwk = (uint32_t)(w >> 23) & 1023u;
-    if (k < j) {
-      nw_before += nwk;
-      if ((w >> 22) & 1ull) lw_before = (int)((w >> 2) & 0xFFFFFu);
-      if (w & 2ull) la_before = (int)(w & 1ull);
-    }
-    nw_all += nwk;
-    if (nwk) jw = (int)k;
-    if (w & 2ull) { jl = (int)k; la_fin = (int)(w & 1ull); }
-  }
-  const uint32_t found = H.found, ver0 = H.ver0, la0 = H.la0;
-  const kv_tab tb = kv->tab[H.table];
-  const uint64_t r0 = ovf[d.y];
-  const uint32_t gk = kv_cut_gk((uint32_t)(r0 >> sh_g), d.x, cut2), q = pay_q(kv_rec_pay(r0));
-  const uint64_t bucket = (uint64_t)(gk - kv->gk_base[H.table]);
-  uint8_t *row = kv_entry_ptr(tb, bucket, H.link) + KV_VAL_OFF + H.slot * F::VS;  // meaningful when found (written, never read, here)
-  if (v) {
-    uint8_t *msg = rep + dint_view_off(V, my_idx, F::MSG);
-    uint32_t code;
-    bool get = false;
-    if (WL == DINT_WL_STORE) {
-      code = my_type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
-      get = my_type == 0 && found;
-    } else {
-      const int seen = ll_below >= 0 ? acq_at(ll_below) : (la_before >= 0 ? la_before : (int)la0);
-      switch (my_type) {
-        case 0: code = found ? 4 : 6; get = found != 0; break;
-        case 1: code = seen ? 8 : 7; break;
-        case 2: code = 9; break;
-        case 12: code = 15; break;
-        default: code = 16; break;  // 13 kCommitBck
+  if (c != 0) {
+    // ---- what the pieces before mine leave me, and who stores the row / the lock byte at the end
+    uint32_t nw_before = 0, nw_all = 0;
+    int lw_before = -1, la_before = -1, jw = -1, jl = -1, la_fin = -1;
+    for (uint32_t k = 0; k < np; k++) {
+      const unsigned long long w = H.pub[k];
+      const uint32_t nwk = (uint32_t)(w >> 23) & 1023u;
+      if (k < j) {
+        nw_before += nwk;
+        if ((w >> 22) & 1ull) lw_before = (int)((w >> 2) & 0xFFFFFu);
+        if (w & 2ull) la_before = (int)(w & 1ull);
       }
+      nw_all += nwk;
+      if (nwk) jw = (int)k;
+      if (w & 2ull) { jl = (int)k; la_fin = (int)(w & 1ull); }
     }
-    if (get) {  // the row as of my position: the last writer before me (its message still holds the value), else the row as
-      const int widx = lw_below >= 0 ? (int)H.idx[lw_below] : lw_before;  // it was before the pass (H.rowv)
-      if (widx >= 0) {
-        kv_copy_words(msg + F::VAL, rep + dint_view_off(V, (uint32_t)widx, F::MSG) + F::VAL, F::VS);
+    const uint32_t found = H.found, ver0 = H.ver0, la0 = H.la0;
+    const kv_tab tb = kv->tab[H.table];
+    const uint32_t gk = kv_cut_gk((uint32_t)(hrec >> sh_g), d.x, cut2);
+    const uint64_t bucket = (uint64_t)(gk - kv->gk_base[H.table]);
+    uint8_t *row = kv_entry_ptr(tb, bucket, H.link) + KV_VAL_OFF + H.slot * F::VS;  // meaningful when found (written, never read, here)
+    if (v) {
+      uint8_t *msg = rep + dint_view_off(V, my_idx, F::MSG);
+      uint32_t code;
+      bool get = false;
+      if (WL == DINT_WL_STORE) {
+        code = my_type == 0 ? (found ? 3 : 7) : (found ? 5 : 7);
+        get = my_type == 0 && found;
       } else {
-#pragma unroll
-        for (uint32_t k = 0; k < F::VS / 4; k++) st_u32(msg + F::VAL + 4 * k, H.rowv[k]);
+        const int seen = ll_below >= 0 ? acq_at(ll_below) : (la_before >= 0 ? la_before : (int)la0);
+        switch (my_type) {
+          case 0: code = found ? 4 : 6; get = found != 0; break;
+          case 1: code = seen ? 8 : 7; break;
+          case 2: code = 9; break;
+          case 12: code = 15; break;
+          default: code = 16; break;  // 13 kCommitBck
+        }
       }
-      st_u32(msg + F::VER, ver0 + nw_before + wr_below);
+      if (get) {  // the row as of my position: the last writer before me (its message still holds the value), else the row as
+        const int widx = lw_below >= 0 ? (int)H.idx[lw_below] : lw_before;  // it was before the pass (H.rowv)
+        if (widx >= 0) {
+          kv_copy_words(msg + F::VAL, rep + dint_view_off(V, (uint32_t)widx, F::MSG) + F::VAL, F::VS);
+        } else {
+#pragma unroll
+          for (uint32_t k = 0; k < F::VS / 4; k++) st_u32(msg + F::VAL + 4 * k, H.rowv[k]);
+        }
+        st_u32(msg + F::VER, ver0 + nw_before + wr_below);
+      }
+      msg[F::TYPE] = (uint8_t)code;
     }
-    msg[F::TYPE] = (uint8_t)code;
+    // ---- the row and the lock byte, once: by the piece that holds the pass's last writer / last lock op
+    if (found && nw_all && (int)j == jw && (int)t == lw_tot) {
+      kv_copy_words(row, rep + dint_view_off(V, my_idx, F::MSG) + F::VAL, F::VS);
+      KV_ST(uint32_t, &kv_entry_hdr(tb, bucket, H.link)->ver[H.slot], ver0 + nw_all);
+    }
+    if (WL == DINT_WL_TATP && t == 0) {
+      if ((int)j == jl && la_fin >= 0 && (uint32_t)la_fin != la0) KV_ST(uint8_t, kv_entry_ptr(tb, bucket, KV_INLINE) + KV_LOCKB_OFF + hq, (uint8_t)la_fin);
+      if (!found && wr_tot) atomicAdd(&stats->missing_keys, (unsigned long long)wr_tot);  // tatp/udp/kvs.h:91 (the reference panics)
+    }
   }
-  // ---- the row and the lock byte, once: by the piece that holds the pass's last writer / last lock op
-  if (found && nw_all && (int)j == jw && (int)t == lw_tot) {
-    kv_copy_words(row, rep + dint_view_off(V, my_idx, F::MSG) + F::VAL, F::VS);
-    KV_ST(uint32_t, &kv_entry_hdr(tb, bucket, H.link)->ver[H.slot], ver0 + nw_all);
-  }
-  if (WL == DINT_WL_TATP && t == 0) {
-    if ((int)j == jl && la_fin >= 0 && (uint32_t)la_fin != la0) KV_ST(uint8_t, kv_entry_ptr(tb, bucket, KV_INLINE) + KV_LOCKB_OFF + q, (uint8_t)la_fin);
-    if (!found && wr_tot) atomicAdd(&stats->missing_keys, (unsigned long long)wr_tot);  // tatp/udp/kvs.h:91 (the reference panics)
-  }
-  return 0;
+  if (c_rem == 0) return 0;
+  // the remainder (compacted above into ovf2): other buckets, or other rows of the hot bucket -- beside the pieces
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ... this workgroup's own ovf2 stores before kv_big_bin's loads
+  *src = 1; *off = d.y; *cnt = c_rem;
+  return 1;
 }
 
 // the pass's big subs, KVB_GRID workgroups per engine taking them in turn (the longest job of a pass: a hot key)
@@ -2853,15 +2812,19 @@ __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
     __syncthreads();
     const uint32_t i = Stk;
     if (i >= nq) break;
-    const uint4 d = A.bigq[2 * (size_t)i];
-    uint32_t off = d.y, cnt = d.z;
+    const uint4 d = A.bigq[KVQ_W * (size_t)i];
+    uint32_t src = 0, off = d.y, cnt = d.z;
     uint64_t *ttr = first ? tr : nullptr;
     if (ttr && t == 0) { ttr[0] = __builtin_amdgcn_s_memrealtime(); ttr[2] = d.z; ttr[3] = d.x; ttr[30] = d.w; }
     int run = 1;
     if ((d.w & 3u) != KVQ_SUB)
-      run = kv_hot_item<WL>(A.rep, cut2, &Skv, d, A.bigq[2 * (size_t)i + 1], A.ovf, A.hotpub, A.seq, A.stats, A.V, Lraw, &off, &cnt);
-    if (run)
-      kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, A.ovf + off, A.ovf2 ? A.ovf2 + off : nullptr, cnt, A.stats, A.force_flags, A.V, Lraw, Lbm, ttr);
+      run = kv_hot_item<WL>(A.rep, cut2, &Skv, d, A.bigq[KVQ_W * (size_t)i + 1], A.bigq[KVQ_W * (size_t)i + 2], A.ovf, A.ovf2, A.hotpub, A.seq,
+                            A.inv_n, A.stats, A.V, Lraw, &src, &off, &cnt);
+    if (run) {
+      // (a remainder lives in ovf2: no second copy of the scratch to regroup it by stretch -- it is small)
+      const uint64_t *recs = (src ? (const uint64_t *)A.ovf2 : A.ovf) + off;
+      kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, recs, src || !A.ovf2 ? nullptr : A.ovf2 + off, cnt, A.stats, A.force_flags, A.V, Lraw, Lbm, ttr);
+    }
     if (ttr && t == 0) ttr[1] = __builtin_amdgcn_s_memrealtime();
   }
 }
@@ -2904,9 +2867,10 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.force_flags = kv.force_rounds | (kv_env("DINT_KV_NO_BM", 0) ? 4 : 0) | (int)(kv_env("DINT_KV_HOT_MIN", 0) << 8);
   // hot keys in pieces (kv_hot_item): store / tatp; never with the closed forms switched off (DINT_FLAG_KV_ROUNDS,
   // DINT_FLAG_LOCK_SAME_KEY, DINT_FLAG_KV_NO_HOT) or for the internal LOAD requests.  DINT_KV_SPLIT_MIN / _TARGET: the
-  // smallest sub that is cut / requests per piece (tests run small values); DINT_KV_NO_SPLIT=1: r04's one workgroup per hot key
+  // smallest sub that takes the path (default: every big sub) / requests per piece (tests run small values);
+  // DINT_KV_NO_SPLIT=1: r04's kv_big_bin for every big sub, one workgroup per hot key
   A.split_min = (kv.workload == DINT_WL_SMALLBANK || (A.force_flags & 3) || load_mode || kv_env("DINT_KV_NO_SPLIT", 0))
-                    ? 0xFFFFFFFFu : std::max(65u, kv_env("DINT_KV_SPLIT_MIN", 768u));
+                    ? 0xFFFFFFFFu : std::max(65u, kv_env("DINT_KV_SPLIT_MIN", 65u));
   A.split_target = std::min(448u, std::max(8u, kv_env("DINT_KV_SPLIT_TARGET", 384u)));
   A.has_log = kv.workload != DINT_WL_STORE;
   A.trace = kv.d_trace;

@@ -575,7 +575,7 @@ def test_tatp_two_hot_rows_in_one_bucket(same_quadrant):
 # ---------------------------------------------------------------- a hot key in pieces, several workgroups at once (r05)
 SPLIT_KNOBS = [{"DINT_KV_SPLIT_MIN": "65", "DINT_KV_SPLIT_TARGET": "16"},    # 16 pieces of a few dozen requests
                {"DINT_KV_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "100"},
-               {},                                                          # the defaults: subs of >= 768 records, ~384 per piece
+               {},                                                          # the defaults: every big sub, ~384 requests per piece
                {"DINT_KV_NO_SPLIT": "1"}]                                   # r04: one workgroup per hot key
 
 

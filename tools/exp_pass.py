@@ -52,7 +52,15 @@ if os.environ.get("DINT_KV_TRACE"):
         du = (big[:, 1] - big[:, 0]) / 100.0
         top = np.argsort(-du)[:8]
         out["big_subs"] = {"n": int(len(big)), "us_mean": round(float(du.mean()), 1), "us_max": round(float(du.max()), 1),
-                           "longest": [[int(big[i, 2]), round(float(du[i]), 1)] for i in top]}
+                           "longest": [[int(big[i, 2]), round(float(du[i]), 1), int(big[i, 30]) & 3] for i in top]}
+        # the first work item of every workgroup by kind (0 whole sub, 1 piece of a hot key, 2 remainder, 3 solo) and sub size
+        kind = big[:, 30] & 3
+        out["big_subs"]["by_kind_n_mean_max_us"] = {int(k): [int((kind == k).sum()), round(float(du[kind == k].mean()), 1), round(float(du[kind == k].max()), 1)]
+                                                    for k in sorted(set(kind.tolist()))}
+        sz = big[:, 2]
+        out["big_subs"]["by_size_n_mean_max_us"] = {f"{lo}-{hi}": [int(m.sum()), round(float(du[m].mean()), 1), round(float(du[m].max()), 1)]
+                                                    for lo, hi in ((65, 128), (128, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 8192))
+                                                    for m in [(sz >= lo) & (sz < hi)] if m.any()}
         # the stamped stretch of the longest sub (kv_big_bin: [4] in .. [13] out)
         bn = ["gathered", "ordered", "heads", "keys", "masks", "located_granted", "tiles", "written", "out"]
         i = int(top[0])
