@@ -2581,65 +2581,524 @@ struct kvh_lds {
   uint32_t key[KVB_T];            // idx << 9 | slot of the record: sorted = the piece in request order
   uint32_t idx[KVB_T];            // request index at each sorted position
   uint8_t typ[KVB_T];             // request type by slot
-  uint64_t Bw[KVB_W], Bl[KVB_W], Ba[KVB_W];  // per wave of sorted positions: writers, lock ops, ACQUIREs
+  uint64_t rem[KVB_T];            // the other keys' records (a remainder / solo item), then their sort words
+  uint64_t all[KVB_T];            // a solo item: every record of the sub (the candidate key may be no hot key at all)
+  uint16_t cs[KVB_T + 2];         // chunks of the sorted remainder: first record of each, then the end
+  uint64_t Bw[KVB_W], Bl[KVB_W], Ba[KVB_W];  // per wave of sorted positions: writers, lock ops, ACQUIREs; group heads of the remainder
   unsigned long long pub[KVR_NPMAX + 1];     // the siblings' words
-  uint32_t bad, timeout, nhot, nrem;
+  uint32_t bad, timeout, nhot, nrem, nall, nsame, nbr, nch, too_big;
   uint32_t found, link, slot, ver0, la0, table;
   uint32_t rowv[10];              // the row's value before the pass
+  // a solo item: the row machine of a key whose requests insert / delete the row (state after each row-changing request)
+  uint32_t best;                  // longest run of one (bucket group, key hash): length << 16 | first sorted position
+  unsigned long long hkey;
+  uint32_t ev_ver[KVB_T];
+  int16_t ev_src[KVB_T];
+  uint8_t ev_ex[KVB_T];
+  uint32_t fin_ex, fin_ver, fin_multi, fin_miss, dupf;
+  int fin_src;
+  // group phases (kv_group_phases): a bucket group request by request where it matters
+  uint8_t qq[KVB_T];              // lock quadrant by slot
+  uint64_t Lq[4][KVB_W], Aq[4][KVB_W];  // per quadrant and wave of idx-sorted positions: lock ops, ACQUIREs
+  uint32_t lockw, bestg, gbad;
 };
+// m <= KVB_T records of OTHER keys in R[] (the big path's 8-byte form), whole workgroup: sorted by (bucket group, key hash,
+// idx), cut into chunks of <= 64 at bucket-group boundaries, every chunk resolved by a wave as k_kv_resolve would (kv_chunk:
+// all closed forms, rounds where they do not apply) -- 4 memory round trips instead of kv_big_bin's stretch machinery (30 .. 40
+// us for a hundred records, r05).  false (nothing touched): a bucket group of more than 64 records -- kv_big_bin's job.
+template <int WL>
+__device__ __forceinline__ static bool kv_rem_chunks(uint8_t *rep, const kv_cut cut2, const kv_dev *kv, uint32_t bin, uint64_t *R, uint32_t m,
+                                                     kvh_lds &H, dint_dev_stats *__restrict__ stats, int force_rounds, const dint_view V,
+                                                     bool sorted = false /* R[] holds sort words in order already */) {
+  using F = Fmt<WL>;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t sh_g = 16 + cut2.ibits, sh_k = 7 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
+  __syncthreads();
+  if (!sorted) {
+    const uint64_t mine = t < m ? kv_sort_key(R[t], cut2) : ~0ull;
+    __syncthreads();
+    R[t] = mine;
+    __syncthreads();
+    uint32_t N = 64;
+    while (N < m) N <<= 1;
+    kvb_sort_blocked<1>(R, N);  // (slots N .. KVB_T - 1 hold ~0: they stay last)
+  }
+  const uint64_t w = R[t];
+  const bool head = t < m && (t == 0 || (R[t - 1] >> sh_g) != (w >> sh_g));
+  const uint64_t hm = __ballot(head);
+  if (lane == 0) H.Bw[wave] = hm;
+  __syncthreads();
+  if (t == 0) {  // greedy chunks: cut at a group's first record whenever the next group no longer fits
+    uint32_t nch = 0, start = 0, prev = 0, big = 0;
+    for (uint32_t wv = 0; wv < KVB_W; wv++)
+      for (uint64_t mm = H.Bw[wv]; mm; mm &= mm - 1) {
+        const uint32_t hp = wv * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
+        if (hp == 0) continue;
+        if (hp - start > 64) { H.cs[nch++] = (uint16_t)start; start = prev; big |= hp - start > 64; }
+        prev = hp;
+      }
+    if (m - start > 64) { H.cs[nch++] = (uint16_t)start; start = prev; big |= m - start > 64; }
+    H.cs[nch++] = (uint16_t)start;
+    H.cs[nch] = (uint16_t)m;
+    H.nch = nch; H.too_big = big;
+  }
+  __syncthreads();
+  if (H.too_big) return false;
+  const uint32_t nch = H.nch;
+  for (uint32_t ch = wave; ch < nch; ch += KVB_W) {
+    const uint32_t a = H.cs[ch], c = H.cs[ch + 1] - a;
+    const bool valid = lane < c;
+    const uint64_t wv = valid ? R[a + lane] : ~0ull;
+    const uint32_t idx = valid ? (uint32_t)(wv >> 7) & idx_mask : 0, gk = kv_cut_gk((uint32_t)(wv >> sh_g), bin, cut2);
+    const uint32_t pay = (uint32_t)wv & 0x7Fu;
+    const uint64_t key = valid ? ld_u64(rep + dint_view_off(V, idx, F::MSG) + F::KEY) : 0;
+    kv_chunk<WL>(rep, valid, idx, gk, (uint32_t)(wv >> sh_k) & 511u, pay_type(pay), valid ? kv_table_of(kv, gk) : 0, pay_q(pay), key, kv, stats,
+                 force_rounds, ch + KVB_W >= nch, V);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __syncthreads();
+  return true;
+}
+// ---- one BUCKET GROUP request by request where it matters, whole workgroup (kv_solo_item) ---------------------------------
+// For a bucket the closed forms do not cover -- a duplicate row in the table (the reference's population makes them), two keys on
+// one lock byte, a neighbour that restructures the chain, two keys behind one key hash, an INSERT of an existing row -- and that
+// holds more requests than a chunk.  What is serial about a bucket is little: its ROW-CHANGING requests (SET / INSERT / DELETE,
+// a handful per pass), and per lock byte which lock op came last.  So: the group's requests in request order (one sort of <= 512
+// words); the lock bytes in closed form per quadrant, across keys (ACQUIRE sees what the last lock op on its byte left); the
+// rows in PHASES -- the READs behind e row-changing requests all at once, each with the reference's own walk of the chain
+// (kv_apply: first match, duplicates and all), then the e-th row-changing request applied to the chain by its own thread.  A
+// phase is two memory round trips; kv_big_bin's stretch machinery with its rounds took 36 us for such a group of 116 (r05).
+// R[Gs, Ge) = the group's sort words; false (nothing touched): more than KVG_MAXW row-changing requests, an INSERT with the
+// overflow pool nearly empty (it may be refused, and then its lock byte stays: kv_do_request), or a request type the servers
+// do not know -- kv_big_bin's.
+#define KVG_MAXW 24u
+template <int WL>
+__device__ __forceinline__ static bool kv_group_phases(uint8_t *rep, const kv_cut cut2, const kv_dev *kv, uint32_t bin, const uint64_t *R, uint32_t Gs,
+                                                       uint32_t Ge, kvh_lds &H, dint_dev_stats *__restrict__ stats, const dint_view V) {
+  using F = Fmt<WL>;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, n = Ge - Gs;
+  const uint32_t sh_g = 16 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
+  auto is_set = [](uint32_t type) -> bool { return WL == DINT_WL_STORE ? type == 1 : (type == 12 || type == 13); };
+  auto is_ins = [](uint32_t type) -> bool { return WL == DINT_WL_STORE ? type == 2 : (type == 18 || type == 19); };
+  auto is_del = [](uint32_t type) -> bool { return WL == DINT_WL_TATP && (type == 22 || type == 23); };
+  const uint32_t gk = kv_cut_gk((uint32_t)(R[Gs] >> sh_g), bin, cut2), table = kv_table_of(kv, gk);
+  const kv_tab tb = kv->tab[table];
+  const uint64_t bucket = (uint64_t)(gk - kv->gk_base[table]);
+  uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
+  __syncthreads();
+  {
+    const uint64_t w = t < n ? R[Gs + t] : 0;
+    const uint32_t idx = (uint32_t)(w >> 7) & idx_mask, pay = (uint32_t)w & 0x7Fu;
+    H.key[t] = t < n ? (idx << 9) | t : 0xFFFFFFFFu;
+    H.typ[t] = (uint8_t)(pay_type(pay) & 0xFFu);
+    H.qq[t] = (uint8_t)pay_q(pay);
+    H.rem[t] = t < n ? ld_u64(rep + dint_view_off(V, idx, F::MSG) + F::KEY) : 0;  // every request with its own full key
+    if (t == 0) { H.gbad = 0; H.lockw = KV_LD(uint32_t, ie + KV_LOCKB_OFF); }
+  }
+  __syncthreads();
+  kvb_sort_blocked_u32<1>(H.key, KVB_T);
+  const uint32_t sk = H.key[t];
+  const bool v = sk != 0xFFFFFFFFu;
+  const uint32_t slot = sk & 511u, my_idx = sk >> 9, my_type = v ? H.typ[slot] : 0xFFu, my_q = v ? H.qq[slot] : 0u;
+  const uint64_t my_key = v ? H.rem[slot] : 0;
+  const bool isW = v && (is_set(my_type) || is_ins(my_type) || is_del(my_type)), isR = v && my_type == 0;
+  const bool lk = v && kv_lock_op<WL>(my_type), aq = v && WL == DINT_WL_TATP && my_type == 1;
+  if (v && !(kv_simple_op<WL>(my_type) || kv_struct_op<WL>(my_type))) H.gbad = 1;
+  if (v && is_ins(my_type) && kv_pool_low(tb)) H.gbad = 1;
+  const uint64_t bw = __ballot(isW);
+  if (lane == 0) H.Bw[wave] = bw;
+  if (WL == DINT_WL_TATP) {
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+      const uint64_t ml = __ballot(lk && my_q == q), ma = __ballot(aq && my_q == q);
+      if (lane == 0) { H.Lq[q][wave] = ml; H.Aq[q][wave] = ma; }
+    }
+  }
+  __syncthreads();
+  uint32_t ev_below = 0, nW = 0;
+#pragma unroll
+  for (uint32_t wv = 0; wv < KVB_W; wv++) {
+    const uint64_t m = H.Bw[wv];
+    nW += (uint32_t)__popcll(m);
+    ev_below += (uint32_t)__popcll(wv < wave ? m : (wv == wave ? m & lanemask_lt() : 0ull));
+  }
+  if (H.gbad || nW > KVG_MAXW) return false;
+  uint8_t *msg = rep + dint_view_off(V, my_idx, F::MSG);
+  for (uint32_t e = 0; e <= nW; e++) {
+    if (isR && ev_below == e) {
+      kv_hdr Hh;
+      kv_hdr_load(Hh, ie);
+      const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, Hh, KV_ACT_GET, my_key, msg + F::VAL, 0, blockIdx.x);
+      if (r.ok) st_u32(msg + F::VER, r.ver);
+      msg[F::TYPE] = (uint8_t)(WL == DINT_WL_STORE ? (r.ok ? 3 : 7) : (r.ok ? 4 : 6));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    if (isW && ev_below == e) {  // (one thread: the e-th row-changing request of the group)
+      kv_hdr Hh;
+      kv_hdr_load(Hh, ie);
+      const uint32_t act = is_set(my_type) ? KV_ACT_SET : is_ins(my_type) ? KV_ACT_INS : KV_ACT_DEL;
+      const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, Hh, act, my_key, msg + F::VAL, 0, blockIdx.x);
+      uint32_t code;
+      if (WL == DINT_WL_STORE) code = my_type == 1 ? (r.ok ? 5 : 7) : 8;
+      else code = my_type == 12 ? 15 : my_type == 13 ? 16 : my_type == 18 ? 20 : my_type == 19 ? 21 : my_type == 22 ? 25 : 26;
+      if (!r.ok) {
+        if (act == KV_ACT_INS) atomicAdd(&stats->pool_exhausted, 1ULL);
+        else if (WL != DINT_WL_STORE) atomicAdd(&stats->missing_keys, 1ULL);
+      }
+      msg[F::TYPE] = (uint8_t)code;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+  }
+  if (WL == DINT_WL_TATP) {
+    // the lock bytes, per quadrant across the group's keys: a last-writer-wins register (ACQUIRE leaves 1, every other lock op 0)
+    const uint32_t lockw = H.lockw;
+    if (v && (my_type == 1 || my_type == 2)) {
+      int last = -1;
+#pragma unroll
+      for (uint32_t wv = 0; wv < KVB_W; wv++) {
+        const uint64_t m = H.Lq[my_q][wv], mb = wv < wave ? m : (wv == wave ? m & lanemask_lt() : 0ull);
+        if (mb) last = (int)(wv * 64 + 63 - __clzll((long long)mb));
+      }
+      const uint32_t seen = last >= 0 ? (uint32_t)((H.Aq[my_q][last >> 6] >> (last & 63)) & 1ull) : (lockw >> (8 * my_q)) & 0xFFu;
+      msg[F::TYPE] = (uint8_t)(my_type == 1 ? (seen ? 8 : 7) : 9);
+    }
+    if (t < 4) {
+      int last = -1;
+      for (uint32_t wv = 0; wv < KVB_W; wv++)
+        if (H.Lq[t][wv]) last = (int)(wv * 64 + 63 - __clzll((long long)H.Lq[t][wv]));
+      if (last >= 0) {
+        const uint32_t fin = (uint32_t)((H.Aq[t][last >> 6] >> (last & 63)) & 1ull);
+        if (fin != ((lockw >> (8 * t)) & 0xFFu)) KV_ST(uint8_t, ie + KV_LOCKB_OFF + t, (uint8_t)fin);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __syncthreads();
+  return true;
+}
+// ---- a SOLO item: a big sub of at most split_target (<= KVB_T) records, one workgroup, nobody to wait for -------------------
+// The sub in LDS, sorted once by (bucket group, key hash, idx): what the chunk path needs anyway.  No run of one key longer
+// than 64: chunks (kv_rem_chunks) and done -- the sub was a handful of keys, or a crowded coarse bin's all-big fallback.
+// Else the LONGEST run is the hot key (found here, not guessed: its requests are contiguous and already in request order):
+// answered in closed form by one thread per request -- the forms of the pieces with nothing before them, plus the ROW MACHINE
+// of kv_chunk for a key whose requests insert / delete its row (tatp's hot CALL_FORWARDING rows: ~100 READs, a dozen ACQUIREs
+// and one INSERT or DELETE per pass; they used to fall back to kv_big_bin's rounds: 36 .. 47 us, r05): one thread walks the
+// row-changing requests {SET, INSERT, DELETE} in order and leaves {exists, version, value source} after each in LDS, every
+// request reads the state behind the last one before it, and the net effect reaches the chain once (kv_chunk step 4b).
+// The rest of the sub goes through the chunks afterwards.  Not in closed form (nothing touched): another key of the hot bucket
+// that restructures the chain or shares the lock byte, a second key behind the hash bits, an INSERT of an existing row
+// (duplicate rows), a duplicate row in the table, a nearly empty overflow pool -- kv_big_bin over the whole sub.
+template <int WL>
+__device__ __forceinline__ static int kv_solo_item(uint8_t *rep, const kv_cut cut2, const kv_dev *kv, const uint4 d,
+                                                   const uint64_t *__restrict__ ovf, uint64_t *__restrict__ ovf2,
+                                                   dint_dev_stats *__restrict__ stats, int force_rounds, const dint_view V, uint8_t *lds_raw,
+                                                   uint32_t *src, uint32_t *off, uint32_t *cnt, uint64_t *ttr) {
+  using F = Fmt<WL>;
+  kvh_lds &H = *(kvh_lds *)lds_raw;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t h = d.z;
+  const uint32_t sh_g = 16 + cut2.ibits, sh_k = 7 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
+  *src = 0; *off = d.y; *cnt = h;  // (the way out when something is not in closed form)
+  if (h > KVB_T) return 1;
+  auto is_set = [](uint32_t type) -> bool { return WL == DINT_WL_STORE ? type == 1 : (type == 12 || type == 13); };
+  auto is_ins = [](uint32_t type) -> bool { return WL == DINT_WL_STORE ? type == 2 : (type == 18 || type == 19); };
+  auto is_del = [](uint32_t type) -> bool { return WL == DINT_WL_TATP && (type == 22 || type == 23); };
+  __syncthreads();  // the LDS buffer is free
+  H.all[t] = t < h ? kv_sort_key(ovf[d.y + t], cut2) : ~0ull;
+  if (t == 0) { H.bad = 0; H.best = 0; H.bestg = 0; H.dupf = 0; }
+  __syncthreads();
+  {
+    uint32_t N = 64;
+    while (N < h) N <<= 1;
+    kvb_sort_blocked<1>(H.all, N);
+  }
+  const uint64_t w = H.all[t];
+  const bool valid = t < h;
+  const uint64_t prevw = t ? H.all[t - 1] : 0;
+  const bool head_k = valid && (t == 0 || (prevw >> sh_k) != (w >> sh_k));  // (bucket group, key hash) changes
+  const bool head_g = valid && (t == 0 || (prevw >> sh_g) != (w >> sh_g));  // the bucket group changes
+  const uint64_t mk = __ballot(head_k), mg = __ballot(head_g);
+  if (lane == 0) { H.Bw[wave] = mk; H.Bl[wave] = mg; }
+  __syncthreads();
+  auto next_head = [&](const uint64_t *M) -> uint32_t {  // the first head above me, or h
+    uint32_t nxt = h;
+    for (uint32_t wv = wave; wv < KVB_W && nxt == h; wv++) {
+      uint64_t mm = M[wv];
+      if (wv == wave) mm &= ~((2ull << lane) - 1ull);
+      if (mm) nxt = wv * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
+    }
+    return nxt;
+  };
+  if (head_k) atomicMax(&H.best, ((next_head(H.Bw) - t) << 16) | t);   // the longest run of one key ...
+  if (head_g) atomicMax(&H.bestg, ((next_head(H.Bl) - t) << 16) | t);  // ... of one bucket group
+  __syncthreads();
+  const uint32_t L = H.best >> 16, P = H.best & 0xFFFFu;
+  // the bucket group of the longest key run (a hot key), else the longest group
+  uint32_t Gs = H.bestg & 0xFFFFu, Ge = Gs + (H.bestg >> 16);
+  if (L > 64) {
+    Gs = 0;
+    for (uint32_t wv = 0; wv < KVB_W; wv++) {  // the last group head at or below P
+      uint64_t mm = H.Bl[wv];
+      if (wv * 64 > P) break;
+      if (wv == (P >> 6)) mm &= (2ull << (P & 63)) - 1ull;
+      if (mm) Gs = wv * 64 + 63 - (uint32_t)__clzll((long long)mm);
+    }
+    Ge = h;
+    for (uint32_t wv = P >> 6; wv < KVB_W && Ge == h; wv++) {  // the first one above it
+      uint64_t mm = H.Bl[wv];
+      if (wv == (P >> 6)) mm &= ~((2ull << (P & 63)) - 1ull);
+      if (mm) Ge = wv * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
+    }
+  }
+  // the records outside [lo, lo + len), still sorted, through the chunks (kv_big_bin for them when a second bucket group is too long)
+  auto rest = [&](uint32_t lo, uint32_t len) -> int {
+    const uint32_t c_rem = h - len;
+    if (c_rem == 0) return 0;
+    __syncthreads();
+    if (valid && (t < lo || t >= lo + len)) H.rem[t < lo ? t : t - len] = w;
+    if (t >= c_rem) H.rem[t] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the hot bucket's write-backs above, then (perhaps) its other rows
+    if (kv_rem_chunks<WL>(rep, cut2, kv, d.x, H.rem, c_rem, H, stats, force_rounds, V, true)) return 0;
+    if (t < c_rem) {  // back into the big path's record form, for kv_big_bin
+      const uint64_t sw = H.rem[t];
+      ovf2[d.y + t] = ((sw >> sh_g) << sh_g) | ((uint64_t)((uint32_t)(sw >> 7) & idx_mask) << 16) | ((uint32_t)sw & 0x7Fu) | (((uint32_t)(sw >> sh_k) & 511u) << 7);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    *src = 1; *off = d.y; *cnt = c_rem;
+    return 1;
+  };
+  // a bucket group the closed forms do not cover: request by request where it matters; the rest through the chunks
+  auto phases = [&]() -> int {
+    if (!kv_group_phases<WL>(rep, cut2, kv, d.x, H.all, Gs, Ge, H, stats, V)) return 1;  // (nothing touched: kv_big_bin, the whole sub)
+    return rest(Gs, Ge - Gs);
+  };
+  if (L <= 64) {  // no hot key here: chunks -- unless one bucket group is too long for a chunk
+    if (ttr && t == 0) ttr[30] = (uint64_t)(d.w & 0xFFFFu) | (1ull << 17) | ((uint64_t)L << 20) | ((uint64_t)h << 32);
+    if (Ge - Gs <= 64) return kv_rem_chunks<WL>(rep, cut2, kv, d.x, H.all, h, H, stats, force_rounds, V, true) ? 0 : 1;
+    return phases();
+  }
+  // ---- the hot run [P, P + L)
+  const uint64_t hw = H.all[P];
+  const uint32_t hq = pay_q((uint32_t)hw & 0x7Fu);
+  const bool v = valid && t >= P && t < P + L;
+  const uint32_t my_idx = (uint32_t)(w >> 7) & idx_mask, my_type = valid ? pay_type((uint32_t)w & 0x7Fu) : 0xFFu;
+  // another key of the hot bucket must not restructure the chain or use the hot key's lock byte
+  if (valid && !v && (w >> sh_g) == (hw >> sh_g) && (kv_struct_op<WL>(my_type) || (kv_lock_op<WL>(my_type) && pay_q((uint32_t)w & 0x7Fu) == hq))) atomicOr(&H.bad, kv_struct_op<WL>(my_type) ? 1u : 2u);
+  const uint64_t my_key = v ? ld_u64(rep + dint_view_off(V, my_idx, F::MSG) + F::KEY) : 0;
+  if (t == P) H.hkey = my_key;
+  const bool setop = v && is_set(my_type), insop = v && is_ins(my_type), delop = v && is_del(my_type);
+  const bool lk = v && kv_lock_op<WL>(my_type), aq = v && WL == DINT_WL_TATP && my_type == 1;
+  if (v && !(kv_simple_op<WL>(my_type) || kv_struct_op<WL>(my_type))) atomicOr(&H.bad, 4u);
+  const uint64_t bev = __ballot(setop || insop || delop), bl = __ballot(lk), ba = __ballot(aq), bst = __ballot(insop || delop);
+  if (lane == 0) { H.Bw[wave] = bev; H.Bl[wave] = bl; H.Ba[wave] = ba; }
+  if (bst && lane == 0) H.dupf = 1;  // (reused below as "the run inserts / deletes"; the real duplicate check is the locator's)
+  H.idx[t] = my_idx;
+  H.typ[t] = (uint8_t)(my_type & 0xFFu);
+  __syncthreads();
+  const uint64_t hkey = H.hkey;
+  if (v && my_key != hkey) atomicOr(&H.bad, 8u);  // 9 hash bits can collide
+  const bool structural = H.dupf != 0;
+  __syncthreads();
+  // ---- thread P: the row (header, location, value), then the row machine over the run's row-changing requests, in order
+  kv_hdr Hd;
+  kv_tab tb;
+  uint64_t bucket = 0;
+  uint32_t table = 0;
+  {
+    const uint32_t gk = kv_cut_gk((uint32_t)(hw >> sh_g), d.x, cut2);
+    table = kv_table_of(kv, gk);
+    tb = kv->tab[table];
+    bucket = (uint64_t)(gk - kv->gk_base[table]);
+  }
+  if (t == P) {
+    kv_hdr_load(Hd, kv_entry_ptr(tb, bucket, KV_INLINE));
+    const kv_where wh = kv_locate(tb, bucket, Hd, hkey);
+    H.found = wh.found; H.link = wh.link; H.slot = wh.slot; H.ver0 = wh.ver;
+    H.la0 = WL == DINT_WL_TATP ? (Hd.lockw >> (8 * hq)) & 0xFFu : 0u;
+    if (wh.found) {
+      const uint8_t *rv = kv_entry_ptr(tb, bucket, wh.link) + KV_VAL_OFF + wh.slot * F::VS;
+#pragma unroll
+      for (uint32_t k = 0; k < F::VS / 4; k++) H.rowv[k] = KV_LD(uint32_t, rv + 4 * k);
+    }
+    uint32_t ex = wh.found, ver = wh.ver, toggles = 0, miss = 0, e = 0;
+    int sr = -1;
+    const uint32_t plow = structural ? kv_pool_low(tb) : 0u;
+    uint32_t bail = plow | ((structural && kv_has_dup(tb, bucket, Hd, hkey, wh)) ? 1u : 0u);
+    for (uint32_t wv = 0; wv < KVB_W; wv++)
+      for (uint64_t mm = H.Bw[wv]; mm; mm &= mm - 1) {
+        const uint32_t p = wv * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
+        const uint32_t ty = H.typ[p];
+        if (!bail) {
+          if (is_set(ty)) { if (ex) { ver++; sr = (int)p; } else if (WL != DINT_WL_STORE) miss++; }
+          else if (is_ins(ty)) { if (ex) bail = 1; else { ex = 1; ver = 0; sr = (int)p; toggles++; } }
+          else { if (ex) { ex = 0; toggles++; } else miss++; }
+          H.ev_ex[e] = (uint8_t)ex; H.ev_ver[e] = ver; H.ev_src[e] = (int16_t)sr;
+        }
+        e++;
+      }
+    // (no closed form for the row -- a duplicate row in the table, which the reference's population makes; an INSERT of an
+    // existing row; the pool nearly empty --: the bucket group goes through kv_group_phases)
+    if (bail) atomicOr(&H.bad, 16u);
+    H.fin_ex = ex; H.fin_ver = ver; H.fin_src = sr; H.fin_multi = toggles > 1; H.fin_miss = miss;
+  }
+  __syncthreads();
+  if (ttr && t == 0) ttr[30] = (uint64_t)(d.w & 0xFFFFu) | ((uint64_t)(H.bad ? 0u : 1u) << 16) | ((uint64_t)(structural ? 1u : 0u) << 18) | ((uint64_t)(L & 0xFFFu) << 20) | ((uint64_t)(H.bad & 31u) << 56) | ((uint64_t)(h - L) << 32);
+  if (H.bad) return phases();  // (nothing has been touched)
+  const uint32_t found = H.found, ver0 = H.ver0, la0 = H.la0;
+  // ---- every request of the run: the state behind the last row-changing request before it, the last lock op before it
+  uint32_t ev_below = 0;
+  int ll_below = -1, ll_tot = -1;
+#pragma unroll
+  for (uint32_t wv = 0; wv < KVB_W; wv++) {
+    const uint64_t me = H.Bw[wv], ml = H.Bl[wv];
+    const uint64_t meb = wv < wave ? me : (wv == wave ? me & lanemask_lt() : 0ull), mlb = wv < wave ? ml : (wv == wave ? ml & lanemask_lt() : 0ull);
+    ev_below += (uint32_t)__popcll(meb);
+    if (mlb) ll_below = (int)(wv * 64 + 63 - __clzll((long long)mlb));
+    if (ml) ll_tot = (int)(wv * 64 + 63 - __clzll((long long)ml));
+  }
+  auto acq_at = [&](int p) -> int { return (int)((H.Ba[p >> 6] >> (p & 63)) & 1ull); };
+  if (v) {
+    const uint32_t ex_b = ev_below ? H.ev_ex[ev_below - 1] : found, ver_b = ev_below ? H.ev_ver[ev_below - 1] : ver0;
+    const int src_b = ev_below ? (int)H.ev_src[ev_below - 1] : -1;
+    uint8_t *msg = rep + dint_view_off(V, my_idx, F::MSG);
+    uint32_t code;
+    bool get = false;
+    if (WL == DINT_WL_STORE) {
+      code = my_type == 0 ? (ex_b ? 3 : 7) : my_type == 1 ? (ex_b ? 5 : 7) : 8;
+      get = my_type == 0 && ex_b;
+    } else {
+      const int seen = ll_below >= 0 ? acq_at(ll_below) : (int)la0;
+      switch (my_type) {
+        case 0: code = ex_b ? 4 : 6; get = ex_b != 0; break;
+        case 1: code = seen ? 8 : 7; break;
+        case 2: code = 9; break;
+        case 12: code = 15; break;
+        case 13: code = 16; break;
+        case 18: code = 20; break;
+        case 19: code = 21; break;
+        case 22: code = 25; break;
+        default: code = 26; break;  // 23 kDeleteBck
+      }
+    }
+    if (get) {
+      if (src_b >= 0) {
+        kv_copy_words(msg + F::VAL, rep + dint_view_off(V, H.idx[src_b], F::MSG) + F::VAL, F::VS);
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < F::VS / 4; k++) st_u32(msg + F::VAL + 4 * k, H.rowv[k]);
+      }
+      st_u32(msg + F::VER, ver_b);
+    }
+    msg[F::TYPE] = (uint8_t)code;
+  }
+  // ---- the run's net effect on the table, once (kv_chunk steps 4a / 4b), by thread P, which holds the header
+  if (t == P) {
+    const uint32_t exists1 = H.fin_ex, fin_ver = H.fin_ver;
+    const int fin_src = H.fin_src;
+    const bool redo = found && exists1 && H.fin_multi;  // deleted and inserted again: the row may move
+    uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
+    const uint8_t *fval = fin_src >= 0 ? rep + dint_view_off(V, H.idx[fin_src], F::MSG) + F::VAL : nullptr;
+    if (found && exists1 && !redo) {
+      if (fin_src >= 0) {
+        kv_copy_words(kv_entry_ptr(tb, bucket, H.link) + KV_VAL_OFF + H.slot * F::VS, fval, F::VS);
+        KV_ST(uint32_t, &kv_entry_hdr(tb, bucket, H.link)->ver[H.slot], fin_ver);
+      }
+    } else if (found != exists1 || redo) {
+      if (redo) {
+        kv_apply<kv_dev_mem>(tb, bucket, Hd, KV_ACT_DEL, hkey, nullptr, 0, blockIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        kv_hdr_load(Hd, ie);
+      }
+      const kv_res r = kv_apply<kv_dev_mem>(tb, bucket, Hd, exists1 ? KV_ACT_INS : KV_ACT_DEL, hkey, (uint8_t *)fval, fin_ver, blockIdx.x);
+      if (exists1 && !r.ok) atomicAdd(&stats->pool_exhausted, 1ULL);
+    }
+    if (WL == DINT_WL_TATP && ll_tot >= 0) {
+      const uint32_t la_fin = (uint32_t)acq_at(ll_tot);
+      if (la_fin != la0) KV_ST(uint8_t, ie + KV_LOCKB_OFF + hq, (uint8_t)la_fin);
+    }
+    if (H.fin_miss) atomicAdd(&stats->missing_keys, (unsigned long long)H.fin_miss);
+  }
+  // ---- the rest of the sub (sorted already): chunks
+  return rest(P, L);
+}
 // returns 0: the item is done (or not this workgroup's to do); 1: run kv_big_bin over recs[*src][*off, *off + *cnt), src 0 = ovf, 1 = ovf2
 template <int WL>
 __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut2, const kv_dev *kv, const uint4 d, const uint4 x, const uint4 y,
                                                   const uint64_t *__restrict__ ovf, uint64_t *__restrict__ ovf2, unsigned long long *hotpub,
-                                                  uint32_t seq, uint32_t inv_n, dint_dev_stats *__restrict__ stats, const dint_view V,
-                                                  uint8_t *lds_raw, uint32_t *src, uint32_t *off, uint32_t *cnt) {
+                                                  uint32_t seq, uint32_t inv_n, dint_dev_stats *__restrict__ stats, int force_rounds, const dint_view V,
+                                                  uint8_t *lds_raw, uint32_t *src, uint32_t *off, uint32_t *cnt, uint64_t *ttr) {
   using F = Fmt<WL>;
   kvh_lds &H = *(kvh_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 31u, np = (d.w >> 7) & 31u;
-  const uint32_t nsib = np > 1 ? np + 1 : 1, first = x.z, h = d.z;
+  const uint32_t first = x.z, h = d.z;
   const uint32_t sh_g = 16 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
   const uint64_t hkey = ((uint64_t)x.y << 32) | x.x, hrec = ((uint64_t)y.y << 32) | y.x;
   const uint32_t hq = pay_q(kv_rec_pay(hrec)), hkh = pay_kh(kv_rec_pay(hrec));
-  const bool do_piece = kind != KVQ_REM, do_rem = kind != KVQ_PIECE;
+  const bool solo = kind == KVQ_SOLO;
+  bool do_piece = kind != KVQ_REM;
+  const bool do_rem = kind != KVQ_PIECE;
   unsigned long long *pub = hotpub + first;
   auto is_writer = [](uint32_t type) -> bool { return WL == DINT_WL_STORE ? type == 1 : (type == 12 || type == 13); };
   __syncthreads();  // the LDS buffer is free (the previous item is done with it)
   H.key[t] = 0xFFFFFFFFu;
-  if (t == 0) { H.bad = 0; H.timeout = 0; H.nhot = 0; H.nrem = 0; }
+  if (t == 0) { H.bad = 0; H.timeout = 0; H.nhot = 0; H.nrem = 0; H.nall = 0; H.nsame = 0; H.nbr = 0; }
   __syncthreads();
 
-  // ---- one pass over the sub's records: mine are the hot key's of my index range (a piece) / everything else (the remainder)
+  // ---- one pass over the sub's records.  The key's requests of my index range are mine (a piece); every record of another
+  // (bucket group, key hash) is the remainder's.  Every item of the sub sees every record, so all of them know alike whether
+  // the hot BUCKET holds requests for another key (`nbr`): only then does the remainder take part in the all-or-nothing vote.
   for (uint32_t k0 = 0; k0 < h; k0 += KVB_T) {
     const uint32_t k = k0 + t;
     const uint64_t r = k < h ? ovf[d.y + k] : 0;
     const uint32_t pay = kv_rec_pay(r), ridx = (uint32_t)(r >> 16) & idx_mask, type = pay_type(pay);
     const bool same_g = k < h && (r >> sh_g) == (hrec >> sh_g), same = same_g && pay_kh(pay) == hkh;
+    if (same_g && !same) {
+      H.nbr = 1;
+      // another key of the hot bucket must not restructure the chain or use the hot key's lock byte
+      if (kv_struct_op<WL>(type) || (kv_lock_op<WL>(type) && pay_q(pay) == hq)) H.bad = 1;
+    }
     if (do_piece) {
       const bool mine = same && (np == 1 || kv_piece_of(ridx, np, inv_n) == j);
       // behind the candidate's hash bits there may be another key (9 bits): the closed form is not for it
       const bool really = mine && ld_u64(rep + dint_view_off(V, ridx, F::MSG) + F::KEY) == hkey;
       if (mine && !really) H.bad = 1;
-      const uint64_t mm = __ballot(really);
+      const uint64_t mm = __ballot(really), ms = __ballot(same);
       uint32_t at = 0;
       if (lane == 0 && mm) at = atomicAdd(&H.nhot, (uint32_t)__popcll(mm));
+      if (lane == 0 && ms) atomicAdd(&H.nsame, (uint32_t)__popcll(ms));
       at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
       if (really && at < KVB_T) { H.key[at] = (ridx << 9) | at; H.typ[at] = (uint8_t)(type & 0xFFu); }
     }
     if (do_rem) {
-      // another key of the hot BUCKET must not restructure the chain or use the hot key's lock byte
-      if (same_g && !same && (kv_struct_op<WL>(type) || (kv_lock_op<WL>(type) && pay_q(pay) == hq))) H.bad = 1;
       const bool other = k < h && !same;
       const uint64_t mm = __ballot(other);
       uint32_t at = 0;
       if (lane == 0 && mm) at = atomicAdd(&H.nrem, (uint32_t)__popcll(mm));
       at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
-      if (other) ovf2[d.y + at] = r;  // the remainder, compacted (ovf itself stays as it is: the old way needs it whole)
+      if (other) {  // compacted: in LDS for the chunk path, in ovf2 for kv_big_bin (ovf itself stays whole: the old way needs it)
+        ovf2[d.y + at] = r;
+        if (at < KVB_T) H.rem[at] = r;
+      }
     }
+    if (solo && k < h && k < KVB_T) H.all[k] = r;  // (a solo sub has at most split_target <= KVB_T records)
   }
   __syncthreads();
-  const uint32_t c = do_piece ? H.nhot : 0u, c_rem = do_rem ? H.nrem : 0u;
+  const uint32_t c_rem = do_rem ? H.nrem : 0u, nbr = H.nbr;
+  if (solo && H.nhot <= 64 && h <= KVB_T) {
+    // the candidate key is no hot key (a sub of several keys, or a crowded coarse bin's all-big fallback): no bucket group of
+    // more than 64 requests in sight -- the whole sub through the chunk path, nothing through the closed form
+    if (ttr && t == 0) ttr[30] = (uint64_t)(d.w & 0xFFFFu) | (1ull << 17) | ((uint64_t)H.nhot << 20) | ((uint64_t)h << 32);
+    if (kv_rem_chunks<WL>(rep, cut2, kv, d.x, H.all, h, H, stats, force_rounds, V)) return 0;
+    *src = 0; *off = d.y; *cnt = h;
+    return 1;
+  }
+  const uint32_t c = do_piece ? H.nhot : 0u;
   if (t == 0 && c > KVB_T) H.bad = 1;  // more of the key's requests in this range than a workgroup has threads
+  const uint32_t nsib = np > 1 ? np + (nbr ? 1u : 0u) : 1u;
+  const bool voting = do_piece || (nbr && np > 1);  // a remainder beside a bucket the hot key has to itself is nobody's business
   // ---- the bucket's header now (the round trip overlaps the sort), the row behind the sort
   kv_hdr Hd;
   kv_tab tb0;
@@ -2690,7 +3149,7 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
   auto acq_at = [&](int p) -> int { return (int)((H.Ba[p >> 6] >> (p & 63)) & 1ull); };
   const unsigned long long mine_w = kvh_word(seq, !H.bad, wr_tot, lw_tot >= 0 ? (int)H.idx[lw_tot] : -1, ll_tot >= 0 ? acq_at(ll_tot) : -1);
   bool all_ok = !H.bad;
-  if (nsib > 1) {  // tell the siblings, hear from them
+  if (nsib > 1 && voting) {  // tell the siblings, hear from them
     if (t == 0) __hip_atomic_store(&pub[j], mine_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < nsib) {
       unsigned long long w = 0;
@@ -2707,13 +3166,34 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
     __syncthreads();
     if (H.timeout) __builtin_trap();
     for (uint32_t k = 0; k < nsib; k++) all_ok = all_ok && ((H.pub[k] >> 33) & 1ull);
-  } else if (t == 0) {
-    H.pub[0] = mine_w;
+  } else {
+    if (t == 0) H.pub[0] = mine_w;
+    __syncthreads();
   }
-  if (nsib == 1) __syncthreads();
-  if (!all_ok) {  // not in closed form: the whole sub the old way, by the sub's first item
-    if (j != 0) return 0;
-    *src = 0; *off = d.y; *cnt = h;
+  // (DINT_KV_TRACE: kind, piece, pieces | in closed form << 16 | the key's requests here << 20 | the remainder's << 32)
+  if (ttr && t == 0) ttr[30] = (uint64_t)(d.w & 0xFFFFu) | ((uint64_t)(all_ok ? 1u : 0u) << 16) | ((uint64_t)(c & 0xFFFu) << 20) | ((uint64_t)c_rem << 32);
+  if (!all_ok && voting) {
+    // not in closed form: the old way, by the sub's first item.  The hot bucket has neighbours: the whole sub (its remainder
+    // waited for the vote and does nothing).  It has none: the hot key's records only, compacted behind the remainder's in
+    // ovf2 -- the remainder went its own way long ago.
+    if (j != 0 || !do_piece) return 0;
+    if (nbr || solo) { *src = 0; *off = d.y; *cnt = h; return 1; }
+    const uint32_t nsame = H.nsame;
+    __syncthreads();
+    if (t == 0) H.nhot = 0;
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < h; k0 += KVB_T) {
+      const uint32_t k = k0 + t;
+      const uint64_t r = k < h ? ovf[d.y + k] : 0;
+      const bool same = k < h && (r >> sh_g) == (hrec >> sh_g) && pay_kh(kv_rec_pay(r)) == hkh;
+      const uint64_t mm = __ballot(same);
+      uint32_t at = 0;
+      if (lane == 0 && mm) at = atomicAdd(&H.nhot, (uint32_t)__popcll(mm));
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
+      if (same) ovf2[d.y + (h - nsame) + at] = r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    *src = 1; *off = d.y + (h - nsame); *cnt = nsame;
     return 1;
   }
   if (c != 0) {
@@ -2777,7 +3257,9 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
     }
   }
   if (c_rem == 0) return 0;
-  // the remainder (compacted above into ovf2): other buckets, or other rows of the hot bucket -- beside the pieces
+  // ---- the remainder: other buckets, or other rows of the hot bucket -- beside the pieces
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (a solo item: the hot row's write-back above, then its bucket's other rows)
+  if (c_rem <= KVB_T && kv_rem_chunks<WL>(rep, cut2, kv, d.x, H.rem, c_rem, H, stats, force_rounds, V)) return 0;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ... this workgroup's own ovf2 stores before kv_big_bin's loads
   *src = 1; *off = d.y; *cnt = c_rem;
   return 1;
@@ -2787,7 +3269,7 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
 // One workgroup per CU: its 8 waves are 2 per SIMD (the second launch bound is waves per SIMD, not workgroups per CU) at
 // the full 256 VGPRs, and its LDS (static_assert below) leaves no room for a second one.
 static_assert(sizeof(kvb_lds) + KVB_BM_BYTES + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
-static_assert(sizeof(kvb_lds) + KV_HOT_BM_W * 10 + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
+static_assert(sizeof(kvb_lds) + (KV_HOT_BM ? KV_HOT_BM_W * 10 : 16) + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
 template <int WL>
 __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __shared__ kv_dev Skv;
@@ -2817,9 +3299,11 @@ __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
     uint64_t *ttr = first ? tr : nullptr;
     if (ttr && t == 0) { ttr[0] = __builtin_amdgcn_s_memrealtime(); ttr[2] = d.z; ttr[3] = d.x; ttr[30] = d.w; }
     int run = 1;
-    if ((d.w & 3u) != KVQ_SUB)
+    if ((d.w & 3u) == KVQ_SOLO)
+      run = kv_solo_item<WL>(A.rep, cut2, &Skv, d, A.ovf, A.ovf2, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
+    else if ((d.w & 3u) != KVQ_SUB)
       run = kv_hot_item<WL>(A.rep, cut2, &Skv, d, A.bigq[KVQ_W * (size_t)i + 1], A.bigq[KVQ_W * (size_t)i + 2], A.ovf, A.ovf2, A.hotpub, A.seq,
-                            A.inv_n, A.stats, A.V, Lraw, &src, &off, &cnt);
+                            A.inv_n, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
     if (run) {
       // (a remainder lives in ovf2: no second copy of the scratch to regroup it by stretch -- it is small)
       const uint64_t *recs = (src ? (const uint64_t *)A.ovf2 : A.ovf) + off;

@@ -573,7 +573,7 @@ def test_tatp_two_hot_rows_in_one_bucket(same_quadrant):
 
 
 # ---------------------------------------------------------------- a hot key in pieces, several workgroups at once (r05)
-SPLIT_KNOBS = [{"DINT_KV_SPLIT_MIN": "65", "DINT_KV_SPLIT_TARGET": "16"},    # 16 pieces of a few dozen requests
+SPLIT_KNOBS = [{"DINT_KV_SPLIT_MIN": "65", "DINT_KV_SPLIT_TARGET": "16"},    # 16 pieces of a few dozen requests, never a solo item
                {"DINT_KV_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "100"},
                {},                                                          # the defaults: every big sub, ~384 requests per piece
                {"DINT_KV_NO_SPLIT": "1"}]                                   # r04: one workgroup per hot key
@@ -601,7 +601,7 @@ def test_tatp_hot_key_in_pieces(p_hot, mix, hot_key, knobs, monkeypatch):
     eng = _engine(W.TATP, n_rows=n_sub, log_entries=400_000)
     eng.populate(n_sub)
     miss0 = 0
-    for k, n in enumerate((900, 3000, 6000, 9000, 2500, 14_000)):
+    for k, n in enumerate((900, 3000, 500, 6000, 9000, 250, 2500, 14_000, 600)):  # (a few hundred hot requests: a solo item, one workgroup)
         req = _hot_tatp(n, p_hot, mix, seed=17 * k + 5, hot_key=hot_key, existing=existing, n_noise_sub=n_sub)
         got, want = eng.submit(req), o.replay(req)
         assert got.tobytes() == want.tobytes(), (k, np.nonzero(np.frombuffer(got.tobytes(), "u1") != np.frombuffer(want.tobytes(), "u1"))[0][:5] // 55)

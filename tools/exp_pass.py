@@ -53,6 +53,8 @@ if os.environ.get("DINT_KV_TRACE"):
         top = np.argsort(-du)[:8]
         out["big_subs"] = {"n": int(len(big)), "us_mean": round(float(du.mean()), 1), "us_max": round(float(du.max()), 1),
                            "longest": [[int(big[i, 2]), round(float(du[i]), 1), int(big[i, 30]) & 3] for i in top]}
+        out["big_subs"]["slowest_items"] = [{"sub": int(big[i, 2]), "us": round(float(du[i]), 1), "kind": int(big[i, 30]) & 3, "closed_form": int(big[i, 30] >> 16) & 1, "chunks_only": int(big[i, 30] >> 17) & 1, "structural": int(big[i, 30] >> 18) & 1, "phased": int(big[i, 30] >> 19) & 1,
+                                             "hot": int(big[i, 30] >> 20) & 0xFFF, "rem": int(big[i, 30] >> 32) & 0xFFFFFF, "why_not": int(big[i, 30] >> 56) & 31} for i in np.argsort(-du)[:16]]
         # the first work item of every workgroup by kind (0 whole sub, 1 piece of a hot key, 2 remainder, 3 solo) and sub size
         kind = big[:, 30] & 3
         out["big_subs"]["by_kind_n_mean_max_us"] = {int(k): [int((kind == k).sum()), round(float(du[kind == k].mean()), 1), round(float(du[kind == k].max()), 1)]
