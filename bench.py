@@ -738,11 +738,11 @@ def bench_store(args, world, rank, dev, transport):
         # for tatp / smallbank; the 53 request bytes of every request are k_kv_part's, which reads them (bench_txn)
         part_b, alg = NB * float(msg), alg_all - NB * float(msg)
         t_part = tim.get("k_kv_part", {"avg_us": 0.0})["avg_us"]
-        us = tim["k_kv_resolve"]["avg_us"] + tim.get("k_kv_big", {"avg_us": 0.0})["avg_us"]
+        us = tim["k_kv_resolve"]["avg_us"] + tim.get("k_kv_hot", {"avg_us": 0.0})["avg_us"] + tim.get("k_kv_big", {"avg_us": 0.0})["avg_us"]
         ach = alg / (us * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_kv_resolve+k_kv_big", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": "k_kv_resolve+k_kv_hot+k_kv_big", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(alg),
-                "kernel_avg_us": round(us, 3), "from_profile": profile_counters("store", ["k_kv_resolve", "k_kv_big"])}
+                "kernel_avg_us": round(us, 3), "from_profile": profile_counters("store", ["k_kv_resolve", "k_kv_hot", "k_kv_big"])}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
@@ -1044,6 +1044,16 @@ def bench_txn(args, world, rank, dev, transport, kind):
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
+    # The recording above is host-bound (seconds of a mostly idle GPU): the first GPU-bound stretch after it runs at idle clocks
+    # for tens of milliseconds (r05: the W warm-up steps alone -- 7 ms -- left the timed region 3x slower than its repeats).
+    # Untimed spin-up first: the warm-up epochs replayed until the GPU has been busy for ~0.3 s; then the state of the
+    # recording's start again, the W warm-up steps, the K timed steps.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.3:
+        rp.run(grp, 0, max(1, E0))
+        grp.sync()
+        grp.restore()
+    grp.sync()
     rp.run(grp, 0, E0)
     grp.sync()
     barrier(world)
@@ -1128,25 +1138,26 @@ def bench_txn(args, world, rank, dev, transport, kind):
         part_b = msgb * n_all + sum((b - msgb) * int(hist[c]) for c, b in alg_tab.items() if c in log_types)
         f_big = big_req / max(1, n_tab)
         L = max(1, launches)
-        t_part, t_res, t_big = avg.get("k_kv_part", 0.0), avg.get("k_kv_resolve", 0.0), avg.get("k_kv_big", 0.0)
+        t_part, t_res = avg.get("k_kv_part", 0.0), avg.get("k_kv_resolve", 0.0)
+        t_big = avg.get("k_kv_hot", 0.0) + avg.get("k_kv_big", 0.0)  # the hot keys: closed forms (k_kv_hot), then what they do not cover
 
         def priced(name, us, nbytes):
             ach = nbytes / L / max(us, 1e-9) / 1e3  # bytes per launch / us -> GB/s
             return {"kernel": name, "kernel_avg_us": round(us, 3), "alg_bytes_per_launch": int(nbytes / L),
                     "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
 
-        stage = priced("k_kv_resolve+k_kv_big", t_res + t_big, tab_b)
+        stage = priced("k_kv_resolve+k_kv_hot+k_kv_big", t_res + t_big, tab_b)
         # `traffic` is not measured inside this run (rocprofv3 cannot attach to itself): null here; the PMC figures of
         # the same command live in profiles/ and are quoted under from_profile only for the same kernel sources
         roof = {"bound": "hbm", **stage, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "requests_in_big_bins": round(f_big, 4),
-                "from_profile": profile_counters(kind, ["k_kv_resolve", "k_kv_big"])}
+                "from_profile": profile_counters(kind, ["k_kv_resolve", "k_kv_hot", "k_kv_big"])}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, tab_b / L), 3)
         roof["kernels"] = [priced("k_kv_part", t_part, part_b), priced("k_kv_resolve", t_res, tab_b * (1.0 - f_big)),
-                           priced("k_kv_big", t_big, tab_b * f_big)]
+                           priced("k_kv_hot+k_kv_big", t_big, tab_b * f_big)]
         # the whole pass of one engine: all its algorithmic bytes over the serial chain of its three kernels (events on the
         # engine's stream, launch gaps included) -- what bounds a step, which is one engine's chain
         chain = t_part + t_res + t_big

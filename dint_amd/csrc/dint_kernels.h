@@ -37,6 +37,7 @@ struct dint_scratch {
   uint64_t kbins_slots = 0;        // records `kbins` holds: C * cap never exceeds it
   uint4 *bigq = nullptr;           // [DINT_KV_BIGQ_MAX][3] the pass's big subs and hot-key pieces (work items of k_kv_big)
   unsigned long long *hotpub = nullptr;  // [DINT_KV_BIGQ_MAX] what the pieces of a hot key tell each other (tagged with pass_seq)
+  uint4 *lateq = nullptr;          // [DINT_KV_BIGQ_MAX] what k_kv_hot leaves to k_kv_big {bin, offset, records, 0: in ovf / 1: in ovf2}
   uint32_t pass_seq = 0;           // host side: passes launched so far (never 0 in a launch)
   uint64_t *lock_trace = nullptr;  // DINT_KV_TRACE=1 on a lock engine: per big-bin workgroup 16 s_memrealtime stamps
                                    // of its first bin, at word DINT_KV_PMAX * 16 + 16 * workgroup (dint_kv_trace_read)

@@ -212,7 +212,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
   if (int rc = order_stream(e, st)) return rc;
   static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_append"};
-  static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve", "k_kv_big"};
+  static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve", "k_kv_hot", "k_kv_big"};
   switch (e->cfg.workload) {
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
@@ -235,7 +235,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
       if (int rc = next_pass_seq(e, st)) return rc;  // tags what the pieces of a hot key publish in this pass
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 3, kv_names), view);
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names), view);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       break;
@@ -343,6 +343,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
       TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
       TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_BIGQ_MAX * 3 * sizeof(uint4), false));  // KVQ_W uint4 per work item (k_kv.hip)
       TRY(dev_alloc((void **)&e->scratch.hotpub, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long)));
+      TRY(dev_alloc((void **)&e->scratch.lateq, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint4), false));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
     }
@@ -413,6 +414,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.kbins);
   hipFree(e->scratch.bigq);
   hipFree(e->scratch.hotpub);
+  hipFree(e->scratch.lateq);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
   hipFree(std::min(e->scratch.blk_pub, e->scratch.blk_pub_next));

@@ -195,6 +195,7 @@ struct kv_pass_args {
   uint64_t *ovf2;        // ... and the same ranges again: a sub of several stretches is regrouped by stretch once
   uint4 *bigq;           // the pass's work items for k_kv_big, two uint4 each (kvq_*): big subs and hot-key pieces; big[3] = how many
   unsigned long long *hotpub;  // [item] what the pieces of one hot key tell each other (kvh_word), tagged with `seq`
+  uint4 *lateq;          // what k_kv_hot leaves to k_kv_big: {bin, offset, records, 0 = in ovf / 1 = in ovf2}; big[5] = how many
   uint32_t split_min;    // a big sub of at least this many records whose requests are nearly all ONE key is cut into pieces
   uint32_t split_target; // ... of about this many requests each (<= KVB_T: one per thread of the workgroup that answers it)
   uint32_t inv_n;        // floor(2^32 / n): the piece of a request index (kv_piece_of)
@@ -3270,11 +3271,15 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
 // the full 256 VGPRs, and its LDS (static_assert below) leaves no room for a second one.
 static_assert(sizeof(kvb_lds) + KVB_BM_BYTES + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
 static_assert(sizeof(kvb_lds) + (KV_HOT_BM ? KV_HOT_BM_W * 10 : 16) + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
+// ---- k_kv_hot: the work items of a store / tatp pass that are hot keys in closed form -- pieces, remainders, solo subs.  A
+// kernel of its own (r05) because it is LIGHT: the LDS of a k_kv_resolve workgroup and half the registers of k_kv_big, whose
+// kv_big_bin (256 VGPRs, ~155 KB of LDS) needs an EMPTY compute unit -- with three shard servers side by side on the GPU
+// its workgroups waited for the other servers' resolve workgroups to drain (k_kv_big: 36 us alone, 47 us in company, for
+// items of 13 .. 25 us).  What the closed forms and the group phases do not cover is left to k_kv_big in `lateq`.
 template <int WL>
-__global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_hot(kv_multi_args M) {
   __shared__ kv_dev Skv;
-  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
-  __shared__ __attribute__((aligned(16))) uint8_t Lbm[WL == DINT_WL_SMALLBANK ? KVB_BM_BYTES : KV_HOT_BM ? KV_HOT_BM_W * 10 : 16];  // (one workgroup per CU either way: 8 waves of 256 VGPRs)
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvh_lds)];
   __shared__ uint32_t Stk;
   const kv_pass_args &A = M.e[blockIdx.y];
   const uint32_t nq = A.big[3];
@@ -3284,6 +3289,50 @@ __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M) {
   __syncthreads();
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
+  uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 32 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;
+  for (bool first = true;; first = false) {  // work items by ticket, in list order (kv_hot_item)
+    __syncthreads();
+    if (t == 0) Stk = atomicAdd(&A.big[4], 1u);
+    __syncthreads();
+    const uint32_t i = Stk;
+    if (i >= nq) break;
+    const uint4 d = A.bigq[KVQ_W * (size_t)i];
+    uint32_t src = 0, off = d.y, cnt = d.z;
+    uint64_t *ttr = first ? tr : nullptr;
+    if (ttr && t == 0) { ttr[0] = __builtin_amdgcn_s_memrealtime(); ttr[2] = d.z; ttr[3] = d.x; ttr[30] = d.w; }
+    int run = 1;
+    if ((d.w & 3u) == KVQ_SOLO)
+      run = kv_solo_item<WL>(A.rep, cut2, &Skv, d, A.ovf, A.ovf2, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
+    else if ((d.w & 3u) != KVQ_SUB)
+      run = kv_hot_item<WL>(A.rep, cut2, &Skv, d, A.bigq[KVQ_W * (size_t)i + 1], A.bigq[KVQ_W * (size_t)i + 2], A.ovf, A.ovf2, A.hotpub, A.seq,
+                            A.inv_n, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
+    if (run && t == 0) A.lateq[atomicAdd(&A.big[5], 1u)] = make_uint4(d.x, off, cnt, src);  // kv_big_bin's: k_kv_big, behind this kernel
+    if (ttr && t == 0) ttr[1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M, uint32_t from_late) {
+  __shared__ kv_dev Skv;
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
+  __shared__ __attribute__((aligned(16))) uint8_t Lbm[WL == DINT_WL_SMALLBANK ? KVB_BM_BYTES : KV_HOT_BM ? KV_HOT_BM_W * 10 : 16];  // (one workgroup per CU either way: 8 waves of 256 VGPRs)
+  __shared__ uint32_t Stk;
+  const kv_pass_args &A = M.e[blockIdx.y];
+  const uint32_t nq = from_late ? A.big[5] : A.big[3];
+  if (blockIdx.x >= nq) return;
+  const uint32_t t = threadIdx.x;
+  if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = ((const uint32_t *)A.kv)[t];
+  __syncthreads();
+  kv_cut cut2 = A.cut;
+  cut2.P = A.cut.P * KVR_F;
+  if (from_late) {  // behind k_kv_hot: what it left (usually nothing)
+    for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) {
+      const uint4 d = A.lateq[i];
+      const uint64_t *recs = (d.w ? (const uint64_t *)A.ovf2 : A.ovf) + d.y;
+      kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, recs, d.w || !A.ovf2 ? nullptr : A.ovf2 + d.y, d.z, A.stats, A.force_flags, A.V, Lraw, Lbm, nullptr);
+    }
+    return;
+  }
   // DINT_KV_TRACE: 32 words per workgroup -- {in, out, records, sub} of the first sub it takes, then kv_big_bin's stamps
   uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 32 * (size_t)(blockIdx.y * KVB_GRID + blockIdx.x) : nullptr;
   // work items by ticket, in list order: the pieces of a hot key sit side by side in the list, so a piece that waits for its
@@ -3345,6 +3394,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.ovf2 = s.ovf2; A.stats = s.stats;
   A.bigq = s.bigq;
   A.hotpub = s.hotpub;
+  A.lateq = s.lateq;
   A.seq = s.pass_seq ? s.pass_seq : 1u;
   A.inv_n = n > 1 ? (uint32_t)((1ull << 32) / n) : 0xFFFFFFFFu;
   A.load_mode = load_mode;
@@ -3375,9 +3425,15 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   if (ev) hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
   if (ev) hipEventRecord(ev[2], st);
-  // (DINT_EXP_SKIP_BIG=1, tools/exp_chain.py only: the chain without its last kernel -- the hot keys stay unanswered)
-  if (!kv_env("DINT_EXP_SKIP_BIG", 0)) hipLaunchKernelGGL((k_kv_big<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
+  // the hot keys.  store / tatp: k_kv_hot (closed forms), then k_kv_big for what it left -- usually nothing: a small grid;
+  // smallbank (counters: no closed form across workgroups yet) and DINT_KV_NO_SPLIT / DINT_KV_ONE_BIG_KERNEL: k_kv_big alone
+  // (DINT_EXP_SKIP_BIG=1, tools/exp_chain.py only: the chain without these kernels -- the hot keys stay unanswered)
+  const bool skip = kv_env("DINT_EXP_SKIP_BIG", 0) != 0;
+  const bool hot = M.e[0].split_min != 0xFFFFFFFFu && !kv_env("DINT_KV_ONE_BIG_KERNEL", 0);
+  if (hot && !skip) hipLaunchKernelGGL((k_kv_hot<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
   if (ev) hipEventRecord(ev[3], st);
+  if (!skip) hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? 64u : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
+  if (ev) hipEventRecord(ev[4], st);
 }
 
 // requests per thread of k_kv_part: longer tiles = fewer, longer runs per (tile, coarse bin), but a pass must still
