@@ -501,8 +501,39 @@ def bench_lock(args, world, rank, dev, transport, kind):
             roof["traffic"] = fp["traffic_bytes"]
 
     value = world * K * B * BATCH / dt / 1e6
+    # ---- the same stream in passes of 2^20 requests: what the lock kernels do per request when a pass fills the GPU.  A 64k-
+    # request pass is 64 + 768 workgroups and three dependent launches: launch-bound (BASELINE's batch size; VERDICT r04 item
+    # 5).  The replies must equal those of the 64k batches -- the serial order does not depend on where a pass ends.
+    big_pass = None
+    if rt is None and (n_batches * BATCH) >> 20 >= 3:
+        big, nb_big = 1 << 20, (n_batches * BATCH) >> 20
+        d_rep2 = torch.empty_like(d_rep)
+        eng.restore()
+
+        def run_big(lo, hi):
+            for b in range(lo, hi):
+                o = b * big * msg
+                eng.submit_device(d_req.data_ptr() + o, big, d_rep2.data_ptr() + o, 0)
+
+        run_big(0, 1)
+        sync()
+        t1 = time.perf_counter()
+        run_big(1, nb_big)
+        sync()
+        dtb = time.perf_counter() - t1
+        same = d_rep2[:nb_big * big * msg].cpu().numpy().tobytes() == got[:nb_big * big * msg]  # (`got`: the timed run's replies, from the empty table)
+        eng.restore()
+        eng.timing_enable(True)
+        run_big(0, nb_big)
+        sync()
+        timb = eng.timing_read()
+        eng.timing_enable(False)
+        big_pass = {"requests_per_pass": big, "value": round((nb_big - 1) * big / dtb / 1e6, 3), "unit": "Mtxn/s",
+                    "kernels_us": {k: round(v["avg_us"], 3) for k, v in timb.items()}, "replies_equal_64k_batches": same}
+        del d_rep2
     if rank != 0:
         return None
+    extra["pass_1m"] = big_pass
     if not args.no_rand64 and rt is None:
         rand_roofline(extra, value * 1e6, dev, 1.0, "one 8-byte slot {lock, ver} / {num_ex, num_sh} of the table per request",
                       args.slots * 8 / 2**30)
@@ -1399,7 +1430,8 @@ def parity_failures(out, path=""):
             p = f"{path}.{k}" if path else k
             if k in ("oracle_parity", "reference_parity") and isinstance(v, dict) and v.get("ok") is False:
                 bad.append(p)
-            elif k in ("pcie_parity_ok", "replay_equals_recorded", "equals_host_driver_run", "equals_host_run_of_two_drivers") and v is False:
+            elif k in ("pcie_parity_ok", "replay_equals_recorded", "equals_host_driver_run", "equals_host_run_of_two_drivers",
+                       "replies_equal_64k_batches") and v is False:
                 bad.append(p)
             elif k == "error" and path.startswith("other_workloads"):
                 bad.append(p)
