@@ -971,7 +971,9 @@ __device__ static inline void kv_chunk(uint8_t *rep, bool valid, uint32_t idx, u
 constexpr uint32_t KVB_BM_W = 4096, KVB_BM_OT = 1024, KVB_BM_MIN = 1024;
 constexpr uint32_t KVB_BM_BYTES = KVB_BM_W * 8 + KVB_BM_W * 2 + KVB_NMAX * 8;
 
-constexpr bool KV_HOT_BM = true;           // dominant-key path: order the key's writers + lock ops by an index bitmap (else: LDS sort + binary search)
+constexpr bool KV_HOT_BM = false;          // dominant-key path of kv_big_bin: order the key's writers + lock ops by an index bitmap (else: LDS sort + binary
+                                           // search).  r05: off -- store / tatp answer their hot keys in k_kv_hot and kv_big_bin only takes what that
+                                           // leaves (usually nothing), and the bitmap is 80 KB of LDS.  smallbank does not use the path.
 constexpr uint32_t KV_HOT_BM_W = 8192;     // ... bitmap words: request-index spans of up to 512k
 constexpr uint32_t KV_MMAX = 2048;  // dominant-key path: writers + lock ops of the key it puts in order (a tatp subscriber of 4,000 requests: ~1,100)
 
@@ -3311,6 +3313,10 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_hot(kv_multi_args M) {
   }
 }
 
+// (r05 tried 128 VGPRs for store / tatp, where the kernel is usually empty, so that a launch need not wait for empty compute
+// units: kv_big_bin then spills 640 bytes per lane, and a dispatch with that much scratch stalls its queue while the runtime
+// resizes it -- k_kv_hot + k_kv_big went from 40 to 62 us.  A SMALL GRID instead: behind k_kv_hot only 4 workgroups per engine
+// have to find an empty compute unit.)
 template <int WL>
 __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M, uint32_t from_late) {
   __shared__ kv_dev Skv;
@@ -3432,7 +3438,7 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   const bool hot = M.e[0].split_min != 0xFFFFFFFFu && !kv_env("DINT_KV_ONE_BIG_KERNEL", 0);
   if (hot && !skip) hipLaunchKernelGGL((k_kv_hot<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
   if (ev) hipEventRecord(ev[3], st);
-  if (!skip) hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? 64u : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
+  if (!skip) hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? 4u : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
   if (ev) hipEventRecord(ev[4], st);
 }
 
