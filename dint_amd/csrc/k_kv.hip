@@ -3315,7 +3315,7 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_hot(kv_multi_args M) {
 
 // (r05 tried 128 VGPRs for store / tatp, where the kernel is usually empty, so that a launch need not wait for empty compute
 // units: kv_big_bin then spills 640 bytes per lane, and a dispatch with that much scratch stalls its queue while the runtime
-// resizes it -- k_kv_hot + k_kv_big went from 40 to 62 us.  A SMALL GRID instead: behind k_kv_hot only 4 workgroups per engine
+// resizes it -- k_kv_hot + k_kv_big went from 40 to 62 us.  A SMALL GRID instead: behind k_kv_hot only 8 workgroups per engine
 // have to find an empty compute unit.)
 template <int WL>
 __global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M, uint32_t from_late) {
@@ -3438,7 +3438,7 @@ static void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hip
   const bool hot = M.e[0].split_min != 0xFFFFFFFFu && !kv_env("DINT_KV_ONE_BIG_KERNEL", 0);
   if (hot && !skip) hipLaunchKernelGGL((k_kv_hot<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
   if (ev) hipEventRecord(ev[3], st);
-  if (!skip) hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? 4u : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
+  if (!skip) hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? 8u : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
   if (ev) hipEventRecord(ev[4], st);
 }
 

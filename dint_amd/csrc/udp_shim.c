@@ -285,7 +285,7 @@ static void *socket_thread(void *arg) {
 
 /* ---- --caladan: the control port (lock_fasst/caladan/server.cc:93-132) ------------------------------------------- */
 struct control_arg { const struct options *o; struct worker *ws; };
-struct dsock { int fd, efd; };
+struct dsock { int fd, efd; uint64_t seen; /* g_fd_seen when it was retired */ };
 static void dsock_close(struct dsock *d) {
   epoll_ctl(d->efd, EPOLL_CTL_DEL, d->fd, NULL);
   close(d->fd);
@@ -308,26 +308,51 @@ static void *control_thread(void *p) {
   setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
   const uint64_t max_live = g_fd_cap > 64 + 8 * (uint64_t)o->threads ? g_fd_cap - 64 - 8 * (uint64_t)o->threads : 0;
   struct dsock *live = (struct dsock *)calloc(max_live ? max_live : 1, sizeof *live);
-  uint64_t n_live = 0, last_reap = now_us(), refused = 0;
+  /* idle sockets are retired in two steps: a socket thread may sit between its
+   * epoll_wait() and its recvmmsg() on the descriptor, or hold it in a batch whose replies have not left yet -- closing it
+   * there would hand the NUMBER to the next handshake's socket and send replies from the wrong port.  Step one takes the
+   * descriptor out of its epoll set (nothing new is picked up from it); step two, a quarter of a second later (a socket
+   * thread's loop takes milliseconds), closes it -- unless a datagram was taken from it in between (it arrived at the
+   * deadline): then it goes back into service. */
+  struct dsock *dying = (struct dsock *)calloc(max_live ? max_live : 1, sizeof *dying);
+  uint64_t n_live = 0, n_dying = 0, last_reap = now_us(), t_retired = 0, refused = 0;
   uint32_t next = 0;
-  if (!live) { fprintf(stderr, "out of memory\n"); g_stop = 1; close(fd); return NULL; }
+  if (!live || !dying) { fprintf(stderr, "out of memory\n"); g_stop = 1; close(fd); return NULL; }
   while (!g_stop) {
     const uint64_t t = now_us();
-    if (o->idle_s && t - last_reap >= 1000000ull) {  /* once a second: close what has been idle for --idle-s */
+    if (n_dying && t - t_retired >= 250000ull) {
+      for (uint64_t k = 0; k < n_dying; k++) {  /* step two */
+        if (g_fd_seen[dying[k].fd] != dying[k].seen) {  /* used after all: back into its thread's epoll set */
+          struct epoll_event ev;
+          memset(&ev, 0, sizeof ev);
+          ev.events = EPOLLIN;
+          ev.data.fd = dying[k].fd;
+          if (epoll_ctl(dying[k].efd, EPOLL_CTL_ADD, dying[k].fd, &ev) == 0) { live[n_live++] = dying[k]; continue; }
+        }
+        close(dying[k].fd);
+      }
+      n_dying = 0;
+    }
+    if (o->idle_s && !n_dying && t - last_reap >= 1000000ull) {  /* once a second: retire what has been idle for --idle-s */
       uint64_t keep = 0;
       for (uint64_t k = 0; k < n_live; k++) {
-        if (t - g_fd_seen[live[k].fd] >= (uint64_t)o->idle_s * 1000000ull) dsock_close(&live[k]);
-        else live[keep++] = live[k];
+        if (t - g_fd_seen[live[k].fd] >= (uint64_t)o->idle_s * 1000000ull) {  /* step one */
+          epoll_ctl(live[k].efd, EPOLL_CTL_DEL, live[k].fd, NULL);
+          live[k].seen = g_fd_seen[live[k].fd];
+          dying[n_dying++] = live[k];
+        } else {
+          live[keep++] = live[k];
+        }
       }
       n_live = keep;
-      last_reap = t;
+      last_reap = t_retired = t;
     }
     int32_t nports = 0;  /* net_req {int nports}, proto.h:38-40 */
     struct sockaddr_in cli;
     socklen_t len = sizeof cli;
     if (recvfrom(fd, &nports, sizeof nports, 0, (struct sockaddr *)&cli, &len) != (ssize_t)sizeof nports) continue;
     if (nports <= 0 || nports > 730) continue;  /* the answer must fit one datagram (server.cc:121-123: rt::UdpConn::kMaxPayloadSize) */
-    if (n_live + (uint64_t)nports > max_live) {
+    if (n_live + n_dying + (uint64_t)nports > max_live) {
       if (refused++ % 64 == 0)
         fprintf(stderr, "handshake refused: %d ports asked, %llu of %llu data sockets live (raise `ulimit -n` or lower --idle-s)\n",
                 nports, (unsigned long long)n_live, (unsigned long long)max_live);
@@ -371,6 +396,8 @@ static void *control_thread(void *p) {
     }
   }
   for (uint64_t k = 0; k < n_live; k++) dsock_close(&live[k]);
+  for (uint64_t k = 0; k < n_dying; k++) close(dying[k].fd);
+  free(dying);
   free(live);
   close(fd);
   return NULL;

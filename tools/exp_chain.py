@@ -77,4 +77,16 @@ out["skip_big"] = {"us_per_epoch": timed(), "kernels_us": kernels()}
 out["skip_big"]["Mtxn_s_if_hidden"] = round(txn / out["skip_big"]["us_per_epoch"], 1)
 out["skip_big_one_engine"] = {"us_per_pass": timed((0,))}
 del os.environ["DINT_EXP_SKIP_BIG"]
+# knobs read at every launch: a sweep costs nothing but the timed replays
+if os.environ.get("EXP_SWEEP"):
+    sw = {}
+    for name, vals in (("DINT_KV_COARSE_LOAD", ("384", "448", "512", "640", "768")), ("DINT_KV_RPT", ("1", "2")),
+                       ("DINT_KV_SPLIT_TARGET", ("192", "256", "384", "448")), ("DINT_KV_SPLIT_MIN", ("65", "96", "128", "256"))):
+        for v in vals:
+            os.environ[name] = v
+            try:
+                sw[f"{name}={v}"] = timed(reps=2)
+            finally:
+                del os.environ[name]
+    out["sweep_us_per_epoch"] = sw
 print(json.dumps(out))
