@@ -2328,7 +2328,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
 // path's stretch machinery (kvb_lds); the two never live at the same time and share one buffer.
 #define KVR_LCAP 1024u   // records of a coarse bin's small subs that fit the LDS split (the average bin holds ~512)
 #define KVR_F 64u        // subs per coarse bin = lanes of the wave that lays them out
-#define KVR_NPMAX 16u     // pieces of one hot key at most
+#define KVR_NPMAX 32u     // pieces of one hot key at most (a key of up to ~12,000 requests per pass; beyond: kv_big_bin)
 struct kvr_lds {
   uint4 rec[KVR_LCAP];         // records of the small subs, sub after sub
   uint32_t hist[KVR_F];        // records per sub
@@ -2348,7 +2348,7 @@ __device__ static inline uint32_t kv_piece_of(uint32_t idx, uint32_t np, uint32_
   return p < np ? p : np - 1;
 }
 // work items of k_kv_big (bigq): KVQ_W uint4 each
-//   [0] = {bin = coarse bin + C * sub, offset of the sub in ovf, records of the sub, kind | piece << 2 | pieces << 7}
+//   [0] = {bin = coarse bin + C * sub, offset of the sub in ovf, records of the sub, kind | piece << 2 | pieces << 8}
 //   [1] = kind 0: unused.  Else {hot key lo, hi, item index of the sub's first item, -}
 //   [2] = kind 0: unused.  Else {one record of the hot key (big path's form) lo, hi, -, -}
 #define KVQ_W 3u
@@ -2527,7 +2527,7 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
     // other keys), side by side -- or, when one piece is enough, as one SOLO item (kv_hot_item); every item names the whole sub.
     const uint2 bs = Sbig[t];
     const kvr_lds &L = *(const kvr_lds *)Lraw;
-    const bool hot = bs.y >= A.split_min;
+    const bool hot = bs.y >= A.split_min && bs.y <= KVR_NPMAX * (KVB_T - 64u);  // (more than the pieces can hold: kv_big_bin's, via k_kv_hot's late list)
     const uint32_t np = hot ? min(KVR_NPMAX, (bs.y + A.split_target - 1) / A.split_target) : 0u;
     const uint32_t nent = bs.y ? (np > 1 ? np + 1 : 1u) : 0u;
     uint32_t tot, at = wave_excl_scan_u32(nent, &tot);
@@ -2543,7 +2543,7 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
       for (uint32_t p = 0; p < nent; p++) {
         const uint32_t kind = np == 1 ? KVQ_SOLO : (p < np ? KVQ_PIECE : KVQ_REM);
         uint4 *q = A.bigq + KVQ_W * (size_t)(at + p);
-        q[0] = make_uint4(bin, bs.x, bs.y, kind | (p << 2) | (np << 7));
+        q[0] = make_uint4(bin, bs.x, bs.y, kind | (p << 2) | (np << 8));
         q[1] = make_uint4((uint32_t)hk, (uint32_t)(hk >> 32), at, 0u);
         q[2] = make_uint4((uint32_t)hr, (uint32_t)(hr >> 32), 0u, 0u);
       }
@@ -3035,7 +3035,7 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
   using F = Fmt<WL>;
   kvh_lds &H = *(kvh_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 31u, np = (d.w >> 7) & 31u;
+  const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 63u, np = (d.w >> 8) & 63u;
   const uint32_t first = x.z, h = d.z;
   const uint32_t sh_g = 16 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
   const uint64_t hkey = ((uint64_t)x.y << 32) | x.x, hrec = ((uint64_t)y.y << 32) | y.x;

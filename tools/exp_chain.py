@@ -77,6 +77,12 @@ out["skip_big"] = {"us_per_epoch": timed(), "kernels_us": kernels()}
 out["skip_big"]["Mtxn_s_if_hidden"] = round(txn / out["skip_big"]["us_per_epoch"], 1)
 out["skip_big_one_engine"] = {"us_per_pass": timed((0,))}
 del os.environ["DINT_EXP_SKIP_BIG"]
+# same box, same process: r04's hot-key path (kv_big_bin for every big sub, one workgroup per hot key, one kernel)
+os.environ["DINT_KV_NO_SPLIT"] = "1"
+out["r04_hot_path"] = {"us_per_epoch": timed(), "kernels_us": kernels()}
+out["r04_hot_path"]["Mtxn_s"] = round(txn / out["r04_hot_path"]["us_per_epoch"], 1)
+out["r04_hot_path_one_engine"] = {"us_per_pass": timed((0,)), "kernels_us": kernels((0,))}
+del os.environ["DINT_KV_NO_SPLIT"]
 # knobs read at every launch: a sweep costs nothing but the timed replays
 if os.environ.get("EXP_SWEEP"):
     sw = {}
