@@ -87,8 +87,10 @@ def parse():
     args = ap.parse_args()
     if args.legs in ("gpu", "headline"):
         args.no_cpu_baseline = args.no_cpu_reference = args.no_shim = args.no_as_shipped = True
+    args.no_pass_1m = False
     if args.legs == "headline":
         args.no_closed_loop = args.no_rand64 = args.no_host_path = args.no_other_workloads = args.no_mixes = args.no_exchange_leg = True
+        args.no_pass_1m = True  # (lock tables: the 2^20-request passes would fall into the profile's "last N dispatches")
     return args
 
 
@@ -505,7 +507,7 @@ def bench_lock(args, world, rank, dev, transport, kind):
     # request pass is 64 + 768 workgroups and three dependent launches: launch-bound (BASELINE's batch size; VERDICT r04 item
     # 5).  The replies must equal those of the 64k batches -- the serial order does not depend on where a pass ends.
     big_pass = None
-    if rt is None and (n_batches * BATCH) >> 20 >= 3:
+    if rt is None and (n_batches * BATCH) >> 20 >= 3 and not getattr(args, "no_pass_1m", False):
         big, nb_big = 1 << 20, (n_batches * BATCH) >> 20
         d_rep2 = torch.empty_like(d_rep)
         eng.restore()
