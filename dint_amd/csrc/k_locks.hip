@@ -44,6 +44,11 @@ __device__ static inline uint64_t lk_rec(uint32_t slot, uint32_t idx, uint32_t o
 __device__ static inline uint32_t lk_slot(uint64_t r) { return (uint32_t)(r >> 23); }
 __device__ static inline uint32_t lk_idx(uint64_t r) { return (uint32_t)(r >> 3) & 0xFFFFFu; }
 __device__ static inline uint32_t lk_op(uint64_t r) { return (uint32_t)r & 7u; }
+// lane `src`'s 64-bit value on every lane (src wave-uniform)
+__device__ static inline uint64_t lk_readlane_u64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
 
 // ------------------------------------------------------------------------------------------
 template <int WL>  // 0 = lock_fasst, 1 = lock_2pl
@@ -346,7 +351,6 @@ lk_small_bin(uint8_t *rep, uint32_t pbits, uint2 *__restrict__ table, uint32_t *
 }
 
 #define TPL_HOT_NMAX 65536u   // lock_2pl dominant-slot path: passes of at most this many requests (an 8 KB index bitmap)
-#define TPL_HOT_WIN 8192u     // ... ranks walked per window (the ordered list lives where the stretch would)
 
 // ---- big bins: one 512-thread workgroup each ---------------------------------------------------------------------
 template <class Ops>
@@ -374,10 +378,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
   __shared__ uint32_t Hs[16];                  // dominant-slot path: counters
   __shared__ uint64_t Mk[KVB_MMAX];            // ... its lock-writing ops, idx << 12 | position, ascending
   __shared__ uint16_t Mcc[KVB_MMAX + 8];       // ... COMMITs among the first j of them
-  __shared__ uint16_t Pw[TPL_HOT_NMAX / 32 + 1];  // dominant slot: bits set in the index words below w
-  __shared__ uint64_t Gm[TPL_HOT_WIN / 64];    // lock_2pl dominant slot: grant mask per group of 64 requests
-  __shared__ uint32_t Gsum[TPL_HOT_WIN / 64];  // ... {shared ACQUIREs : 8 | shared RELEASEs : 8 | has exclusive ACQUIRE | RELEASE}
-  __shared__ uint8_t Gk[TPL_HOT_WIN / 64];     // ... 0 walked, 1 inert while HELD, 2 inert while FREE
+  __shared__ uint16_t Pw[TPL_HOT_NMAX / 32 + 1];  // dominant slot (lock_fasst): COMMITs in the index words below w
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // request-index buckets that cut a bin of more than KVB_NMAX records into stretches (every request of a stretch
   // precedes every request of the next one)
@@ -394,8 +395,9 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
     // ---- the bin's DOMINANT SLOT in a pass of <= 65,536 requests (a lid that hundreds of closed-loop workers keep
     // retrying: most of a big bin is one slot, up to a sixth of a 64k batch) is resolved WITHOUT a sort: every request
     // owns one bit of an index bitmap, so "in request order" is "in bit order".
-    //   lock_2pl  : rank = bits below mine (a prefix count per word) puts the slot's requests in order; one wave walks
-    //               them 64 at a time (TplOps::walk64: once per mode change of the counters, not once per request).
+    //   lock_2pl  : four bitmaps -- ACQUIREs and RELEASEs, shared and exclusive; the requests of one 64-bit word are a group,
+    //               and one wave goes through the groups 64 at a time (below; TplOps::walk64_mask for the few that change
+    //               the counters' mode: once per mode change, not once per request).
     //   lock_fasst: three bitmaps -- lock-writing ops, ACQUIREs, COMMITs -- answer every request in O(1): lock seen =
     //               was the last lock-writing op below me an ACQUIRE, version seen = ver0 + COMMITs below me; no limit
     //               on the number of ordering ops (the stretch-level path below sorts at most 1024 of them).
@@ -415,8 +417,8 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
       }                                                                           \
     }
     if (c >= hot_min && n <= TPL_HOT_NMAX) {
-      uint32_t *Bm = (uint32_t *)Mk;              // [n / 32] lock_2pl: the slot's requests; lock_fasst: its lock-writing ops
-      uint32_t *R = (uint32_t *)Sk;               // lock_2pl: [TPL_HOT_WIN] idx << 3 | op, by rank
+      uint32_t *Bm = (uint32_t *)Mk;              // [n / 32] lock_2pl: the slot's shared ACQUIREs, then the grants; lock_fasst: its lock-writing ops
+      uint32_t *Bax = (uint32_t *)Sk, *Brs = Bax + TPL_HOT_NMAX / 32, *Brx = Brs + TPL_HOT_NMAX / 32;  // lock_2pl: exclusive ACQUIREs, RELEASEs shared / exclusive
       uint32_t *Bacq = (uint32_t *)Sk, *Bcom = Bacq + TPL_HOT_NMAX / 32, *Lw = Bcom + TPL_HOT_NMAX / 32;  // lock_fasst
       uint32_t cand[8], cc[8];
 #pragma unroll
@@ -425,6 +427,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
       for (uint32_t w = t; w < TPL_HOT_NMAX / 32; w += KVB_T) {
         Bm[w] = 0;
         if (Ops::CLOSED) { Bacq[w] = 0; Bcom[w] = 0; }
+        else { Bax[w] = 0; Brs[w] = 0; Brx[w] = 0; }
       }
       __syncthreads();
       LK_FOR_RECORDS({
@@ -448,8 +451,9 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
         LK_FOR_RECORDS({
           if (lk_slot(r) == hslot) {
             const uint32_t idx = lk_idx(r), op = lk_op(r), w = idx >> 5, bit = 1u << (idx & 31u);
-            if (!Ops::CLOSED) atomicOr(&Bm[w], bit);
-            else if (op != 0) {
+            if (!Ops::CLOSED) {
+              if (op < 4) atomicOr(op == 0 ? &Bm[w] : op == 1 ? &Bax[w] : op == 2 ? &Brs[w] : &Brx[w], bit);  // (4: a RELEASE of an unknown lock type changes nothing)
+            } else if (op != 0) {
               atomicOr(&Bm[w], bit);
               if (op == 1) atomicOr(&Bacq[w], bit);
               if (op == 3) atomicOr(&Bcom[w], bit);
@@ -457,9 +461,9 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
           }
         })
         __syncthreads();
-        {  // Pw[w] = bits set in the words before w (lock_2pl: of Bm; lock_fasst: of Bcom); thread t owns words 4t .. 4t + 3.
-           // lock_fasst also: Lw[w] = index of the last lock-writing op in the words before w, ~0u = none
-          const uint32_t *src = Ops::CLOSED ? Bcom : Bm;
+        if (Ops::CLOSED) {  // Pw[w] = COMMITs in the words before w; thread t owns words 4t .. 4t + 3.
+           // Lw[w] = index of the last lock-writing op in the words before w, ~0u = none
+          const uint32_t *src = Bcom;
           uint32_t pc[4], run = 0, last = ~0u;
 #pragma unroll
           for (uint32_t j = 0; j < 4; j++) {
@@ -513,72 +517,65 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
             st.y += Hs[6];
           }
         } else {
-          for (uint32_t r0 = 0; r0 < hot_n; r0 += TPL_HOT_WIN) {
-            const uint32_t wn = min(TPL_HOT_WIN, hot_n - r0);
-            LK_FOR_RECORDS({
-              if (lk_slot(r) == hslot) {
-                const uint32_t idx = lk_idx(r);
-                const uint32_t rk = Pw[idx >> 5] + (uint32_t)__popc(Bm[idx >> 5] & ((1u << (idx & 31u)) - 1u));
-                if (rk - r0 < wn) R[rk - r0] = (idx << 3) | lk_op(r);
+          // lock_2pl: the slot's requests as FOUR index bitmaps, one per op class.  A GROUP = the requests whose index falls
+          // into one 64-bit word: consecutive requests of the slot, whatever their number.  Most groups cannot change the
+          // counters' mode, whatever order their requests come in:
+          //   HELD (num_ex != 0), no exclusive RELEASE in the group: every ACQUIRE is rejected, num_sh -= shared RELEASEs;
+          //   FREE (num_ex == 0), no exclusive RELEASE, and no exclusive ACQUIRE that could find num_sh == 0 (num_sh
+          //   stays above 0 even if all the group's shared RELEASEs came first): every shared ACQUIRE is granted,
+          //   every exclusive one rejected, num_sh += shared ACQUIREs - shared RELEASEs.
+          // One wave takes 64 groups at a time: ASSUMING the mode holds, num_sh at every group's entry is a prefix sum
+          // over the groups before it, and every lane checks its own group; up to the first group that is not inert the
+          // assumption was right -- that group is walked (walk64_mask: its word IS the lane mask), and the rest of the 64
+          // is checked again from the state it leaves.  Steps = words / 64 + groups walked, where r03 / r04 ranked the
+          // slot's requests into windows of 8,192 and went through their groups of 64 one by one (55 us for a slot of
+          // 12,800 requests: a lid that a fifth of the closed-loop workers keep retrying; r05 trace).  The grant bits
+          // replace the shared-ACQUIRE bitmap; the replies are written from them.
+          uint64_t *G64 = (uint64_t *)Bm;
+          const uint64_t *AX64 = (const uint64_t *)Bax, *RS64 = (const uint64_t *)Brs, *RX64 = (const uint64_t *)Brx;
+          if (wave == 0) {
+            uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.x), lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.y);
+            const uint32_t ng = (n + 63) / 64;  // <= TPL_HOT_NMAX / 64
+            for (uint32_t g0 = 0; g0 < ng; g0 += 64) {
+              const uint32_t g = g0 + lane;
+              const bool in = g < ng;
+              const uint64_t as = in ? G64[g] : 0, ax = in ? AX64[g] : 0, rs = in ? RS64[g] : 0, rx = in ? RX64[g] : 0;
+              const uint32_t nas = (uint32_t)__popcll(as), nrs = (uint32_t)__popcll(rs);
+              uint64_t pend = __ballot(in && (as | ax | rs | rx) != 0);  // groups without a request of the slot: nothing to do
+              while (pend) {
+                const bool mine = (pend >> lane) & 1ull;
+                const uint32_t dl = mine ? (la != 0 ? 0u - nrs : nas - nrs) : 0u;  // what my group adds to num_sh if it is inert
+                uint32_t tot, pre = wave_excl_scan_u32(dl, &tot);
+                const uint32_t lb_in = lb + pre;
+                const bool inert = la != 0 ? rx == 0 : (rx == 0 && (ax == 0 || (lb_in > nrs && lb_in <= 0xFFFFFFFFu - nas)));
+                const uint64_t stop = __ballot(mine && !inert);
+                const uint64_t ok = stop ? pend & ((stop & (0 - stop)) - 1ull) : pend;  // the groups before the first one that is not
+                if ((ok >> lane) & 1ull) G64[g] = la == 0 ? as : 0ull;
+                if (!stop) { lb += tot; break; }
+                const int f = __ffsll((unsigned long long)stop) - 1;
+                lb += (uint32_t)__builtin_amdgcn_readlane((int)pre, f);  // (the groups before f)
+                // group f, request by request as far as the mode changes: lane l = request index 64 (g0 + f) + l
+                const uint64_t fas = lk_readlane_u64(as, f), fax = lk_readlane_u64(ax, f), frs = lk_readlane_u64(rs, f), frx = lk_readlane_u64(rx, f);
+                const bool v = ((fas | fax | frs | frx) >> lane) & 1ull;
+                const uint32_t op = (uint32_t)((fax >> lane) & 1ull) + 2u * (uint32_t)((frs >> lane) & 1ull) + 3u * (uint32_t)((frx >> lane) & 1ull);
+                uint2 sw = make_uint2(la, lb);
+                const uint64_t Gf = Ops::walk64_mask(v, op, sw);
+                la = sw.x; lb = sw.y;
+                if ((int)lane == f) G64[g] = Gf;
+                pend &= ~(ok | (1ull << f));
               }
-            })
-            __syncthreads();
-            // Most groups of 64 requests cannot change the counters' mode, whatever order their requests come in:
-            //   HELD (num_ex != 0), no exclusive RELEASE in the group: every ACQUIRE is rejected, num_sh -= shared RELEASEs;
-            //   FREE (num_ex == 0), no exclusive RELEASE, and no exclusive ACQUIRE that could find num_sh == 0 (num_sh
-            //   stays above 0 even if all the group's shared RELEASEs came first): every shared ACQUIRE is granted,
-            //   every exclusive one rejected, num_sh += shared ACQUIREs - shared RELEASEs.
-            // So: (1) all waves summarise the groups {shared ACQUIREs, shared RELEASEs, has exclusive ACQUIRE / RELEASE};
-            // (2) one wave goes through the summaries -- a few scalar operations per inert group -- and walks only the
-            // others (walk64_mask); (3) all waves write the replies from the groups' grant masks.
-            const uint32_t ng = (wn + 63) / 64;  // <= TPL_HOT_WIN / 64 = 128
-            for (uint32_t g = wave; g < ng; g += KVB_W) {
-              const bool valid = g * 64 + lane < wn;
-              const uint32_t op = valid ? R[g * 64 + lane] & 7u : 7u;
-              const uint64_t mAS = __ballot(op == 0), mAX = __ballot(op == 1), mRS = __ballot(op == 2), mRX = __ballot(op == 3);
-              if (lane == 0) Gsum[g] = (uint32_t)__popcll(mAS) | ((uint32_t)__popcll(mRS) << 8) | (mAX ? 1u << 16 : 0u) | (mRX ? 1u << 17 : 0u);
             }
-            __syncthreads();
-            if (wave == 0) {
-              const uint32_t s0 = lane < ng ? Gsum[lane] : 0, s1 = 64 + lane < ng ? Gsum[64 + lane] : 0;  // lane l: groups l, 64 + l
-              uint64_t g0 = 0, g1 = 0;  // ... their grant masks (walked groups)
-              uint32_t k0 = 0, k1 = 0;  // ... and kinds: 0 walked, 1 inert while HELD, 2 inert while FREE
-              st.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.x);
-              st.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.y);
-              for (uint32_t g = 0; g < ng; g++) {  // wave-uniform
-                const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)(g < 64 ? s0 : s1), (int)(g & 63));
-                const uint32_t nas = sm & 0xFFu, nrs = (sm >> 8) & 0xFFu;
-                const bool has_ax = (sm >> 16) & 1u, has_rx = (sm >> 17) & 1u;
-                uint64_t G = 0;
-                uint32_t kind = 0;
-                if (st.x != 0 && !has_rx) {
-                  st.y -= nrs;
-                  kind = 1;
-                } else if (st.x == 0 && !has_rx && (!has_ax || (st.y > nrs && st.y <= 0xFFFFFFFFu - nas))) {
-                  st.y += nas - nrs;
-                  kind = 2;
-                } else {
-                  const bool valid = g * 64 + lane < wn;
-                  const uint32_t e = valid ? R[g * 64 + lane] : 0;
-                  G = Ops::walk64_mask(valid, e & 7u, st);
-                }
-                if (lane == (g & 63)) {
-                  if (g < 64) { g0 = G; k0 = kind; } else { g1 = G; k1 = kind; }
-                }
-              }
-              if (lane < ng) { Gm[lane] = g0; Gk[lane] = (uint8_t)k0; }
-              if (64 + lane < ng) { Gm[64 + lane] = g1; Gk[64 + lane] = (uint8_t)k1; }
-            }
-            __syncthreads();
-            for (uint32_t k = t; k < wn; k += KVB_T) {
-              const uint32_t e = R[k], op = e & 7u;
-              const uint32_t kind = Gk[k >> 6];
-              const bool granted = kind == 0 ? (Gm[k >> 6] >> (k & 63)) & 1ull : (kind == 2 && op == 0);
-              const uint32_t code = op <= 1 ? (granted ? 2u : 3u) : 5u;
-              Ops::write_reply(rep, V, e >> 3, op, code, 0);
-            }
-            __syncthreads();
+            st.x = la; st.y = lb;
           }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          __syncthreads();
+          LK_FOR_RECORDS({
+            if (lk_slot(r) == hslot) {
+              const uint32_t idx = lk_idx(r), op = lk_op(r);
+              const uint32_t code = op <= 1 ? (((Bm[idx >> 5] >> (idx & 31u)) & 1u) ? 2u : 3u) : 5u;
+              Ops::write_reply(rep, V, idx, op, code, 0);
+            }
+          })
         }
         if (t == 0 && (st.x != st_in.x || st.y != st_in.y)) table[hslot] = st;
         if (tw && t == 0 && bi == vb) tw[12] = __builtin_amdgcn_s_memrealtime();
@@ -625,15 +622,24 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
         for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = rec_at(k);
         if (t == 0) Swn = c;
       } else {
-        for (uint32_t k0 = 0; k0 < c; k0 += KVB_T) {
-          const uint32_t k = k0 + t;
-          const uint64_t r = k < c ? rec_at(k) : 0;
-          const bool in = k < c && lk_slot(r) != hslot_done && (c_rest <= KVB_NMAX || Bwin[lk_idx(r) >> bs] == win);
-          const uint64_t im = __ballot(in);
-          uint32_t base = 0;
-          if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          if (in) Sk[base + (uint32_t)__popcll(im & lanemask_lt())] = r;
+        for (uint32_t k0 = 0; k0 < c; k0 += 8 * KVB_T) {  // (8 loads per thread in flight, as every pass over the bin's records)
+          uint64_t r8[8];
+#pragma unroll
+          for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t k = k0 + j * KVB_T + t;
+            r8[j] = k < c ? rec_at(k) : 0;
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t k = k0 + j * KVB_T + t;
+            const uint64_t r = r8[j];
+            const bool in = k < c && lk_slot(r) != hslot_done && (c_rest <= KVB_NMAX || Bwin[lk_idx(r) >> bs] == win);
+            const uint64_t im = __ballot(in);
+            uint32_t base = 0;
+            if (lane == 0 && im) base = atomicAdd(&Swn, (uint32_t)__popcll(im));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (in) Sk[base + (uint32_t)__popcll(im & lanemask_lt())] = r;
+          }
         }
       }
       __syncthreads();

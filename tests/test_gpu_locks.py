@@ -186,6 +186,9 @@ def test_locks_big_passes_vs_oracle(wl, n, nslots, n_hot, p_hot):
     (200_000, 65536, 0.85, 0.55),   # several passes, the counters carry over
     (200_000, 0, 0.85, 0.55),  # one pass of more than 65,536 requests: the general big-bin path (sorted stretches + walk)
     (20_000, 0, 0.3, 0.5),     # a dominant slot of a few thousand among other traffic
+    (65536, 0, 0.06, 0.5),     # ... of 4,000 in a 64k pass: three requests per 64-bit word of the index bitmaps
+    (65536, 0, 0.2, 0.93),     # the bench shape: a fifth of the pass retries one lock, nearly all of it ACQUIREs
+    (60_001, 0, 0.5, 0.5),     # a pass that ends inside a bitmap word
 ])
 def test_2pl_dominant_slot_vs_oracle(n, max_pass, p_hot, p_acq):
     """the closed-loop shape that makes a lock hot (hundreds of workers retrying it), plus releases nobody holds (the
@@ -197,6 +200,7 @@ def test_2pl_dominant_slot_vs_oracle(n, max_pass, p_hot, p_acq):
     hot = rng.random(n) < p_hot
     m["lid"] = np.where(hot, 777, rng.integers(0, 24_000_000, n)).astype("<u4")
     m["lid"][rng.random(n) < 0.02] = 778  # a second, smaller hot slot
+    m["type"][(rng.random(n) < 0.01) & (m["action"] == 1)] = 7  # RELEASEs of an unknown lock type: acked, nothing changes (server.cc:104-118)
     eng = _engine(wire.Workload.TPL, n_slots=1 << 20, max_pass=max_pass)
     o = orc.TplOracle(1 << 20)
     assert eng.submit(m).tobytes() == o.replay(m).tobytes()
