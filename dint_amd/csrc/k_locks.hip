@@ -44,6 +44,20 @@ __device__ static inline uint64_t lk_rec(uint32_t slot, uint32_t idx, uint32_t o
 __device__ static inline uint32_t lk_slot(uint64_t r) { return (uint32_t)(r >> 23); }
 __device__ static inline uint32_t lk_idx(uint64_t r) { return (uint32_t)(r >> 3) & 0xFFFFFu; }
 __device__ static inline uint32_t lk_op(uint64_t r) { return (uint32_t)r & 7u; }
+// exclusive prefix sum over the 64 lanes at VALU speed: four row_shr steps inside the rows of 16, row_bcast:15 / :31 across
+// them (the six dependent ds_bpermute round trips of wave_excl_scan_u32 are 0.4 us -- the mode walk of lock_2pl's dominant
+// slot does one scan per 64 groups)
+__device__ static inline uint32_t lk_excl_scan_u32(uint32_t x, uint32_t *total) {
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1 (lanes without a source keep `old` = 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  *total = (uint32_t)__builtin_amdgcn_readlane(v, 63);
+  return (uint32_t)v - x;
+}
 // lane `src`'s 64-bit value on every lane (src wave-uniform)
 __device__ static inline uint64_t lk_readlane_u64(uint64_t v, int src) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
@@ -140,6 +154,13 @@ k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod
     __syncthreads();
     if (over) ovl[Sov[1] + orank] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
   }
+  // The reply code a request gets UNLESS the table grants it something (Ops::write_reply): every RELEASE / ABORT / COMMIT is
+  // acked whatever the table holds, an ACQUIRE is rejected unless granted.  Written here, beside the copy of the request
+  // bytes -- neighbouring threads, neighbouring messages --, so that the resolve kernel stores only the grants: a lock that
+  // a fifth of the closed-loop workers keep retrying is 12,800 REJECTs per 64k batch, and its workgroup waited for
+  // 12,800 scattered byte stores between the rounds of its record loads (r05: 14 of its 30 us).
+  // (after the barriers above: the vector copy of this slice is complete)
+  if (bin != KV_NONE) rep[off] = (uint8_t)(WL == 0 ? (op == 0 ? 4u : op == 1 ? 6u : op == 2 ? 7u : 8u) : (op <= 1 ? 3u : 5u));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -190,8 +211,8 @@ struct FasstOps {
   __device__ static uint64_t walk64_mask(bool, uint32_t, uint2 &) { return 0; }
   __device__ static void write_reply(uint8_t *rep, const dint_view &V, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
     fasst_msg *m = (fasst_msg *)(rep + dint_view_off(V, idx, sizeof(fasst_msg)));
-    m->type = (uint8_t)code;
     if (op == 0) m->ver = rv;  // ver is echoed on every non-READ reply
+    else if (code == 5) m->type = 5;  // GRANT_LOCK; every other code is what k_lock_count wrote already
   }
 };
 
@@ -298,7 +319,7 @@ struct TplOps {
   }
   __device__ static void write_reply(uint8_t *rep, const dint_view &V, uint32_t idx, uint32_t op, uint32_t code, uint32_t rv) {
     (void)op; (void)rv;
-    ((tpl_msg *)(rep + dint_view_off(V, idx, sizeof(tpl_msg))))->action = (uint8_t)code;
+    if (code == 2) ((tpl_msg *)(rep + dint_view_off(V, idx, sizeof(tpl_msg))))->action = 2;  // GRANT_LOCK; REJECT / RELEASE_ACK: k_lock_count's
   }
 };
 
@@ -351,14 +372,17 @@ lk_small_bin(uint8_t *rep, uint32_t pbits, uint2 *__restrict__ table, uint32_t *
 }
 
 #define TPL_HOT_NMAX 65536u   // lock_2pl dominant-slot path: passes of at most this many requests (an 8 KB index bitmap)
+static_assert(TPL_HOT_NMAX / 32 * 4 == KVB_NMAX / 4 * 8, "an index bitmap of the dominant-slot path is a quarter of the stretch buffer");
 
 // ---- big bins: one 512-thread workgroup each ---------------------------------------------------------------------
 template <class Ops>
 __device__ static inline void
 lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
             const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-            const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, const dint_view &V, const uint32_t vb,
+            const uint64_t *__restrict__ ovf, uint32_t hot_min_, uint64_t *trace, const dint_view &V, const uint32_t vb,
             const uint32_t n_walk) {  // workgroup vb of the n_walk that walk the big-bin list
+  const uint32_t hot_min = hot_min_ & 0x7FFFFFFFu;
+  const bool misguess = hot_min_ >> 31;  // DINT_LOCK_MISGUESS (tests): the bitmaps are filled for nobody first, then for the dominant slot
   const uint32_t bin_first = big[4 + vb];  // speculative: in flight together with the list length
   const uint32_t nbig = big[0];
   if (vb >= nbig) return;
@@ -374,7 +398,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
   __shared__ kvb_edge Eset;
   __shared__ kvb_pop Pcom;
   __shared__ uint32_t Xs[KVB_NW][2];  // slots whose requests cross 64-record chunks: [a, b) in the sorted stretch
-  __shared__ uint32_t Swn, Snx, Sred[KVB_W];
+  __shared__ uint32_t Swn, Snx, Sred[KVB_W], Srest;
   __shared__ uint32_t Hs[16];                  // dominant-slot path: counters
   __shared__ uint64_t Mk[KVB_MMAX];            // ... its lock-writing ops, idx << 12 | position, ascending
   __shared__ uint16_t Mcc[KVB_MMAX + 8];       // ... COMMITs among the first j of them
@@ -387,9 +411,14 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
   for (uint32_t bi = vb; bi < nbig; bi += n_walk) {
     const uint32_t bin = bi == vb ? bin_first : big[4 + bi];
     __syncthreads();
+    const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
+    // eight of the bin's first 64 records (they exist whatever the count is: on the same round trip as the count) name the
+    // candidates for its dominant slot
+    uint32_t cand[8];
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) cand[k] = lk_slot(recs_lo[8 * k + 3]);
     const uint32_t c = bin_cnt[bin];
     if (tw && threadIdx.x == 0 && bi == vb) { tw[0] = __builtin_amdgcn_s_memrealtime(); tw[8] = c; tw[9] = nbig; }
-    const uint64_t *recs_lo = bins + (size_t)bin * DINT_KV_BINCAP;
     const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;
     auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
     // ---- the bin's DOMINANT SLOT in a pass of <= 65,536 requests (a lid that hundreds of closed-loop workers keep
@@ -402,8 +431,11 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
     //               was the last lock-writing op below me an ACQUIRE, version seen = ver0 + COMMITs below me; no limit
     //               on the number of ordering ops (the stretch-level path below sorts at most 1024 of them).
     // The rest of the bin takes the general path below.  All passes over the bin's records keep 8 loads per thread
-    // in flight (one memory round trip per 4096 records instead of one per 512).
+    // in flight (one memory round trip per 4096 records instead of one per 512), and there are two of them (r03 / r04:
+    // four): the pass that counts the candidates fills the bitmaps for the likeliest one (the majority of the samples) on
+    // the way, and the pass that writes the slot's replies collects the bin's other records (<= 1024 of them) in LDS.
     uint32_t hslot_done = KV_NONE, c_rest = c;
+    bool rest_lds = false;
 #define LK_FOR_RECORDS(...)                                                       \
     for (uint32_t k0_ = 0; k0_ < c; k0_ += 8 * KVB_T) {                           \
       uint64_t r8_[8];                                                            \
@@ -420,19 +452,40 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
       uint32_t *Bm = (uint32_t *)Mk;              // [n / 32] lock_2pl: the slot's shared ACQUIREs, then the grants; lock_fasst: its lock-writing ops
       uint32_t *Bax = (uint32_t *)Sk, *Brs = Bax + TPL_HOT_NMAX / 32, *Brx = Brs + TPL_HOT_NMAX / 32;  // lock_2pl: exclusive ACQUIREs, RELEASEs shared / exclusive
       uint32_t *Bacq = (uint32_t *)Sk, *Bcom = Bacq + TPL_HOT_NMAX / 32, *Lw = Bcom + TPL_HOT_NMAX / 32;  // lock_fasst
-      uint32_t cand[8], cc[8];
+      uint32_t cc[8], guess = cand[0], gv = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < 8; k++) { cand[k] = lk_slot(rec_at((uint32_t)(((uint64_t)c * k) >> 3))); cc[k] = 0; }
+      for (uint32_t j = 0; j < 8; j++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) v += cand[k] == cand[j];
+        if (v > gv) { gv = v; guess = cand[j]; }
+        cc[j] = 0;
+      }
+      if (misguess) guess = KV_NONE;
       if (t < 16) Hs[t] = 0;
+      if (t == 0) Srest = 0;
       for (uint32_t w = t; w < TPL_HOT_NMAX / 32; w += KVB_T) {
         Bm[w] = 0;
         if (Ops::CLOSED) { Bacq[w] = 0; Bcom[w] = 0; }
         else { Bax[w] = 0; Brs[w] = 0; Brx[w] = 0; }
       }
       __syncthreads();
+#define LK_FILL_BITMAPS()                                                                                          \
+      do {                                                                                                         \
+        const uint32_t idx = lk_idx(r), op = lk_op(r), w = idx >> 5, bit = 1u << (idx & 31u);                      \
+        if (!Ops::CLOSED) {                                                                                        \
+          /* (4: a RELEASE of an unknown lock type changes nothing) */                                             \
+          if (op < 4) atomicOr(op == 0 ? &Bm[w] : op == 1 ? &Bax[w] : op == 2 ? &Brs[w] : &Brx[w], bit);          \
+        } else if (op != 0) {                                                                                      \
+          atomicOr(&Bm[w], bit);                                                                                   \
+          if (op == 1) atomicOr(&Bacq[w], bit);                                                                    \
+          if (op == 3) atomicOr(&Bcom[w], bit);                                                                    \
+        }                                                                                                          \
+      } while (0)
       LK_FOR_RECORDS({
         const uint32_t sl = lk_slot(r);
         _Pragma("unroll") for (uint32_t j = 0; j < 8; j++) cc[j] += sl == cand[j];
+        if (sl == guess) LK_FILL_BITMAPS();
       })
 #pragma unroll
       for (uint32_t j = 0; j < 8; j++) {
@@ -448,19 +501,18 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
       __syncthreads();
       if (tw && t == 0 && bi == vb) { tw[10] = __builtin_amdgcn_s_memrealtime(); tw[13] = hot_n; }
       if (hot_n >= hot_min && 2 * hot_n >= c) {  // workgroup-uniform
-        LK_FOR_RECORDS({
-          if (lk_slot(r) == hslot) {
-            const uint32_t idx = lk_idx(r), op = lk_op(r), w = idx >> 5, bit = 1u << (idx & 31u);
-            if (!Ops::CLOSED) {
-              if (op < 4) atomicOr(op == 0 ? &Bm[w] : op == 1 ? &Bax[w] : op == 2 ? &Brs[w] : &Brx[w], bit);  // (4: a RELEASE of an unknown lock type changes nothing)
-            } else if (op != 0) {
-              atomicOr(&Bm[w], bit);
-              if (op == 1) atomicOr(&Bacq[w], bit);
-              if (op == 3) atomicOr(&Bcom[w], bit);
-            }
+        if (hslot != guess) {  // (the samples misled: the bitmaps again, for the slot that is)
+          for (uint32_t w = t; w < TPL_HOT_NMAX / 32; w += KVB_T) {
+            Bm[w] = 0;
+            if (Ops::CLOSED) { Bacq[w] = 0; Bcom[w] = 0; }
+            else { Bax[w] = 0; Brs[w] = 0; Brx[w] = 0; }
           }
-        })
-        __syncthreads();
+          __syncthreads();
+          LK_FOR_RECORDS({ if (lk_slot(r) == hslot) LK_FILL_BITMAPS(); })
+          __syncthreads();
+        }
+        rest_lds = c - hot_n <= KVB_NMAX / 4;
+        uint64_t *Rest = Sk + 3 * (KVB_NMAX / 4);  // (the bitmaps take three quarters of Sk)
         if (Ops::CLOSED) {  // Pw[w] = COMMITs in the words before w; thread t owns words 4t .. 4t + 3.
            // Lw[w] = index of the last lock-writing op in the words before w, ~0u = none
           const uint32_t *src = Bcom;
@@ -509,7 +561,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
               uint32_t code = 0, rv = 0;
               Ops::closed(op, lock_before, st.y + Pw[w] + (uint32_t)__popc(Bcom[w] & below), code, rv);
               Ops::write_reply(rep, V, idx, op, code, rv);
-            }
+            } else if (rest_lds) Rest[atomicAdd(&Srest, 1u)] = r;
           })
           if (t == 0) {
             const uint32_t lastop = Hs[7];
@@ -545,7 +597,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
               while (pend) {
                 const bool mine = (pend >> lane) & 1ull;
                 const uint32_t dl = mine ? (la != 0 ? 0u - nrs : nas - nrs) : 0u;  // what my group adds to num_sh if it is inert
-                uint32_t tot, pre = wave_excl_scan_u32(dl, &tot);
+                uint32_t tot, pre = lk_excl_scan_u32(dl, &tot);
                 const uint32_t lb_in = lb + pre;
                 const bool inert = la != 0 ? rx == 0 : (rx == 0 && (ax == 0 || (lb_in > nrs && lb_in <= 0xFFFFFFFFu - nas)));
                 const uint64_t stop = __ballot(mine && !inert);
@@ -574,7 +626,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
               const uint32_t idx = lk_idx(r), op = lk_op(r);
               const uint32_t code = op <= 1 ? (((Bm[idx >> 5] >> (idx & 31u)) & 1u) ? 2u : 3u) : 5u;
               Ops::write_reply(rep, V, idx, op, code, 0);
-            }
+            } else if (rest_lds) Rest[atomicAdd(&Srest, 1u)] = r;
           })
         }
         if (t == 0 && (st.x != st_in.x || st.y != st_in.y)) table[hslot] = st;
@@ -618,7 +670,10 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
     for (uint32_t win = 0; win < nwin; win++) {
       if (t == 0) { Swn = 0; Snx = 0; }
       __syncthreads();
-      if (c_rest <= KVB_NMAX && hslot_done == KV_NONE) {
+      if (rest_lds) {  // the dominant slot's reply pass has collected the bin's other records
+        for (uint32_t k = t; k < c_rest; k += KVB_T) Sk[k] = Sk[3 * (KVB_NMAX / 4) + k];
+        if (t == 0) Swn = c_rest;
+      } else if (c_rest <= KVB_NMAX && hslot_done == KV_NONE) {
         for (uint32_t k = t; k < c; k += KVB_T) Sk[k] = rec_at(k);
         if (t == 0) Swn = c;
       } else {
@@ -646,6 +701,13 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
       uint32_t m = Swn;
       if (m == 0) continue;  // workgroup-uniform
       LK_STAMP(1);
+      if (m <= 64) {  // (what a dominant slot leaves of its bin, mostly: one wave, as a small bin)
+        if (wave == 0) lk_chunk<Ops>(rep, V, table, wave_sort_u64(lane < m ? Sk[lane] : ~0ull), lane < m, true, true);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+        LK_STAMP(5);
+        continue;
+      }
       // ---- the stretch's DOMINANT SLOT (lock_fasst; a hot lid: most of a big bin is one slot) without sorting the
       // stretch: only its lock-writing ops (ACQUIRE / ABORT / COMMIT, a minority) are put in request order -- one LDS sort
       // of <= 1024 words -- and every request of the slot finds by binary search on its index how many precede it:
@@ -904,7 +966,8 @@ static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *tabl
   if (ev) hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits,
                      table, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
-                     (const uint64_t *)s.ovf, dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS), s.lock_trace, view);
+                     (const uint64_t *)s.ovf, dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS) | (getenv("DINT_LOCK_MISGUESS") ? 0x80000000u : 0u),  // (tests: the samples name no slot)
+                     s.lock_trace, view);
   if (ev) hipEventRecord(ev[3], st);
 }
 

@@ -208,6 +208,25 @@ def test_2pl_dominant_slot_vs_oracle(n, max_pass, p_hot, p_acq):
     assert (ex == o.num_ex).all() and (sh == o.num_sh).all()
 
 
+@pytest.mark.parametrize("wl", ["fasst", "tpl"])
+def test_dominant_slot_when_the_samples_name_another_slot(wl, monkeypatch):
+    """the dominant-slot path fills its index bitmaps for the majority of eight sampled records while it counts the
+    candidates; DINT_LOCK_MISGUESS makes that guess wrong every time, so the bitmaps are cleared and filled again"""
+    monkeypatch.setenv("DINT_LOCK_MISGUESS", "1")
+    n = 65536
+    if wl == "fasst":
+        req, W_, mk = tracegen.fasst_random(n, seed=5, n_hot=2, p_hot=0.5), wire.Workload.FASST, orc.FasstOracle
+    else:
+        req, W_, mk = tracegen.tpl_random(n, seed=5, n_hot=2, p_hot=0.5), wire.Workload.TPL, orc.TplOracle
+    eng, o = _engine(W_, n_slots=1 << 20), mk(1 << 20)
+    assert eng.submit(req).tobytes() == o.replay(req).tobytes()
+    a, b = eng.read_locks()
+    if wl == "fasst":
+        assert (a == o.locks).all() and (b == o.vers).all()
+    else:
+        assert (a == o.num_ex).all() and (b == o.num_sh).all()
+
+
 def test_2pl_client_trace_vs_oracle():
     """the lock_2pl client loop (dint_amd.driver.TplClient) against the engine, 64k-request passes; the oracle replays it"""
     from dint_amd.driver import tpl_trace
