@@ -431,9 +431,10 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
     //               was the last lock-writing op below me an ACQUIRE, version seen = ver0 + COMMITs below me; no limit
     //               on the number of ordering ops (the stretch-level path below sorts at most 1024 of them).
     // The rest of the bin takes the general path below.  All passes over the bin's records keep 8 loads per thread
-    // in flight (one memory round trip per 4096 records instead of one per 512), and there are two of them (r03 / r04:
-    // four): the pass that counts the candidates fills the bitmaps for the likeliest one (the majority of the samples) on
-    // the way, and the pass that writes the slot's replies collects the bin's other records (<= 1024 of them) in LDS.
+    // in flight (one memory round trip per 4096 records instead of one per 512), and there is one of them for lock_2pl, two
+    // for lock_fasst (r03 / r04: four): the pass that counts the candidates fills the bitmaps for the likeliest one (the
+    // majority of the samples) and collects the bin's other records (<= 1024 of them) in LDS on the way; lock_2pl's replies
+    // are the grant bits that are left, lock_fasst reads the records once more to write them.
     uint32_t hslot_done = KV_NONE, c_rest = c;
     bool rest_lds = false;
 #define LK_FOR_RECORDS(...)                                                       \
@@ -482,10 +483,15 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
           if (op == 3) atomicOr(&Bcom[w], bit);                                                                    \
         }                                                                                                          \
       } while (0)
+      uint64_t *Rest = Sk + 3 * (KVB_NMAX / 4);  // (the bitmaps take three quarters of Sk)
+#define LK_COLLECT_REST() do { const uint32_t k_ = atomicAdd(&Srest, 1u); if (k_ < KVB_NMAX / 4) Rest[k_] = r; } while (0)
+      uint2 st_guess = make_uint2(0, 0);
+      if (guess != KV_NONE) st_guess = table[guess];  // (on its way while the records are read; nobody else writes a slot of this bin)
       LK_FOR_RECORDS({
         const uint32_t sl = lk_slot(r);
         _Pragma("unroll") for (uint32_t j = 0; j < 8; j++) cc[j] += sl == cand[j];
         if (sl == guess) LK_FILL_BITMAPS();
+        else LK_COLLECT_REST();
       })
 #pragma unroll
       for (uint32_t j = 0; j < 8; j++) {
@@ -507,12 +513,15 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
             if (Ops::CLOSED) { Bacq[w] = 0; Bcom[w] = 0; }
             else { Bax[w] = 0; Brs[w] = 0; Brx[w] = 0; }
           }
+          if (t == 0) Srest = 0;
           __syncthreads();
-          LK_FOR_RECORDS({ if (lk_slot(r) == hslot) LK_FILL_BITMAPS(); })
+          LK_FOR_RECORDS({
+            if (lk_slot(r) == hslot) LK_FILL_BITMAPS();
+            else LK_COLLECT_REST();
+          })
           __syncthreads();
         }
-        rest_lds = c - hot_n <= KVB_NMAX / 4;
-        uint64_t *Rest = Sk + 3 * (KVB_NMAX / 4);  // (the bitmaps take three quarters of Sk)
+        rest_lds = c - hot_n <= KVB_NMAX / 4;  // (= Srest: the bin's other records are in LDS)
         if (Ops::CLOSED) {  // Pw[w] = COMMITs in the words before w; thread t owns words 4t .. 4t + 3.
            // Lw[w] = index of the last lock-writing op in the words before w, ~0u = none
           const uint32_t *src = Bcom;
@@ -546,7 +555,8 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
           if (t == KVB_T - 1) { Hs[6] = base; Hs[7] = (uint32_t)ex; }  // totals: COMMITs (a 32-bit word: 65,536 COMMITs on one slot do not fit Pw's 16 bits) / last op of all
         }
         __syncthreads();
-        uint2 st = table[hslot];  // workgroup-uniform address
+        uint2 st = st_guess;
+        if (hslot != guess) st = table[hslot];  // workgroup-uniform address
         const uint2 st_in = st;
         if (tw && t == 0 && bi == vb) tw[11] = __builtin_amdgcn_s_memrealtime();
         if (Ops::CLOSED) {
@@ -561,7 +571,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
               uint32_t code = 0, rv = 0;
               Ops::closed(op, lock_before, st.y + Pw[w] + (uint32_t)__popc(Bcom[w] & below), code, rv);
               Ops::write_reply(rep, V, idx, op, code, rv);
-            } else if (rest_lds) Rest[atomicAdd(&Srest, 1u)] = r;
+            }
           })
           if (t == 0) {
             const uint32_t lastop = Hs[7];
@@ -621,13 +631,9 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
           }
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           __syncthreads();
-          LK_FOR_RECORDS({
-            if (lk_slot(r) == hslot) {
-              const uint32_t idx = lk_idx(r), op = lk_op(r);
-              const uint32_t code = op <= 1 ? (((Bm[idx >> 5] >> (idx & 31u)) & 1u) ? 2u : 3u) : 5u;
-              Ops::write_reply(rep, V, idx, op, code, 0);
-            } else if (rest_lds) Rest[atomicAdd(&Srest, 1u)] = r;
-          })
+          // the replies: a GRANT for every bit that is left (every other request of the slot has its reply: k_lock_count's)
+          for (uint32_t w = t; w < (n + 31) / 32; w += KVB_T)
+            for (uint32_t m = Bm[w]; m; m &= m - 1) Ops::write_reply(rep, V, w * 32 + (uint32_t)__ffs((int)m) - 1, 0, 2, 0);
         }
         if (t == 0 && (st.x != st_in.x || st.y != st_in.y)) table[hslot] = st;
         if (tw && t == 0 && bi == vb) tw[12] = __builtin_amdgcn_s_memrealtime();
