@@ -1,5 +1,6 @@
 // dint_kv.h -- HBM key-value tables of the store / tatp / smallbank workloads (k_kv.hip).
 #pragma once
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -35,6 +36,13 @@ struct dint_kv {
   size_t entry_bytes[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
 };
 
+// records a coarse bin of a kv pass holds IN PLACE, in units of the mean load of a bin (engine.hip sizes the scratch for it,
+// k_kv.hip's kv_fill_pass sets the pass's `cap`); DINT_KV_CAP_MULT overrides (2 = r04 / r05: a hot key's bin overflows)
+static inline uint32_t dint_kv_cap_mult() {
+  const char *v = getenv("DINT_KV_CAP_MULT");
+  const unsigned long m = v && *v ? strtoul(v, nullptr, 10) : 64ul;
+  return (uint32_t)(m < 2 ? 2 : m > 256 ? 256 : m);
+}
 int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard shard, uint32_t pool_entries = 0,
                    uint32_t flags = 0);
 void dint_kv_destroy(dint_kv *kv);

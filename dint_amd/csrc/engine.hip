@@ -338,8 +338,13 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   add_region(e, e->scratch.stats, sizeof(dint_dev_stats));
   if (wl != DINT_WL_LOG) {  // the bins of one pass: 64 records in place per bin + the pass's overflow area
     TRY(dev_alloc((void **)&e->scratch.bin_cnt, DINT_KV_PMAX * sizeof(uint32_t)));
-    if (is_kv) {  // coarse bins of 16-byte records: C * cap = C * (2 ceil(n / C) + 64) <= 2 n + 66 C
-      e->scratch.kbins_slots = 2ull * e->pass_max + 66ull * DINT_KV_CMAX;
+    if (is_kv) {
+      // coarse bins of 16-byte records, DINT_KV_CAP_MULT (64) times the mean load in place each: C * cap = C * (64 ceil(n / C)
+      // + 64) <= 64 n + 128 C slots -- 1 GB for passes of 2^20 requests, of which a pass touches what it fills.  (r04 / r05
+      // kept 2 x the mean and sent a hot key's excess to the pass's overflow list, which every bin that has records there
+      // reads from end to end, twice: smallbank at Zipf 0.99 -- 100,000 entries, a dozen such bins -- spent 100 us of its
+      // 135 us resolve kernel there.  288 GB of HBM are there to be used.)
+      e->scratch.kbins_slots = (uint64_t)dint_kv_cap_mult() * e->pass_max + 128ull * DINT_KV_CMAX;
       TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
       TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_BIGQ_MAX * 3 * sizeof(uint4), false));  // KVQ_W uint4 per work item (k_kv.hip)
       TRY(dev_alloc((void **)&e->scratch.hotpub, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long)));

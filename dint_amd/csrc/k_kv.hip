@@ -7,27 +7,34 @@
 // Every request touches exactly one bucket of one table (lock_hash % hash_size == kvs bucket), or only
 // the log ring.  Requests on different buckets commute; requests on one bucket apply in request order.
 //
-// One pass (n <= 2^20 requests) = three kernels (k_kv_part, k_kv_resolve, k_kv_big), a TWO-LEVEL partition; the passes of
-// several engines share one set of launches (grid.y / grid ranges = engine, dint_launch_kv_multi):
+// One pass (n <= 2^20 requests) = four kernels (k_kv_part, k_kv_resolve, k_kv_hot, k_kv_big), a TWO-LEVEL partition; the passes
+// of several engines share one set of launches (grid.y / grid ranges = engine, dint_launch_kv_multi):
 //   k_kv_part    : KV_TB * RPT requests per workgroup -- copy the messages to the reply array, classify, hash, count the
 //                  records per COARSE bin (coarse = group % C, C ~ n / 512, any number: kv_cut) in LDS, reserve each run
 //                  with one device atomic per (workgroup, coarse bin) and store the 16-byte records {key, group / C |
-//                  idx | type | lock quadrant | 9 key-hash bits}; a coarse bin holds `cap` records in place, a hot
-//                  key's excess goes to the pass's overflow list.  Log requests are finished here: the canonical
-//                  64-byte record goes to ring position tail + (#log requests below i)  [deterministic: an exclusive
-//                  scan, not an atomic].
+//                  idx | type | lock quadrant | 9 key-hash bits}; a coarse bin holds `cap` records in place (64 x the mean
+//                  load: a hot key's bin fits; what does not goes to the pass's overflow list).  Log requests are finished
+//                  here: the canonical 64-byte record goes to ring position tail + (#log requests below i)
+//                  [deterministic: an exclusive scan, not an atomic].
 //   k_kv_resolve : one 512-thread workgroup per coarse bin.  It splits the bin's records by sub = (group / C) % 64 in
 //                  LDS and packs neighbouring subs into chunks of <= 64 records; every chunk is one wave: sorted by
 //                  (bucket group, key hash, idx) in registers and resolved at once (kv_chunk).  A sub of more than 64
-//                  records (a hot key) is listed for k_kv_big.
-//   k_kv_big     : one 512-thread workgroup per big sub: sorted in LDS, ballot masks over the whole sorted stretch with
-//                  O(1) range tables, then leaders / 512-request tiles / write-back (kv_big_bin); the hottest key of a
-//                  pass is cut into pieces that several workgroups answer at once (kv_hot_piece).
+//                  records (a hot key) is listed as work items: its records move to the big path's 8-byte form.
+//   k_kv_hot     : store / tatp: the items that have a closed form -- a hot key alone in its sub (a SOLO item), or cut by
+//                  request-index range into PIECES that several workgroups answer at once, publishing to each other what
+//                  a piece needs of its predecessors, plus the sub's REMAINDER (kv_solo_item, kv_hot_item, kv_rem_chunks,
+//                  kv_group_phases).  128 VGPRs, 19 KB of LDS: it runs beside anything.  What it cannot answer it lists
+//                  for k_kv_big.
+//   k_kv_big     : one 512-thread workgroup per listed sub (smallbank: every big sub): sorted in LDS -- or ordered by index
+//                  bitmaps --, ballot masks over the whole sorted stretch with O(1) range tables, then leaders /
+//                  512-request tiles / write-back (kv_big_bin).
 //                  Inside a chunk or stretch, several requests on ONE key are resolved in closed form
 //                  (version = v0 + #writers below, value = message of the last writer below, lock = last lock op
-//                  below); what the closed forms do not cover runs in rounds (k-th request of a bucket run in round k,
-//                  workgroup fence between rounds), so every request sees the table exactly as the serial reference
-//                  would.  The table is the HBM layout of dint_kv_core.h: one 64-byte header sector answers the probe.
+//                  below; smallbank's counters: a walk per mode change, and whole chunks that cannot change the mode
+//                  skipped at once); what the closed forms do not cover runs in rounds (k-th request of a bucket run
+//                  in round k, workgroup fence between rounds), so every request sees the table exactly as the serial
+//                  reference would.  The table is the HBM layout of dint_kv_core.h: one 64-byte header sector answers
+//                  the probe.
 // (r01-r03: one level, bin = group % (n / 32), 8-byte records, three launches: one returning device atomic and one
 // partial-sector scatter per request in the count kernel, a key gather per request and half-empty waves in the resolve
 // kernel.  NOTEBOOK.md section 1.)
@@ -1735,6 +1742,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     KVB_STAMP(7);
     // ---- pass B: a segment must be one key (9 hash bits can collide) and carry only ops the closed form knows;
     // list the segment heads
+    // (r05 also tried the keys of all eight tiles in flight before the checks: the sixteen registers more spill, 8.8 -> 11.2 us)
     for (uint32_t j = 0; j < ntile; j++) {
       const uint32_t p = j * KVB_T + t;
       const uint64_t cur = Sk[p];
@@ -1930,13 +1938,39 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
         const int nx = kvb_first(Mhead, Ehead, b0);
         const uint32_t hb2 = nx >= 0 ? (uint32_t)nx : m;
         uint32_t la = (uint32_t)__builtin_amdgcn_readfirstlane((int)Carry[sa].la), lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)Carry[sa].lb);
-        for (uint32_t q0 = b0; q0 < hb2; q0 += 64) {  // the op kinds of chunk c come out of lane c's registers
-          const uint64_t in = hb2 - q0 >= 64 ? ~0ull : (1ull << (hb2 - q0)) - 1ull;
-          const int c = (int)(q0 >> 6);
-          const uint64_t mAS = readlane_u64(vAS, c) & in, mAX = readlane_u64(vAX, c) & in;
-          const uint64_t mRS = readlane_u64(vRS, c) & in, mRX = readlane_u64(vRX, c) & in;
-          const uint64_t G = sb_walk(mAS | mAX | mRS | mRX, mAS, mAX, mRS, mRX, la, lb);
-          if (lane == 0 && G) atomicOr((unsigned long long *)&Mlk[c], (unsigned long long)G);
+        // Lane c holds the op kinds of chunk c.  Most chunks of a contended account cannot change the counters' mode whatever
+        // order their requests come in (as lock_2pl's groups, k_locks.hip): HELD and no RELEASE_EXCLUSIVE in the chunk --
+        // every ACQUIRE rejected, num_sh -= RELEASE_SHAREDs; FREE, no RELEASE_EXCLUSIVE and no ACQUIRE_EXCLUSIVE that could
+        // find num_sh == 0 -- every ACQUIRE_SHARED granted.  So all chunks of the segment are checked AT ONCE under the
+        // assumption that the mode holds (num_sh at a chunk's entry = a prefix sum over the chunks before it); up to the first
+        // chunk that is not inert the assumption was right, that chunk is walked (sb_walk), and the rest is checked again from
+        // the state it leaves.  (r02 - r05 walked the ~60 chunks of a hot account's stretch one after the other: ~10 us of the
+        // stretch's 57.)
+        {
+          const uint32_t c0 = b0 >> 6, c1 = (hb2 - 1) >> 6;
+          const bool mine_c = lane >= c0 && lane <= c1;
+          const uint32_t tail = hb2 - 64 * c1;  // requests of the segment in its last chunk: 1 .. 64
+          const uint64_t in = !mine_c ? 0ull : (lane == c1 && tail < 64 ? (1ull << tail) - 1ull : ~0ull);
+          const uint64_t cAS = vAS & in, cAX = vAX & in, cRS = vRS & in, cRX = vRX & in;
+          const uint32_t nas = (uint32_t)__popcll(cAS), nrs = (uint32_t)__popcll(cRS);
+          uint64_t pend = __ballot((cAS | cAX | cRS | cRX) != 0);
+          while (pend) {
+            const bool me = (pend >> lane) & 1ull;
+            const uint32_t dl = me ? (la != 0 ? 0u - nrs : nas - nrs) : 0u;  // what my chunk adds to num_sh if it is inert
+            uint32_t tot, pre = wave_excl_scan_u32(dl, &tot);
+            const uint32_t lb_in = lb + pre;
+            const bool inert = la != 0 ? cRX == 0 : (cRX == 0 && (cAX == 0 || (lb_in > nrs && lb_in <= 0xFFFFFFFFu - nas)));
+            const uint64_t stop = __ballot(me && !inert);
+            const uint64_t ok = stop ? pend & ((stop & (0 - stop)) - 1ull) : pend;  // the chunks before the first one that is not
+            if (((ok >> lane) & 1ull) && la == 0 && cAS) atomicOr((unsigned long long *)&Mlk[lane], (unsigned long long)cAS);
+            if (!stop) { lb += tot; break; }
+            const int f = __ffsll((unsigned long long)stop) - 1;
+            lb += (uint32_t)__builtin_amdgcn_readlane((int)pre, f);  // (the chunks before f)
+            const uint64_t mAS = readlane_u64(cAS, f), mAX = readlane_u64(cAX, f), mRS = readlane_u64(cRS, f), mRX = readlane_u64(cRX, f);
+            const uint64_t G = sb_walk(mAS | mAX | mRS | mRX, mAS, mAX, mRS, mRX, la, lb);
+            if (lane == 0 && G) atomicOr((unsigned long long *)&Mlk[f], (unsigned long long)G);
+            pend &= ~(ok | (1ull << f));
+          }
         }
         if (lane == 0) { Carry[sa].la = la; Carry[sa].lb = lb; }
       }
@@ -2373,9 +2407,32 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   auto for_each_record = [&](auto &&f) {
     if (t < n_in) f(r0);
     if (t + NT < n_in) f(r1);
-    for (uint32_t k = t + 2 * NT; k < n_in; k += NT) f(recs[k]);
-    for (uint32_t k = t; k < novl; k += NT)
-      if (A.ovl[2 * (size_t)k + 1].x == coarse) f(A.ovl[2 * (size_t)k]);
+    // (a hot key's bin: thousands of records in place -- eight loads per thread in flight; one at a time was 31 dependent round
+    // trips, 50 us, for smallbank's 16,000-record bin in each of the two phases, r05 trace)
+    for (uint32_t k0 = 2 * NT; k0 < n_in; k0 += 8 * NT) {
+      uint4 q4[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t k = k0 + j * NT + t;
+        q4[j] = k < n_in ? recs[k] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++)
+        if (k0 + j * NT + t < n_in) f(q4[j]);
+    }
+    // (the pass's overflow list, all of it, by every bin that has records there -- smallbank at Zipf 0.99: 40,000 entries, a
+    // dozen such bins: eight loads per thread in flight, not one -- r05 trace: 2 x 50 us of a 120 us workgroup were this loop)
+    for (uint32_t k0 = 0; k0 < novl; k0 += 8 * NT) {
+      uint32_t b8[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t k = k0 + j * NT + t;
+        b8[j] = k < novl ? A.ovl[2 * (size_t)k + 1].x : KV_NONE;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++)
+        if (b8[j] == coarse) f(A.ovl[2 * (size_t)(k0 + j * NT + t)]);
+    }
   };
   // ---- phase A: records per sub; and per sub the key of whichever record comes first (a sub of hundreds of records is one
   // hot key's: k_kv_big cuts it into pieces around that key, kv_hot_item)
@@ -2383,7 +2440,11 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   for_each_record([&](const uint4 &r) {
     const uint64_t m = u4_meta(r);
     const uint32_t sub = (uint32_t)(m >> sh) & (KVR_F - 1);
-    atomicAdd(&L.hist[sub], 1u);
+    // (a hot key's bin is one sub: the lanes that share the first active lane's sub count themselves with ONE LDS atomic)
+    const uint32_t sub0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
+    const uint64_t same = __ballot(sub == sub0);
+    if (sub != sub0) atomicAdd(&L.hist[sub], 1u);
+    else if (lane == (uint32_t)__ffsll((unsigned long long)same) - 1) atomicAdd(&L.hist[sub], (uint32_t)__popcll(same));
     if (L.cflag[sub] == 0 && atomicCAS(&L.cflag[sub], 0u, 1u) == 0u) { L.ckey[sub] = u4_key(r); L.hrec[sub] = big_rec(m); }
   });
   __syncthreads();
@@ -2442,7 +2503,14 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   for_each_record([&](const uint4 &r) {
     const uint64_t m = u4_meta(r);
     const uint32_t sub = (uint32_t)(m >> sh) & (KVR_F - 1);
-    const uint32_t pos = atomicAdd(&L.cur[sub], 1u), bo = L.bigoff[sub];
+    const uint32_t sub0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
+    const uint64_t same = __ballot(sub == sub0);
+    const int lead = __ffsll((unsigned long long)same) - 1;
+    uint32_t pos = 0;
+    if (sub != sub0) pos = atomicAdd(&L.cur[sub], 1u);
+    else if ((int)lane == lead) pos = atomicAdd(&L.cur[sub], (uint32_t)__popcll(same));
+    if (sub == sub0) pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, lead) + (uint32_t)__popcll(same & lanemask_lt());
+    const uint32_t bo = L.bigoff[sub];
     if (bo == KV_NONE) L.rec[L.off[sub] + pos] = r;
     else A.ovf[bo + pos] = big_rec(m);  // the big path's record
   });
@@ -3317,8 +3385,11 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_hot(kv_multi_args M) {
 // units: kv_big_bin then spills 640 bytes per lane, and a dispatch with that much scratch stalls its queue while the runtime
 // resizes it -- k_kv_hot + k_kv_big went from 40 to 62 us.  A SMALL GRID instead: behind k_kv_hot only 8 workgroups per engine
 // have to find an empty compute unit.)
+// (256 VGPRs x 8 waves: one workgroup per compute unit whatever the LDS says; the stretch machinery still spills a few dozen
+// registers -- profiles/r05_kernel_resources.txt has the numbers of the build)
 template <int WL>
-__global__ void __launch_bounds__(KVB_T, 2) k_kv_big(kv_multi_args M, uint32_t from_late) {
+__global__ void __launch_bounds__(KVB_T, 1) k_kv_big(kv_multi_args M, uint32_t from_late) {
+  static_assert(sizeof(kv_dev) + sizeof(kvb_lds) + (WL == DINT_WL_SMALLBANK ? KVB_BM_BYTES : 16) + 64 <= 160 * 1024, "k_kv_big's LDS must fit a gfx950 compute unit");
   __shared__ kv_dev Skv;
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvb_lds)];
   __shared__ __attribute__((aligned(16))) uint8_t Lbm[WL == DINT_WL_SMALLBANK ? KVB_BM_BYTES : KV_HOT_BM ? KV_HOT_BM_W * 10 : 16];  // (one workgroup per CU either way: 8 waves of 256 VGPRs)
@@ -3389,7 +3460,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   const uint32_t load = std::min(8192u, std::max(64u, kv_env("DINT_KV_COARSE_LOAD", KVB_T)));
   const uint32_t C = kv_pick_coarse(n, load);
   const uint32_t mean = (n + C - 1) / C;
-  uint32_t cap = 2 * mean + 64;
+  uint32_t cap = dint_kv_cap_mult() * mean + 64;  // (engine.hip sizes kbins for it)
   cap = std::min(cap, (uint32_t)(s.kbins_slots / C));
   cap = std::max(1u, std::min(cap, kv_env("DINT_KV_CAP", cap)));
   A.req = (const uint8_t *)d_req; A.rep = (uint8_t *)d_rep; A.n = n;
