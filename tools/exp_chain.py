@@ -86,12 +86,15 @@ del os.environ["DINT_KV_NO_SPLIT"]
 # knobs read at every launch: a sweep costs nothing but the timed replays
 if os.environ.get("EXP_SWEEP"):
     sw = {}
-    for name, vals in (("DINT_KV_COARSE_LOAD", ("384", "448", "512", "640", "768")), ("DINT_KV_RPT", ("1", "2")),
-                       ("DINT_KV_SPLIT_TARGET", ("192", "256", "384", "448")), ("DINT_KV_SPLIT_MIN", ("65", "96", "128", "256"))):
-        for v in vals:
+    knobs = (("DINT_KV_COARSE_LOAD", ("384", "448", "512", "640", "768")), ("DINT_KV_RPT", ("1", "2")),
+             ("DINT_KV_SPLIT_TARGET", ("192", "256", "384", "448")), ("DINT_KV_SPLIT_MIN", ("65", "96", "128", "256")))
+    if "=" in os.environ["EXP_SWEEP"]:  # EXP_SWEEP="NAME=v1,v2;NAME2=..." (a value may repeat: the spread of the box)
+        knobs = tuple((kv.split("=")[0], tuple(kv.split("=")[1].split(","))) for kv in os.environ["EXP_SWEEP"].split(";"))
+    for name, vals in knobs:
+        for k, v in enumerate(vals):
             os.environ[name] = v
             try:
-                sw[f"{name}={v}"] = timed(reps=2)
+                sw[f"{name}={v}" + (f"#{k}" if vals.count(v) > 1 else "")] = timed(reps=2)
             finally:
                 del os.environ[name]
     out["sweep_us_per_epoch"] = sw
