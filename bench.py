@@ -411,6 +411,8 @@ def bench_lock(args, world, rank, dev, transport, kind):
     from dint_amd.driver import fasst_trace, tpl_trace
 
     wl, dtype = (wire.Workload.FASST, wire.FASST_MSG) if fasst else (wire.Workload.TPL, wire.TPL_MSG)
+    from dint_amd import _lib
+    piped = world == 1 and not args.force_exchange  # the `inputs_ready` leg below (not with an exchange: the routed path submits segments)
     eng = Engine(wl, n_slots=args.slots, device=dev, shard_index=rank, shard_count=world)
     rt = Router([eng], world, rank, transport=None if world > 1 else "self", n_max=BATCH) if (world > 1 or args.force_exchange) else None
 
@@ -463,6 +465,38 @@ def bench_lock(args, world, rank, dev, transport, kind):
     # several: a 64k batch takes 16 epochs of rank 0 before rank 1's, the recording interleaved them epoch by epoch)
     replay_ok = (got == recorded.tobytes()) if world == 1 else None
     overflow = rt.overflow() if rt is not None else 0
+    # DINT_FLAG_INPUTS_READY (include/dint_abi.h): the replay hands the engine batches that are complete in HBM, in buffers of
+    # their own -- the engine may then run the first half of a pass (k_lock_count, k_kv_scan_place: no table access) on a
+    # stream of its own beside the previous pass's resolve kernel.  A leg, not `value`: two cross-stream dependencies per pass
+    # cost most of what the overlap saves, and a lone batch gets slower (NOTEBOOK.md section 2).
+    stream_ordered = None
+    if piped:
+        eng2 = Engine(wl, n_slots=args.slots, device=dev, flags=_lib.FLAG_INPUTS_READY)
+        d_rep2 = torch.empty_like(d_rep)
+
+        def run2(lo, hi):
+            for b in range(lo, hi):
+                o = b * BATCH * msg
+                eng2.submit_device(d_req.data_ptr() + o, BATCH, d_rep2.data_ptr() + o, 0)
+
+        run2(0, W * B)
+        eng2.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run2(W * B, n_batches)
+        eng2.sync(); torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        same2 = d_rep2.cpu().numpy().tobytes() == got  # (before the latency loop below submits batches again)
+        lat2 = []
+        for b in range(W * B, min(n_batches, W * B + 50)):
+            eng2.sync(); torch.cuda.synchronize()
+            t = time.perf_counter()
+            run2(b, b + 1)
+            eng2.sync(); torch.cuda.synchronize()
+            lat2.append((time.perf_counter() - t) * 1e6)
+        stream_ordered = {"value": round(K * B * BATCH / dt2 / 1e6, 3), "unit": "Mtxn/s", "replies_equal": same2,
+                          "latency_us_p50": pct(np.array(lat2), 50),
+                          "what": "the same batches through an engine created with DINT_FLAG_INPUTS_READY: count + scan / place of pass k + 1 on the engine's helper stream beside the resolve kernel of pass k"}
+        del eng2, d_rep2
 
     lat = []
     for b in range(W * B, min(n_batches, W * B + 100)):
@@ -536,6 +570,7 @@ def bench_lock(args, world, rank, dev, transport, kind):
     if rank != 0:
         return None
     extra["pass_1m"] = big_pass
+    extra["inputs_ready"] = stream_ordered
     if not args.no_rand64 and rt is None:
         rand_roofline(extra, value * 1e6, dev, 1.0, "one 8-byte slot {lock, ver} / {num_ex, num_sh} of the table per request",
                       args.slots * 8 / 2**30)

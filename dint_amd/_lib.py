@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdint.so")
 
 ABI_VERSION = 3
+#: dint_config.flags (include/dint_abi.h)
+FLAG_KV_ROUNDS, FLAG_COPY_STREAMS, FLAG_LOCK_SAME_KEY, FLAG_KV_NO_HOT, FLAG_INPUTS_READY = 1, 2, 4, 8, 16
 MICRO_BATCH = 65536
 
 #: every symbol include/dint_abi.h declares (checked by tests/test_abi.py)

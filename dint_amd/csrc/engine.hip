@@ -17,6 +17,10 @@
 #include "dint_kv.h"
 #include "dint_populate.h"
 
+// k_locks.hip: one half of a lock pass (stage 1 = count + scan / place, 2 = resolve) on `st`
+void dint_launch_lock_stage(uint32_t workload, int stage, const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots,
+                            dint_shard shard, dint_scratch s, hipStream_t st, const dint_view &view);
+
 namespace {
 
 thread_local std::string g_err;
@@ -95,6 +99,19 @@ struct dint_engine {
   hipStream_t route_last_stream = nullptr;
   hipEvent_t ev_route_order = nullptr;
   hipEvent_t ev_wait = nullptr, ev_signal = nullptr;  // dint_stream_wait / dint_stream_signal (re-recorded every call)
+
+  // lock tables with DINT_FLAG_INPUTS_READY: the first half of pass k + 1 (k_lock_count, k_kv_scan_place: no table access) on
+  // `helper` beside the second half of pass k; three scratch sets used in turn ([0] = `scratch`), an event pair per set
+  struct LockPipe {
+    static const int kSets = 3;
+    bool ready = false;
+    hipStream_t helper = nullptr;
+    dint_scratch set[kSets];
+    hipEvent_t counted[kSets] = {}, freed[kSets] = {}, ev_in = nullptr;
+    bool used[kSets] = {};
+    uint64_t seq = 0;
+    bool after_serial = true;  // the previous pass ran on one stream (or there was none): the helper first waits for the caller's stream
+  } lp;
 
   // lock tables (fasst / 2pl)
   uint2 *d_lock_tbl = nullptr;
@@ -207,13 +224,82 @@ int next_pass_seq(dint_engine *e, hipStream_t st) {
 }
 
 // one pass (n <= pass_max) on device buffers
+// scratch sets 1 .. of the lock pipe: what k_lock_count / k_kv_scan_place / k_lock_resolve share within one pass
+int lock_pipe_init(dint_engine *e) {
+  dint_engine::LockPipe &lp = e->lp;
+  if (lp.ready) return 0;
+  HIP_TRY(hipStreamCreateWithFlags(&lp.helper, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&lp.ev_in, hipEventDisableTiming));
+  for (int k = 0; k < dint_engine::LockPipe::kSets; k++) {
+    HIP_TRY(hipEventCreateWithFlags(&lp.counted[k], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&lp.freed[k], hipEventDisableTiming));
+    if (k == 0) continue;  // set 0 is e->scratch itself
+    dint_scratch &s = lp.set[k];
+    s = e->scratch;  // (stats, lock_trace: shared)
+    int rc = dev_alloc((void **)&s.bin_cnt, DINT_KV_PMAX * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc((void **)&s.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false);
+    if (!rc) rc = dev_alloc((void **)&s.blk_pub, 2 * 1024 * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc((void **)&s.big, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc((void **)&s.bin_off, DINT_KV_PMAX * sizeof(uint32_t));
+    if (!rc) rc = dev_alloc((void **)&s.ovl, (size_t)e->pass_max * sizeof(uint4), false);
+    if (!rc) rc = dev_alloc((void **)&s.ovf, (size_t)e->pass_max * sizeof(uint64_t), false);
+    if (rc) return rc;
+    s.blk_pub_next = s.blk_pub + 1024;
+    s.big_next = s.big + (4 + DINT_KV_PMAX);
+  }
+  lp.ready = true;
+  return 0;
+}
+void lock_pipe_destroy(dint_engine *e) {
+  dint_engine::LockPipe &lp = e->lp;
+  if (lp.helper) { hipStreamSynchronize(lp.helper); hipStreamDestroy(lp.helper); }
+  if (lp.ev_in) hipEventDestroy(lp.ev_in);
+  for (int k = 0; k < dint_engine::LockPipe::kSets; k++) {
+    if (lp.counted[k]) hipEventDestroy(lp.counted[k]);
+    if (lp.freed[k]) hipEventDestroy(lp.freed[k]);
+    if (k == 0 || !lp.ready) continue;
+    dint_scratch &s = lp.set[k];
+    hipFree(s.bin_cnt); hipFree(s.bins); hipFree(std::min(s.blk_pub, s.blk_pub_next)); hipFree(std::min(s.big, s.big_next));
+    hipFree(s.bin_off); hipFree(s.ovl); hipFree(s.ovf);
+  }
+}
+// a lock pass in two halves (DINT_FLAG_INPUTS_READY, dint_submit_device): count + scan / place on the helper stream as soon
+// as the scratch set is free, resolve on the caller's stream behind it -- and behind the previous pass's resolve, which owns
+// the table.  `st` has been ordered behind the previous pass's stream already (order_stream).
+int run_lock_pass_piped(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, const dint_view &view) {
+  if (int rc = lock_pipe_init(e)) return rc;
+  dint_engine::LockPipe &lp = e->lp;
+  const int b = (int)(lp.seq++ % dint_engine::LockPipe::kSets);
+  dint_scratch &s = b == 0 ? e->scratch : lp.set[b];
+  if (lp.after_serial) {  // whatever ran on one stream before (a pass with timing on, a restore, the first call): behind it
+    HIP_TRY(hipEventRecord(lp.ev_in, st));
+    HIP_TRY(hipStreamWaitEvent(lp.helper, lp.ev_in, 0));
+    lp.after_serial = false;
+  }
+  if (lp.used[b]) HIP_TRY(hipStreamWaitEvent(lp.helper, lp.freed[b], 0));  // the resolve that read this set last
+  dint_launch_lock_stage(e->cfg.workload, 1, d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, s, lp.helper, view);
+  HIP_TRY(hipEventRecord(lp.counted[b], lp.helper));
+  HIP_TRY(hipStreamWaitEvent(st, lp.counted[b], 0));
+  dint_launch_lock_stage(e->cfg.workload, 2, d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, s, st, view);
+  HIP_TRY(hipEventRecord(lp.freed[b], st));
+  lp.used[b] = true;
+  std::swap(s.big, s.big_next);  // the big-bin lists alternate between the passes of a set
+  std::swap(s.blk_pub, s.blk_pub_next);
+  return 0;
+}
+
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0,
-             const dint_view &view = dint_flat_view()) {
+             const dint_view &view = dint_flat_view(), bool inputs_ready = false) {
   if (int rc = order_stream(e, st)) return rc;
+  const bool piped = inputs_ready && n && !e->timer.on && (e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL);
+  if (!piped) e->lp.after_serial = true;
   static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_append"};
   static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve", "k_kv_hot", "k_kv_big"};
-  switch (e->cfg.workload) {
+  switch (piped ? DINT_WL_COUNT : e->cfg.workload) {
+    case DINT_WL_COUNT:
+      if (int rc = run_lock_pass_piped(e, d_req, n, d_rep, st, view)) return rc;
+      break;
     case DINT_WL_FASST:
       dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
                         timer_events(e, 3, lock_names), view);
@@ -447,6 +533,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   if (e->ev_signal) hipEventDestroy(e->ev_signal);
   if (e->s_h2d && e->s_h2d != e->stream) hipStreamDestroy(e->s_h2d);
   if (e->s_d2h && e->s_d2h != e->stream) hipStreamDestroy(e->s_d2h);
+  lock_pipe_destroy(e);
   hipFree(e->d_lock_tbl);
   hipFree(e->log.ring);
   hipFree(e->log.tail);
@@ -464,7 +551,8 @@ int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d
   uint8_t *rp = (uint8_t *)d_replies;
   for (uint32_t off = 0; off < n; off += e->pass_max) {
     uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
-    int rc = run_pass(e, rq + (size_t)off * e->msg_size, m, rp + (size_t)off * e->msg_size, st);
+    int rc = run_pass(e, rq + (size_t)off * e->msg_size, m, rp + (size_t)off * e->msg_size, st, 0, dint_flat_view(),
+                      (e->cfg.flags & DINT_FLAG_INPUTS_READY) != 0);
     if (rc) return rc;
   }
   return 0;

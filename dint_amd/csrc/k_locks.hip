@@ -956,25 +956,40 @@ k_lock_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, uint2 *__restrict__ tab
 }
 
 // ------------------------------------------------------------------------------------------
+// stages: 1 = count + scan / place, 2 = resolve, 3 = both (one stream).  The two halves of a pass touch disjoint state but
+// for the pass scratch `s`: the first reads the requests and writes records, counters and the replies' default bytes; the
+// second reads the records and owns the table (dint_launch_lock_stage: the engine may run stage 1 of pass k + 1 beside stage 2
+// of pass k, on scratch sets of their own)
 template <int WL, class Ops>
 static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,
-                         dint_scratch s, hipStream_t st, hipEvent_t *ev, const dint_view &view) {
+                         dint_scratch s, hipStream_t st, hipEvent_t *ev, const dint_view &view, int stages = 3) {
   if (n == 0) return;
   const uint32_t P = dint_pick_bins_kv(n);
   uint32_t pbits = 0;
   while ((1u << pbits) < P) pbits++;
-  if (ev) hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL((k_lock_count<WL>), dim3((n + KV_TB - 1) / KV_TB), dim3(KV_TB), 0, st, (const uint8_t *)d_req,
-                     (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view);
-  if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
-                     (const uint32_t *)s.big, s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats, (const uint4 *)s.ovl, s.ovf);
-  if (ev) hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits,
-                     table, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
-                     (const uint64_t *)s.ovf, dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS) | (getenv("DINT_LOCK_MISGUESS") ? 0x80000000u : 0u),  // (tests: the samples name no slot)
-                     s.lock_trace, view);
-  if (ev) hipEventRecord(ev[3], st);
+  if (stages & 1) {
+    if (ev) hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL((k_lock_count<WL>), dim3((n + KV_TB - 1) / KV_TB), dim3(KV_TB), 0, st, (const uint8_t *)d_req,
+                       (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view);
+    if (ev) hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
+                       (const uint32_t *)s.big, s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats, (const uint4 *)s.ovl, s.ovf);
+  }
+  if (stages & 2) {
+    if (ev) hipEventRecord(ev[2], st);
+    hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits,
+                       table, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+                       (const uint64_t *)s.ovf, dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS) | (getenv("DINT_LOCK_MISGUESS") ? 0x80000000u : 0u),  // (tests: the samples name no slot)
+                       s.lock_trace, view);
+    if (ev) hipEventRecord(ev[3], st);
+  }
+}
+
+// one half of a lock pass on `st` (declared in engine.hip: DINT_FLAG_INPUTS_READY)
+void dint_launch_lock_stage(uint32_t workload, int stage, const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots,
+                            dint_shard shard, dint_scratch s, hipStream_t st, const dint_view &view) {
+  if (workload == 0 /* DINT_WL_FASST */) launch_locks<0, FasstOps>(d_req, d_rep, n, table, slots, shard, s, st, nullptr, view, stage);
+  else launch_locks<1, TplOps>(d_req, d_rep, n, table, slots, shard, s, st, nullptr, view, stage);
 }
 
 void dint_launch_fasst(const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard,

@@ -58,6 +58,18 @@ extern "C" {
 
 #define DINT_FLAG_KV_NO_HOT 8u /* kv workloads: big bins never take the dominant-key path (A/B runs; identical results) */
 
+#define DINT_FLAG_INPUTS_READY 16u /* lock tables, dint_submit_device only.  The caller promises that (1) the request bytes of a
+                                      batch are in device memory when the call is made -- not produced by work still
+                                      pending on `stream` --, and (2) the request / reply buffers of a call do not overlap
+                                      the buffers of EARLIER calls whose replies have not been consumed yet.  The engine
+                                      then runs the first half of a pass (classify, hash, bin the requests: it touches
+                                      no table) on a stream of its own beside the second half of the previous pass;
+                                      replies still complete in the order of the calls on `stream`, and the table is
+                                      still updated batch after batch.  A receive ring that is filled by a copy engine
+                                      and handed over when complete -- what the reference's recv loop does with its
+                                      socket buffer (lock_fasst/udp/net.h:33-48) -- satisfies both.  Without the flag a
+                                      call is fully stream-ordered (the default) */
+
 /* workloads (dint_config.workload) */
 enum {
   DINT_WL_FASST = 0,     /* lock_fasst: 9-byte {u8 type; u32 lid; u32 ver}            net.h:23-29 */

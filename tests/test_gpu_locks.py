@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 import tracegen
 from dint_amd import wire
@@ -225,6 +226,49 @@ def test_dominant_slot_when_the_samples_name_another_slot(wl, monkeypatch):
         assert (a == o.locks).all() and (b == o.vers).all()
     else:
         assert (a == o.num_ex).all() and (b == o.num_sh).all()
+
+
+@pytest.mark.parametrize("wl", ["fasst", "tpl"])
+def test_inputs_ready_passes_overlap_and_match_the_oracle(wl):
+    """DINT_FLAG_INPUTS_READY: the first half of a lock pass (k_lock_count, k_kv_scan_place) runs on the engine's helper stream
+    beside the previous pass's resolve kernel, three scratch sets in turn.  Forty batches back to back -- separate reply
+    buffers, replies in place, a call of several passes, caller streams, a stretch with kernel timing on (one stream), a
+    snapshot / restore in between -- and every reply byte and the final table equal the oracle's."""
+    from dint_amd import _lib
+    n, nb = 40_000, 40
+    if wl == "fasst":
+        mk_req, W_, mk, msg = tracegen.fasst_random, wire.Workload.FASST, orc.FasstOracle, wire.FASST_MSG.itemsize
+    else:
+        mk_req, W_, mk, msg = tracegen.tpl_random, wire.Workload.TPL, orc.TplOracle, wire.TPL_MSG.itemsize
+    reqs = [mk_req(n, seed=100 + k, n_hot=3, p_hot=0.4) for k in range(nb)]
+    eng, o = _engine(W_, n_slots=1 << 16, flags=_lib.FLAG_INPUTS_READY, max_pass=16_384), mk(1 << 16)  # three passes per call
+    want = [o.replay(r) for r in reqs]
+    d_req = [torch.from_numpy(np.frombuffer(r.tobytes(), np.uint8).copy()).cuda() for r in reqs]
+    d_rep = [torch.empty_like(x) for x in d_req]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    eng.snapshot()
+    for rnd in range(2):  # the second round after a restore: the same replies again
+        for k in range(nb):
+            if k == 17:
+                eng.timing_enable(True)  # passes on one stream in between
+            if k == 21:
+                eng.timing_enable(False)
+            out = d_req[k] if (k % 5 == 4 and rnd == 1) else d_rep[k]  # in place (the requests are not needed again)
+            st = 0 if k % 3 == 0 else streams[k & 1].cuda_stream
+            eng.submit_device(d_req[k], n, out, st)
+        torch.cuda.synchronize()
+        eng.sync()
+        for k in range(nb):
+            got = (d_req[k] if (k % 5 == 4 and rnd == 1) else d_rep[k]).cpu().numpy().tobytes()
+            assert got == want[k].tobytes(), (rnd, k)
+        a, b = eng.read_locks()
+        if wl == "fasst":
+            assert (a == o.locks).all() and (b == o.vers).all()
+        else:
+            assert (a == o.num_ex).all() and (b == o.num_sh).all()
+        if rnd == 0:
+            eng.restore()
 
 
 def test_2pl_client_trace_vs_oracle():
