@@ -241,6 +241,8 @@ int lock_pipe_init(dint_engine *e) {
     if (!rc) rc = dev_alloc((void **)&s.blk_pub, 2 * 1024 * sizeof(uint32_t));
     if (!rc) rc = dev_alloc((void **)&s.big, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t));
     if (!rc) rc = dev_alloc((void **)&s.bin_off, DINT_KV_PMAX * sizeof(uint32_t));
+    if (!rc && hipMemset(s.bin_off, 0xFF, DINT_KV_PMAX * sizeof(uint32_t)) != hipSuccess) rc = fail(DINT_EHIP, "hipMemset");
+    if (!rc && e->scratch.kbins) rc = dev_alloc((void **)&s.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint64_t), false);
     if (!rc) rc = dev_alloc((void **)&s.ovl, (size_t)e->pass_max * sizeof(uint4), false);
     if (!rc) rc = dev_alloc((void **)&s.ovf, (size_t)e->pass_max * sizeof(uint64_t), false);
     if (rc) return rc;
@@ -261,6 +263,7 @@ void lock_pipe_destroy(dint_engine *e) {
     dint_scratch &s = lp.set[k];
     hipFree(s.bin_cnt); hipFree(s.bins); hipFree(std::min(s.blk_pub, s.blk_pub_next)); hipFree(std::min(s.big, s.big_next));
     hipFree(s.bin_off); hipFree(s.ovl); hipFree(s.ovf);
+    if (s.kbins != e->scratch.kbins) hipFree(s.kbins);
   }
 }
 // a lock pass in two halves (DINT_FLAG_INPUTS_READY, dint_submit_device): count + scan / place on the helper stream as soon
@@ -437,12 +440,21 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
       TRY(dev_alloc((void **)&e->scratch.lateq, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint4), false));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
+      // lock tables, passes of <= 65,536 requests (k_locks.hip, LK_DIRECT_NMAX): a big bin's records beyond the 64 in place go
+      // straight to a region of its own -- 1,024 regions (a pass of 65,536 has at most that many bins of more than 64) of
+      // 65,536 records (a bin holds at most the pass): 512 MB of address space, touched as filled.  DINT_LOCK_NO_DIRECT at
+      // creation: not allocated (r01-r05's overflow list + k_kv_scan_place for every pass).
+      if (!getenv("DINT_LOCK_NO_DIRECT")) {
+        e->scratch.kbins_slots = 1024ull * 65536ull;
+        TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint64_t), false));
+      }
     }
     TRY(dev_alloc((void **)&e->scratch.blk_pub, 2 * 1024 * sizeof(uint32_t)));
     e->scratch.blk_pub_next = e->scratch.blk_pub + 1024;
     TRY(dev_alloc((void **)&e->scratch.big, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
     e->scratch.big_next = e->scratch.big + (4 + DINT_KV_PMAX);
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
+    TRY(hipMemset(e->scratch.bin_off, 0xFF, DINT_KV_PMAX * sizeof(uint32_t)) == hipSuccess ? 0 : fail(DINT_EHIP, "hipMemset"));  // (lock tables, direct big bins: "no region named" between passes)
     TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4) * (is_kv ? 2 : 1), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
     if (is_kv) TRY(dev_alloc((void **)&e->scratch.ovf2, (size_t)e->pass_max * sizeof(uint64_t), false));

@@ -13,7 +13,10 @@
 //                        one bin are merged in an LDS hash, so a hot slot costs one device atomic per workgroup -- and
 //                        store the 64-bit record {slot, idx, op} in place (positions < 64) or on the overflow list;
 //                        copy the request bytes to the reply array.
-//   k_kv_scan_place    : ranges of the overflow area for the bins of more than 64 records (shared with the kv passes)
+//                        (passes of <= 65,536 requests: a big bin's records beyond 64 go straight to a region of the bin's
+//                        own, named by whoever took the bin past 64 -- no overflow list, no k_kv_scan_place: two launches;
+//                        the copy also carries every request's DEFAULT reply code, so the resolve kernel stores only grants)
+//   k_kv_scan_place    : larger passes: ranges of the overflow area for the bins of more than 64 records, records placed
 //   k_lock_resolve     : every bin of the pass in one launch.  One wave per bin of <= 64 records: sort by (slot, idx) in
 //                        registers -- slots commute, so any order that keeps each slot's requests in request order is
 //                        serial-equivalent -- fetch every slot's 8-byte word once, resolve all slots of the chunk at
@@ -44,6 +47,7 @@ __device__ static inline uint64_t lk_rec(uint32_t slot, uint32_t idx, uint32_t o
 __device__ static inline uint32_t lk_slot(uint64_t r) { return (uint32_t)(r >> 23); }
 __device__ static inline uint32_t lk_idx(uint64_t r) { return (uint32_t)(r >> 3) & 0xFFFFFu; }
 __device__ static inline uint32_t lk_op(uint64_t r) { return (uint32_t)r & 7u; }
+#define LK_DIRECT_NMAX 65536u  // passes of at most this many requests put a big bin's records beyond 64 straight into its own region (a bin holds at most the pass)
 // exclusive prefix sum over the 64 lanes at VALU speed: four row_shr steps inside the rows of 16, row_bcast:15 / :31 across
 // them (the six dependent ds_bpermute round trips of wave_excl_scan_u32 are 0.4 us -- the mode walk of lock_2pl's dominant
 // slot does one scan per 64 groups)
@@ -69,7 +73,8 @@ template <int WL>  // 0 = lock_fasst, 1 = lock_2pl
 __global__ void __launch_bounds__(KV_TB)
 k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod slots, dint_shard shard, uint32_t pbits,
              uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
-             uint4 *__restrict__ ovl, dint_dev_stats *__restrict__ stats, dint_view V) {
+             uint4 *__restrict__ ovl, dint_dev_stats *__restrict__ stats, dint_view V,
+             uint64_t *__restrict__ bigrec, uint32_t *slot_of) {  // DIRECT big bins (passes of <= LK_DIRECT_NMAX requests), else nullptr
   constexpr uint32_t MSG = WL == 0 ? sizeof(fasst_msg) : sizeof(tpl_msg);
   __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
   __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
@@ -138,7 +143,13 @@ k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod
     if (Hb[sl] != KV_NONE) {
       const uint32_t cnt = Hc[sl], base = atomicAdd(&bin_cnt[Hb[sl]], cnt);
       Hc[sl] = base;
-      if (base <= DINT_KV_BINCAP && base + cnt > DINT_KV_BINCAP) big[4 + atomicAdd(&big[0], 1u)] = Hb[sl];
+      if (base <= DINT_KV_BINCAP && base + cnt > DINT_KV_BINCAP) {  // this run takes the bin past its in-place region: list it
+        const uint32_t k_big = atomicAdd(&big[0], 1u);
+        big[4 + k_big] = Hb[sl];
+        // direct: the bin's position in the list names its region of `bigrec`; published for the workgroups whose runs
+        // landed behind this one (they hold a reservation that only exists because this thread has made its own)
+        if (bigrec) __hip_atomic_store(&slot_of[Hb[sl]], k_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   __syncthreads();
@@ -146,6 +157,22 @@ k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod
   const uint64_t rec = lk_rec(local, i, op);
   const bool over = bin != KV_NONE && mypos >= DINT_KV_BINCAP;
   if (bin != KV_NONE && !over) bins[(size_t)bin * DINT_KV_BINCAP + mypos] = rec;
+  if (bigrec) {
+    // A record beyond the 64 in place goes STRAIGHT to its bin's region -- no overflow list, no k_kv_scan_place between this
+    // kernel and the resolve kernel (r01-r05: 7 us of a 37 us pass).  The region is named by whoever took the bin past 64: a
+    // thread of this kernel that has done its atomic already and publishes right behind it, before any barrier -- the wait
+    // below is a few hundred nanoseconds, and bounded: it traps instead of hanging should that ever not hold.
+    if (over) {
+      uint32_t sl = KV_NONE;
+      for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+        sl = __hip_atomic_load(&slot_of[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sl != KV_NONE) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (sl == KV_NONE) __builtin_trap();
+      bigrec[(size_t)sl * LK_DIRECT_NMAX + (mypos - DINT_KV_BINCAP)] = rec;
+    }
+  } else {
   uint32_t orank = 0;
   if (over) orank = atomicAdd(&Sov[0], 1u);
   __syncthreads();
@@ -153,6 +180,7 @@ k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod
     if (t == 0) Sov[1] = atomicAdd(&big[1], Sov[0]);
     __syncthreads();
     if (over) ovl[Sov[1] + orank] = make_uint4((uint32_t)rec, (uint32_t)(rec >> 32), bin, mypos);
+  }
   }
   // The reply code a request gets UNLESS the table grants it something (Ops::write_reply): every RELEASE / ABORT / COMMIT is
   // acked whatever the table holds, an ACQUIRE is rejected unless granted.  Written here, beside the copy of the request
@@ -378,9 +406,10 @@ static_assert(TPL_HOT_NMAX / 32 * 4 == KVB_NMAX / 4 * 8, "an index bitmap of the
 template <class Ops>
 __device__ static inline void
 lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
-            const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
+            const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, uint32_t *bin_off,
             const uint64_t *__restrict__ ovf, uint32_t hot_min_, uint64_t *trace, const dint_view &V, const uint32_t vb,
-            const uint32_t n_walk) {  // workgroup vb of the n_walk that walk the big-bin list
+            const uint32_t n_walk,  // workgroup vb of the n_walk that walk the big-bin list
+            const uint64_t *__restrict__ bigrec, dint_dev_stats *__restrict__ stats) {  // direct big bins (else nullptr): bin bi of the list owns region bi
   const uint32_t hot_min = hot_min_ & 0x7FFFFFFFu;
   const bool misguess = hot_min_ >> 31;  // DINT_LOCK_MISGUESS (tests): the bitmaps are filled for nobody first, then for the dominant slot
   const uint32_t bin_first = big[4 + vb];  // speculative: in flight together with the list length
@@ -419,7 +448,7 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
     for (uint32_t k = 0; k < 8; k++) cand[k] = lk_slot(recs_lo[8 * k + 3]);
     const uint32_t c = bin_cnt[bin];
     if (tw && threadIdx.x == 0 && bi == vb) { tw[0] = __builtin_amdgcn_s_memrealtime(); tw[8] = c; tw[9] = nbig; }
-    const uint64_t *recs_hi = ovf + bin_off[bin] - DINT_KV_BINCAP;
+    const uint64_t *recs_hi = (bigrec ? bigrec + (size_t)bi * LK_DIRECT_NMAX : ovf + bin_off[bin]) - DINT_KV_BINCAP;
     auto rec_at = [&](uint32_t k) -> uint64_t { return k < DINT_KV_BINCAP ? recs_lo[k] : recs_hi[k]; };
     // ---- the bin's DOMINANT SLOT in a pass of <= 65,536 requests (a lid that hundreds of closed-loop workers keep
     // retrying: most of a big bin is one slot, up to a sixth of a 64k batch) is resolved WITHOUT a sort: every request
@@ -672,7 +701,11 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
       nwin = (c_rest - 1) / wcap + 1;
     }
     __syncthreads();
-    if (t == 0) bin_cnt[bin] = 0;  // every thread has read c
+    if (t == 0) {
+      bin_cnt[bin] = 0;  // every thread has read c
+      bin_off[bin] = KV_NONE;  // ... and where the bin's records beyond 64 were: a direct pass's k_lock_count names a region anew
+      if (bigrec) atomicAdd(&stats->big_bin_requests, (unsigned long long)c);  // (k_kv_scan_place's job otherwise)
+    }
     for (uint32_t win = 0; win < nwin; win++) {
       if (t == 0) { Swn = 0; Snx = 0; }
       __syncthreads();
@@ -949,9 +982,14 @@ lk_big_bins(uint8_t *rep, uint32_t n, uint2 *__restrict__ table, uint32_t *__res
 template <class Ops>
 __global__ void __launch_bounds__(KVB_T)
 k_lock_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
-               const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, const uint32_t *__restrict__ bin_off,
-               const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, dint_view V) {
-  if (blockIdx.x < KVB_GRID) lk_big_bins<Ops>(rep, n, table, bin_cnt, bins, big, bin_off, ovf, hot_min, trace, V, blockIdx.x, KVB_GRID);
+               const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, uint32_t *bin_off,
+               const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, dint_view V,
+               const uint64_t *__restrict__ bigrec, uint32_t *big_next, uint32_t *blk_pub_next, dint_dev_stats *stats) {
+  if (bigrec && blockIdx.x == KVB_GRID) {  // direct passes have no k_kv_scan_place: the next pass's counters, here
+    if (threadIdx.x < 4) big_next[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < 1024; k += KVB_T) blk_pub_next[k] = 0;
+  }
+  if (blockIdx.x < KVB_GRID) lk_big_bins<Ops>(rep, n, table, bin_cnt, bins, big, bin_off, ovf, hot_min, trace, V, blockIdx.x, KVB_GRID, bigrec, stats);
   else lk_small_bin<Ops>(rep, pbits, table, bin_cnt, bins, V, (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6));
 }
 
@@ -967,20 +1005,26 @@ static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *tabl
   const uint32_t P = dint_pick_bins_kv(n);
   uint32_t pbits = 0;
   while ((1u << pbits) < P) pbits++;
+  // DIRECT big bins: a pass of at most LK_DIRECT_NMAX requests on an engine that holds the regions (s.kbins: 1,024 regions of
+  // LK_DIRECT_NMAX records -- a lock engine's `kbins` is this, engine.hip; s.bin_off holds the regions' names, KV_NONE between
+  // passes) is TWO launches: k_lock_count stores a big bin's records beyond 64 straight into its region, the resolve kernel
+  // does what is left of k_kv_scan_place's work.  DINT_LOCK_NO_DIRECT=1: r01-r05's three launches (tests run both).
+  uint64_t *bigrec = s.kbins && n <= LK_DIRECT_NMAX && !getenv("DINT_LOCK_NO_DIRECT") ? (uint64_t *)s.kbins : nullptr;
   if (stages & 1) {
     if (ev) hipEventRecord(ev[0], st);
     hipLaunchKernelGGL((k_lock_count<WL>), dim3((n + KV_TB - 1) / KV_TB), dim3(KV_TB), 0, st, (const uint8_t *)d_req,
-                       (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view);
+                       (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view, bigrec, s.bin_off);
     if (ev) hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
-                       (const uint32_t *)s.big, s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats, (const uint4 *)s.ovl, s.ovf);
+    if (!bigrec)
+      hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
+                         (const uint32_t *)s.big, s.big_next, s.blk_pub_next, (uint32_t *)nullptr, s.stats, (const uint4 *)s.ovl, s.ovf);
   }
   if (stages & 2) {
     if (ev) hipEventRecord(ev[2], st);
     hipLaunchKernelGGL((k_lock_resolve<Ops>), dim3(KVB_GRID + (P + KVB_W - 1) / KVB_W), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits,
-                       table, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, (const uint32_t *)s.bin_off,
+                       table, s.bin_cnt, (const uint64_t *)s.bins, (const uint32_t *)s.big, s.bin_off,
                        (const uint64_t *)s.ovf, dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS) | (getenv("DINT_LOCK_MISGUESS") ? 0x80000000u : 0u),  // (tests: the samples name no slot)
-                       s.lock_trace, view);
+                       s.lock_trace, view, (const uint64_t *)bigrec, s.big_next, s.blk_pub_next, s.stats);
     if (ev) hipEventRecord(ev[3], st);
   }
 }

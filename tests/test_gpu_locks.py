@@ -271,6 +271,35 @@ def test_inputs_ready_passes_overlap_and_match_the_oracle(wl):
             eng.restore()
 
 
+@pytest.mark.parametrize("wl", ["fasst", "tpl"])
+def test_direct_big_bins_and_the_overflow_list_agree(wl, monkeypatch):
+    """a pass of <= 65,536 requests stores a big bin's records beyond the 64 in place straight into a region of its own (two
+    launches); larger passes, and DINT_LOCK_NO_DIRECT, take the overflow list and k_kv_scan_place (three).  One engine goes
+    through both kinds of pass in turn -- the region names must not survive a pass -- and an engine without regions replays
+    the same stream; every reply byte against the oracle."""
+    if wl == "fasst":
+        mk_req, W_, mk = tracegen.fasst_random, wire.Workload.FASST, orc.FasstOracle
+    else:
+        mk_req, W_, mk = tracegen.tpl_random, wire.Workload.TPL, orc.TplOracle
+    sizes = [65536, 200_000, 30_000, 65536, 100_000, 500, 65536]
+    reqs = [mk_req(n, seed=7 + k, n_hot=5, p_hot=0.5) for k, n in enumerate(sizes)]
+    o = mk(1 << 18)
+    want = [o.replay(r) for r in reqs]
+    eng = _engine(W_, n_slots=1 << 18)  # passes of up to 2^20: 200,000 requests are ONE pass (the overflow list), 65,536 a direct one
+    for r, w in zip(reqs, want):
+        assert eng.submit(r).tobytes() == w.tobytes()
+    monkeypatch.setenv("DINT_LOCK_NO_DIRECT", "1")
+    eng2 = _engine(W_, n_slots=1 << 18)
+    for r, w in zip(reqs, want):
+        assert eng2.submit(r).tobytes() == w.tobytes()
+    for e in (eng, eng2):
+        a, b = e.read_locks()
+        if wl == "fasst":
+            assert (a == o.locks).all() and (b == o.vers).all()
+        else:
+            assert (a == o.num_ex).all() and (b == o.num_sh).all()
+
+
 def test_2pl_client_trace_vs_oracle():
     """the lock_2pl client loop (dint_amd.driver.TplClient) against the engine, 64k-request passes; the oracle replays it"""
     from dint_amd.driver import tpl_trace
