@@ -50,6 +50,15 @@ def test_config_struct_layout():
     assert C.sizeof(_lib.Stats) == 8 * 8
 
 
+def test_flag_constants_match_the_header():
+    """the Python mirror of dint_config.flags (dint_amd._lib.FLAG_*) against include/dint_abi.h"""
+    src = open(os.path.join(ROOT, "include", "dint_abi.h")).read()
+    hdr = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define DINT_FLAG_([A-Z_]+) (\d+)u", src)}
+    assert hdr == {"KV_ROUNDS": _lib.FLAG_KV_ROUNDS, "COPY_STREAMS": _lib.FLAG_COPY_STREAMS, "LOCK_SAME_KEY": _lib.FLAG_LOCK_SAME_KEY,
+                   "KV_NO_HOT": _lib.FLAG_KV_NO_HOT, "INPUTS_READY": _lib.FLAG_INPUTS_READY}
+    assert len(set(hdr.values())) == len(hdr) and all(v & (v - 1) == 0 for v in hdr.values())  # distinct single bits
+
+
 def test_product_path_does_not_import_oracle():
     pkg = os.path.join(ROOT, "dint_amd")
     for dp, _, files in os.walk(pkg):
