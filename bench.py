@@ -82,6 +82,12 @@ def parse():
                     help="one switch over the --no-* flags: all = every leg (the driver's run); gpu = no CPU leg (cpu baseline, "
                          "reference, as-shipped servers, UDP shim); headline = the timed region, its kernel times and roofline "
                          "only (what tools/profile_bench.py runs under rocprofv3)")
+    ap.add_argument("--replay", default="inplace", choices=["inplace", "copy"],
+                    help="tatp / smallbank / store replay: inplace = every batch answered in place, as the reference answers a "
+                         "datagram (the receive buffers are refilled from pristine copies outside the timed region: the NIC's DMA); "
+                         "copy = separate reply buffers (r01-r05: the partition kernel copies request -> reply)")
+    ap.add_argument("--no-ahead", action="store_true",
+                    help="tatp / store replay: plain dint_submit_device calls (r05), no dint_submit_device_ahead")
     ap.add_argument("--sweep-clients", action="store_true",
                     help="tatp / smallbank: abort rate and Mtxn/s at 4096 / 32768 / 131072 / 524288 closed-loop clients")
     args = ap.parse_args()
@@ -509,6 +515,7 @@ def bench_lock(args, world, rank, dev, transport, kind):
 
     roof, extra = None, {}
     if rt is None:
+        reset()
         eng.timing_enable(True)
         run(W * B, min(n_batches, W * B + 200))
         sync()
@@ -760,12 +767,21 @@ def bench_store(args, world, rank, dev, transport):
     msg = wire.STORE_MSG.itemsize
     rt = Router([eng], world, rank, n_max=NB) if world > 1 else None
     torch.cuda.synchronize()
+    # r06: the replay answers in place (store/udp/server.cc:75-97 mutates the received struct) and announces the next batch
+    inplace, ahead = args.replay == "inplace" and rt is None, not args.no_ahead and rt is None
+
+    def reset():  # the receive buffers hold the pristine requests again (outside every timed region: the NIC's DMA)
+        if inplace:
+            d_rep.copy_(d_req)
+            torch.cuda.synchronize()
 
     def run(lo, hi):
+        src = d_rep if inplace else d_req
         for b in range(lo, hi):
             o = b * NB * msg
             if rt is None:
-                eng.submit_device(d_req.data_ptr() + o, NB, d_rep.data_ptr() + o, 0)
+                nxt = (src.data_ptr() + o + NB * msg, NB, d_rep.data_ptr() + o + NB * msg) if ahead and b + 1 < hi else None
+                eng.submit_device(src.data_ptr() + o, NB, d_rep.data_ptr() + o, 0, ahead=nxt)
             else:
                 rt.step([d_req.data_ptr() + o], [NB], [d_rep.data_ptr() + o])
 
@@ -775,6 +791,7 @@ def bench_store(args, world, rank, dev, transport):
         eng.sync()
         torch.cuda.synchronize()
 
+    reset()
     run(0, W * B)
     sync()
     barrier(world)
@@ -784,6 +801,7 @@ def bench_store(args, world, rank, dev, transport):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, transport)
     got = d_rep.cpu().numpy()
+    reset()
     lat = []
     for b in range(W * B, min(n_batches, W * B + 100)):
         sync()
@@ -850,7 +868,7 @@ def bench_store(args, world, rank, dev, transport):
     if rt is None and not args.no_mixes:
         n_s = min(len(stream), 8 * NB)
         eng.restore()
-        eng.submit_device(d_req.data_ptr(), n_s, d_rep.data_ptr(), 0)
+        eng.submit_device(d_req.data_ptr(), n_s, d_rep.data_ptr(), 0)  # (several passes: they look ahead at each other)
         sync()
         for name, p_set in (("100/0", 0.0), ("50/50", 0.5)):
             ms = store_stream(NB * 16, n_sub, theta, 991 + rank, p_set)
@@ -873,7 +891,8 @@ def bench_store(args, world, rank, dev, transport):
         "dtype": "u64", "data": "synthetic", "mixes": mixes or None,
         "config": {"workload": f"store KV on {world} MI355X: {n_sub * 12} keys x 40-B values, 95/5 read/write, "
                                f"s_id ~ Zipf-{theta}, {NB}-request batches; 1 step = {B} batches", "keys": n_sub * 12, "batch": NB,
-                   "batches_per_step": B, "parallelism": f"hash-shard x{world}", "transport": transport},
+                   "batches_per_step": B, "parallelism": f"hash-shard x{world}", "transport": transport,
+                   "replay": "in place" if inplace else "separate reply buffers", "look_ahead": bool(ahead)},
         "latency_us": {"p50": pct(lat, 50), "p99": pct(lat, 99), "what": "one batch, submit -> replies in HBM"},
         "roofline": roof, "cpu_baseline": cpu, "setup_s": round(t_setup, 2), **extra,
     }
@@ -1104,7 +1123,10 @@ def bench_txn(args, world, rank, dev, transport, kind):
     grp.sync()
     grp.snapshot()
     drv = Driver(wl, C, n_rows, first_client=rank * C, zipf_theta=zipf)
-    rp, done, _ = Replay.recording(drv, grp, E1)  # the closed loop, once, through the real engines; every epoch stays in HBM
+    # the closed loop, once, through the real engines; every epoch stays in HBM.  The replay answers in place and announces
+    # every next batch (r06; --replay copy --no-ahead = r05's replay); through the exchange the batches are routed copies anyway
+    inplace = args.replay == "inplace" and grp.router is None
+    rp, done, _ = Replay.recording(drv, grp, E1, inplace=inplace, ahead=not args.no_ahead and grp.router is None)
     stats = drv.stats()
     grp.sync()
     caps = grp.router.tighten_caps() if grp.router is not None else None  # slot capacities from the recorded maxima
@@ -1118,10 +1140,12 @@ def bench_txn(args, world, rank, dev, transport, kind):
     # recording's start again, the W warm-up steps, the K timed steps.
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.3:
+        rp.reset(0, max(1, E0))
         rp.run(grp, 0, max(1, E0))
         grp.sync()
         grp.restore()
     grp.sync()
+    rp.reset()  # (in-place replay: the receive buffers hold the pristine requests again -- before the clock starts)
     rp.run(grp, 0, E0)
     grp.sync()
     barrier(world)
@@ -1153,6 +1177,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
     repeats = []
     for _ in range(0 if compact else 4):
         grp.restore()
+        rp.reset()
         rp.run(grp, 0, E0)
         grp.sync()
         barrier(world)
@@ -1164,6 +1189,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
 
     # per-epoch latency, device side: submit of the three batches -> all replies visible in HBM
     grp.restore()
+    rp.reset()
     lat = []
     for e in range(min(E1, 120)):
         grp.sync()
@@ -1176,14 +1202,21 @@ def bench_txn(args, world, rank, dev, transport, kind):
     roof, extra = None, {}
     if world == 1 and grp.router is None:
         grp.restore()
+        rp.reset()
         for e in grp.engines:
             e.timing_enable(True)
         n_t = min(E1, 200)
-        big0 = sum(e.stats()["big_bin_requests"] for e in grp.engines)
+        st0 = [e.stats() for e in grp.engines]
+        big0 = sum(x["big_bin_requests"] for x in st0)
         rp.run(grp, 0, n_t)
         grp.sync()
         tims = [e.timing_read() for e in grp.engines]
-        big_req = sum(e.stats()["big_bin_requests"] for e in grp.engines) - big0
+        st1 = [e.stats() for e in grp.engines]
+        big_req = sum(x["big_bin_requests"] for x in st1) - big0
+        # what no closed form of k_kv_hot covered (the slow passes): requests, and work items by kind {sub as listed, solo, pieces}
+        extra["late"] = {"requests": sum(b["late_requests"] - a["late_requests"] for a, b in zip(st0, st1)),
+                         "items_by_kind": [sum(b["late_items"][k] - a["late_items"][k] for a, b in zip(st0, st1)) for k in range(3)],
+                         "passes": 3 * n_t}
         for e in grp.engines:
             e.timing_enable(False)
         names = list(tims[0].keys())
@@ -1214,18 +1247,29 @@ def bench_txn(args, world, rank, dev, transport, kind):
             return {"kernel": name, "kernel_avg_us": round(us, 3), "alg_bytes_per_launch": int(nbytes / L),
                     "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
 
-        stage = priced("k_kv_resolve+k_kv_hot+k_kv_big", t_res + t_big, tab_b)
+        if rp.ahead:
+            # look-ahead replay (r06): a pass's chain is k_kv_resolve -> k_kv_hot_part (its hot keys AND the next batch's
+            # partition) -> k_kv_big (empty); the engine's "k_kv_hot" interval is that fused launch, "k_kv_part" only the first
+            # pass's.  The priced stage is therefore the WHOLE pass: every algorithmic byte over the whole chain.
+            stage = priced("k_kv_resolve+k_kv_hot_part+k_kv_big", t_part + t_res + t_big, tab_b + part_b)
+        else:
+            stage = priced("k_kv_resolve+k_kv_hot+k_kv_big", t_res + t_big, tab_b)
         # `traffic` is not measured inside this run (rocprofv3 cannot attach to itself): null here; the PMC figures of
         # the same command live in profiles/ and are quoted under from_profile only for the same kernel sources
         roof = {"bound": "hbm", **stage, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "requests_in_big_bins": round(f_big, 4),
-                "from_profile": profile_counters(kind, ["k_kv_resolve", "k_kv_hot", "k_kv_big"])}
+                "from_profile": profile_counters(kind, ["k_kv_resolve", "k_kv_hot_part", "k_kv_hot", "k_kv_big"] +
+                                                 (["k_kv_part"] if rp.ahead else []))}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
-            roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, tab_b / L), 3)
-        roof["kernels"] = [priced("k_kv_part", t_part, part_b), priced("k_kv_resolve", t_res, tab_b * (1.0 - f_big)),
-                           priced("k_kv_hot+k_kv_big", t_big, tab_b * f_big)]
+            roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, stage["alg_bytes_per_launch"]), 3)
+        if rp.ahead:
+            roof["kernels"] = [priced("k_kv_part (first pass only)", t_part, 0), priced("k_kv_resolve", t_res, tab_b * (1.0 - f_big)),
+                               priced("k_kv_hot_part+k_kv_big", t_big, tab_b * f_big + part_b)]
+        else:
+            roof["kernels"] = [priced("k_kv_part", t_part, part_b), priced("k_kv_resolve", t_res, tab_b * (1.0 - f_big)),
+                               priced("k_kv_hot+k_kv_big", t_big, tab_b * f_big)]
         # the whole pass of one engine: all its algorithmic bytes over the serial chain of its three kernels (events on the
         # engine's stream, launch gaps included) -- what bounds a step, which is one engine's chain
         chain = t_part + t_res + t_big
@@ -1237,6 +1281,9 @@ def bench_txn(args, world, rank, dev, transport, kind):
         roof["gpu"] = {"alg_bytes_per_request": round(alg_all, 1), "achieved": round(ops / dt * alg_all / 1e9, 2),
                        "frac": round(ops / dt * alg_all / 1e9 / HBM_PEAK_GBS, 5),
                        "what": "requests/s of the timed region x mean algorithmic bytes per request / 8 TB/s"}
+        # (scalar copies: the driver's record of the line keeps the scalars of `roofline`, not its nested objects)
+        roof["pass_chain_us"], roof["pass_frac"] = roof["pass"]["chain_us"], roof["pass"]["frac"]
+        roof["gpu_achieved"], roof["gpu_frac"] = roof["gpu"]["achieved"], roof["gpu"]["frac"]
 
     # ---- the closed loop itself, resident on the GPU: the same clients as device code emit the same
     # stream (tests/test_gpu_gdriver.py), the engines read the batch sizes on the device, nothing crosses PCIe
@@ -1315,6 +1362,9 @@ def bench_txn(args, world, rank, dev, transport, kind):
         u_what = ("bucket header sector per table request + 1.5 value sectors when a row is read or written; log appends are sequential"
                   if kind == "tatp" else "bucket header sector + the sector of the four values and the counters, per table request")
         rand_roofline(extra, ops / dt, dev, txn_U(kind, rp, E0, min(E1, E0 + 32)), u_what, eng_table_gb(grp.engines[0], 3))
+        r64 = extra.get("roofline_rand64")
+        if roof is not None and r64:  # the north star's own fraction, where the driver's record keeps it
+            roof["rand64_frac"], roof["rand64_U"], roof["rand64_gathers_per_s"] = r64["frac"], r64["U"], r64["gathers_per_s"]
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline_txn(kind, rp, done, n_rows, E0, min(E1, E0 + (12 if compact else 60)))
@@ -1331,6 +1381,7 @@ def bench_txn(args, world, rank, dev, transport, kind):
                 cpu["reference"] = r
             else:
                 r["port_on_bench_config"] = cpu
+                r["port_on_bench_config_value"] = cpu.get("value")
                 cpu = r
         if shipped is not None:
             shipped.close()
@@ -1374,7 +1425,16 @@ def bench_txn(args, world, rank, dev, transport, kind):
                    "scaling_rule": ("--subscribers is PER GPU since r04 (rows = subscribers x N: weak scaling of clients and rows)"
                                     if kind == "tatp" else "--accounts is the TOTAL over all GPUs (default 10M per GPU = configs[4]'s 80M on 8)"),
                    "requests_per_step": round(ops / K / world), "parallelism": f"3 shard servers x hash-shard x{world}",
-                   "transport": transport, "exchange_slot_caps": caps},
+                   "transport": transport, "exchange_slot_caps": caps,
+                   "replay": ("every batch answered IN PLACE (the reply is the request struct mutated, tatp/udp/server_shard.cc:116-121); the "
+                              "receive buffers are refilled from pristine copies outside the timed region" if rp.inplace else
+                              "separate reply buffers (the partition kernel copies request -> reply)"),
+                   "look_ahead": bool(rp.ahead),
+                   # scalar copies of the legs the north star is judged on (the driver's record keeps `config`'s scalars)
+                   "goodput_Mtxn_s": round(value * commit_rate, 3),
+                   "closed_loop_Mtxn_s": closed["value"] if closed else None,
+                   "value_pcie_Mtxn_s": host.get("value_pcie"),
+                   "latency_p50_us": pct(lat, 50), "latency_p99_us": pct(lat, 99)},
         "Mops_s": round(ops / dt / 1e6, 3), "ops_per_txn": round(ops / max(1.0, txns), 3), "ms_per_epoch": round(dt / (E1 - E0) * 1e3, 5),
         # the reference client's two rates (tatp/caladan/client_udp_shard.cc:102-103): throughput = finished
         # transactions, goodput = committed ones (a NOT_EXIST read of a row the population never made counts as not
@@ -1468,7 +1528,7 @@ def parity_failures(out, path=""):
             if k in ("oracle_parity", "reference_parity") and isinstance(v, dict) and v.get("ok") is False:
                 bad.append(p)
             elif k in ("pcie_parity_ok", "replay_equals_recorded", "equals_host_driver_run", "equals_host_run_of_two_drivers",
-                       "replies_equal_64k_batches") and v is False:
+                       "replies_equal_64k_batches", "replies_equal") and v is False:
                 bad.append(p)
             elif k == "error" and path.startswith("other_workloads"):
                 bad.append(p)
@@ -1511,6 +1571,7 @@ def main():
             ex["what"] = "--force-exchange on one GPU: the routing kernels and both exchange legs (device copies) around the same passes"
             if out is not None and out.get("value"):
                 ex["ratio_to_value"] = round(r["value"] / out["value"], 3)
+                out["config"]["exchange_Mtxn_s"], out["config"]["exchange_ratio_to_value"] = r["value"], ex["ratio_to_value"]
         except Exception as e_:
             ex = {"error": f"{type(e_).__name__}: {e_}"}
         gc.collect()

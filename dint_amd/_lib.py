@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdint.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 #: dint_config.flags (include/dint_abi.h)
 FLAG_KV_ROUNDS, FLAG_COPY_STREAMS, FLAG_LOCK_SAME_KEY, FLAG_KV_NO_HOT, FLAG_INPUTS_READY = 1, 2, 4, 8, 16
 MICRO_BATCH = 65536
@@ -25,7 +25,7 @@ SYMBOLS = [
     "dint_submit_async", "dint_wait", "dint_alloc_pinned", "dint_free_pinned", "dint_engine_stream", "dint_max_pass",
     "dint_stream_wait", "dint_stream_signal", "dint_route_pack", "dint_route_unpack", "dint_submit_segments",
     "dint_log_drain", "dint_refuse", "dint_route_pack_multi", "dint_route_unpack_multi", "dint_bench_access", "dint_selftest",
-    "dint_submit_segments_multi",
+    "dint_submit_segments_multi", "dint_submit_device_ahead",
 ]
 
 
@@ -49,7 +49,8 @@ class Stats(C.Structure):
     _fields_ = [
         ("batches", C.c_uint64), ("requests", C.c_uint64), ("bad_requests", C.c_uint64),
         ("missing_keys", C.c_uint64), ("foreign_requests", C.c_uint64), ("pool_exhausted", C.c_uint64),
-        ("route_overflow", C.c_uint64), ("big_bin_requests", C.c_uint64),
+        ("route_overflow", C.c_uint64), ("big_bin_requests", C.c_uint64), ("late_requests", C.c_uint64),
+        ("reserved", C.c_uint64 * 3),
     ]
 
 
@@ -92,6 +93,7 @@ def load() -> C.CDLL:
         "dint_last_error": (C.c_char_p, []),
         "dint_submit": (C.c_int, [vp, vp, u32, vp]),
         "dint_submit_device": (C.c_int, [vp, vp, u32, vp, vp]),
+        "dint_submit_device_ahead": (C.c_int, [vp, vp, u32, vp, vp, u32, vp, vp]),
         "dint_sync": (C.c_int, [vp]),
         "dint_load_rows": (C.c_int, [vp, u32, vp, vp, vp, u64]),
         "dint_populate": (C.c_int, [vp, u64]),

@@ -13,6 +13,8 @@ struct dint_dev_stats {
   unsigned long long pool_exhausted;
   unsigned long long route_overflow;  // requests dropped by dint_route_pack: a destination slot was full
   unsigned long long big_bin_requests;  // requests resolved by the big-bin workgroups (bins of > 64 records)
+  unsigned long long late_requests;     // store / tatp: requests k_kv_hot's closed forms left to the general path (k_kv_late / k_kv_big)
+  unsigned long long late_items[3];     // ... the work items they came from, by kind: a sub listed as it was / a solo item / the pieces of a hot key
 };
 
 // scratch shared by every workload: bins of batch records

@@ -8,7 +8,7 @@
 #include "dint_kv_core.h"
 
 #define DINT_KV_MAX_TABLES 5
-#define DINT_KV_CTL_BYTES (64 + 16 * KV_NLISTS)  // per table: pool_top, free_head[], pend_head[]
+#define DINT_KV_CTL_BYTES (64 + 24 * KV_NLISTS)  // per table: pool_top, free_head[], pend_head[2][] (two sets: dint_kv_core.h, kv_pool_rotate)
 #define DINT_KV_TRACE_WORDS ((size_t)DINT_KV_PMAX * 16 + 16 * 8192)  // per bin 16 words, then per workgroup 16
 #define DINT_KV_LOAD_OP 0xF0u  // internal request type: insert a row with the version carried in msg.ver
 
@@ -23,6 +23,27 @@ struct kv_dev {
   uint32_t same_key;  // tatp, DINT_FLAG_LOCK_SAME_KEY: lock slots remember their owner's key (tatp/ebpf/lock_kern.c)
 };
 
+// Tuning / test knobs of the kv passes, read from the environment ONCE, when the engine is created (r01-r05 read them with
+// getenv at every launch -- ten per pass; VERDICT / ADVICE r05).  Tests set the variable before they create their engine.
+struct dint_kv_knobs {
+  uint32_t coarse_load = 512;   // DINT_KV_COARSE_LOAD: records per coarse bin
+  uint32_t cap = 0;             // DINT_KV_CAP: records a coarse bin holds in place (0 = cap_mult x the mean load + 64)
+  uint32_t lcap = 1024;         // DINT_KV_LCAP: records of a bin's small subs resolved from LDS
+  uint32_t cap_mult = 64;       // DINT_KV_CAP_MULT
+  uint32_t rpt = 0;             // DINT_KV_RPT: requests per thread of k_kv_part (0 = by pass size)
+  uint32_t no_bm = 0;           // DINT_KV_NO_BM: kv_big_bin sorts where it would rank by index bitmap
+  uint32_t hot_min = 0;         // DINT_KV_HOT_MIN
+  uint32_t no_split = 0;        // DINT_KV_NO_SPLIT: r04's kv_big_bin for every big sub
+  uint32_t split_min = 65;      // DINT_KV_SPLIT_MIN
+  uint32_t split_target = 384;  // DINT_KV_SPLIT_TARGET
+  uint32_t one_big_kernel = 0;  // DINT_KV_ONE_BIG_KERNEL: no k_kv_hot launch
+  uint32_t no_ahead = 0;        // DINT_KV_NO_AHEAD: never run a pass's partition beside the previous pass's hot keys
+  uint32_t late_grid = 8;       // DINT_KV_LATE_GRID: workgroups of the k_kv_big launch behind k_kv_hot (DINT_KV_LATE_BIG)
+  uint32_t exp_no_late = 0;     // DINT_EXP_NO_LATE: experiments only -- no launch behind k_kv_hot at all (late items stay unanswered)
+  uint32_t late_fat = 0;        // DINT_KV_LATE_FAT: k_kv_late at 256 VGPRs (no spills, but its workgroups want an empty compute unit)
+  uint32_t late_big = 0;        // DINT_KV_LATE_BIG: what k_kv_hot leaves goes to k_kv_big (r05) instead of k_kv_late
+};
+
 struct dint_kv {
   uint32_t workload = 0;
   uint32_t n_tables = 0;
@@ -34,6 +55,7 @@ struct dint_kv {
   uint8_t *d_ctl = nullptr;  // pool_top / free_head / pend_head words of all tables
   uint64_t *d_trace = nullptr;  // DINT_KV_TRACE=1: [DINT_PMAX][16] per-wave s_memtime stamps of the last resolve launch
   size_t entry_bytes[DINT_KV_MAX_TABLES] = {0, 0, 0, 0, 0};
+  dint_kv_knobs knobs;
 };
 
 // records a coarse bin of a kv pass holds IN PLACE, in units of the mean load of a bin (engine.hip sizes the scratch for it,
@@ -54,8 +76,19 @@ int64_t dint_kv_read_locks(dint_kv *kv, uint32_t table, uint32_t *a, uint32_t *b
 // one pass (n <= DINT_MICRO and, when a log is attached, n <= log.cap).  load_mode: accept DINT_KV_LOAD_OP
 // rows and ignore rows of other shards silently.
 // `view`: where request i lives (contiguous array, or the segments of a multi-GPU exchange buffer)
+// Look-ahead (r06; store / tatp): `next` = the batch of the engine's NEXT pass, complete in device memory in the order of
+// `st`: its partition stage (k_kv_part: no table access) then runs in ONE launch with this pass's hot keys (k_kv_hot_part),
+// and that next pass is launched with part_done = true.  dint_kv_ahead_ok says whether a pass of this engine can take one.
+struct dint_kv_ahead {
+  const void *d_req;
+  void *d_rep;
+  uint32_t n;
+  dint_view view;
+};
+bool dint_kv_ahead_ok(const dint_kv &kv, int load_mode);
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
-                    int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view = dint_flat_view());
+                    int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view = dint_flat_view(),
+                    bool part_done = false, const dint_kv_ahead *next = nullptr);
 // the passes of several engines of one kv workload in one launch set (grid.y = engine), all on one stream: what a
 // closed-loop epoch or an exchange step hands the GPU's shard servers at the same moment (n > 0 for every engine)
 #define DINT_KV_MULTI_MAX 4u

@@ -150,14 +150,23 @@ KV_HD static inline void kv_pool_free(const kv_tab &t, uint32_t link, uint32_t l
   }
   // give up: the entry leaks (bounded spin, never reached in practice)
 }
-// pass boundary (one thread per list, no pass in flight): entries freed during earlier passes become poppable
+// Pass boundary (one thread per list): entries freed during EARLIER passes become poppable.  The device keeps TWO sets of
+// pend lists and a pass pushes its frees to set (pass number & 1) (k_kv.hip: kv_dev_to_lds), so the set a pass is about to
+// push to -- `ph_off` = that set's offset in lists -- holds frees of the pass before the previous one and older: nobody
+// pushes to it while it is rotated, also when this pass's partition kernel runs beside the previous pass's hot-key kernels
+// (r06: k_kv_hot_part).  A free list is only ever rotated INTO when it is empty, through a CAS: a concurrent pop of an empty
+// list fails and bump-allocates, so pops of the previous pass beside the rotation are safe.  (Host build: one set, offset 0.)
 template <class M>
-KV_HD static inline void kv_pool_rotate(const kv_tab &t, uint32_t lst) {
-  unsigned long long *fh = t.free_head + lst, *ph = t.pend_head + lst;
-  const unsigned long long f = *fh, p = *ph;
+KV_HD static inline void kv_pool_rotate(const kv_tab &t, uint32_t lst, uint32_t ph_off = 0) {
+  unsigned long long *fh = t.free_head + lst, *ph = t.pend_head + ph_off + lst;
+  const unsigned long long f = M::load64(fh), p = M::load64(ph);
   if ((uint32_t)f == KV_NULL && (uint32_t)p != KV_NULL) {
-    *fh = ((f >> 32) + 1ull) << 32 | (uint32_t)p;
-    *ph = ((p >> 32) + 1ull) << 32;
+    if (M::cas64(ph, p, ((p >> 32) + 1ull) << 32)) {  // (nobody pushes to this set now; the CAS only keeps the tag discipline)
+      if (!M::cas64(fh, f, ((f >> 32) + 1ull) << 32 | (uint32_t)p)) {
+        // the free list changed under us (cannot happen: only a rotation writes an empty list) -- put the chain back
+        M::cas64(ph, ((p >> 32) + 1ull) << 32, ((p >> 32) + 2ull) << 32 | (uint32_t)p);
+      }
+    }
   }
 }
 

@@ -125,6 +125,14 @@ struct dint_engine {
 
   // kv workloads (store / tatp / smallbank)
   dint_kv kv{};
+  // look-ahead (r06, store / tatp): the batch whose partition stage ran inside the previous pass's k_kv_hot_part -- the
+  // engine's next pass MUST be this one (its log records are in the ring, its records in the coarse bins)
+  struct Ahead {
+    bool valid = false;
+    const void *req = nullptr;
+    void *rep = nullptr;
+    uint32_t n = 0;
+  } ahead;
 
   // snapshot
   std::vector<std::pair<void *, size_t>> regions;  // device regions making up the engine state
@@ -291,8 +299,41 @@ int run_lock_pass_piped(dint_engine *e, const void *d_req, uint32_t n, void *d_r
   return 0;
 }
 
+// An announced batch (dint_submit_device_ahead) that will not be submitted after all: its partition stage has filled the
+// coarse bins and the control words of the next pass -- drain the GPU and leave the pass scratch as between passes.  What
+// the stage wrote outside the scratch stays: the announced batch's log records (the ring is about to be restored or reset
+// by the callers that cancel silently; the others report DINT_ESTATE).
+int ahead_cancel(dint_engine *e) {
+  if (!e->ahead.valid) return 0;
+  e->ahead.valid = false;
+  HIP_TRY(hipDeviceSynchronize());
+  dint_scratch &s = e->scratch;
+  HIP_TRY(hipMemset(s.bin_cnt, 0, DINT_KV_PMAX * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(std::min(s.big, s.big_next), 0, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(std::min(s.blk_pub, s.blk_pub_next), 0, 2 * 1024 * sizeof(uint32_t)));
+  if (e->log.tail) {  // the tail the cancelled partition published is not the current one
+    uint32_t t[4];
+    HIP_TRY(hipMemcpy(t, e->log.tail, sizeof t, hipMemcpyDeviceToHost));
+    uint64_t appended = (uint64_t)t[2] | ((uint64_t)t[3] << 32);
+    appended -= std::min<uint64_t>(appended, (t[1] + e->log.cap - t[0]) % e->log.cap);
+    t[1] = t[0]; t[2] = (uint32_t)appended; t[3] = (uint32_t)(appended >> 32);
+    HIP_TRY(hipMemcpy(e->log.tail, t, sizeof t, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
 int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStream_t st, int load_mode = 0,
-             const dint_view &view = dint_flat_view(), bool inputs_ready = false) {
+             const dint_view &view = dint_flat_view(), bool inputs_ready = false, const dint_kv_ahead *next = nullptr) {
+  bool part_done = false;
+  if (e->ahead.valid) {  // the pass that was announced, and nothing else
+    if (e->ahead.req != d_req || e->ahead.rep != d_rep || e->ahead.n != n || view.seg_cap || load_mode) {
+      if (int rc = ahead_cancel(e)) return rc;
+      return fail(DINT_ESTATE, "the batch announced by dint_submit_device_ahead (%u requests at %p) must be the engine's next "
+                               "submission; its log records are appended already", e->ahead.n, e->ahead.req);
+    }
+    e->ahead.valid = false;
+    part_done = true;
+  }
   if (int rc = order_stream(e, st)) return rc;
   const bool piped = inputs_ready && n && !e->timer.on && (e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL);
   if (!piped) e->lp.after_serial = true;
@@ -324,9 +365,14 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_TATP:
     case DINT_WL_SMALLBANK:
       if (int rc = next_pass_seq(e, st)) return rc;  // tags what the pieces of a hot key publish in this pass
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names), view);
+      if (next && (!n || !next->n || view.seg_cap || next->view.seg_cap || !dint_kv_ahead_ok(e->kv, load_mode))) next = nullptr;
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names), view, part_done, next);
       std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
       std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
+      if (next) {
+        e->ahead.valid = true;
+        e->ahead.req = next->d_req; e->ahead.rep = next->d_rep; e->ahead.n = next->n;
+      }
       break;
     default:
       return fail(DINT_EINVAL, "bad workload");
@@ -415,8 +461,11 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
   const uint32_t wl = cfg->workload;
   const bool is_kv = wl == DINT_WL_STORE || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK;
   // requests per kernel pass: the request index must fit the batch record (20 bits)
-  e->pass_max = DINT_KV_PASS;
-  if (cfg->max_pass) e->pass_max = std::min<uint32_t>(e->pass_max, std::max<uint32_t>(cfg->max_pass, 64u));
+  // The lock tables default to BASELINE's batch size: their dominant-slot path (index bitmaps, k_locks.hip) covers passes of
+  // up to 65,536 requests, and a longer pass runs 3x (lock_fasst) to 16x (lock_2pl) slower PER REQUEST on a Zipf stream (r05
+  // bench, pass_1m) -- so a dint_submit of a million requests is sixteen passes unless the caller asks for longer ones.
+  e->pass_max = (wl == DINT_WL_FASST || wl == DINT_WL_2PL) ? DINT_MICRO_BATCH : DINT_KV_PASS;
+  if (cfg->max_pass) e->pass_max = std::min<uint32_t>(DINT_KV_PASS, std::max<uint32_t>(cfg->max_pass, 64u));
   if (wl == DINT_WL_LOG || wl == DINT_WL_TATP || wl == DINT_WL_SMALLBANK) {
     // a pass never laps the log ring, so a DELETE_LOG record keeps the val bytes of the record it overwrites
     // exactly as in the serial reference
@@ -554,20 +603,44 @@ void dint_engine_destroy(dint_engine_t *e) {
   delete e;
 }
 
-int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, void *stream) {
-  if (!e || (n && (!d_reqs || !d_replies))) return fail(DINT_EINVAL, "null argument");
-  std::lock_guard<std::mutex> lk(e->mu);
+namespace {
+int submit_device_locked(dint_engine *e, const void *d_reqs, uint32_t n, void *d_replies, const void *d_next_reqs, uint32_t next_n,
+                         void *d_next_replies, void *stream) {
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t st = stream ? (hipStream_t)stream : e->stream;
   const uint8_t *rq = (const uint8_t *)d_reqs;
   uint8_t *rp = (uint8_t *)d_replies;
+  if (n == 0 && e->ahead.valid) return run_pass(e, d_reqs, 0, d_replies, st);  // (reports the broken announcement)
   for (uint32_t off = 0; off < n; off += e->pass_max) {
     uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
+    // what the engine's next pass will be: the next slice of this array (stream order has it complete: the whole array
+    // precedes this call) -- or the first pass of the batch the caller announced
+    dint_kv_ahead nx = {nullptr, nullptr, 0, dint_flat_view()};
+    if (off + m < n) {
+      nx.d_req = rq + (size_t)(off + m) * e->msg_size; nx.d_rep = rp + (size_t)(off + m) * e->msg_size;
+      nx.n = std::min<uint32_t>(e->pass_max, n - off - m);
+    } else if (next_n) {
+      nx.d_req = d_next_reqs; nx.d_rep = d_next_replies; nx.n = std::min<uint32_t>(e->pass_max, next_n);
+    }
     int rc = run_pass(e, rq + (size_t)off * e->msg_size, m, rp + (size_t)off * e->msg_size, st, 0, dint_flat_view(),
-                      (e->cfg.flags & DINT_FLAG_INPUTS_READY) != 0);
+                      (e->cfg.flags & DINT_FLAG_INPUTS_READY) != 0, e->kv.n_tables && nx.n ? &nx : nullptr);
     if (rc) return rc;
   }
   return 0;
+}
+}  // namespace
+
+int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, void *stream) {
+  if (!e || (n && (!d_reqs || !d_replies))) return fail(DINT_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  return submit_device_locked(e, d_reqs, n, d_replies, nullptr, 0, nullptr, stream);
+}
+
+int dint_submit_device_ahead(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, const void *d_next_reqs,
+                             uint32_t next_n, void *d_next_replies, void *stream) {
+  if (!e || (n && (!d_reqs || !d_replies)) || (next_n && (!d_next_reqs || !d_next_replies))) return fail(DINT_EINVAL, "null argument");
+  std::lock_guard<std::mutex> lk(e->mu);
+  return submit_device_locked(e, d_reqs, n, d_replies, d_next_reqs, next_n, d_next_replies, stream);
 }
 
 int dint_submit_segments(dint_engine_t *e, void *d_base, uint32_t n_seg, uint32_t seg_cap, uint64_t seg_stride,
@@ -626,6 +699,11 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
   for (dint_engine *e : es) locks.emplace_back(e->mu);  // address order: two calls that share engines cannot deadlock
   HIP_TRY(hipSetDevice(items[0].engine->device));
   dint_kv_pass pass[DINT_KV_MULTI_MAX];
+  for (uint32_t k = 0; k < n_items; k++)
+    if (items[k].engine->ahead.valid) {
+      if (int rc = ahead_cancel(items[k].engine)) return rc;
+      return fail(DINT_ESTATE, "a batch announced by dint_submit_device_ahead must be the engine's next submission");
+    }
   for (uint32_t k = 0; k < n_items; k++) {
     const dint_segments_item &it = items[k];
     dint_engine *e = it.engine;
@@ -1053,6 +1131,8 @@ int dint_get_stats(dint_engine_t *e, dint_stats *out) {
   out->pool_exhausted = d.pool_exhausted;
   out->route_overflow = d.route_overflow;
   out->big_bin_requests = d.big_bin_requests;
+  out->late_requests = d.late_requests;
+  for (int k = 0; k < 3; k++) out->reserved[k] = d.late_items[k];  // (diagnostic: late work items by kind -- sub / solo / pieces)
   return 0;
 }
 
@@ -1061,6 +1141,7 @@ int dint_reset(dint_engine_t *e) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (int rc = ahead_cancel(e)) return rc;
   for (auto &r : e->regions) HIP_TRY(hipMemset(r.first, 0, r.second));
   e->batches = e->requests = 0;
   e->log_drained = 0;
@@ -1075,6 +1156,7 @@ int dint_snapshot(dint_engine_t *e) {
   std::lock_guard<std::mutex> lk(e->mu);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (e->ahead.valid) return fail(DINT_ESTATE, "a batch announced by dint_submit_device_ahead is pending (its log records are appended)");
   if (e->snap.empty()) {
     for (auto &r : e->regions) {
       void *p = nullptr;
@@ -1096,6 +1178,7 @@ int dint_restore(dint_engine_t *e) {
   if (e->snap.empty()) return fail(DINT_ESTATE, "no snapshot taken");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
+  if (int rc = ahead_cancel(e)) return rc;
   for (size_t i = 0; i < e->regions.size(); i++)
     HIP_TRY(hipMemcpy(e->regions[i].first, e->snap[i], e->regions[i].second, hipMemcpyDeviceToDevice));
   HIP_TRY(hipDeviceSynchronize());

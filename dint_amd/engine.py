@@ -93,10 +93,17 @@ class Engine:
         _lib.check(self._L.dint_submit(self._h, reqs.ctypes.data, n, out.ctypes.data))
         return out
 
-    def submit_device(self, d_reqs, n: int, d_replies=None, stream: int = 0) -> None:
-        """Enqueue a batch that already lives in HBM (asynchronous)."""
+    def submit_device(self, d_reqs, n: int, d_replies=None, stream: int = 0, ahead=None) -> None:
+        """Enqueue a batch that already lives in HBM (asynchronous).  `ahead` = (d_reqs, n, d_replies) of the engine's NEXT
+        submit_device call, complete in HBM already (dint_submit_device_ahead: its partition stage runs beside this batch's
+        hot keys; that call must follow, with exactly these buffers)."""
         d_replies = d_reqs if d_replies is None else d_replies
-        _lib.check(self._L.dint_submit_device(self._h, _ptr(d_reqs), n, _ptr(d_replies), stream))
+        if ahead is None or not ahead[1]:
+            _lib.check(self._L.dint_submit_device(self._h, _ptr(d_reqs), n, _ptr(d_replies), stream))
+        else:
+            nq, nn, nr = ahead
+            _lib.check(self._L.dint_submit_device_ahead(self._h, _ptr(d_reqs), n, _ptr(d_replies), _ptr(nq), nn,
+                                                        _ptr(nq if nr is None else nr), stream))
 
     def submit_async(self, reqs, n: int, replies) -> int:
         """Pipelined host submit on raw host pointers (page-locked for real overlap); returns the ticket."""
@@ -181,7 +188,9 @@ class Engine:
     def stats(self) -> dict:
         s = _lib.Stats()
         _lib.check(self._L.dint_get_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}  # (no reserved fields left)
+        d = {k: getattr(s, k) for k, _ in s._fields_ if k != "reserved"}
+        d["late_items"] = list(s.reserved)  # diagnostic: late work items by kind (a sub as listed / a solo item / pieces)
+        return d
 
     def reset(self): _lib.check(self._L.dint_reset(self._h))
     def snapshot(self): _lib.check(self._L.dint_snapshot(self._h))

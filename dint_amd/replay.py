@@ -44,14 +44,17 @@ class ShardGroup:
         return self.router.submit(reqs)  # every rank enters the collectives, also with an empty batch
 
     # ---- device path (replay) --------------------------------------------------------------------------
-    def submit_device(self, d_reqs, counts, d_reps) -> None:
+    def submit_device(self, d_reqs, counts, d_reps, ahead=None) -> None:
         """d_reqs / d_reps: per shard uint8 tensors; asynchronous.  Single GPU: each engine runs on its own
         stream (the three shard servers are independent).  Multi GPU: pack -> all-to-all -> the three engines on
-        their own streams -> all-to-all -> unpack, without host round trips (fixed-capacity slots)."""
+        their own streams -> all-to-all -> unpack, without host round trips (fixed-capacity slots).
+        `ahead` = (d_reqs, counts, d_reps) of the NEXT call (single GPU: dint_submit_device_ahead -- the batches of a
+        receive ring are in HBM before their turn comes)."""
         if self.router is None:
             for s in range(N_SHARDS):
                 if counts[s]:
-                    self.engines[s].submit_device(d_reqs[s], counts[s], d_reps[s], 0)
+                    nxt = None if ahead is None else (ahead[0][s], ahead[1][s], ahead[2][s])
+                    self.engines[s].submit_device(d_reqs[s], counts[s], d_reps[s], 0, ahead=nxt)
         else:
             self.router.step(d_reqs, counts, d_reps)
 
@@ -89,10 +92,17 @@ def record(driver: Driver, group, n_epochs: int):
 
 class Replay:
     """A recorded trace resident in HBM: per epoch and shard server the request batch, a reply buffer, and the replies
-    of the recorded run (also in HBM: `check` compares on the device)."""
+    of the recorded run (also in HBM: `check` compares on the device).
 
-    def __init__(self, trace=(), msg_size: int = 0):
+    `inplace` (round 6): the replay answers every batch IN PLACE, as the reference does (the reply is the request
+    struct mutated, tatp/udp/server_shard.cc:116-121) -- the engines then skip the request -> reply copy of their
+    partition kernel.  The batches the engines work on are the reply buffers, refilled from the pristine requests by
+    `reset()` OUTSIDE any timed region (that refill is the NIC's DMA into the receive ring, not server work).
+    `ahead`: every submission announces the next epoch's batch (dint_submit_device_ahead)."""
+
+    def __init__(self, trace=(), msg_size: int = 0, inplace: bool = False, ahead: bool = False):
         self.msg = msg_size
+        self.inplace, self.ahead = inplace, ahead
         self.counts, self.d_req, self.d_rep, self.d_want = [], [], [], []
         for req, rep in ((t[0], t[1]) for t in trace):
             self.append(req, rep)
@@ -113,10 +123,10 @@ class Replay:
         self.d_rep.append([torch.empty(len(req[s]) * self.msg, dtype=torch.uint8, device="cuda") for s in range(N_SHARDS)])
 
     @classmethod
-    def recording(cls, driver: Driver, group, n_epochs: int, keep_host: int = 0):
+    def recording(cls, driver: Driver, group, n_epochs: int, keep_host: int = 0, inplace: bool = False, ahead: bool = False):
         """Run the closed loop for n_epochs and keep every epoch in HBM; host copies only of the first `keep_host`
         epochs (what the CPU legs replay).  Returns (replay, finished txns per epoch, host trace)."""
-        rp, done, host = cls(msg_size=group.msg), [], []
+        rp, done, host = cls(msg_size=group.msg, inplace=inplace, ahead=ahead), [], []
         last = driver.stats()["txns"]
         for e in range(n_epochs):
             req = driver.next()
@@ -133,12 +143,23 @@ class Replay:
     def __len__(self):
         return len(self.counts)
 
+    def reset(self, lo: int = 0, hi: int = None) -> None:
+        """in-place replay: the pristine request batches into the buffers the engines answer in (device copies)"""
+        if not self.inplace:
+            return
+        for e in range(lo, len(self) if hi is None else hi):
+            for s in range(N_SHARDS):
+                self.d_rep[e][s].copy_(self.d_req[e][s])
+        torch.cuda.current_stream().synchronize()
+
     def run(self, group: ShardGroup, lo: int, hi: int) -> None:
         if group.router is not None:  # the epochs of a recorded trace are independent batches: pipelined exchange
             group.router.run([(self.d_req[e], self.counts[e], self.d_rep[e]) for e in range(lo, hi)])
             return
+        src = self.d_rep if self.inplace else self.d_req
         for e in range(lo, hi):
-            group.submit_device(self.d_req[e], self.counts[e], self.d_rep[e])
+            nxt = (src[e + 1], self.counts[e + 1], self.d_rep[e + 1]) if self.ahead and e + 1 < hi else None
+            group.submit_device(src[e], self.counts[e], self.d_rep[e], ahead=nxt)
 
     def check(self, lo: int, hi: int) -> None:
         """The replayed replies must equal the recorded ones byte for byte."""

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DINT_ABI_VERSION 3
+#define DINT_ABI_VERSION 4 /* v4 (round 6): dint_submit_device_ahead, dint_stats.late_requests */
 
 /* dint_config.flags */
 #define DINT_FLAG_KV_ROUNDS 1u /* kv workloads: resolve same-key conflicts request by request instead of in
@@ -121,8 +121,9 @@ typedef struct dint_config {
    * shard_count 0 or 1 = unsharded. */
   uint32_t shard_index;
   uint32_t shard_count;
-  /* requests per kernel pass; longer submissions run as several passes.  0 = the engine's maximum
-   * (1,048,576 -- LOG / TATP / SMALLBANK never more than log_entries; LOG was 65,536 until r03). */
+  /* requests per kernel pass; longer submissions run as several passes.  0 = the engine's default: 1,048,576 (LOG / TATP /
+   * SMALLBANK never more than log_entries), FASST / 2PL 65,536 (BASELINE's batch size: the lock kernels' hot-slot path
+   * covers passes up to that; a longer pass is legal -- ask for it here -- and slower per request on skewed streams). */
   uint32_t max_pass;
   /* STORE / TATP / SMALLBANK: overflow entries per table (a bucket whose 4 inline slots are taken chains 4-slot
    * entries from this pool; the reference `new`s them without bound, store/udp/kvs.h:95-102).  0 = local buckets / 4
@@ -145,6 +146,9 @@ typedef struct dint_stats {
   uint64_t route_overflow; /* requests dint_route_pack could not place (destination slot full): answered by
                               dint_route_unpack with the back-pressure reply of dint_refuse ("not now, send again") */
   uint64_t big_bin_requests; /* kv workloads: requests that were resolved by the big-bin kernel (hot keys) */
+  uint64_t late_requests;  /* store / tatp (ABI v4): requests of hot subs that no closed form of k_kv_hot covered and the general
+                              path answered (k_kv_late) -- a diagnostic: they are the slow ones */
+  uint64_t reserved[3];
 } dint_stats;
 
 typedef struct dint_engine dint_engine_t;
@@ -186,6 +190,22 @@ void dint_free_pinned(void *p);
  * CALLER enqueues on other streams (producing d_reqs, consuming d_replies) is the caller's to order --
  * dint_stream_wait / dint_stream_signal do that for the engine's own stream. */
 int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, void *stream);
+/* The same with a LOOK-AHEAD (round 6; store / tatp -- every other workload ignores the announcement): (d_next_reqs, next_n,
+ * d_next_replies) is the batch of the engine's NEXT dint_submit_device[_ahead] call.  The caller promises that (1) that call
+ * will be made, with exactly these pointers and this count, before anything else is submitted to the engine, (2) the
+ * batch's request bytes are complete in device memory in the order of `stream` -- produced by work enqueued on `stream`
+ * before THIS call, or simply there: a receive ring the NIC has filled, as the reference's recv loop finds a whole
+ * `message` in its socket buffer before the switch runs (tatp/udp/server_shard.cc:110-114) --, and (3) its buffers do not
+ * overlap this call's.  The engine then runs the next batch's table-free first stage (classify, hash, partition into the
+ * pass's coarse bins, and the log appends of its COMMIT_LOG / DELETE_LOG requests) in the SAME kernel launch as this batch's
+ * hot keys (k_kv_hot_part) and starts the next call at its resolve kernel: a pass's chain is two launches instead of four.
+ * Replies, table state and log ring are exactly those of two plain calls; between the two calls dint_read_log /
+ * dint_log_drain already show the announced batch's log records.  A different next submission (or dint_snapshot) fails
+ * with DINT_ESTATE after the engine has cleaned its scratch -- the announced batch's log records stay where they are;
+ * dint_reset / dint_restore drop the announcement silently.  A dint_submit_device of more requests than one pass takes looks
+ * ahead from pass to pass by itself (stream order already has the whole array complete). */
+int dint_submit_device_ahead(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, const void *d_next_reqs,
+                             uint32_t next_n, void *d_next_replies, void *stream);
 /* wait for everything enqueued on the engine's own streams */
 int dint_sync(dint_engine_t *e);
 /* the engine's own stream (a hipStream_t) */

@@ -47,7 +47,7 @@ def test_no_cpu_fallback():
 
 def test_config_struct_layout():
     assert C.sizeof(_lib.Config) == 4 * 4 + 8 * 2 + 4 * 3 + 4 * 5
-    assert C.sizeof(_lib.Stats) == 8 * 8
+    assert C.sizeof(_lib.Stats) == 8 * 12  # ABI v4: + late_requests, reserved[3]
 
 
 def test_flag_constants_match_the_header():

@@ -576,7 +576,8 @@ def test_tatp_two_hot_rows_in_one_bucket(same_quadrant):
 SPLIT_KNOBS = [{"DINT_KV_SPLIT_MIN": "65", "DINT_KV_SPLIT_TARGET": "16"},    # 16 pieces of a few dozen requests, never a solo item
                {"DINT_KV_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "100"},
                {},                                                          # the defaults: every big sub, ~384 requests per piece
-               {"DINT_KV_NO_SPLIT": "1"}]                                   # r04: one workgroup per hot key
+               {"DINT_KV_NO_SPLIT": "1"},                                   # r04: one workgroup per hot key
+               {"DINT_KV_LATE_BIG": "1"}]                                   # r05: what k_kv_hot leaves goes to k_kv_big, not k_kv_late
 
 
 @pytest.mark.parametrize("knobs", SPLIT_KNOBS, ids=lambda k: "+".join(f"{a[8:]}={b}" for a, b in k.items()) or "default")
@@ -615,7 +616,7 @@ def test_tatp_hot_key_in_pieces(p_hot, mix, hot_key, knobs, monkeypatch):
         assert st["missing_keys"] > 100  # every COMMIT of the missing hot row is counted (tatp/udp/kvs.h:91)
 
 
-@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3], ids=["t16", "t100", "default"])
+@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3] + SPLIT_KNOBS[4:], ids=["t16", "t100", "default", "late_big"])
 def test_store_hot_key_in_pieces(knobs, monkeypatch):
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
@@ -634,7 +635,7 @@ def test_store_hot_key_in_pieces(knobs, monkeypatch):
     assert _same_rows(eng.dump_rows(0), o.dump())
 
 
-@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3], ids=["t16", "t100", "default"])
+@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3] + SPLIT_KNOBS[4:], ids=["t16", "t100", "default", "late_big"])
 @pytest.mark.parametrize("same_quadrant", [False, True])
 def test_tatp_hot_key_in_pieces_beside_a_neighbour_in_its_bucket(same_quadrant, knobs, monkeypatch):
     """The sub's other keys (the remainder) are resolved beside the pieces -- unless one of the hot BUCKET uses the hot key's
