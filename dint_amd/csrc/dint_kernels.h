@@ -17,6 +17,21 @@ struct dint_dev_stats {
   unsigned long long late_items[3];     // ... the work items they came from, by kind: a sub listed as it was / a solo item / the pieces of a hot key
 };
 
+// kv passes (r06): a pass's partition stage may run in the SAME launch as the previous pass's resolve stage (k_kv_pass), so
+// what the partition writes exists twice (pass number & 1), and the control words -- zeroed one pass before they are used, by
+// the resolve stage -- three times (pass number % 3).  What only the resolve / hot / late stages of one pass touch (ovf, ovf2,
+// bigq, hotpub, lateq, bigrdy) exists once: those stages of two passes never overlap.
+struct dint_kv_sets {
+  uint32_t *ctl[3] = {nullptr, nullptr, nullptr};   // [16] {[0] records handed to the big-sub path, [1] overflow-list entries, [2] tiles handed
+                                                    // out, [3] work items listed, [4] item tickets, [5] late items, [6] coarse bins that have listed}
+  uint32_t *pub[3] = {nullptr, nullptr, nullptr};   // [1024] log requests per tile of the partition, bit 31 = published
+  uint32_t *bin_cnt[2] = {nullptr, nullptr};        // [DINT_KV_CMAX] records per coarse bin
+  uint4 *kbins[2] = {nullptr, nullptr};             // [C][cap] the coarse bins
+  uint4 *ovl[2] = {nullptr, nullptr};               // the pass's overflow list
+  uint32_t *bigrdy = nullptr;                       // [DINT_KV_BIGQ_MAX] work item i is listed: the pass's tag (pass_seq)
+  uint64_t pass_no = 0;                             // passes launched so far (host side)
+};
+
 // scratch shared by every workload: bins of batch records
 struct dint_scratch {
   uint32_t *bin_cnt;   // [DINT_KV_PMAX]   zero between passes (the resolve kernels re-zero their own)
@@ -41,6 +56,7 @@ struct dint_scratch {
   unsigned long long *hotpub = nullptr;  // [DINT_KV_BIGQ_MAX] what the pieces of a hot key tell each other (tagged with pass_seq)
   uint4 *lateq = nullptr;          // [DINT_KV_BIGQ_MAX] what k_kv_hot leaves to k_kv_big {bin, offset, records, 0: in ovf / 1: in ovf2}
   uint32_t pass_seq = 0;           // host side: passes launched so far (never 0 in a launch)
+  dint_kv_sets kvs;                // kv workloads: the sets by pass number (the fields above are their set 0 / unused)
   uint64_t *lock_trace = nullptr;  // DINT_KV_TRACE=1 on a lock engine: per big-bin workgroup 16 s_memrealtime stamps
                                    // of its first bin, at word DINT_KV_PMAX * 16 + 16 * workgroup (dint_kv_trace_read)
 };

@@ -224,12 +224,18 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 // When the counter wraps, the words are cleared on the pass's stream first, so a word left by the pass that carried the
 // same tag 2^30 passes ago cannot be taken for this pass's.
 int next_pass_seq(dint_engine *e, hipStream_t st) {
+  e->scratch.kvs.pass_no++;  // (which set of the pass scratch a pass uses: dint_kv_sets)
   if (++e->scratch.pass_seq >= 0x3FFFFFFFu) {
     if (e->scratch.hotpub) HIP_TRY(hipMemsetAsync(e->scratch.hotpub, 0, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long), st));
+    if (e->scratch.kvs.bigrdy) HIP_TRY(hipMemsetAsync(e->scratch.kvs.bigrdy, 0, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint32_t), st));
     e->scratch.pass_seq = 1;
   }
   return 0;
 }
+// kv engines: the log's ring position after the last pass lives in tail[(passes + 1) & 1] -- the partition of pass p reads
+// tail[p & 1] and writes tail[(p + 1) & 1], because it may run beside the resolve stage of pass p - 1 (k_kv_pass), which used to
+// copy one word onto the other.  dint_snapshot / dint_restore / dint_reset leave both words equal.
+int log_cur(const dint_engine *e) { return e->kv.n_tables ? (int)((e->scratch.kvs.pass_no + 1) & 1) : 1; }
 
 // one pass (n <= pass_max) on device buffers
 // scratch sets 1 .. of the lock pipe: what k_lock_count / k_kv_scan_place / k_lock_resolve share within one pass
@@ -308,15 +314,16 @@ int ahead_cancel(dint_engine *e) {
   e->ahead.valid = false;
   HIP_TRY(hipDeviceSynchronize());
   dint_scratch &s = e->scratch;
-  HIP_TRY(hipMemset(s.bin_cnt, 0, DINT_KV_PMAX * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(std::min(s.big, s.big_next), 0, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(std::min(s.blk_pub, s.blk_pub_next), 0, 2 * 1024 * sizeof(uint32_t)));
+  for (int k = 0; k < 2; k++) HIP_TRY(hipMemset(s.kvs.bin_cnt[k], 0, DINT_KV_PMAX * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(s.kvs.ctl[0], 0, 3 * 16 * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(s.kvs.pub[0], 0, 3 * 1024 * sizeof(uint32_t)));
   if (e->log.tail) {  // the tail the cancelled partition published is not the current one
     uint32_t t[4];
     HIP_TRY(hipMemcpy(t, e->log.tail, sizeof t, hipMemcpyDeviceToHost));
+    const int c = log_cur(e);  // (the cancelled pass was never counted: `c` is the word it read, c ^ 1 the one it wrote)
     uint64_t appended = (uint64_t)t[2] | ((uint64_t)t[3] << 32);
-    appended -= std::min<uint64_t>(appended, (t[1] + e->log.cap - t[0]) % e->log.cap);
-    t[1] = t[0]; t[2] = (uint32_t)appended; t[3] = (uint32_t)(appended >> 32);
+    appended -= std::min<uint64_t>(appended, (t[c ^ 1] + e->log.cap - t[c]) % e->log.cap);
+    t[c ^ 1] = t[c]; t[2] = (uint32_t)appended; t[3] = (uint32_t)(appended >> 32);
     HIP_TRY(hipMemcpy(e->log.tail, t, sizeof t, hipMemcpyHostToDevice));
   }
   return 0;
@@ -367,8 +374,6 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
       if (int rc = next_pass_seq(e, st)) return rc;  // tags what the pieces of a hot key publish in this pass
       if (next && (!n || !next->n || view.seg_cap || next->view.seg_cap || !dint_kv_ahead_ok(e->kv, load_mode))) next = nullptr;
       dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names), view, part_done, next);
-      std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
-      std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
       if (next) {
         e->ahead.valid = true;
         e->ahead.req = next->d_req; e->ahead.rep = next->d_rep; e->ahead.n = next->n;
@@ -487,6 +492,11 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
       TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_BIGQ_MAX * 3 * sizeof(uint4), false));  // KVQ_W uint4 per work item (k_kv.hip)
       TRY(dev_alloc((void **)&e->scratch.hotpub, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long)));
       TRY(dev_alloc((void **)&e->scratch.lateq, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint4), false));
+      // the second set of what the partition stage writes (dint_kv_sets): 288 GB of HBM are there to be used
+      TRY(dev_alloc((void **)&e->scratch.kvs.bin_cnt[1], DINT_KV_PMAX * sizeof(uint32_t)));
+      TRY(dev_alloc((void **)&e->scratch.kvs.kbins[1], (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
+      TRY(dev_alloc((void **)&e->scratch.kvs.ovl[1], (size_t)e->pass_max * sizeof(uint4) * 2, false));
+      TRY(dev_alloc((void **)&e->scratch.kvs.bigrdy, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint32_t)));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
       // lock tables, passes of <= 65,536 requests (k_locks.hip, LK_DIRECT_NMAX): a big bin's records beyond the 64 in place go
@@ -498,15 +508,20 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
         TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint64_t), false));
       }
     }
-    TRY(dev_alloc((void **)&e->scratch.blk_pub, 2 * 1024 * sizeof(uint32_t)));
+    TRY(dev_alloc((void **)&e->scratch.blk_pub, 3 * 1024 * sizeof(uint32_t)));
     e->scratch.blk_pub_next = e->scratch.blk_pub + 1024;
     TRY(dev_alloc((void **)&e->scratch.big, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
     e->scratch.big_next = e->scratch.big + (4 + DINT_KV_PMAX);
+    if (is_kv)  // (the three sets of control words and tile counts live in the allocations the lock tables use as two)
+      for (int k = 0; k < 3; k++) { e->scratch.kvs.ctl[k] = e->scratch.big + 16 * k; e->scratch.kvs.pub[k] = e->scratch.blk_pub + 1024 * k; }
     TRY(dev_alloc((void **)&e->scratch.bin_off, DINT_KV_PMAX * sizeof(uint32_t)));
     TRY(hipMemset(e->scratch.bin_off, 0xFF, DINT_KV_PMAX * sizeof(uint32_t)) == hipSuccess ? 0 : fail(DINT_EHIP, "hipMemset"));  // (lock tables, direct big bins: "no region named" between passes)
     TRY(dev_alloc((void **)&e->scratch.ovl, (size_t)e->pass_max * sizeof(uint4) * (is_kv ? 2 : 1), false));
     TRY(dev_alloc((void **)&e->scratch.ovf, (size_t)e->pass_max * sizeof(uint64_t), false));
-    if (is_kv) TRY(dev_alloc((void **)&e->scratch.ovf2, (size_t)e->pass_max * sizeof(uint64_t), false));
+    if (is_kv) {
+      TRY(dev_alloc((void **)&e->scratch.ovf2, (size_t)e->pass_max * sizeof(uint64_t), false));
+      e->scratch.kvs.bin_cnt[0] = e->scratch.bin_cnt; e->scratch.kvs.kbins[0] = e->scratch.kbins; e->scratch.kvs.ovl[0] = e->scratch.ovl;
+    }
     if ((e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL) && getenv("DINT_KV_TRACE")) {
       TRY(dev_alloc((void **)&e->kv.d_trace, (size_t)DINT_KV_TRACE_WORDS * 8, true));
       e->scratch.lock_trace = e->kv.d_trace;
@@ -567,6 +582,10 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.bigq);
   hipFree(e->scratch.hotpub);
   hipFree(e->scratch.lateq);
+  hipFree(e->scratch.kvs.bin_cnt[1]);
+  hipFree(e->scratch.kvs.kbins[1]);
+  hipFree(e->scratch.kvs.ovl[1]);
+  hipFree(e->scratch.kvs.bigrdy);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
   hipFree(std::min(e->scratch.blk_pub, e->scratch.blk_pub_next));
@@ -718,8 +737,6 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
   for (uint32_t k = 0; k < n_items; k++) {
     dint_engine *e = items[k].engine;
-    std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists and log counts alternate between passes
-    std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
     if (int rc = mark_stream(e, st)) return rc;
     e->batches++;
     e->requests += pass[k].n;
@@ -1051,7 +1068,7 @@ int64_t dint_read_log(dint_engine_t *e, void *records, uint64_t cap) {
   if (records && n) HIP_TRY(hipMemcpy(records, e->log.ring, n * 64, hipMemcpyDeviceToHost));
   uint32_t t[2];
   HIP_TRY(hipMemcpy(t, e->log.tail, sizeof t, hipMemcpyDeviceToHost));
-  return (int64_t)t[1];
+  return (int64_t)t[log_cur(e)];
 }
 
 int64_t dint_log_drain(dint_engine_t *e, void *records, uint64_t cap, uint64_t *lost) {
@@ -1157,6 +1174,12 @@ int dint_snapshot(dint_engine_t *e) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipDeviceSynchronize());
   if (e->ahead.valid) return fail(DINT_ESTATE, "a batch announced by dint_submit_device_ahead is pending (its log records are appended)");
+  if (e->kv.n_tables && e->log.tail) {  // both tail words say where the ring stands: whatever the parity of the passes after a restore
+    uint32_t t[2];
+    HIP_TRY(hipMemcpy(t, e->log.tail, sizeof t, hipMemcpyDeviceToHost));
+    t[0] = t[1] = t[log_cur(e)];
+    HIP_TRY(hipMemcpy(e->log.tail, t, sizeof t, hipMemcpyHostToDevice));
+  }
   if (e->snap.empty()) {
     for (auto &r : e->regions) {
       void *p = nullptr;

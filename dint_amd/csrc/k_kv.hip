@@ -76,6 +76,9 @@ static dint_kv_knobs kv_read_knobs() {
   k.split_target = std::min(448u, std::max(8u, kv_env("DINT_KV_SPLIT_TARGET", 384u)));
   k.one_big_kernel = kv_env("DINT_KV_ONE_BIG_KERNEL", 0);
   k.no_ahead = kv_env("DINT_KV_NO_AHEAD", 0);
+  k.no_fuse = kv_env("DINT_KV_NO_FUSE", 0);
+  k.workers = std::min(1024u, std::max(KVR_NPMAX + 2u, kv_env("DINT_KV_WORKERS", KVW_GRID)));  // (a hot key's pieces + remainder wait for each other: never fewer workers)
+  k.part_first = kv_env("DINT_KV_PART_FIRST", 1);
   k.late_grid = std::min(KVB_GRID, std::max(1u, kv_env("DINT_KV_LATE_GRID", 8u)));
   k.late_big = kv_env("DINT_KV_LATE_BIG", 0);
   k.exp_no_late = kv_env("DINT_EXP_NO_LATE", 0);
@@ -107,8 +110,15 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.n_tiles = (n + tile - 1) / tile;
   A.kv = kv.d_dev; A.log = log; A.cut = kv_make_cut(C, n); A.cap = cap;
   A.lcap = K.lcap;
-  A.bin_cnt = s.bin_cnt; A.kbins = s.kbins; A.big = s.big; A.big_next = s.big_next;
-  A.blk_pub = s.blk_pub; A.blk_pub_next = s.blk_pub_next; A.ovl = s.ovl; A.ovf = s.ovf; A.ovf2 = s.ovf2; A.stats = s.stats;
+  // the sets of this pass (dint_kv_sets): what its partition writes by pass number & 1, its control words by pass number % 3;
+  // its resolve stage zeroes the control words of the pass after next
+  const uint64_t pn = s.kvs.pass_no;
+  A.pno = (uint32_t)(pn & 1u);
+  A.bin_cnt = s.kvs.bin_cnt[pn & 1]; A.kbins = s.kvs.kbins[pn & 1]; A.ovl = s.kvs.ovl[pn & 1];
+  A.big = s.kvs.ctl[pn % 3]; A.big_z = s.kvs.ctl[(pn + 2) % 3];
+  A.blk_pub = s.kvs.pub[pn % 3]; A.blk_pub_z = s.kvs.pub[(pn + 2) % 3];
+  A.bigrdy = s.kvs.bigrdy;
+  A.ovf = s.ovf; A.ovf2 = s.ovf2; A.stats = s.stats;
   A.bigq = s.bigq;
   A.hotpub = s.hotpub;
   A.lateq = s.lateq;
@@ -164,10 +174,9 @@ void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &k
   kv_pass_args N;
   uint32_t next_rpt = 0;
   if (next && next->n && dint_kv_ahead_ok(kv, load_mode)) {
-    // the next pass's view of the scratch: the OTHER set of control words and tile counts, the next tag
+    // the next pass's view of the scratch: its own sets (by pass number), the next tag
     dint_scratch sn = s;
-    std::swap(sn.big, sn.big_next);
-    std::swap(sn.blk_pub, sn.blk_pub_next);
+    sn.kvs.pass_no = s.kvs.pass_no + 1;
     sn.pass_seq = s.pass_seq + 1 >= 0x3FFFFFFFu ? 1u : s.pass_seq + 1;
     next_rpt = kv_pick_rpt_ahead(next->n, kv.knobs);
     memset(&N, 0, sizeof N);

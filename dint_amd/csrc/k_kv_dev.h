@@ -79,8 +79,21 @@ struct kv_dev_mem {
 // The table descriptors in LDS (every resolve / hot / big workgroup copies them first): frees of pass `seq` go to pend set
 // (seq & 1) -- kv_pool_rotate (k_kv_part, the next pass but one) makes them poppable.  Call between the barrier behind the
 // copy and the next barrier; nothing touches a pend list before that.
-__device__ static inline void kv_dev_pend_set(kv_dev &Skv, uint32_t seq) {
-  if (threadIdx.x < DINT_KV_MAX_TABLES && (seq & 1u)) Skv.tab[threadIdx.x].pend_head += KV_NLISTS;
+__device__ static inline void kv_dev_pend_set(kv_dev &Skv, uint32_t pno) {
+  if (threadIdx.x < DINT_KV_MAX_TABLES && (pno & 1u)) Skv.tab[threadIdx.x].pend_head += KV_NLISTS;
+}
+// What a resolve workgroup hands to the hot-key workers of the SAME launch (k_kv_pass): the 8-byte records of a big sub, its work
+// items and their "listed" tags.  The two sit on different XCDs as a rule, whose L2s are not coherent: agent-scope accesses
+// (write-through / L2-bypassing on gfx950) instead of a release that would write a whole L2 back.
+__device__ static inline void kv_st_agent(uint64_t *p, uint64_t v) { __hip_atomic_store((unsigned long long *)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ static inline uint64_t kv_ld_agent(const uint64_t *p) { return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ static inline void kv_st_agent(uint4 *p, const uint4 &v) {
+  kv_st_agent((uint64_t *)p, ((uint64_t)v.y << 32) | v.x);
+  kv_st_agent((uint64_t *)p + 1, ((uint64_t)v.w << 32) | v.z);
+}
+__device__ static inline uint4 kv_ld_agent(const uint4 *p) {
+  const uint64_t a = kv_ld_agent((const uint64_t *)p), b = kv_ld_agent((const uint64_t *)p + 1);
+  return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
 
 // ---- batch record of the kv passes: one 64-bit word per table request ------------------------------------
@@ -159,8 +172,10 @@ struct kv_pass_args {
   uint32_t lcap;         // records of a coarse bin's small subs that are resolved from LDS (<= KVR_LCAP)
   uint32_t *bin_cnt;     // [C] records per coarse bin (the resolve workgroups leave them zero)
   uint4 *kbins;          // [C][cap] records
-  uint32_t *big, *big_next;  // {[0] records handed to the big-sub path (bump pointer into ovf), [1] overflow-list entries, [2] tiles handed out}
-  uint32_t *blk_pub, *blk_pub_next;
+  uint32_t *big, *big_z;     // the pass's control words (dint_kv_sets::ctl) / the set this pass's resolve stage zeroes (the pass after next's)
+  uint32_t *blk_pub, *blk_pub_z;
+  uint32_t *bigrdy;          // [item] listed: tagged with `seq`
+  uint32_t pno;              // pass number & 1: which pend set the pass's frees go to, which log tail word its partition reads
   uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
   uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
   uint64_t *ovf2;        // ... and the same ranges again: a sub of several stretches is regrouped by stretch once
@@ -220,7 +235,7 @@ __device__ __forceinline__ static void kv_part_body(const kv_pass_args &A, kv_pa
   // are already running: what the log-position look-back below waits for
   if (t == 0) { Stile = atomicAdd(&A.big[2], 1u); Sov[0] = 0; }
   if (first_block && t < KV_NLISTS)  // entries freed by earlier passes become reusable: the pend set THIS pass will push to
-    for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t, (A.seq & 1u) * KV_NLISTS);
+    for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t, (A.pno & 1u) * KV_NLISTS);
   for (uint32_t k = t; k < C; k += TB) Hc[k] = 0;
   __syncthreads();
   const uint32_t tile = Stile;
@@ -345,9 +360,10 @@ __device__ __forceinline__ static void kv_part_body(const kv_pass_args &A, kv_pa
     uint32_t base = 0, tile_total = 0;
     for (uint32_t w = 0; w < NWV; w++) base += Swp[w];
     for (uint32_t w = 0; w < NWV * RPT; w++) tile_total += Swl[w];
-    if (tile == A.n_tiles - 1 && t == 0) {  // the pass's new tail (the resolve kernel makes it current)
+    const uint32_t tw = A.pno & 1u;  // the ring position before this pass: tail[pno], after it: tail[pno ^ 1] (engine.hip, log_cur)
+    if (tile == A.n_tiles - 1 && t == 0) {
       const uint32_t total = base + tile_total;
-      log.tail[1] = (uint32_t)(((uint64_t)log.tail[0] + total) % log.cap);
+      log.tail[tw ^ 1u] = (uint32_t)(((uint64_t)log.tail[tw] + total) % log.cap);
       *(unsigned long long *)(log.tail + 2) += total;  // records ever appended (dint_log_drain)
     }
 #pragma unroll
@@ -355,7 +371,7 @@ __device__ __forceinline__ static void kv_part_body(const kv_pass_args &A, kv_pa
       if (r[j].cls != 2) continue;
       uint32_t pos_in_batch = base + (uint32_t)__popcll(lm[j] & lanemask_lt());
       for (uint32_t w = 0; w < (uint32_t)j * NWV + wv; w++) pos_in_batch += Swl[w];
-      const uint32_t pos = (uint32_t)(((uint64_t)log.tail[0] + pos_in_batch) % log.cap);
+      const uint32_t pos = (uint32_t)(((uint64_t)log.tail[tw] + pos_in_batch) % log.cap);
       uint8_t *e8 = log.ring + (size_t)pos * 64;
       const uint8_t *m = req + moff[j];
       const uint32_t ver = ld_u32(m + F::VER);
@@ -2353,6 +2369,42 @@ __device__ static inline uint32_t kv_piece_of(uint32_t idx, uint32_t np, uint32_
 #define KVQ_W 3u
 enum : uint32_t { KVQ_SUB = 0, KVQ_PIECE = 1, KVQ_REM = 2, KVQ_SOLO = 3 };
 
+// One wave lists the big subs of a coarse bin as work items (k_kv_hot / the workers of k_kv_pass / k_kv_big).
+// A sub of at least split_min records is listed as `np` hot-key PIECES (ranges of the request index) + its REMAINDER (the other
+// keys), side by side -- or, when one piece is enough, as one SOLO item (kv_hot_item); every item names the whole sub.  Entries
+// and "listed" tags are agent-scope stores, entries first: a worker that sees item i's tag sees the item and its records.
+// Last: this bin counts as listed (big[6]) -- when all C have, big[3] is final.
+__device__ static inline void kv_list_items(const kv_pass_args &A, uint32_t b, const kvr_lds &L, const uint2 *Sbig) {
+  const uint32_t t = threadIdx.x & 63u;
+  const uint2 bs = Sbig[t];
+  const bool hot = bs.y >= A.split_min && bs.y <= KVR_NPMAX * (KVB_T - 64u);  // (more than the pieces can hold: kv_big_bin's / k_kv_late's, via the late list)
+  const uint32_t np = hot ? min(KVR_NPMAX, (bs.y + A.split_target - 1) / A.split_target) : 0u;
+  const uint32_t nent = bs.y ? (np > 1 ? np + 1 : 1u) : 0u;
+  uint32_t tot, at = wave_excl_scan_u32(nent, &tot);
+  uint32_t base = 0;
+  if (t == 0 && tot) base = atomicAdd(&A.big[3], tot);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  at += base;
+  const uint32_t bin = b + A.cut.P * t;
+  if (nent && !hot) {
+    kv_st_agent(A.bigq + KVQ_W * (size_t)at, make_uint4(bin, bs.x, bs.y, KVQ_SUB));
+  } else if (nent) {
+    const uint64_t hk = L.ckey[t], hr = L.hrec[t];
+    for (uint32_t p = 0; p < nent; p++) {
+      const uint32_t kind = np == 1 ? KVQ_SOLO : (p < np ? KVQ_PIECE : KVQ_REM);
+      uint4 *q = A.bigq + KVQ_W * (size_t)(at + p);
+      kv_st_agent(q, make_uint4(bin, bs.x, bs.y, kind | (p << 2) | (np << 8)));
+      kv_st_agent(q + 1, make_uint4((uint32_t)hk, (uint32_t)(hk >> 32), at, 0u));
+      kv_st_agent(q + 2, make_uint4((uint32_t)hr, (uint32_t)(hr >> 32), 0u, 0u));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (uint32_t p = 0; p < nent; p++)
+    if (at + p < DINT_KV_BIGQ_MAX) __hip_atomic_store(&A.bigrdy[at + p], A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (t == 0) atomicAdd(&A.big[6], 1u);
+}
+
 template <int WL, uint32_t NT>
 __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev *kv, uint32_t coarse, uint8_t *lds_raw,
                                             uint2 *Sbig /* [KVR_F] {offset in ovf, records} of the bin's big subs */,
@@ -2363,7 +2415,10 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
   const uint32_t C = cut.P, cap = A.cap, sh = 16 + cut.ibits;
   const uint32_t idx_mask = (uint32_t)((1ull << cut.ibits) - 1ull);
   const uint4 *__restrict__ recs = A.kbins + (size_t)coarse * cap;
-  if (cnt == 0) return;  // workgroup-uniform
+  if (cnt == 0) {  // workgroup-uniform: nothing to resolve, nothing to list
+    if (t == 0) atomicAdd(&A.big[6], 1u);
+    return;
+  }
   const uint32_t n_in = min(cnt, cap);
   const uint32_t novl = cnt > cap ? A.big[1] : 0u;  // my records beyond `cap` are somewhere in the pass's overflow list
   // (the first two records of every thread -- r0, r1, loaded by the kernel together with the counter -- stay in
@@ -2477,10 +2532,14 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
     if (sub == sub0) pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, lead) + (uint32_t)__popcll(same & lanemask_lt());
     const uint32_t bo = L.bigoff[sub];
     if (bo == KV_NONE) L.rec[L.off[sub] + pos] = r;
-    else A.ovf[bo + pos] = big_rec(m);  // the big path's record
+    else kv_st_agent(&A.ovf[bo + pos], big_rec(m));  // the big path's record (read by another workgroup of this launch: kv_st_agent)
   });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every record is where a worker will look for it before the items are listed)
   __syncthreads();
   if (tr && t == 0) tr[4] = __builtin_amdgcn_s_memrealtime();
+  // ---- the bin's big subs become work items NOW (r06), before the chunks: the hot-key workers of this launch take them while
+  // this workgroup resolves its small subs.  The last wave lists (wave 0 starts the first chunk).
+  if (wave == NT / 64 - 1) kv_list_items(A, coarse, L, Sbig);
   // ---- the chunks, one wave each: sort by (group / C, key hash, idx) in registers -- groups commute, so any order that
   // keeps each group's requests in idx order is serial-equivalent, and after the sort the requests of a group sit in
   // adjacent lanes.  The sort word carries the lane the record came from; key and payload follow by one shuffle each.
@@ -2517,14 +2576,8 @@ __device__ static inline void kv_coarse_bin(const kv_pass_args &A, const kv_dev 
 // overlap that costs the big path its registers again (one kernel, 128 VGPRs, ~100 spilled): TATP 1,750 against 2,170
 // Mtxn/s, store 2,370 against 3,290.  NOTEBOOK.md section 1.
 template <int WL>
-__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
+__device__ __forceinline__ static void kv_resolve_role(const kv_pass_args &A, uint32_t b, kv_dev &Skv, uint8_t *Lraw, uint2 *Sbig) {
   constexpr uint32_t NT = KVB_T;
-  __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
-  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvr_lds)];
-  __shared__ uint2 Sbig[KVR_F];
-  uint32_t e = 0, b = blockIdx.x;
-  while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
-  const kv_pass_args &A = M.e[e];
   const uint32_t t = threadIdx.x;
   uint64_t *tr = A.trace ? A.trace + 32 * (size_t)b : nullptr;  // per engine (its own trace buffer), by ITS bin: < 2048 * 32, where k_kv_big's rows start
   if (tr && t == 0) tr[0] = __builtin_amdgcn_s_memrealtime();
@@ -2544,46 +2597,27 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32
     kvr_lds &L = *(kvr_lds *)Lraw;
     L.hist[t] = 0; L.cur[t] = 0; L.cflag[t] = 0;
   }
-  if (b == 0) {  // what the next pass will find: its counters zero ([4] = k_kv_big's ticket), the log tail current
-    if (t < 8) A.big_next[t] = 0;
-    for (uint32_t k = t; k < 1024; k += NT) A.blk_pub_next[k] = 0;
-    if (t == 0 && A.has_log) A.log.tail[0] = A.log.tail[1];
+  if (b == 0) {  // the control words of the pass AFTER NEXT: the next pass's partition may be running beside this workgroup (k_kv_pass)
+    if (t < 16) A.big_z[t] = 0;
+    for (uint32_t k = t; k < 1024; k += NT) A.blk_pub_z[k] = 0;
   }
   __syncthreads();
-  kv_dev_pend_set(Skv, A.seq);  // (the LDS phases of kv_coarse_bin put barriers between this and the first table access)
+  kv_dev_pend_set(Skv, A.pno);  // (the LDS phases of kv_coarse_bin put barriers between this and the first table access)
   if (tr && t == 0) tr[1] = __builtin_amdgcn_s_memrealtime();
   // (r04b also prefetched every record's bucket header here, ~6 us of LDS work ahead of the chunk that needs it: the
   // header round trip of the chunk fell from 2.4 to 1.6 us and the bench lost 3 % -- the prefetch is one more transaction
   // per request on a memory system that is the bottleneck once three engines run side by side.  Removed.)
   kv_coarse_bin<WL, NT>(A, &Skv, b, Lraw, Sbig, cnt, r0, r1, tr);
-  if (t < KVR_F) {  // one wave: list the bin's big subs for k_kv_big
-    // A sub of at least split_min records is listed as `np` hot-key PIECES (ranges of the request index) + its REMAINDER (the
-    // other keys), side by side -- or, when one piece is enough, as one SOLO item (kv_hot_item); every item names the whole sub.
-    const uint2 bs = Sbig[t];
-    const kvr_lds &L = *(const kvr_lds *)Lraw;
-    const bool hot = bs.y >= A.split_min && bs.y <= KVR_NPMAX * (KVB_T - 64u);  // (more than the pieces can hold: kv_big_bin's, via k_kv_hot's late list)
-    const uint32_t np = hot ? min(KVR_NPMAX, (bs.y + A.split_target - 1) / A.split_target) : 0u;
-    const uint32_t nent = bs.y ? (np > 1 ? np + 1 : 1u) : 0u;
-    uint32_t tot, at = wave_excl_scan_u32(nent, &tot);
-    uint32_t base = 0;
-    if (t == 0 && tot) base = atomicAdd(&A.big[3], tot);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    at += base;
-    const uint32_t bin = b + A.cut.P * t;
-    if (nent && !hot) {
-      A.bigq[KVQ_W * (size_t)at] = make_uint4(bin, bs.x, bs.y, KVQ_SUB);
-    } else if (nent) {
-      const uint64_t hk = L.ckey[t], hr = L.hrec[t];
-      for (uint32_t p = 0; p < nent; p++) {
-        const uint32_t kind = np == 1 ? KVQ_SOLO : (p < np ? KVQ_PIECE : KVQ_REM);
-        uint4 *q = A.bigq + KVQ_W * (size_t)(at + p);
-        q[0] = make_uint4(bin, bs.x, bs.y, kind | (p << 2) | (np << 8));
-        q[1] = make_uint4((uint32_t)hk, (uint32_t)(hk >> 32), at, 0u);
-        q[2] = make_uint4((uint32_t)hr, (uint32_t)(hr >> 32), 0u, 0u);
-      }
-    }
-  }
   if (tr && t == 0) { tr[11] = tr[12] = __builtin_amdgcn_s_memrealtime(); tr[13] = b; }
+}
+template <int WL>
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_resolve(kv_multi_args M, uint32_t n_eng) {
+  __shared__ kv_dev Skv;  // table descriptors: per-lane lookups by table id become LDS reads
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvr_lds)];
+  __shared__ uint2 Sbig[KVR_F];
+  uint32_t e = 0, b = blockIdx.x;
+  while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
+  kv_resolve_role<WL>(M.e[e], b, Skv, Lraw, Sbig);
 }
 
 // ---- hot keys: one key's hundreds or thousands of requests, in closed form, several workgroups at once ---------------------
@@ -2845,7 +2879,7 @@ __device__ __forceinline__ static int kv_solo_item(uint8_t *rep, const kv_cut cu
   auto is_ins = [](uint32_t type) -> bool { return WL == DINT_WL_STORE ? type == 2 : (type == 18 || type == 19); };
   auto is_del = [](uint32_t type) -> bool { return WL == DINT_WL_TATP && (type == 22 || type == 23); };
   __syncthreads();  // the LDS buffer is free
-  if (!preloaded) H.all[t] = t < h ? kv_sort_key(ovf[d.y + t], cut2) : ~0ull;
+  if (!preloaded) H.all[t] = t < h ? kv_sort_key(kv_ld_agent(&ovf[d.y + t]), cut2) : ~0ull;
   if (t == 0) { H.bad = 0; H.best = 0; H.bestg = 0; H.dupf = 0; }
   __syncthreads();
   {
@@ -3091,7 +3125,7 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
   // the hot BUCKET holds requests for another key (`nbr`): only then does the remainder take part in the all-or-nothing vote.
   for (uint32_t k0 = 0; k0 < h; k0 += KVB_T) {
     const uint32_t k = k0 + t;
-    const uint64_t r = k < h ? ovf[d.y + k] : 0;
+    const uint64_t r = k < h ? kv_ld_agent(&ovf[d.y + k]) : 0;
     const uint32_t pay = kv_rec_pay(r), ridx = (uint32_t)(r >> 16) & idx_mask, type = pay_type(pay);
     const bool same_g = k < h && (r >> sh_g) == (hrec >> sh_g), same = same_g && pay_kh(pay) == hkh;
     if (same_g && !same) {
@@ -3223,7 +3257,7 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
     __syncthreads();
     for (uint32_t k0 = 0; k0 < h; k0 += KVB_T) {
       const uint32_t k = k0 + t;
-      const uint64_t r = k < h ? ovf[d.y + k] : 0;
+      const uint64_t r = k < h ? kv_ld_agent(&ovf[d.y + k]) : 0;
       const bool same = k < h && (r >> sh_g) == (hrec >> sh_g) && pay_kh(kv_rec_pay(r)) == hkh;
       const uint64_t mm = __ballot(same);
       uint32_t at = 0;
@@ -3473,7 +3507,7 @@ __global__ void __launch_bounds__(KVB_T, WPS) k_kv_late(kv_multi_args M, uint32_
   const uint32_t t = threadIdx.x;
   if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = ((const uint32_t *)A.kv)[t];
   __syncthreads();
-  kv_dev_pend_set(Skv, A.seq);
+  kv_dev_pend_set(Skv, A.pno);
   __syncthreads();
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
@@ -3489,24 +3523,40 @@ static_assert(sizeof(kvb_lds) + (KV_HOT_BM ? KV_HOT_BM_W * 10 : 16) + sizeof(kv_
 // kv_big_bin (256 VGPRs, ~155 KB of LDS) needs an EMPTY compute unit -- with three shard servers side by side on the GPU
 // its workgroups waited for the other servers' resolve workgroups to drain (k_kv_big: 36 us alone, 47 us in company, for
 // items of 13 .. 25 us).  What the closed forms and the group phases do not cover is left to k_kv_big in `lateq`.
+// A WORKER: takes the pass's work items by ticket, in list order, as they are listed -- by the resolve workgroups of the SAME
+// launch (k_kv_pass, r06) or of the launch before (k_kv_hot, k_kv_hot_part).  Ticket i waits for item i's tag; it gives up when
+// every coarse bin has listed (big[6] == C) and there are no more than i items.  Workers never hold anything a resolve
+// workgroup waits for, and a launch places every resolve workgroup before its first worker (block order), so whoever a worker
+// waits for is running; the siblings of a hot key's piece are listed together and sit side by side in the list, so whoever a
+// piece waits for holds a ticket or draws the very next ones (kv_hot_item).
+#define KVW_GRID 192u  // workers per engine of k_kv_pass (a tatp pass of the bench lists ~160 items; a worker takes as many as it gets)
 template <int WL>
 __device__ __forceinline__ static void kv_hot_role(const kv_pass_args &A, kv_dev &Skv, uint8_t *Lraw, uint32_t &Stk, uint32_t bx, uint32_t by) {
-  const uint32_t nq = A.big[3];
-  if (bx >= nq) return;
   const uint32_t t = threadIdx.x;
   if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = ((const uint32_t *)A.kv)[t];
   __syncthreads();
-  kv_dev_pend_set(Skv, A.seq);  // (the ticket loop below starts with a barrier)
+  kv_dev_pend_set(Skv, A.pno);  // (the ticket loop below starts with a barrier)
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
   uint64_t *tr = A.trace ? A.trace + 2048 * 32 + 32 * (size_t)(by * KVB_GRID + bx) : nullptr;
-  for (bool first = true;; first = false) {  // work items by ticket, in list order (kv_hot_item)
+  for (bool first = true;; first = false) {
     __syncthreads();
-    if (t == 0) Stk = atomicAdd(&A.big[4], 1u);
+    if (t == 0) {
+      const uint32_t i = atomicAdd(&A.big[4], 1u);
+      uint32_t got = KV_NONE;
+      for (uint32_t spins = 0; i < DINT_KV_BIGQ_MAX; spins++) {
+        if (__hip_atomic_load(&A.bigrdy[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.seq) { got = i; break; }
+        if (__hip_atomic_load(&A.big[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.cut.P &&
+            i >= __hip_atomic_load(&A.big[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // every bin has listed: there is no item i
+        if (spins > (1u << 22)) __builtin_trap();  // (a hung GPU is worse than a trap)
+        __builtin_amdgcn_s_sleep(4);
+      }
+      Stk = got;
+    }
     __syncthreads();
     const uint32_t i = Stk;
-    if (i >= nq) break;
-    const uint4 d = A.bigq[KVQ_W * (size_t)i];
+    if (i == KV_NONE) break;
+    const uint4 d = kv_ld_agent(A.bigq + KVQ_W * (size_t)i);
     uint32_t src = 0, off = d.y, cnt = d.z;
     uint64_t *ttr = first ? tr : nullptr;
     if (ttr && t == 0) { ttr[0] = __builtin_amdgcn_s_memrealtime(); ttr[2] = d.z; ttr[3] = d.x; ttr[30] = d.w; }
@@ -3514,8 +3564,8 @@ __device__ __forceinline__ static void kv_hot_role(const kv_pass_args &A, kv_dev
     if ((d.w & 3u) == KVQ_SOLO)
       run = kv_solo_item<WL>(A.rep, cut2, &Skv, d, A.ovf, A.ovf2, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
     else if ((d.w & 3u) != KVQ_SUB)
-      run = kv_hot_item<WL>(A.rep, cut2, &Skv, d, A.bigq[KVQ_W * (size_t)i + 1], A.bigq[KVQ_W * (size_t)i + 2], A.ovf, A.ovf2, A.hotpub, A.seq,
-                            A.inv_n, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
+      run = kv_hot_item<WL>(A.rep, cut2, &Skv, d, kv_ld_agent(A.bigq + KVQ_W * (size_t)i + 1), kv_ld_agent(A.bigq + KVQ_W * (size_t)i + 2), A.ovf, A.ovf2,
+                            A.hotpub, A.seq, A.inv_n, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
     if (run && t == 0) {  // not in closed form: k_kv_late's (or k_kv_big's), behind this kernel
       A.lateq[atomicAdd(&A.big[5], 1u)] = make_uint4(d.x, off, cnt, src);
       atomicAdd(&A.stats->late_requests, (unsigned long long)cnt);
@@ -3529,16 +3579,18 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_hot(kv_multi_args M) {
   __shared__ kv_dev Skv;
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[sizeof(kvh_lds)];
   __shared__ uint32_t Stk;
-  kv_hot_role<WL>(M.e[blockIdx.y], Skv, Lraw, Stk, blockIdx.x, blockIdx.y);
+  const kv_pass_args &A = M.e[blockIdx.y];
+  if (blockIdx.x >= A.big[3]) return;  // (behind the resolve kernel: the list is final)
+  kv_hot_role<WL>(A, Skv, Lraw, Stk, blockIdx.x, blockIdx.y);
 }
 
 // ---- k_kv_hot_part (r06): the hot keys of pass k AND the partition of pass k + 1 in one launch.  The partition touches no
-// table (it reads the next batch, writes its records into the coarse bins -- which k_kv_resolve(k) has emptied --, its log
-// records behind the tail resolve(k) made current, and the control words of the OTHER set), the hot keys are ~150 work
-// items of 13 .. 25 us on a mostly idle GPU: side by side the pair costs what the longer one costs, and a pass's chain is
-// resolve -> this kernel instead of part -> resolve -> hot (-> big).  One engine per launch; workgroups 0 .. KVB_GRID-1 take
-// the hot items (dispatched first: they are the long pole), the others a tile each of KVB_T x RPT requests.  The pool
-// rotation of pass k + 1 runs here beside pass k's frees and pops: two pend sets, kv_pool_rotate.
+// table (it reads the next batch, writes its records into the coarse bins of the OTHER set, its log records behind the tail
+// the previous partition left, and the control words of the next set), the hot keys are ~150 work items of 13 .. 25 us on a
+// mostly idle GPU: side by side the pair costs what the longer one costs.  One engine per launch; workgroups 0 ..
+// KVB_GRID-1 take the hot items (dispatched first: they are the long pole), the others a tile each of KVB_T x RPT
+// requests.  The pool rotation of pass k + 1 runs here beside pass k's frees and pops: two pend sets, kv_pool_rotate.
+// (DINT_KV_NO_FUSE=1: since k_kv_pass the default pass is ONE launch -- resolve, hot keys and the next partition together.)
 template <int WL, int RPT>
 __global__ void __launch_bounds__(KVB_T, 4) k_kv_hot_part(kv_pass_args H, kv_pass_args P) {
   constexpr size_t LB = sizeof(kvh_lds) > sizeof(kv_part_lds<RPT, KVB_T>) ? sizeof(kvh_lds) : sizeof(kv_part_lds<RPT, KVB_T>);
@@ -3546,12 +3598,55 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_hot_part(kv_pass_args H, kv_pas
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[LB];
   __shared__ uint32_t Stk;
   if (blockIdx.x < KVB_GRID) {
-    kv_hot_role<WL>(H, Skv, Lraw, Stk, blockIdx.x, 0);
+    if (blockIdx.x < H.big[3]) kv_hot_role<WL>(H, Skv, Lraw, Stk, blockIdx.x, 0);
     return;
   }
   const uint32_t b = blockIdx.x - KVB_GRID;
   if (b >= P.n_tiles) return;
   kv_part_body<WL, RPT, KVB_T>(P, *(kv_part_lds<RPT, KVB_T> *)Lraw, b == 0);
+}
+
+// ---- k_kv_pass (r06): ONE launch per pass -- the resolve stage of pass k, its hot keys, and the partition of pass k + 1.
+//   blocks [0, sum C)                 one coarse bin each (kv_resolve_role): lists its big subs as work items BEFORE its chunks
+//   blocks [sum C, + KVW_GRID * n_eng) workers (kv_hot_role): take the items as they are listed, while the chunks run
+//   blocks behind them                (one engine, look-ahead) a tile each of the NEXT pass's partition (kv_part_body)
+// r05's pass was four launches (part, resolve, hot, big) and a launch boundary between the engines' kernels costs its stream
+// 5 .. 15 us; the hot keys (~150 items of 13 .. 25 us) ran on an idle GPU behind the resolve kernel, the partition (bandwidth)
+// behind them.  Here the three overlap: the pass's chain is the resolve workgroups plus the tail of the items listed last.
+// The hand-over resolve -> worker crosses XCDs: agent-scope stores and loads for records, items and tags (kv_st_agent), no L2
+// write-back.  The next partition beside this resolve needs its own coarse bins and control words: dint_kv_sets.
+// RPT = 0: no partition role (plain dint_submit_device calls, launch sets of several engines).
+template <int WL, int RPT>
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_pass(kv_multi_args M, uint32_t n_eng, uint32_t sum_c, kv_pass_args P, uint32_t n_work /* workers per engine */,
+                                                       uint32_t part_first /* the partition's tiles are placed before the workers */) {
+  constexpr size_t L1 = sizeof(kvh_lds) > sizeof(kvr_lds) ? sizeof(kvh_lds) : sizeof(kvr_lds);
+  constexpr size_t LB = L1 > sizeof(kv_part_lds<RPT ? RPT : 1, KVB_T>) ? L1 : sizeof(kv_part_lds<RPT ? RPT : 1, KVB_T>);
+  __shared__ kv_dev Skv;
+  __shared__ __attribute__((aligned(16))) uint8_t Lraw[LB];
+  __shared__ uint2 Sbig[KVR_F];
+  __shared__ uint32_t Stk;
+  uint32_t b = blockIdx.x;
+  if (b < sum_c) {
+    uint32_t e = 0;
+    while (e + 1 < n_eng && b >= M.e[e].cut.P) { b -= M.e[e].cut.P; e++; }
+    kv_resolve_role<WL>(M.e[e], b, Skv, Lraw, Sbig);
+    return;
+  }
+  b -= sum_c;
+  const uint32_t nw = n_work * n_eng, nt = RPT != 0 ? P.n_tiles : 0u;
+  const bool worker = part_first ? b >= nt : b < nw;
+  if (worker) {
+    if (part_first) b -= nt;
+    if (b >= nw) return;
+    const uint32_t e = b / n_work;
+    kv_hot_role<WL>(M.e[e], Skv, Lraw, Stk, b - e * n_work, e);
+    return;
+  }
+  if constexpr (RPT != 0) {
+    if (!part_first) b -= nw;
+    if (b >= P.n_tiles) return;
+    kv_part_body<WL, RPT, KVB_T>(P, *(kv_part_lds<RPT, KVB_T> *)Lraw, b == 0);
+  }
 }
 
 // (r05 tried 128 VGPRs for store / tatp, where the kernel is usually empty, so that a launch need not wait for empty compute
@@ -3573,7 +3668,7 @@ __global__ void __launch_bounds__(KVB_T, 1) k_kv_big(kv_multi_args M, uint32_t f
   const uint32_t t = threadIdx.x;
   if (t < sizeof(kv_dev) / 4) ((uint32_t *)&Skv)[t] = ((const uint32_t *)A.kv)[t];
   __syncthreads();
-  kv_dev_pend_set(Skv, A.seq);
+  kv_dev_pend_set(Skv, A.pno);
   __syncthreads();
   kv_cut cut2 = A.cut;
   cut2.P = A.cut.P * KVR_F;
@@ -3630,14 +3725,27 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
   else if (rpt == 2) hipLaunchKernelGGL((k_kv_part<WL, 2>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   else hipLaunchKernelGGL((k_kv_part<WL, 4>), dim3(max_tiles, n_eng), dim3(KV_TB), 0, st, M);
   if (ev) hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
-  if (ev) hipEventRecord(ev[2], st);
-  // the hot keys.  store / tatp: k_kv_hot (closed forms), then k_kv_big for what it left -- usually nothing: a small grid;
+  // the hot keys.  store / tatp: workers in the resolve launch (k_kv_pass; DINT_KV_NO_FUSE: k_kv_hot / k_kv_hot_part behind
+  // k_kv_resolve, r05 / early r06), then k_kv_late for what the closed forms left -- usually nothing;
   // smallbank (counters: no closed form across workgroups yet) and DINT_KV_NO_SPLIT / DINT_KV_ONE_BIG_KERNEL: k_kv_big alone
   const bool hot = M.e[0].split_min != 0xFFFFFFFFu && !K.one_big_kernel;
-  bool fused = false;
+  bool fused = false, one = false;
   if constexpr (WL != DINT_WL_SMALLBANK) {
-    if (hot && next) {
+    if (hot && !K.no_fuse) {
+      kv_pass_args none;
+      memset(&none, 0, sizeof none);
+      const kv_pass_args &P = next ? *next : none;
+      const dim3 g(sum_c + K.workers * n_eng + P.n_tiles);
+      if (!next) hipLaunchKernelGGL((k_kv_pass<WL, 0>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, P, K.workers, K.part_first);
+      else if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, P, K.workers, K.part_first);
+      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, P, K.workers, K.part_first);
+      one = fused = true;
+    }
+  }
+  if (!one) hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+  if (ev) hipEventRecord(ev[2], st);
+  if constexpr (WL != DINT_WL_SMALLBANK) {
+    if (hot && next && !one) {
       const dim3 g(KVB_GRID + next->n_tiles);
       if (next_rpt == 2) hipLaunchKernelGGL((k_kv_hot_part<WL, 2>), g, dim3(KVB_T), 0, st, M.e[0], *next);
       else hipLaunchKernelGGL((k_kv_hot_part<WL, 4>), g, dim3(KVB_T), 0, st, M.e[0], *next);
