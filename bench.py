@@ -186,7 +186,7 @@ KERNEL_SOURCES = {  # the files the device code of a workload's pass is compiled
     "fasst": ("k_locks.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h"),
     "2pl": ("k_locks.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h"),
     "log": ("k_log.hip", "dint_device.h", "dint_kernels.h"),
-    None: ("k_kv.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h", "dint_kv.h", "dint_kv_core.h"),
+    None: ("k_kv_dev.h", "k_kv.hip", "dint_bins.h", "dint_device.h", "dint_kernels.h", "dint_kv.h", "dint_kv_core.h"),
 }
 
 
@@ -515,7 +515,6 @@ def bench_lock(args, world, rank, dev, transport, kind):
 
     roof, extra = None, {}
     if rt is None:
-        reset()
         eng.timing_enable(True)
         run(W * B, min(n_batches, W * B + 200))
         sync()
@@ -813,6 +812,7 @@ def bench_store(args, world, rank, dev, transport):
     roof, extra, cpu = None, {}, None
     ty = stream[W * B * NB:]["type"]
     if rt is None:
+        reset()
         eng.timing_enable(True)
         run(W * B, min(n_batches, W * B + 200))
         sync()
@@ -826,17 +826,24 @@ def bench_store(args, world, rank, dev, transport):
         t_part = tim.get("k_kv_part", {"avg_us": 0.0})["avg_us"]
         us = tim["k_kv_resolve"]["avg_us"] + tim.get("k_kv_hot", {"avg_us": 0.0})["avg_us"] + tim.get("k_kv_big", {"avg_us": 0.0})["avg_us"]
         ach = alg / (us * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_kv_resolve+k_kv_hot+k_kv_big", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        one_launch = os.environ.get("DINT_KV_NO_FUSE", "0") in ("", "0")
+        if one_launch:  # r06: k_kv_pass (resolve + hot-key workers + the next batch's partition) + k_kv_late: the whole pass is the priced stage
+            alg, us = alg_all, us + t_part
+            ach = alg / (us * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_kv_pass+k_kv_late" if one_launch else "k_kv_resolve+k_kv_hot+k_kv_big", "achieved": round(ach, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(alg),
-                "kernel_avg_us": round(us, 3), "from_profile": profile_counters("store", ["k_kv_resolve", "k_kv_hot", "k_kv_big"])}
+                "kernel_avg_us": round(us, 3),
+                "from_profile": profile_counters("store", ["k_kv_pass", "k_kv_late", "k_kv_part", "k_kv_resolve", "k_kv_hot", "k_kv_big"])}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, alg), 3)
         roof["kernels"] = [{"kernel": k, "kernel_avg_us": round(tim[k]["avg_us"], 3)} for k in tim]
         roof["kernels"][0].update({"alg_bytes_per_launch": int(part_b), "frac": round(part_b / max(t_part, 1e-9) / 1e3 / HBM_PEAK_GBS, 5)})
-        roof["pass"] = {"alg_bytes": int(alg_all), "chain_us": round(t_part + us, 3),
-                        "frac": round(alg_all / max(t_part + us, 1e-9) / 1e3 / HBM_PEAK_GBS, 5),
+        chain_us = us if one_launch else t_part + us
+        roof["pass"] = {"alg_bytes": int(alg_all), "chain_us": round(chain_us, 3),
+                        "frac": round(alg_all / max(chain_us, 1e-9) / 1e3 / HBM_PEAK_GBS, 5),
                         "what": "the pass: algorithmic bytes of all its requests / (part + resolve + big)"}
         roof["gpu"] = {"alg_bytes_per_request": round(alg_all / NB, 1), "achieved": round(K * B * NB / dt * alg_all / NB / 1e9, 2),
                        "frac": round(K * B * NB / dt * alg_all / NB / 1e9 / HBM_PEAK_GBS, 5),
@@ -1247,10 +1254,15 @@ def bench_txn(args, world, rank, dev, transport, kind):
             return {"kernel": name, "kernel_avg_us": round(us, 3), "alg_bytes_per_launch": int(nbytes / L),
                     "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5)}
 
-        if rp.ahead:
-            # look-ahead replay (r06): a pass's chain is k_kv_resolve -> k_kv_hot_part (its hot keys AND the next batch's
-            # partition) -> k_kv_big (empty); the engine's "k_kv_hot" interval is that fused launch, "k_kv_part" only the first
-            # pass's.  The priced stage is therefore the WHOLE pass: every algorithmic byte over the whole chain.
+        one_launch = kind != "smallbank" and os.environ.get("DINT_KV_NO_FUSE", "0") in ("", "0")
+        if one_launch:
+            # r06: a store / tatp pass is ONE launch, k_kv_pass -- the resolve stage, the hot-key workers and (look-ahead replay) the
+            # NEXT batch's partition -- plus k_kv_late (what no closed form covered; usually an empty launch).  The engine's
+            # "k_kv_resolve" interval is k_kv_pass, "k_kv_big" is k_kv_late, "k_kv_part" the first pass's partition only (or, without
+            # look-ahead, every pass's).  The priced stage is the WHOLE pass: every algorithmic byte over the whole chain.
+            stage = priced("k_kv_pass+k_kv_late" + ("" if rp.ahead else "+k_kv_part"), t_part + t_res + t_big, tab_b + part_b)
+        elif rp.ahead:
+            # look-ahead replay, DINT_KV_NO_FUSE: k_kv_resolve -> k_kv_hot_part (the hot keys AND the next batch's partition) -> k_kv_late
             stage = priced("k_kv_resolve+k_kv_hot_part+k_kv_big", t_part + t_res + t_big, tab_b + part_b)
         else:
             stage = priced("k_kv_resolve+k_kv_hot+k_kv_big", t_res + t_big, tab_b)
@@ -1258,13 +1270,17 @@ def bench_txn(args, world, rank, dev, transport, kind):
         # the same command live in profiles/ and are quoted under from_profile only for the same kernel sources
         roof = {"bound": "hbm", **stage, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "requests_in_big_bins": round(f_big, 4),
-                "from_profile": profile_counters(kind, ["k_kv_resolve", "k_kv_hot_part", "k_kv_hot", "k_kv_big"] +
-                                                 (["k_kv_part"] if rp.ahead else []))}
+                "from_profile": profile_counters(kind, ["k_kv_pass", "k_kv_late", "k_kv_resolve", "k_kv_hot_part", "k_kv_hot", "k_kv_big"] +
+                                                 (["k_kv_part"] if rp.ahead or one_launch else []))}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, stage["alg_bytes_per_launch"]), 3)
-        if rp.ahead:
+        if one_launch:
+            roof["kernels"] = [priced("k_kv_part" + (" (first pass only)" if rp.ahead else ""), t_part, 0 if rp.ahead else part_b),
+                               priced("k_kv_pass", t_res + avg.get("k_kv_hot", 0.0), tab_b + (part_b if rp.ahead else 0)),
+                               priced("k_kv_late", avg.get("k_kv_big", 0.0), 0)]
+        elif rp.ahead:
             roof["kernels"] = [priced("k_kv_part (first pass only)", t_part, 0), priced("k_kv_resolve", t_res, tab_b * (1.0 - f_big)),
                                priced("k_kv_hot_part+k_kv_big", t_big, tab_b * f_big + part_b)]
         else:

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdint.so")
+LIB_PATH = os.environ.get("DINT_LIB_PATH") or os.path.join(HERE, "libdint.so")  # (DINT_LIB_PATH: same-box A/B runs of two builds, tools/)
 
 ABI_VERSION = 4
 #: dint_config.flags (include/dint_abi.h)

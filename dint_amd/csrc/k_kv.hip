@@ -77,8 +77,11 @@ static dint_kv_knobs kv_read_knobs() {
   k.one_big_kernel = kv_env("DINT_KV_ONE_BIG_KERNEL", 0);
   k.no_ahead = kv_env("DINT_KV_NO_AHEAD", 0);
   k.no_fuse = kv_env("DINT_KV_NO_FUSE", 0);
+  // (never fewer workers than a hot key has pieces + a remainder, + 1: the pieces wait for each other.  An idle worker holds half
+  // a compute unit that another shard server's resolve workgroup is waiting for: 320 / 192 / 96 / 48 workers per engine gave
+  // 2,320 / 2,650 .. 2,840 / 2,980 .. 3,030 / 2,820 Mtxn/s on the tatp bench stream -- ~160 items per pass)
   k.workers = std::min(1024u, std::max(KVR_NPMAX + 2u, kv_env("DINT_KV_WORKERS", KVW_GRID)));  // (a hot key's pieces + remainder wait for each other: never fewer workers)
-  k.part_first = kv_env("DINT_KV_PART_FIRST", 1);
+  k.part_first = kv_env("DINT_KV_PART_FIRST", 0) & 1u;
   k.late_grid = std::min(KVB_GRID, std::max(1u, kv_env("DINT_KV_LATE_GRID", 8u)));
   k.late_big = kv_env("DINT_KV_LATE_BIG", 0);
   k.exp_no_late = kv_env("DINT_EXP_NO_LATE", 0);

@@ -3429,7 +3429,8 @@ __device__ __forceinline__ static void kv_late_stretch(uint8_t *rep, const kv_cu
       return;
     }
     if (force_rounds || !kv_group_phases<WL>(rep, cut2, kv, bin, H.all, Gs, Gs + len, H, stats, V))
-      kv_serial_group<WL>(rep, cut2, kv, bin, H.all, Gs, Gs + len, H, stats, V);
+      kv_serial_group<WL>(rep, cut2, kv, bin, H.all, Gs, Gs + len, H, stats, V);  // (kv_do_request: 550 of k_kv_late's 760 bytes of scratch per lane
+                                                                                   // -- a build without it ran the bench no faster, r06)
     __syncthreads();
     const bool mv = t >= Gs + len && t < m;  // the group leaves the array
     const uint64_t mw = mv ? H.all[t] : 0;
@@ -3529,7 +3530,7 @@ static_assert(sizeof(kvb_lds) + (KV_HOT_BM ? KV_HOT_BM_W * 10 : 16) + sizeof(kv_
 // workgroup waits for, and a launch places every resolve workgroup before its first worker (block order), so whoever a worker
 // waits for is running; the siblings of a hot key's piece are listed together and sit side by side in the list, so whoever a
 // piece waits for holds a ticket or draws the very next ones (kv_hot_item).
-#define KVW_GRID 192u  // workers per engine of k_kv_pass (a tatp pass of the bench lists ~160 items; a worker takes as many as it gets)
+#define KVW_GRID 96u  // workers per engine of k_kv_pass by default (DINT_KV_WORKERS; a worker takes as many items as it gets)
 template <int WL>
 __device__ __forceinline__ static void kv_hot_role(const kv_pass_args &A, kv_dev &Skv, uint8_t *Lraw, uint32_t &Stk, uint32_t bx, uint32_t by) {
   const uint32_t t = threadIdx.x;
