@@ -234,8 +234,6 @@ __device__ __forceinline__ static void kv_part_body(const kv_pass_args &A, kv_pa
   // tiles are handed out in start order (a ticket, not blockIdx), so the tiles before mine belong to workgroups that
   // are already running: what the log-position look-back below waits for
   if (t == 0) { Stile = atomicAdd(&A.big[2], 1u); Sov[0] = 0; }
-  if (first_block && t < KV_NLISTS)  // entries freed by earlier passes become reusable: the pend set THIS pass will push to
-    for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t, (A.pno & 1u) * KV_NLISTS);
   for (uint32_t k = t; k < C; k += TB) Hc[k] = 0;
   __syncthreads();
   const uint32_t tile = Stile;
@@ -394,6 +392,12 @@ __device__ __forceinline__ static void kv_part_body(const kv_pass_args &A, kv_pa
       }
     }
   }
+  // entries freed by earlier passes become reusable: the pend set THIS pass will push to (kv_pool_rotate).  LAST, by the
+  // workgroup of the first block: the rotation is a chain of device-scope atomics per list (10 .. 20 us), and every tile's
+  // log look-back waits for the counts of the tiles before it -- in front of tile 0's work (early r06) it delayed the whole
+  // launch (k_kv_part 26 -> 39 us).  Nothing pops a free list before the next resolve stage, a launch later.
+  if (first_block && t < KV_NLISTS)
+    for (uint32_t k = 0; k < kv->n_tables; k++) kv_pool_rotate<kv_dev_mem>(kv->tab[k], t, (A.pno & 1u) * KV_NLISTS);
 }
 
 template <int WL, int RPT>
@@ -2377,8 +2381,19 @@ enum : uint32_t { KVQ_SUB = 0, KVQ_PIECE = 1, KVQ_REM = 2, KVQ_SOLO = 3 };
 __device__ static inline void kv_list_items(const kv_pass_args &A, uint32_t b, const kvr_lds &L, const uint2 *Sbig) {
   const uint32_t t = threadIdx.x & 63u;
   const uint2 bs = Sbig[t];
-  const bool hot = bs.y >= A.split_min && bs.y <= KVR_NPMAX * (KVB_T - 64u);  // (more than the pieces can hold: kv_big_bin's / k_kv_late's, via the late list)
-  const uint32_t np = hot ? min(KVR_NPMAX, (bs.y + A.split_target - 1) / A.split_target) : 0u;
+  // A piece is a range of the request INDEX, and the requests of a segmented pass (the closed loop's batches, the exchange's
+  // slots) fill only the front of each segment: a range that lies in a filled stretch holds n / live times the average.  The
+  // pieces are sized for that -- r05 / early r06 sized them for the average, every hot key of a closed-loop pass (slots 80 %
+  // full) had a piece of more than KVB_T requests, said so, and went the slow way: k_kv_late 240 us per epoch.
+  uint32_t target = A.split_target;
+  if (A.V.seg_cap) {
+    uint32_t live = t < A.V.n_seg ? min(A.V.seg_cap, *(const uint32_t *)(A.V.cnt + (size_t)t * A.V.cnt_stride)) : 0u, tot;
+    (void)wave_excl_scan_u32(live, &tot);
+    if (tot < A.n) target = max(8u, (uint32_t)(((uint64_t)target * max(tot, 1u)) / A.n));
+  }
+  const uint32_t np0 = (bs.y + target - 1) / target;
+  const bool hot = bs.y >= A.split_min && np0 <= KVR_NPMAX;  // (more than the pieces can hold: k_kv_late's / kv_big_bin's, via the late list)
+  const uint32_t np = hot ? np0 : 0u;
   const uint32_t nent = bs.y ? (np > 1 ? np + 1 : 1u) : 0u;
   uint32_t tot, at = wave_excl_scan_u32(nent, &tot);
   uint32_t base = 0;

@@ -585,3 +585,44 @@ def test_eight_ranks_at_the_baseline_shape_equal_one_unsharded_server(wl, n_rows
         assert st["bad_requests"] == 0 and st["pool_exhausted"] == 0
     if wire.Workload(wl) == W.TATP:
         assert any(h % world for h in res[0][5][0]), res[0][5]  # a bucket count the ranks cannot divide evenly
+
+
+@pytest.mark.parametrize("fill", [0.55, 0.8, 1.0])
+def test_hot_keys_in_half_filled_segments_stay_in_closed_form(fill):
+    """A hot key's pieces are ranges of the request INDEX, and a segmented pass (the closed loop's batches, the slots of the
+    exchange) fills only the front of each segment: the pieces are sized for the filled stretches (kv_list_items), so no piece
+    holds more requests than a workgroup has threads and nothing goes the slow way (dint_stats.late_requests: early r06 sent
+    every hot key of a closed-loop pass there, 240 us per epoch).  Against the contiguous run of the same requests."""
+    T = wire.Tatp
+    n, n_sub, nseg = 60_000, 3000, 3
+    o = orc.TatpOracle(n_sub, log_entries=200_000)
+    existing = [o.dump(t)[0] for t in range(5)]
+    rng = np.random.default_rng(11)
+    req = tracegen.tatp_random(n, existing, seed=12, n_sub_touch=n_sub)
+    u = rng.random(n)
+    for key, lo, hi in ((5, 0.0, 0.10), (77, 0.10, 0.15), (1234, 0.15, 0.175)):  # 6,000 / 3,000 / 1,500 requests on three subscribers
+        hot = (u >= lo) & (u < hi)
+        req["table"][hot] = 0
+        req["key"][hot] = key
+        req["type"][hot] = rng.choice([T.READ, T.ACQUIRE_LOCK, T.ABORT, T.COMMIT_PRIM, T.COMMIT_BCK], int(hot.sum()), p=[0.7, 0.1, 0.04, 0.08, 0.08])
+    per = n // nseg
+    cuts = [0, per, 2 * per, n]
+    cap = int(per / fill) + 8
+
+    def mk():
+        e = _engine(W.TATP, n_rows=n_sub, log_entries=200_000)
+        e.populate(n_sub)
+        return e
+    a, b = mk(), mk()
+    want = a.submit(req)
+    assert want.tobytes() == o.replay(req).tobytes()
+    buf, stride, _ = _segmented(req, cuts, cap)
+    d = torch.from_numpy(buf).cuda()
+    b.submit_segments(d.data_ptr() + 64, nseg, cap, stride, d.data_ptr(), stride)
+    b.sync()
+    got = _unsegment(d.cpu().numpy(), cuts, stride, req.dtype)
+    assert got.tobytes() == want.tobytes()
+    for t in range(5):
+        assert all((x == y).all() for x, y in zip(a.dump_rows(t), b.dump_rows(t)))
+    st = b.stats()
+    assert st["big_bin_requests"] > 9_000 and st["late_requests"] == 0, st
