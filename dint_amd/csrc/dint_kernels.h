@@ -29,6 +29,7 @@ struct dint_kv_sets {
   uint4 *kbins[2] = {nullptr, nullptr};             // [C][cap] the coarse bins
   uint4 *ovl[2] = {nullptr, nullptr};               // the pass's overflow list
   uint32_t *bigrdy = nullptr;                       // [DINT_KV_BIGQ_MAX] work item i is listed: the pass's tag (pass_seq)
+  uint64_t *sbx = nullptr;                          // smallbank: [DINT_KV_SBX_ITEMS][40] the pieces' op masks and grants (k_kv_dev.h, kv_sb_item)
   uint64_t pass_no = 0;                             // passes launched so far (host side)
 };
 

@@ -497,6 +497,8 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
       TRY(dev_alloc((void **)&e->scratch.kvs.kbins[1], (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
       TRY(dev_alloc((void **)&e->scratch.kvs.ovl[1], (size_t)e->pass_max * sizeof(uint4) * 2, false));
       TRY(dev_alloc((void **)&e->scratch.kvs.bigrdy, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint32_t)));
+      if (wl == DINT_WL_SMALLBANK)  // what the pieces of a hot account's row tell each other: 40 words per work item (kv_sb_item)
+        TRY(dev_alloc((void **)&e->scratch.kvs.sbx, (size_t)DINT_KV_BIGQ_MAX * 40 * sizeof(uint64_t), false));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
       // lock tables, passes of <= 65,536 requests (k_locks.hip, LK_DIRECT_NMAX): a big bin's records beyond the 64 in place go
@@ -586,6 +588,7 @@ void dint_engine_destroy(dint_engine_t *e) {
   hipFree(e->scratch.kvs.kbins[1]);
   hipFree(e->scratch.kvs.ovl[1]);
   hipFree(e->scratch.kvs.bigrdy);
+  hipFree(e->scratch.kvs.sbx);
   hipFree(e->scratch.stats);
   hipFree(e->scratch.blk_cnt);
   hipFree(std::min(e->scratch.blk_pub, e->scratch.blk_pub_next));

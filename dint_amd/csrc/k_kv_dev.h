@@ -175,6 +175,8 @@ struct kv_pass_args {
   uint32_t *big, *big_z;     // the pass's control words (dint_kv_sets::ctl) / the set this pass's resolve stage zeroes (the pass after next's)
   uint32_t *blk_pub, *blk_pub_z;
   uint32_t *bigrdy;          // [item] listed: tagged with `seq`
+  uint64_t *sbx;             // smallbank, [item][KSB_WORDS]: what the pieces of a hot row and their coordinator tell each other (kv_sb_item)
+  uint32_t np_max;           // pieces of one hot key at most: KVR_NPMAX (store / tatp), KSB_NPMAX (smallbank)
   uint32_t pno;              // pass number & 1: which pend set the pass's frees go to, which log tail word its partition reads
   uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
   uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
@@ -989,6 +991,52 @@ struct kvb_lds {
   uint32_t Hs[16];                 // dominant-key path: candidate counts, flags, the row's location
   int Hc[2][KVB_W];                // ... wave carries of its prefix tables
 };
+
+// ---- smallbank's counters over <= 64 requests of one key in request order (smallbank/udp/server_shard.cc:121-161), one wave:
+// returns the granted lanes of `rem` (ACQUIREs and RELEASEs by kind as lane masks); la = num_ex, lb = num_sh, wave-uniform.
+__device__ static inline uint64_t kv_sb_walk(uint64_t rem, uint64_t mAS, uint64_t mAX, uint64_t mRS, uint64_t mRX, uint32_t &la, uint32_t &lb) {
+  const uint32_t lane = lane_id();
+  // The counters move between two modes.  FREE (num_ex == 0): every ACQUIRE_SHARED is granted (num_sh++),
+  // RELEASE_SHARED decrements, and nothing else happens until an EVENT: an ACQUIRE_EXCLUSIVE that finds
+  // num_sh == 0 (granted: num_ex = 1) or a RELEASE_EXCLUSIVE (num_ex wraps to 2^32 - 1, as the reference's
+  // unsigned counter does).  HELD (num_ex != 0): every ACQUIRE is rejected, RELEASE_SHARED still decrements,
+  // until the num_ex-th RELEASE_EXCLUSIVE.  Between events all lanes are resolved at once (num_sh before a lane
+  // = num_sh + ACQUIRE_SHAREDs - RELEASE_SHAREDs below it): a contended account changes mode rarely.
+  uint64_t G = 0;
+  while (rem) {
+    if (la == 0) {
+      const uint64_t blw = rem & lanemask_lt();
+      const uint32_t lb_before = lb + (uint32_t)__popcll(blw & mAS) - (uint32_t)__popcll(blw & mRS);
+      const bool me = (rem >> lane) & 1ull;
+      const uint64_t ev = __ballot(me && ((((mAX >> lane) & 1ull) && lb_before == 0) || ((mRX >> lane) & 1ull)));
+      const uint64_t upto = ev ? (ev & (0 - ev)) - 1ull : ~0ull;  // the lanes below the first event
+      const uint64_t seg = rem & upto;
+      G |= seg & mAS;
+      lb += (uint32_t)__popcll(seg & mAS) - (uint32_t)__popcll(seg & mRS);
+      rem &= ~upto;
+      if (ev) {
+        const uint64_t bit = ev & (0 - ev);
+        if (bit & mAX) { G |= bit; la = 1; } else la = 0xFFFFFFFFu;
+        rem &= ~bit;
+      }
+    } else {
+      uint64_t rx = rem & mRX;
+      const uint32_t nrx = (uint32_t)__popcll(rx);
+      if (nrx < la) {  // held to the end of these lanes
+        lb -= (uint32_t)__popcll(rem & mRS);
+        la -= nrx;
+        rem = 0;
+      } else {
+        for (uint32_t k = 1; k < la; k++) rx &= rx - 1;  // the la-th RELEASE_EXCLUSIVE (la is 1 unless the counter wrapped)
+        const uint64_t bit = rx & (0 - rx), upto = bit - 1ull;
+        lb -= (uint32_t)__popcll(rem & upto & mRS);
+        la = 0;
+        rem &= ~(upto | bit);
+      }
+    }
+  }
+  return G;
+}
 
 // ---- big subs (more than 64 records on one sub of a coarse bin: hot keys), the whole 512-thread workgroup -----------
 // The same algorithm as kv_chunk, over up to KVB_NMAX requests at a time:
@@ -1846,46 +1894,7 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
     if (WL == DINT_WL_SMALLBANK) {
       // returns the granted lanes of `rem` (ACQUIREs and RELEASEs of one key in request order); la = num_ex, lb = num_sh
       auto sb_walk = [&](uint64_t rem, uint64_t mAS, uint64_t mAX, uint64_t mRS, uint64_t mRX, uint32_t &la, uint32_t &lb) -> uint64_t {
-        // The counters move between two modes.  FREE (num_ex == 0): every ACQUIRE_SHARED is granted (num_sh++),
-        // RELEASE_SHARED decrements, and nothing else happens until an EVENT: an ACQUIRE_EXCLUSIVE that finds
-        // num_sh == 0 (granted: num_ex = 1) or a RELEASE_EXCLUSIVE (num_ex wraps to 2^32 - 1, as the reference's
-        // unsigned counter does).  HELD (num_ex != 0): every ACQUIRE is rejected, RELEASE_SHARED still decrements,
-        // until the num_ex-th RELEASE_EXCLUSIVE.  Between events all lanes are resolved at once (num_sh before a lane
-        // = num_sh + ACQUIRE_SHAREDs - RELEASE_SHAREDs below it): a contended account changes mode rarely.
-        uint64_t G = 0;
-        while (rem) {
-          if (la == 0) {
-            const uint64_t blw = rem & lanemask_lt();
-            const uint32_t lb_before = lb + (uint32_t)__popcll(blw & mAS) - (uint32_t)__popcll(blw & mRS);
-            const bool me = (rem >> lane) & 1ull;
-            const uint64_t ev = __ballot(me && ((((mAX >> lane) & 1ull) && lb_before == 0) || ((mRX >> lane) & 1ull)));
-            const uint64_t upto = ev ? (ev & (0 - ev)) - 1ull : ~0ull;  // the lanes below the first event
-            const uint64_t seg = rem & upto;
-            G |= seg & mAS;
-            lb += (uint32_t)__popcll(seg & mAS) - (uint32_t)__popcll(seg & mRS);
-            rem &= ~upto;
-            if (ev) {
-              const uint64_t bit = ev & (0 - ev);
-              if (bit & mAX) { G |= bit; la = 1; } else la = 0xFFFFFFFFu;
-              rem &= ~bit;
-            }
-          } else {
-            uint64_t rx = rem & mRX;
-            const uint32_t nrx = (uint32_t)__popcll(rx);
-            if (nrx < la) {  // held to the end of these lanes
-              lb -= (uint32_t)__popcll(rem & mRS);
-              la -= nrx;
-              rem = 0;
-            } else {
-              for (uint32_t k = 1; k < la; k++) rx &= rx - 1;  // the la-th RELEASE_EXCLUSIVE (la is 1 unless the counter wrapped)
-              const uint64_t bit = rx & (0 - rx), upto = bit - 1ull;
-              lb -= (uint32_t)__popcll(rem & upto & mRS);
-              la = 0;
-              rem &= ~(upto | bit);
-            }
-          }
-        }
-        return G;
+        return kv_sb_walk(rem, mAS, mAX, mRS, mRX, la, lb);
       };
       for (uint32_t c = wave; c * 64 < m; c += KVB_W) {  // the segments that start in chunk c, as far as the chunk goes
         const uint32_t p = c * 64 + lane;
@@ -2392,7 +2401,8 @@ __device__ static inline void kv_list_items(const kv_pass_args &A, uint32_t b, c
     if (tot < A.n) target = max(8u, (uint32_t)(((uint64_t)target * max(tot, 1u)) / A.n));
   }
   const uint32_t np0 = (bs.y + target - 1) / target;
-  const bool hot = bs.y >= A.split_min && np0 <= KVR_NPMAX;  // (more than the pieces can hold: k_kv_late's / kv_big_bin's, via the late list)
+  // (more than the pieces can hold: k_kv_late's / kv_big_bin's, via the late list; smallbank (np_max = KSB_NPMAX): pieces or nothing)
+  const bool hot = bs.y >= A.split_min && np0 <= A.np_max && (A.np_max == KVR_NPMAX || np0 >= 2);
   const uint32_t np = hot ? np0 : 0u;
   const uint32_t nent = bs.y ? (np > 1 ? np + 1 : 1u) : 0u;
   uint32_t tot, at = wave_excl_scan_u32(nent, &tot);
@@ -2408,7 +2418,7 @@ __device__ static inline void kv_list_items(const kv_pass_args &A, uint32_t b, c
     for (uint32_t p = 0; p < nent; p++) {
       const uint32_t kind = np == 1 ? KVQ_SOLO : (p < np ? KVQ_PIECE : KVQ_REM);
       uint4 *q = A.bigq + KVQ_W * (size_t)(at + p);
-      kv_st_agent(q, make_uint4(bin, bs.x, bs.y, kind | (p << 2) | (np << 8)));
+      kv_st_agent(q, make_uint4(bin, bs.x, bs.y, kind | (p << 2) | (np << 10)));
       kv_st_agent(q + 1, make_uint4((uint32_t)hk, (uint32_t)(hk >> 32), at, 0u));
       kv_st_agent(q + 2, make_uint4((uint32_t)hr, (uint32_t)(hr >> 32), 0u, 0u));
     }
@@ -3120,7 +3130,7 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
   using F = Fmt<WL>;
   kvh_lds &H = *(kvh_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 63u, np = (d.w >> 8) & 63u;
+  const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 255u, np = (d.w >> 10) & 255u;
   const uint32_t first = x.z, h = d.z;
   const uint32_t sh_g = 16 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
   const uint64_t hkey = ((uint64_t)x.y << 32) | x.x, hrec = ((uint64_t)y.y << 32) | y.x;
@@ -3530,6 +3540,280 @@ __global__ void __launch_bounds__(KVB_T, WPS) k_kv_late(kv_multi_args M, uint32_
   for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) kv_late_item<WL>(A, cut2, &Skv, A.lateq[i], *(kvh_lds *)Lraw, Ll);
 }
 
+// ---- smallbank: a hot account's row in PIECES, several workgroups at once (r06; VERDICT r03 .. r05) ----------------------------------
+// kv_big_bin takes a hot account -- 16,000 .. 35,000 requests of a 360k-request pass at Zipf 0.99 -- in stretches of 4,096, one
+// after the other on ONE workgroup: 4 .. 9 x 45 us while 255 compute units wait.  Of a stretch only the grant decisions are
+// serial (the shared / exclusive counters: FREE until an ACQUIRE_EXCLUSIVE finds num_sh == 0, HELD until the num_ex-th
+// RELEASE_EXCLUSIVE -- kv_sb_walk), ~5 us of the 45; collecting, ordering, key checks and the replies are not.  So, as store /
+// tatp's hot keys (kv_hot_item): the resolve workgroup lists the sub as np PIECES (ranges of the request index, <= KVB_T requests
+// of the hot key each) + a REMAINDER (the sub's other keys), and
+//   every piece   picks its requests out of the sub's records, orders them by index, checks their keys, reads header and row, and
+//                 publishes its op kinds as lane masks per 64-request chunk {ACQ_SHARED, ACQ_EXCL, REL_SHARED, REL_EXCL} (32 words)
+//                 + one word {ok, writers, index of the last writer};
+//   piece 0       -- the COORDINATOR -- waits for all np words, gathers the masks (np x 8 chunks, one per lane, 64 at a time) and
+//                 walks them with the counters in registers: all chunks of a round checked AT ONCE for whether they can change the
+//                 counters' mode, only those that can are walked (the scan kv_big_bin runs inside one stretch, lock_2pl's groups);
+//                 it publishes every chunk's granted lanes, stores the counters, and says "go";
+//   every piece   answers its requests: grants from the coordinator's masks, version = v0 + writers before me, value = message of
+//                 the last writer before me (else the row) -- the writers before a piece come from the pieces' words;
+//                 the piece with the pass's last COMMIT stores row and version.
+// The serial part of a 35,000-request account is one wave's pass over ~560 chunk masks instead of nine stretches.  ALL OR NOTHING as
+// kv_hot_item: a piece with more than KVB_T requests, a second key behind the hash bits, another key on the hot row's counter pair,
+// an unknown op -- then piece 0 takes the whole sub the old way (kv_big_bin) and its siblings do nothing.
+// Semantics per op: smallbank/udp/server_shard.cc:121-173 (as kv_do_request).  Nobody stores to the table before the
+// coordinator's word is out, i.e. before every piece has read header and row.
+#define KSB_NPMAX 128u   // pieces of one hot row at most (~49,000 requests; beyond: kv_big_bin)
+#define KSB_WORDS 40u    // words per item in sbx: [4 c + k] op kind k of chunk c (k: AS, AX, RS, RX), [32 + c] the granted lanes of chunk c
+struct kvs_lds {
+  uint32_t key[KVB_T];            // idx << 9 | slot: sorted = the piece in request order
+  uint32_t idx[KVB_T];            // request index at each sorted position
+  uint8_t typ[KVB_T];             // request type by slot
+  uint64_t Mk[4][KVB_W], Mw[KVB_W], G[KVB_W];
+  unsigned long long pub[KSB_NPMAX + 1];
+  uint64_t cm[4][KSB_NPMAX * KVB_W];  // the coordinator: every piece's op masks, chunk after chunk
+  uint64_t cg[KSB_NPMAX * KVB_W];     // ... and the grants
+  uint32_t bad, timeout, nhot, nrem, found, link, slot, ver0, table, la, lb, allok;
+  uint32_t rowv[2];
+};
+template <int WL>
+__device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2, const kv_dev *kv, const uint4 d, const uint4 x, const uint4 y,
+                                                 const uint64_t *__restrict__ ovf, uint64_t *__restrict__ ovf2, unsigned long long *hotpub, uint64_t *sbx,
+                                                 uint32_t seq, uint32_t inv_n, dint_dev_stats *__restrict__ stats, const dint_view V, uint8_t *lds_raw,
+                                                 uint32_t *src, uint32_t *off, uint32_t *cnt) {
+  using F = Fmt<WL>;
+  static_assert(sizeof(kvs_lds) <= sizeof(kvb_lds), "the pieces' LDS lives in kv_big_bin's buffer");
+  kvs_lds &H = *(kvs_lds *)lds_raw;
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 255u, np = (d.w >> 10) & 255u;
+  const uint32_t first = x.z, h = d.z;
+  const uint32_t sh_g = 16 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
+  const uint64_t hkey = ((uint64_t)x.y << 32) | x.x, hrec = ((uint64_t)y.y << 32) | y.x;
+  const uint32_t hq = pay_q(kv_rec_pay(hrec)), hkh = pay_kh(kv_rec_pay(hrec));
+  const bool do_piece = kind == KVQ_PIECE;
+  unsigned long long *pub = hotpub + first;  // [0, np): the pieces' words; [np]: the coordinator's
+  *src = 0; *off = d.y; *cnt = h;
+  auto spin_for = [&](unsigned long long *p) -> unsigned long long {  // a word of this pass (siblings hold tickets or draw the next ones)
+    unsigned long long w = 0;
+    for (uint32_t spins = 0;; spins++) {
+      w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((uint32_t)(w >> 34) == (seq & 0x3FFFFFFFu)) break;
+      if (spins > (1u << 22)) { H.timeout = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    return w;
+  };
+  __syncthreads();  // the LDS buffer is free
+  H.key[t] = 0xFFFFFFFFu;
+  if (t == 0) { H.bad = 0; H.timeout = 0; H.nhot = 0; H.nrem = 0; H.allok = 0; }
+  __syncthreads();
+  // ---- one pass over the sub's records: the hot row's requests of my index range are mine; the others are the remainder's
+  for (uint32_t k0 = 0; k0 < h; k0 += KVB_T) {
+    const uint32_t k = k0 + t;
+    const uint64_t r = k < h ? kv_ld_agent(&ovf[d.y + k]) : 0;
+    const uint32_t pay = kv_rec_pay(r), ridx = (uint32_t)(r >> 16) & idx_mask, type = pay_type(pay);
+    const bool same_g = k < h && (r >> sh_g) == (hrec >> sh_g), same = same_g && pay_kh(pay) == hkh;
+    if (same_g && !same && pay_q(pay) == hq && type <= 3u) H.bad = 1;  // another key on the hot row's counter pair (every item sees it alike)
+    if (do_piece) {
+      const bool mine = same && kv_piece_of(ridx, np, inv_n) == j;
+      const uint64_t mm = __ballot(mine);
+      uint32_t at = 0;
+      if (lane == 0 && mm) at = atomicAdd(&H.nhot, (uint32_t)__popcll(mm));
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
+      if (mine && at < KVB_T) { H.key[at] = (ridx << 9) | at; H.typ[at] = (uint8_t)(type & 0xFFu); }
+    } else {
+      const bool other = k < h && !same;
+      const uint64_t mm = __ballot(other);
+      uint32_t at = 0;
+      if (lane == 0 && mm) at = atomicAdd(&H.nrem, (uint32_t)__popcll(mm));
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
+      if (other) ovf2[d.y + at] = r;  // compacted, for kv_big_bin
+    }
+  }
+  __syncthreads();
+  if (!do_piece) {  // the REMAINDER: once the pieces are in closed form, the sub's other keys the old way -- else nothing (piece 0 takes the sub)
+    if (t == 0) H.pub[0] = spin_for(&pub[np]);
+    __syncthreads();
+    if (H.timeout) __builtin_trap();
+    if (!((H.pub[0] >> 33) & 1ull) || H.nrem == 0) return 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    *src = 1; *off = d.y; *cnt = H.nrem;
+    return 1;
+  }
+  const uint32_t c = H.nhot;
+  if (t == 0 && c > KVB_T) H.bad = 1;
+  // ---- the row (every piece: the value a read may need) and, piece 0, the counters -- BEFORE anything is published
+  kv_tab tb;
+  uint64_t bucket = 0;
+  uint32_t table = 0;
+  {
+    const uint32_t gk = kv_cut_gk((uint32_t)(hrec >> sh_g), d.x, cut2);
+    table = kv_table_of(kv, gk);
+    tb = kv->tab[table];
+    bucket = (uint64_t)(gk - kv->gk_base[table]);
+  }
+  uint8_t *ie = kv_entry_ptr(tb, bucket, KV_INLINE);
+  if (t == 0) {
+    kv_hdr Hd;
+    kv_hdr_load(Hd, ie);
+    const kv_where w = kv_locate(tb, bucket, Hd, hkey);
+    H.found = w.found; H.link = w.link; H.slot = w.slot; H.ver0 = w.ver; H.table = table;
+    if (w.found) {
+      const uint8_t *rv = kv_entry_ptr(tb, bucket, w.link) + KV_VAL_OFF + w.slot * F::VS;
+      H.rowv[0] = KV_LD(uint32_t, rv); H.rowv[1] = KV_LD(uint32_t, rv + 4);
+    }
+    const uint2 cc = *(const uint2 *)(ie + KV_SB_LOCK_OFF + 8 * hq);
+    H.la = cc.x; H.lb = cc.y;
+  }
+  __syncthreads();
+  kvb_sort_blocked_u32<1>(H.key, KVB_T);
+  const uint32_t sk = H.key[t];
+  const bool v = sk != 0xFFFFFFFFu;
+  const uint32_t my_idx = sk >> 9, my_type = v ? H.typ[sk & 511u] : 0xFFu;
+  uint8_t *msg = rep + dint_view_off(V, v ? my_idx : 0u, F::MSG);
+  if (v && ld_u64(msg + F::KEY) != hkey) H.bad = 1;     // 9 hash bits can collide
+  if (v && !(my_type <= 5u || my_type == 17u)) H.bad = 1;
+  const bool wr = v && (my_type == 4u || my_type == 5u);
+  {
+    const uint64_t b0 = __ballot(v && my_type == 0u), b1 = __ballot(v && my_type == 1u), b2 = __ballot(v && my_type == 2u), b3 = __ballot(v && my_type == 3u);
+    const uint64_t bw = __ballot(wr);
+    if (lane == 0) { H.Mk[0][wave] = b0; H.Mk[1][wave] = b1; H.Mk[2][wave] = b2; H.Mk[3][wave] = b3; H.Mw[wave] = bw; }
+  }
+  H.idx[t] = my_idx;
+  __syncthreads();
+  uint32_t wr_below = 0, wr_tot = 0;
+  int lw_below = -1, lw_tot = -1;
+#pragma unroll
+  for (uint32_t w = 0; w < KVB_W; w++) {
+    const uint64_t mw = H.Mw[w], mwb = w < wave ? mw : (w == wave ? mw & lanemask_lt() : 0ull);
+    wr_below += (uint32_t)__popcll(mwb); wr_tot += (uint32_t)__popcll(mw);
+    if (mwb) lw_below = (int)(w * 64 + 63 - __clzll((long long)mwb));
+    if (mw) lw_tot = (int)(w * 64 + 63 - __clzll((long long)mw));
+  }
+  // ---- publish: the op masks, then the word
+  if (t < 4 * KVB_W) kv_st_agent(&sbx[(size_t)(first + j) * KSB_WORDS + t], H.Mk[t & 3u][t >> 2]);
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t == 0) __hip_atomic_store(&pub[j], kvh_word(seq, !H.bad, wr_tot, lw_tot >= 0 ? (int)H.idx[lw_tot] : -1, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- piece 0, the coordinator
+  if (j == 0) {
+    if (t < np) H.pub[t] = spin_for(&pub[t]);
+    __syncthreads();
+    if (H.timeout) __builtin_trap();
+    bool all_ok = true;
+    for (uint32_t k = 0; k < np; k++) all_ok = all_ok && ((H.pub[k] >> 33) & 1ull);
+    const uint32_t nchunk = np * KVB_W;
+    if (all_ok) {
+      for (uint32_t w = t; w < np * 4 * KVB_W; w += KVB_T) {
+        const uint32_t p = w / (4 * KVB_W), r = w % (4 * KVB_W);
+        H.cm[r & 3u][p * KVB_W + (r >> 2)] = kv_ld_agent(&sbx[(size_t)(first + p) * KSB_WORDS + r]);
+      }
+      __syncthreads();
+      if (wave == 0) {  // lane l holds chunk base + l; all 64 checked at once under the assumption that the mode holds (kv_big_bin)
+        uint32_t la = H.la, lb = H.lb;
+        for (uint32_t base = 0; base < nchunk; base += 64) {
+          const uint32_t ci = base + lane;
+          const bool inr = ci < nchunk;
+          const uint64_t cAS = inr ? H.cm[0][ci] : 0ull, cAX = inr ? H.cm[1][ci] : 0ull, cRS = inr ? H.cm[2][ci] : 0ull, cRX = inr ? H.cm[3][ci] : 0ull;
+          const uint32_t nas = (uint32_t)__popcll(cAS), nrs = (uint32_t)__popcll(cRS);
+          uint64_t g = 0, pend = __ballot((cAS | cAX | cRS | cRX) != 0);
+          while (pend) {
+            const bool me = (pend >> lane) & 1ull;
+            const uint32_t dl = me ? (la != 0 ? 0u - nrs : nas - nrs) : 0u;  // what my chunk adds to num_sh if it is inert
+            uint32_t tot, pre = wave_excl_scan_u32(dl, &tot);
+            const uint32_t lb_in = lb + pre;
+            const bool inert = la != 0 ? cRX == 0 : (cRX == 0 && (cAX == 0 || (lb_in > nrs && lb_in <= 0xFFFFFFFFu - nas)));
+            const uint64_t stop = __ballot(me && !inert);
+            const uint64_t ok = stop ? pend & ((stop & (0 - stop)) - 1ull) : pend;  // the chunks before the first one that is not
+            if (((ok >> lane) & 1ull) && la == 0) g |= cAS;
+            if (!stop) { lb += tot; break; }
+            const int f = __ffsll((unsigned long long)stop) - 1;
+            lb += (uint32_t)__builtin_amdgcn_readlane((int)pre, f);  // (the chunks before f)
+            const uint64_t mAS = readlane_u64(cAS, f), mAX = readlane_u64(cAX, f), mRS = readlane_u64(cRS, f), mRX = readlane_u64(cRX, f);
+            const uint64_t G = kv_sb_walk(mAS | mAX | mRS | mRX, mAS, mAX, mRS, mRX, la, lb);
+            if ((int)lane == f) g |= G;
+            pend &= ~(ok | (1ull << f));
+          }
+          if (inr) H.cg[ci] = g;
+        }
+        if (lane == 0 && (la != H.la || lb != H.lb)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * hq) = make_uint2(la, lb);  // (every piece has read the row: their words are in)
+      }
+      __syncthreads();
+      for (uint32_t w = t; w < nchunk; w += KVB_T) kv_st_agent(&sbx[(size_t)(first + w / KVB_W) * KSB_WORDS + 4 * KVB_W + (w % KVB_W)], H.cg[w]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&pub[np], kvh_word(seq, all_ok, 0, -1, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- every piece: the coordinator's word, my grants, the siblings' words
+  if (t == 0) H.pub[KSB_NPMAX] = spin_for(&pub[np]);
+  __syncthreads();
+  if (H.timeout) __builtin_trap();
+  if (!((H.pub[KSB_NPMAX] >> 33) & 1ull)) {  // not in closed form: piece 0 takes the whole sub (nobody has touched it), the others nothing
+    if (j != 0) return 0;
+    *src = 0; *off = d.y; *cnt = h;
+    return 1;
+  }
+  if (t < KVB_W) H.G[t] = kv_ld_agent(&sbx[(size_t)(first + j) * KSB_WORDS + 4 * KVB_W + t]);
+  if (t < np) H.pub[t] = __hip_atomic_load(&pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (c == 0) return 0;
+  uint32_t nw_before = 0, nw_all = 0;
+  int lw_before = -1, jw = -1;
+  for (uint32_t k = 0; k < np; k++) {
+    const unsigned long long w = H.pub[k];
+    const uint32_t nwk = (uint32_t)(w >> 23) & 1023u;
+    if (k < j) {
+      nw_before += nwk;
+      if ((w >> 22) & 1ull) lw_before = (int)((w >> 2) & 0xFFFFFu);
+    }
+    nw_all += nwk;
+    if (nwk) jw = (int)k;
+  }
+  const uint32_t found = H.found, ver0 = H.ver0;
+  uint32_t miss = 0;
+  if (v) {
+    const bool granted = (H.G[wave] >> lane) & 1ull;
+    uint32_t code;
+    bool get = false;
+    switch (my_type) {
+      case 0: code = granted ? 7 : 8; get = granted; break;
+      case 1: code = granted ? 9 : 10; get = granted; break;
+      case 2: code = 11; break;
+      case 3: code = 12; break;
+      case 4: code = 13; miss = !found; break;
+      case 5: code = 14; miss = !found; break;
+      default: code = 18; get = true; break;  // 17 WARMUP_READ
+    }
+    if (get && found) {  // the row as of my position: the last COMMIT before me (its message holds the value), else the row before the pass
+      const int widx = lw_below >= 0 ? (int)H.idx[lw_below] : lw_before;
+      if (widx >= 0) {
+        const uint8_t *fm = rep + dint_view_off(V, (uint32_t)widx, F::MSG) + F::VAL;
+        const uint32_t a0 = ld_u32(fm), a1 = ld_u32(fm + 4);
+        st_u32(msg + F::VAL, a0); st_u32(msg + F::VAL + 4, a1);
+      } else {
+        st_u32(msg + F::VAL, H.rowv[0]); st_u32(msg + F::VAL + 4, H.rowv[1]);
+      }
+      st_u32(msg + F::VER, ver0 + nw_before + wr_below);
+    } else if (get && my_type != 17u) {
+      miss = 1;  // a granted ACQUIRE reads a row that is not there (the reference panics: smallbank/udp/kvs.h; counted)
+    }
+    msg[F::TYPE] = (uint8_t)code;
+  }
+  {
+    const uint64_t mm = __ballot(miss != 0);
+    if (lane == 0 && mm) atomicAdd(&stats->missing_keys, (unsigned long long)__popcll(mm));
+  }
+  // ---- row and version, once: by the piece that holds the pass's last COMMIT
+  if (found && nw_all && (int)j == jw && (int)t == lw_tot) {
+    uint8_t *row = kv_entry_ptr(tb, bucket, H.link) + KV_VAL_OFF + H.slot * F::VS;
+    KV_ST(uint32_t, row, ld_u32(msg + F::VAL));
+    KV_ST(uint32_t, row + 4, ld_u32(msg + F::VAL + 4));
+    KV_ST(uint32_t, &kv_entry_hdr(tb, bucket, H.link)->ver[H.slot], ver0 + nw_all);
+  }
+  return 0;
+}
+
 // One workgroup per CU: its 8 waves are 2 per SIMD (the second launch bound is waves per SIMD, not workgroups per CU) at
 // the full 256 VGPRs, and its LDS (static_assert below) leaves no room for a second one.
 static_assert(sizeof(kvb_lds) + KVB_BM_BYTES + sizeof(kv_dev) <= 160 * 1024, "k_kv_big must fit the 160 KB of LDS of a gfx950 CU");
@@ -3713,6 +3997,9 @@ __global__ void __launch_bounds__(KVB_T, 1) k_kv_big(kv_multi_args M, uint32_t f
     int run = 1;
     if ((d.w & 3u) == KVQ_SOLO)
       run = kv_solo_item<WL>(A.rep, cut2, &Skv, d, A.ovf, A.ovf2, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
+    else if ((d.w & 3u) != KVQ_SUB && WL == DINT_WL_SMALLBANK)
+      run = kv_sb_item<WL>(A.rep, cut2, &Skv, d, A.bigq[KVQ_W * (size_t)i + 1], A.bigq[KVQ_W * (size_t)i + 2], A.ovf, A.ovf2, A.hotpub, A.sbx, A.seq,
+                           A.inv_n, A.stats, A.V, Lraw, &src, &off, &cnt);
     else if ((d.w & 3u) != KVQ_SUB)
       run = kv_hot_item<WL>(A.rep, cut2, &Skv, d, A.bigq[KVQ_W * (size_t)i + 1], A.bigq[KVQ_W * (size_t)i + 2], A.ovf, A.ovf2, A.hotpub, A.seq,
                             A.inv_n, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
@@ -3744,7 +4031,7 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
   // the hot keys.  store / tatp: workers in the resolve launch (k_kv_pass; DINT_KV_NO_FUSE: k_kv_hot / k_kv_hot_part behind
   // k_kv_resolve, r05 / early r06), then k_kv_late for what the closed forms left -- usually nothing;
   // smallbank (counters: no closed form across workgroups yet) and DINT_KV_NO_SPLIT / DINT_KV_ONE_BIG_KERNEL: k_kv_big alone
-  const bool hot = M.e[0].split_min != 0xFFFFFFFFu && !K.one_big_kernel;
+  const bool hot = WL != DINT_WL_SMALLBANK && M.e[0].split_min != 0xFFFFFFFFu && !K.one_big_kernel;  // (smallbank's pieces run in k_kv_big)
   bool fused = false, one = false;
   if constexpr (WL != DINT_WL_SMALLBANK) {
     if (hot && !K.no_fuse) {

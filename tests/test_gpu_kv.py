@@ -731,3 +731,90 @@ def test_partition_corners(wl, knob, monkeypatch):
         _sb_state(eng, o)
     else:
         assert _same_rows(eng.dump_rows(0), o.dump())
+
+
+# ---------------------------------------------------------------- smallbank: a hot account's row in pieces (r06, kv_sb_item)
+SB_KNOBS = [{}, {"DINT_KV_SB_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "64"}, {"DINT_KV_SB_SPLIT_MIN": "600", "DINT_KV_SPLIT_TARGET": "300"},
+            {"DINT_KV_SB_SPLIT_MIN": "0"}]
+
+
+def _sb_hot(n, p_hot, mix, hot, seed, n_acct):
+    """n requests; a share p_hot on the hot rows `hot` = [(table, key), ...] with op mix `mix` {type: weight}, the rest noise"""
+    rng = np.random.default_rng(seed)
+    req = tracegen.sb_random(n, seed=seed, n_acct_touch=n_acct)
+    for tb, key in hot:  # (the noise leaves the hot rows alone)
+        req["key"][(req["table"] == tb) & (req["key"] == key)] = (key + 1) % n_acct
+    u = rng.random(n)
+    types, w = list(mix.keys()), np.array(list(mix.values()), float)
+    for k, (tb, key) in enumerate(hot):
+        sel = (u >= k * p_hot / len(hot)) & (u < (k + 1) * p_hot / len(hot))
+        req["table"][sel] = tb
+        req["key"][sel] = key
+        req["type"][sel] = rng.choice(types, int(sel.sum()), p=w / w.sum())
+    return req
+
+
+@pytest.mark.parametrize("knobs", SB_KNOBS, ids=["default", "t64", "t300", "off"])
+@pytest.mark.parametrize("p_hot,mix,hot", [
+    (0.6, {0: 30, 1: 25, 2: 15, 3: 12, 4: 10, 5: 8}, [(0, 7), (1, 7)]),          # the account's savings and checking rows, every op kind
+    (0.7, {0: 40, 1: 10, 2: 38, 3: 6, 4: 6}, [(0, 3)]),                           # mostly shared traffic: long FREE stretches
+    (0.7, {0: 10, 1: 45, 2: 5, 3: 38, 5: 2}, [(1, 11)]),                          # mostly exclusive: the mode changes all the time
+    (0.5, {0: 20, 1: 20, 2: 25, 3: 25, 17: 10}, [(0, 5)]),                        # more releases than acquires (the counters wrap), WARMUP_READs
+    (0.6, {0: 30, 1: 25, 2: 15, 3: 12, 4: 10, 5: 8}, [(0, 900_000)]),             # the hot row does not exist (missing_keys)
+])
+def test_smallbank_hot_row_in_pieces(p_hot, mix, hot, knobs, monkeypatch):
+    """A hot account's row is answered by several workgroups at once: pieces by request index publish their op kinds as lane
+    masks, one coordinator walks the shared / exclusive counters over all of them, every piece answers its requests (kv_sb_item).
+    Against the oracle (smallbank/udp/server_shard.cc:121-173), pass after pass on one engine -- the counters, versions and values a
+    pass leaves are what the next one starts from -- at sizes from one piece to a hundred; small thresholds force the path on
+    small passes, 0 is r05's single workgroup."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    n_acct = 1_000_000 if hot[0][1] >= 1000 else 2000
+    o = orc.SmallbankOracle(n_acct, populate_n=2000)
+    eng = _engine(W.SMALLBANK, n_rows=n_acct)
+    eng.populate(2000)
+    for k, n in enumerate((3000, 900, 20_000, 6000, 70_000, 1500, 40_000)):
+        req = _sb_hot(n, p_hot, mix, hot, seed=31 * k + 7, n_acct=2000)
+        got, want = eng.submit(req), o.replay(req)
+        assert got.tobytes() == want.tobytes(), (k, np.nonzero(np.frombuffer(got.tobytes(), "u1") != np.frombuffer(want.tobytes(), "u1"))[0][:5] // 23)
+    _sb_state(eng, o)
+    st = eng.stats()
+    assert st["bad_requests"] == 0 and st["big_bin_requests"] > 0
+    assert st["missing_keys"] == o.errors
+    if hot[0][1] >= 1000:
+        assert st["missing_keys"] > 1000
+
+
+@pytest.mark.parametrize("knobs", SB_KNOBS[:2], ids=["default", "t64"])
+def test_smallbank_hot_row_beside_a_key_on_its_counter_pair(knobs, monkeypatch):
+    """two accounts whose rows share a bucket AND a lock quadrant (one counter pair): no closed form -- every piece sees the
+    neighbour's lock ops in the sub's records and says so, piece 0 takes the sub the old way"""
+    import struct
+
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    n_acct = 2000
+    o = orc.SmallbankOracle(n_acct, populate_n=n_acct)
+    hs = o.hash_size(0)
+    seen, pair = {}, None
+    for a in range(n_acct):
+        h = orc.fasthash64(struct.pack("<Q", a))
+        slot = h % (4 * hs)
+        if slot in seen and pair is None:
+            pair = (seen[slot], a)
+        seen.setdefault(slot, a)
+    assert pair is not None
+    eng = _engine(W.SMALLBANK, n_rows=n_acct)
+    eng.populate(n_acct)
+    rng = np.random.default_rng(3)
+    for k, n in enumerate((8000, 30_000)):
+        req = tracegen.sb_random(n, seed=50 + k, n_acct_touch=n_acct)
+        u = rng.random(n)
+        for key, lo, hi in ((pair[0], 0.0, 0.6), (pair[1], 0.6, 0.7)):
+            sel = (u >= lo) & (u < hi)
+            req["table"][sel] = 0
+            req["key"][sel] = key
+            req["type"][sel] = rng.choice(6, int(sel.sum()), p=[0.3, 0.25, 0.15, 0.12, 0.1, 0.08])
+        assert eng.submit(req).tobytes() == o.replay(req).tobytes(), k
+    _sb_state(eng, o)
