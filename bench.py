@@ -444,11 +444,14 @@ def bench_lock(args, world, rank, dev, transport, kind):
     msg = dtype.itemsize
     torch.cuda.synchronize()
 
+    ahead = not args.no_ahead  # r06: every batch announces the next (dint_submit_device_ahead: its count stage rides in this batch's resolve launch)
+
     def run(lo, hi):  # batches [lo, hi)
         if rt is None:
             for b in range(lo, hi):
                 o = b * BATCH * msg
-                eng.submit_device(d_req.data_ptr() + o, BATCH, d_rep.data_ptr() + o, 0)
+                nxt = (d_req.data_ptr() + o + BATCH * msg, BATCH, d_rep.data_ptr() + o + BATCH * msg) if ahead and b + 1 < hi else None
+                eng.submit_device(d_req.data_ptr() + o, BATCH, d_rep.data_ptr() + o, 0, ahead=nxt)
         else:
             rt.run([([d_req.data_ptr() + b * BATCH * msg], [BATCH], [d_rep.data_ptr() + b * BATCH * msg]) for b in range(lo, hi)])
 

@@ -20,6 +20,10 @@
 // k_locks.hip: one half of a lock pass (stage 1 = count + scan / place, 2 = resolve) on `st`
 void dint_launch_lock_stage(uint32_t workload, int stage, const void *d_req, void *d_rep, uint32_t n, uint2 *table, dint_mod slots,
                             dint_shard shard, dint_scratch s, hipStream_t st, const dint_view &view);
+// k_locks.hip: the resolve stage of a pass (set `s`) and the count stage of the next (set `sn`) in one launch; false = not possible
+bool dint_launch_lock_fused(uint32_t workload, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard, dint_scratch s,
+                            const dint_view &view, const void *next_req, void *next_rep, uint32_t next_n, dint_scratch sn,
+                            const dint_view &next_view, hipStream_t st);
 
 namespace {
 
@@ -132,6 +136,7 @@ struct dint_engine {
     const void *req = nullptr;
     void *rep = nullptr;
     uint32_t n = 0;
+    int set = 0;  // lock tables: the scratch set (0 = `scratch`, 1 = lp.set[1]) the announced batch's count stage filled
   } ahead;
 
   // snapshot
@@ -242,13 +247,25 @@ int log_cur(const dint_engine *e) { return e->kv.n_tables ? (int)((e->scratch.kv
 int lock_pipe_init(dint_engine *e) {
   dint_engine::LockPipe &lp = e->lp;
   if (lp.ready) return 0;
-  HIP_TRY(hipStreamCreateWithFlags(&lp.helper, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&lp.ev_in, hipEventDisableTiming));
+  // (a call after a failed one -- an allocation that did not fit -- must not create streams, events or buffers a second time)
+  if (!lp.helper) HIP_TRY(hipStreamCreateWithFlags(&lp.helper, hipStreamNonBlocking));
+  if (!lp.ev_in) HIP_TRY(hipEventCreateWithFlags(&lp.ev_in, hipEventDisableTiming));
   for (int k = 0; k < dint_engine::LockPipe::kSets; k++) {
-    HIP_TRY(hipEventCreateWithFlags(&lp.counted[k], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&lp.freed[k], hipEventDisableTiming));
+    if (!lp.counted[k]) HIP_TRY(hipEventCreateWithFlags(&lp.counted[k], hipEventDisableTiming));
+    if (!lp.freed[k]) HIP_TRY(hipEventCreateWithFlags(&lp.freed[k], hipEventDisableTiming));
     if (k == 0) continue;  // set 0 is e->scratch itself
     dint_scratch &s = lp.set[k];
+    if (s.stats) {  // a set an earlier, failed call began: what it got is given back first
+      const dint_scratch &o = e->scratch;
+      if (s.bin_cnt != o.bin_cnt) hipFree(s.bin_cnt);
+      if (s.bins != o.bins) hipFree(s.bins);
+      if (s.blk_pub != o.blk_pub && s.blk_pub != o.blk_pub_next && s.blk_pub_next != o.blk_pub) hipFree(std::min(s.blk_pub, s.blk_pub_next));
+      if (s.big != o.big && s.big != o.big_next && s.big_next != o.big) hipFree(std::min(s.big, s.big_next));
+      if (s.bin_off != o.bin_off) hipFree(s.bin_off);
+      if (s.ovl != o.ovl) hipFree(s.ovl);
+      if (s.ovf != o.ovf) hipFree(s.ovf);
+      if (s.kbins != o.kbins) hipFree(s.kbins);
+    }
     s = e->scratch;  // (stats, lock_trace: shared)
     int rc = dev_alloc((void **)&s.bin_cnt, DINT_KV_PMAX * sizeof(uint32_t));
     if (!rc) rc = dev_alloc((void **)&s.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false);
@@ -273,11 +290,19 @@ void lock_pipe_destroy(dint_engine *e) {
   for (int k = 0; k < dint_engine::LockPipe::kSets; k++) {
     if (lp.counted[k]) hipEventDestroy(lp.counted[k]);
     if (lp.freed[k]) hipEventDestroy(lp.freed[k]);
-    if (k == 0 || !lp.ready) continue;
+    if (k == 0) continue;
+    // (whatever lock_pipe_init got before a failed allocation is freed too: a set's pointers start as copies of the engine's own
+    // and are replaced one by one -- only the replaced ones are this set's)
     dint_scratch &s = lp.set[k];
-    hipFree(s.bin_cnt); hipFree(s.bins); hipFree(std::min(s.blk_pub, s.blk_pub_next)); hipFree(std::min(s.big, s.big_next));
-    hipFree(s.bin_off); hipFree(s.ovl); hipFree(s.ovf);
-    if (s.kbins != e->scratch.kbins) hipFree(s.kbins);
+    const dint_scratch &o = e->scratch;
+    if (s.bin_cnt != o.bin_cnt) hipFree(s.bin_cnt);
+    if (s.bins != o.bins) hipFree(s.bins);
+    if (s.blk_pub != o.blk_pub && s.blk_pub != o.blk_pub_next && s.blk_pub_next != o.blk_pub) hipFree(std::min(s.blk_pub, s.blk_pub_next));
+    if (s.big != o.big && s.big != o.big_next && s.big_next != o.big) hipFree(std::min(s.big, s.big_next));
+    if (s.bin_off != o.bin_off) hipFree(s.bin_off);
+    if (s.ovl != o.ovl) hipFree(s.ovl);
+    if (s.ovf != o.ovf) hipFree(s.ovf);
+    if (s.kbins != o.kbins) hipFree(s.kbins);
   }
 }
 // a lock pass in two halves (DINT_FLAG_INPUTS_READY, dint_submit_device): count + scan / place on the helper stream as soon
@@ -313,6 +338,13 @@ int ahead_cancel(dint_engine *e) {
   if (!e->ahead.valid) return 0;
   e->ahead.valid = false;
   HIP_TRY(hipDeviceSynchronize());
+  if (!e->kv.n_tables) {  // a lock engine: the counters, the big-bin list and the region names of the set the count stage filled
+    dint_scratch &ls = e->ahead.set == 0 ? e->scratch : e->lp.set[e->ahead.set];
+    HIP_TRY(hipMemset(ls.bin_cnt, 0, DINT_KV_PMAX * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(std::min(ls.big, ls.big_next), 0, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ls.bin_off, 0xFF, DINT_KV_PMAX * sizeof(uint32_t)));
+    return 0;
+  }
   dint_scratch &s = e->scratch;
   for (int k = 0; k < 2; k++) HIP_TRY(hipMemset(s.kvs.bin_cnt[k], 0, DINT_KV_PMAX * sizeof(uint32_t)));
   HIP_TRY(hipMemset(s.kvs.ctl[0], 0, 3 * 16 * sizeof(uint32_t)));
@@ -352,17 +384,41 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
       if (int rc = run_lock_pass_piped(e, d_req, n, d_rep, st, view)) return rc;
       break;
     case DINT_WL_FASST:
-      dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                        timer_events(e, 3, lock_names), view);
-      std::swap(e->scratch.big, e->scratch.big_next);  // the big-bin lists alternate between passes
-      std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
+    case DINT_WL_2PL: {
+      // r06: with the next batch announced (or the next slice of one long submission), this pass's resolve stage and the next
+      // pass's count stage are ONE launch (k_lock_pass) -- two scratch sets used in turn, `scratch` and lp.set[1]
+      const int b = part_done ? e->ahead.set : 0;
+      if (next && (!n || !next->n || view.seg_cap || next->view.seg_cap || n > DINT_MICRO_BATCH || next->n > DINT_MICRO_BATCH ||
+                   !e->scratch.kbins || getenv("DINT_LOCK_NO_FUSE")))
+        next = nullptr;
+      if ((next || b) && !e->lp.ready)
+        if (int rc = lock_pipe_init(e)) return rc;
+      dint_scratch &s = b == 0 ? e->scratch : e->lp.set[b];
+      hipEvent_t *ev = timer_events(e, 3, lock_names);
+      if (!part_done && !next) {
+        if (e->cfg.workload == DINT_WL_FASST) dint_launch_fasst(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, s, st, ev, view);
+        else dint_launch_2pl(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, s, st, ev, view);
+      } else {
+        if (ev) HIP_TRY(hipEventRecord(ev[0], st));
+        if (!part_done) dint_launch_lock_stage(e->cfg.workload, 1, d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, s, st, view);
+        if (ev) { HIP_TRY(hipEventRecord(ev[1], st)); HIP_TRY(hipEventRecord(ev[2], st)); }
+        dint_scratch &sn = b == 0 ? e->lp.set[1] : e->scratch;
+        if (!next || !dint_launch_lock_fused(e->cfg.workload, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, s, view, next->d_req, next->d_rep,
+                                             next->n, sn, next->view, st)) {
+          dint_launch_lock_stage(e->cfg.workload, 2, d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, s, st, view);
+          next = nullptr;
+        }
+        if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+      }
+      std::swap(s.big, s.big_next);  // the big-bin lists alternate between the passes of a set
+      std::swap(s.blk_pub, s.blk_pub_next);
+      if (next) {
+        e->ahead.valid = true;
+        e->ahead.req = next->d_req; e->ahead.rep = next->d_rep; e->ahead.n = next->n;
+        e->ahead.set = b ^ 1;
+      }
       break;
-    case DINT_WL_2PL:
-      dint_launch_2pl(d_req, d_rep, n, e->d_lock_tbl, e->slots_mod, e->shard, e->scratch, st,
-                      timer_events(e, 3, lock_names), view);
-      std::swap(e->scratch.big, e->scratch.big_next);
-      std::swap(e->scratch.blk_pub, e->scratch.blk_pub_next);
-      break;
+    }
     case DINT_WL_LOG:
       if (view.seg_cap) return fail(DINT_ESTATE, "the log workload is not sharded by key");
       dint_launch_log(d_req, d_rep, n, e->log, e->scratch, st, timer_events(e, 1, log_names));
@@ -576,6 +632,8 @@ void dint_engine_destroy(dint_engine_t *e) {
   if (!e) return;
   hipSetDevice(e->device);
   hipDeviceSynchronize();
+  for (auto &sl : e->slot)  // (everything has left the GPU: undelivered replies of pageable callers are not dropped)
+    if (sl.deliver_to && sl.h_rep) { memcpy(sl.deliver_to, sl.h_rep, sl.deliver_bytes); sl.deliver_to = nullptr; }
   for (hipEvent_t ev : e->timer.ev) hipEventDestroy(ev);
   for (void *p : e->snap) hipFree(p);
   hipFree(e->scratch.bin_cnt);
@@ -645,7 +703,8 @@ int submit_device_locked(dint_engine *e, const void *d_reqs, uint32_t n, void *d
       nx.d_req = d_next_reqs; nx.d_rep = d_next_replies; nx.n = std::min<uint32_t>(e->pass_max, next_n);
     }
     int rc = run_pass(e, rq + (size_t)off * e->msg_size, m, rp + (size_t)off * e->msg_size, st, 0, dint_flat_view(),
-                      (e->cfg.flags & DINT_FLAG_INPUTS_READY) != 0, e->kv.n_tables && nx.n ? &nx : nullptr);
+                      (e->cfg.flags & DINT_FLAG_INPUTS_READY) != 0,
+                      (e->kv.n_tables || e->cfg.workload == DINT_WL_FASST || e->cfg.workload == DINT_WL_2PL) && nx.n ? &nx : nullptr);
     if (rc) return rc;
   }
   return 0;
@@ -767,6 +826,14 @@ bool host_range_pinned(const void *p, size_t bytes) {
   }
   return true;
 }
+// a DEVICE pointer handed to the host path (dint_submit / dint_submit_async): the staging memcpy would read it on the CPU
+bool is_device_ptr(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice;
+}
 // copy a delivered chunk's replies out of the slot's bounce buffer (the chunk has left the GPU: sl.done was waited for)
 void slot_deliver(dint_engine::Slot &sl) {
   if (sl.deliver_to) memcpy(sl.deliver_to, sl.h_rep, sl.deliver_bytes);
@@ -854,6 +921,8 @@ int dint_submit_async(dint_engine_t *e, const void *reqs, uint32_t n, void *repl
   const uint8_t *rq = (const uint8_t *)reqs;
   uint8_t *rp = (uint8_t *)replies;
   uint64_t seq = e->next_seq - 1;  // n == 0: the ticket of whatever was submitted last
+  if (n && (is_device_ptr(rq) || is_device_ptr(rp)))
+    return fail(DINT_EINVAL, "dint_submit / dint_submit_async take HOST buffers; device memory goes to dint_submit_device");
   const bool rq_pinned = host_range_pinned(rq, (size_t)n * e->msg_size), rp_pinned = host_range_pinned(rp, (size_t)n * e->msg_size);
   for (uint32_t off = 0; off < n; off += e->pass_max) {
     const uint32_t m = std::min<uint32_t>(e->pass_max, n - off);
@@ -1035,6 +1104,14 @@ int dint_sync(dint_engine_t *e) {
   HIP_TRY(hipStreamSynchronize(s0));
   if (s1 && s1 != s0) HIP_TRY(hipStreamSynchronize(s1));
   if (s2 && s2 != s0) HIP_TRY(hipStreamSynchronize(s2));
+  // replies of pageable callers that still sit in a slot's page-locked buffer reach the caller's memory here as well (ADVICE r05:
+  // a dint_submit_async + dint_sync caller never calls dint_wait)
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (auto &sl : e->slot)
+    if (sl.deliver_to) {
+      HIP_TRY(hipEventSynchronize(sl.done));
+      slot_deliver(sl);
+    }
   return 0;
 }
 

@@ -150,6 +150,9 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
 
 // (launch_kv_passes<WL>: k_kv_dev.h -- instantiated by k_kv_store.hip / k_kv_tatp.hip / k_kv_smallbank.hip, one workload each,
 // so that the three compile side by side)
+extern template int kv_piece_residency<DINT_WL_STORE>(int);
+extern template int kv_piece_residency<DINT_WL_TATP>(int);
+extern template int kv_piece_residency<DINT_WL_SMALLBANK>(int);
 extern template void launch_kv_passes<DINT_WL_STORE>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_pass_args *, uint32_t);
 extern template void launch_kv_passes<DINT_WL_TATP>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_pass_args *, uint32_t);
 extern template void launch_kv_passes<DINT_WL_SMALLBANK>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_pass_args *, uint32_t);
@@ -291,6 +294,20 @@ int dint_kv_create(dint_kv *kv, uint32_t workload, uint64_t n_rows, dint_shard s
     gk += tb.n_local;
   }
   kv->knobs = kv_read_knobs();
+  {
+    // the pieces of a hot key wait for each other: only where all of a key's siblings (and as many again) fit the device at once
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int res = workload == DINT_WL_STORE ? kv_piece_residency<DINT_WL_STORE>(dev)
+                    : workload == DINT_WL_TATP ? kv_piece_residency<DINT_WL_TATP>(dev) : kv_piece_residency<DINT_WL_SMALLBANK>(dev);
+    kv->knobs.residency = (uint32_t)std::max(res, 0);
+    if (workload == DINT_WL_SMALLBANK) {
+      if (res < (int)(KSB_NPMAX + 2u + 32u)) kv->knobs.sb_split_min = 0;  // (k_kv_big: one workgroup per compute unit, 256 on an MI355X)
+    } else {
+      if (res < 2 * (int)(KVR_NPMAX + 2u)) kv->knobs.no_split = 1;
+      kv->knobs.workers = std::max(KVR_NPMAX + 2u, std::min(kv->knobs.workers, (uint32_t)std::max(res, 0) / 2u));
+    }
+  }
   if (getenv("DINT_KV_TRACE")) {
     if (hipMalloc((void **)&kv->d_trace, (size_t)DINT_KV_TRACE_WORDS * 8) != hipSuccess) return DINT_ENOMEM;
     hipMemset(kv->d_trace, 0, (size_t)DINT_KV_TRACE_WORDS * 8);

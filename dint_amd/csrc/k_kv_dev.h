@@ -4012,6 +4012,20 @@ __global__ void __launch_bounds__(KVB_T, 1) k_kv_big(kv_multi_args M, uint32_t f
   }
 }
 
+// Workgroups of the kernel that answers a hot key's PIECES that the device can hold at once (the pieces of a key wait for each
+// other: kv_hot_item, kv_sb_item).  dint_kv_create switches the pieces off where that is fewer than twice the siblings a key can
+// have -- a CU mask, a partitioned or shared GPU: the hot keys then go through kv_big_bin, one workgroup each.
+template <int WL>
+int kv_piece_residency(int device) {
+  int per_cu = 0, cus = 0;
+  hipError_t e1 = WL == DINT_WL_SMALLBANK
+                      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_kv_big<WL>, (int)KVB_T, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_kv_pass<WL, 0>, (int)KVB_T, 0);
+  hipError_t e2 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return per_cu * cus;
+}
+
 // ---- launch of one pass set (all engines of `M` side by side) -------------------------------------------------------------------
 // `next` (one engine only): the partition of the engine's next pass, launched with this pass's hot keys (k_kv_hot_part)
 template <int WL>

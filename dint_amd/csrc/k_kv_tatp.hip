@@ -3,3 +3,4 @@
 
 template void launch_kv_passes<DINT_WL_TATP>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool,
                                      const kv_pass_args *, uint32_t);
+template int kv_piece_residency<DINT_WL_TATP>(int);

@@ -69,19 +69,52 @@ __device__ static inline uint64_t lk_readlane_u64(uint64_t v, int src) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <int WL>  // 0 = lock_fasst, 1 = lock_2pl
-__global__ void __launch_bounds__(KV_TB)
-k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod slots, dint_shard shard, uint32_t pbits,
-             uint32_t *__restrict__ bin_cnt, uint64_t *__restrict__ bins, uint32_t *__restrict__ big,
-             uint4 *__restrict__ ovl, dint_dev_stats *__restrict__ stats, dint_view V,
-             uint64_t *__restrict__ bigrec, uint32_t *slot_of) {  // DIRECT big bins (passes of <= LK_DIRECT_NMAX requests), else nullptr
+// (TB threads = TB requests per workgroup: KV_TB in k_lock_count, KVB_T in k_lock_pass, where the count of the NEXT batch rides
+// beside this batch's resolve workgroups; `blk` = which slice of the batch)
+template <uint32_t TB>
+__device__ static inline uint32_t lk_hash_insert(uint32_t *keys, uint32_t k) {  // 2 * TB slots, keys != KV_NONE
+  uint32_t h = ((k * 0x9E3779B1u) >> 8) & (2 * TB - 1);
+  for (;;) {
+    const uint32_t old = atomicCAS(&keys[h], KV_NONE, k);
+    if (old == KV_NONE || old == k) return h;
+    h = (h + 1) & (2 * TB - 1);
+  }
+}
+struct lk_count_args {
+  const uint8_t *req;
+  uint8_t *rep;
+  uint32_t n;
+  dint_mod slots;
+  dint_shard shard;
+  uint32_t pbits;
+  uint32_t *bin_cnt;
+  uint64_t *bins;
+  uint32_t *big;
+  uint4 *ovl;
+  dint_dev_stats *stats;
+  dint_view V;
+  uint64_t *bigrec;    // DIRECT big bins (passes of <= LK_DIRECT_NMAX requests), else nullptr
+  uint32_t *slot_of;
+};
+template <int WL, uint32_t TB>  // WL: 0 = lock_fasst, 1 = lock_2pl
+__device__ __forceinline__ static void lk_count_body(const lk_count_args &A, uint32_t blk) {
   constexpr uint32_t MSG = WL == 0 ? sizeof(fasst_msg) : sizeof(tpl_msg);
-  __shared__ uint32_t Hb[2 * KV_TB];  // bins this workgroup appends to
-  __shared__ uint32_t Hc[2 * KV_TB];  // ... how many records each; then the position of the workgroup's first one
+  const uint8_t *__restrict__ req = A.req;
+  uint8_t *rep = A.rep;
+  const uint32_t n = A.n, pbits = A.pbits;
+  const dint_mod slots = A.slots;
+  const dint_shard shard = A.shard;
+  uint32_t *__restrict__ bin_cnt = A.bin_cnt, *__restrict__ big = A.big, *slot_of = A.slot_of;
+  uint64_t *__restrict__ bins = A.bins, *__restrict__ bigrec = A.bigrec;
+  uint4 *__restrict__ ovl = A.ovl;
+  dint_dev_stats *__restrict__ stats = A.stats;
+  const dint_view V = A.V;
+  __shared__ uint32_t Hb[2 * TB];  // bins this workgroup appends to
+  __shared__ uint32_t Hc[2 * TB];  // ... how many records each; then the position of the workgroup's first one
   __shared__ uint32_t Sov[2];
-  const uint32_t t = threadIdx.x, i = blockIdx.x * KV_TB + t;
-  Hb[t] = KV_NONE; Hb[t + KV_TB] = KV_NONE;
-  Hc[t] = 0; Hc[t + KV_TB] = 0;
+  const uint32_t t = threadIdx.x, i = blk * TB + t;
+  Hb[t] = KV_NONE; Hb[t + TB] = KV_NONE;
+  Hc[t] = 0; Hc[t + TB] = 0;
   if (t == 0) Sov[0] = 0;
   __syncthreads();
   bool live;
@@ -89,13 +122,13 @@ k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod
   live = live && i < n;
   // replies are the request mutated in place: copy this slice (contiguous passes with separate arrays only)
   if (rep != req) {
-    const size_t lo = (size_t)blockIdx.x * KV_TB * MSG, hi = min((size_t)n * MSG, lo + (size_t)KV_TB * MSG);
+    const size_t lo = (size_t)blk * TB * MSG, hi = min((size_t)n * MSG, lo + (size_t)TB * MSG);
     if ((((uintptr_t)req | (uintptr_t)rep) & 15) == 0) {
-      const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 576 vectors
+      const uint32_t nv = (uint32_t)((hi - lo) / 16);  // <= 9 / 16 of TB vectors
       if (t < nv) ((uint4 *)(rep + lo))[t] = ((const uint4 *)(req + lo))[t];
-      for (size_t k = lo + (size_t)nv * 16 + t; k < hi; k += KV_TB) rep[k] = req[k];
+      for (size_t k = lo + (size_t)nv * 16 + t; k < hi; k += TB) rep[k] = req[k];
     } else {
-      for (size_t k = lo + t; k < hi; k += KV_TB) rep[k] = req[k];
+      for (size_t k = lo + t; k < hi; k += TB) rep[k] = req[k];
     }
   }
   uint32_t lid = 0, op = 0;
@@ -133,13 +166,13 @@ k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod
   }
   uint32_t e = 0, mypos = 0;
   if (bin != KV_NONE) {
-    e = block_hash_insert(Hb, bin);
+    e = lk_hash_insert<TB>(Hb, bin);
     mypos = atomicAdd(&Hc[e], 1u);
   }
   __syncthreads();
 #pragma unroll
   for (uint32_t k = 0; k < 2; k++) {
-    const uint32_t sl = t + k * KV_TB;
+    const uint32_t sl = t + k * TB;
     if (Hb[sl] != KV_NONE) {
       const uint32_t cnt = Hc[sl], base = atomicAdd(&bin_cnt[Hb[sl]], cnt);
       Hc[sl] = base;
@@ -189,6 +222,11 @@ k_lock_count(const uint8_t *__restrict__ req, uint8_t *rep, uint32_t n, dint_mod
   // 12,800 scattered byte stores between the rounds of its record loads (r05: 14 of its 30 us).
   // (after the barriers above: the vector copy of this slice is complete)
   if (bin != KV_NONE) rep[off] = (uint8_t)(WL == 0 ? (op == 0 ? 4u : op == 1 ? 6u : op == 2 ? 7u : 8u) : (op <= 1 ? 3u : 5u));
+}
+template <int WL>
+__global__ void __launch_bounds__(KV_TB)
+k_lock_count(lk_count_args A) {
+  lk_count_body<WL, KV_TB>(A, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -993,6 +1031,31 @@ k_lock_resolve(uint8_t *rep, uint32_t n, uint32_t pbits, uint2 *__restrict__ tab
   else lk_small_bin<Ops>(rep, pbits, table, bin_cnt, bins, V, (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6));
 }
 
+// ---- k_lock_pass (r06): the resolve stage of pass k AND the count stage of pass k + 1 in one launch ----------------------------
+// A lock pass of 65,536 requests is launch-bound: count 11 us + resolve 20 us (rocprofv3) and a launch boundary between them,
+// 33 us per pass for 1.8 MB of traffic.  The count stage touches no table -- it reads the NEXT batch and fills that batch's own
+// scratch set (bins, counters, big-bin list, direct regions; engine.hip keeps two) -- so with the next batch announced
+// (dint_submit_device_ahead, or the next 65,536 requests of one long dint_submit_device) it rides beside this batch's resolve
+// workgroups, which are placed first: a pass is one launch, as long as its hot slot's workgroup.  Direct passes only (<= 65,536).
+template <int WL, class Ops>
+__global__ void __launch_bounds__(KVB_T)
+k_lock_pass(uint8_t *rep, uint32_t n, uint32_t pbits, uint2 *__restrict__ table, uint32_t *__restrict__ bin_cnt,
+            const uint64_t *__restrict__ bins, const uint32_t *__restrict__ big, uint32_t *bin_off,
+            const uint64_t *__restrict__ ovf, uint32_t hot_min, uint64_t *trace, dint_view V,
+            const uint64_t *__restrict__ bigrec, uint32_t *big_next, uint32_t *blk_pub_next, dint_dev_stats *stats,
+            uint32_t n_resolve, lk_count_args C) {
+  if (blockIdx.x >= n_resolve) {
+    lk_count_body<WL, KVB_T>(C, blockIdx.x - n_resolve);
+    return;
+  }
+  if (blockIdx.x == KVB_GRID) {
+    if (threadIdx.x < 4) big_next[threadIdx.x] = 0;
+    for (uint32_t k = threadIdx.x; k < 1024; k += KVB_T) blk_pub_next[k] = 0;
+  }
+  if (blockIdx.x < KVB_GRID) lk_big_bins<Ops>(rep, n, table, bin_cnt, bins, big, bin_off, ovf, hot_min, trace, V, blockIdx.x, KVB_GRID, bigrec, stats);
+  else lk_small_bin<Ops>(rep, pbits, table, bin_cnt, bins, V, (blockIdx.x - KVB_GRID) * KVB_W + (threadIdx.x >> 6));
+}
+
 // ------------------------------------------------------------------------------------------
 // stages: 1 = count + scan / place, 2 = resolve, 3 = both (one stream).  The two halves of a pass touch disjoint state but
 // for the pass scratch `s`: the first reads the requests and writes records, counters and the replies' default bytes; the
@@ -1012,8 +1075,8 @@ static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *tabl
   uint64_t *bigrec = s.kbins && n <= LK_DIRECT_NMAX && !getenv("DINT_LOCK_NO_DIRECT") ? (uint64_t *)s.kbins : nullptr;
   if (stages & 1) {
     if (ev) hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL((k_lock_count<WL>), dim3((n + KV_TB - 1) / KV_TB), dim3(KV_TB), 0, st, (const uint8_t *)d_req,
-                       (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view, bigrec, s.bin_off);
+    const lk_count_args C = {(const uint8_t *)d_req, (uint8_t *)d_rep, n, slots, shard, pbits, s.bin_cnt, s.bins, s.big, s.ovl, s.stats, view, bigrec, s.bin_off};
+    hipLaunchKernelGGL((k_lock_count<WL>), dim3((n + KV_TB - 1) / KV_TB), dim3(KV_TB), 0, st, C);
     if (ev) hipEventRecord(ev[1], st);
     if (!bigrec)
       hipLaunchKernelGGL(k_kv_scan_place, dim3(KV_PLACE_GRID), dim3(KV_TB), 0, st, (const uint32_t *)s.bin_cnt, s.bin_off,
@@ -1027,6 +1090,31 @@ static void launch_locks(const void *d_req, void *d_rep, uint32_t n, uint2 *tabl
                        s.lock_trace, view, (const uint64_t *)bigrec, s.big_next, s.blk_pub_next, s.stats);
     if (ev) hipEventRecord(ev[3], st);
   }
+}
+
+// the resolve stage of one pass (scratch set `s`: its count stage has run) and the count stage of the next (`sn`, `next_*`) in ONE
+// launch; both passes direct (n, next_n <= LK_DIRECT_NMAX, regions allocated).  false: not possible -- the caller launches the stages
+template <int WL, class Ops>
+static bool launch_lock_pass_fused(void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard, dint_scratch s, const dint_view &view,
+                                   const void *next_req, void *next_rep, uint32_t next_n, dint_scratch sn, const dint_view &next_view, hipStream_t st) {
+  if (!n || !next_n || n > LK_DIRECT_NMAX || next_n > LK_DIRECT_NMAX || !s.kbins || !sn.kbins || getenv("DINT_LOCK_NO_DIRECT") || getenv("DINT_LOCK_NO_FUSE")) return false;
+  const uint32_t P = dint_pick_bins_kv(n), Pn = dint_pick_bins_kv(next_n);
+  uint32_t pbits = 0, pbits_n = 0;
+  while ((1u << pbits) < P) pbits++;
+  while ((1u << pbits_n) < Pn) pbits_n++;
+  const lk_count_args C = {(const uint8_t *)next_req, (uint8_t *)next_rep, next_n, slots, shard, pbits_n, sn.bin_cnt, sn.bins, sn.big, sn.ovl, sn.stats,
+                           next_view, (uint64_t *)sn.kbins, sn.bin_off};
+  const uint32_t n_resolve = KVB_GRID + (P + KVB_W - 1) / KVB_W;
+  hipLaunchKernelGGL((k_lock_pass<WL, Ops>), dim3(n_resolve + (next_n + KVB_T - 1) / KVB_T), dim3(KVB_T), 0, st, (uint8_t *)d_rep, n, pbits, table, s.bin_cnt,
+                     (const uint64_t *)s.bins, (const uint32_t *)s.big, s.bin_off, (const uint64_t *)s.ovf,
+                     dint_hot_min("DINT_LOCK_HOT_MIN", KVB_HOT_MIN_LOCKS) | (getenv("DINT_LOCK_MISGUESS") ? 0x80000000u : 0u), s.lock_trace, view,
+                     (const uint64_t *)s.kbins, s.big_next, s.blk_pub_next, s.stats, n_resolve, C);
+  return true;
+}
+bool dint_launch_lock_fused(uint32_t workload, void *d_rep, uint32_t n, uint2 *table, dint_mod slots, dint_shard shard, dint_scratch s, const dint_view &view,
+                            const void *next_req, void *next_rep, uint32_t next_n, dint_scratch sn, const dint_view &next_view, hipStream_t st) {
+  if (workload == 0) return launch_lock_pass_fused<0, FasstOps>(d_rep, n, table, slots, shard, s, view, next_req, next_rep, next_n, sn, next_view, st);
+  return launch_lock_pass_fused<1, TplOps>(d_rep, n, table, slots, shard, s, view, next_req, next_rep, next_n, sn, next_view, st);
 }
 
 // one half of a lock pass on `st` (declared in engine.hip: DINT_FLAG_INPUTS_READY)

@@ -68,7 +68,9 @@ extern "C" {
                                       still updated batch after batch.  A receive ring that is filled by a copy engine
                                       and handed over when complete -- what the reference's recv loop does with its
                                       socket buffer (lock_fasst/udp/net.h:33-48) -- satisfies both.  Without the flag a
-                                      call is fully stream-ordered (the default) */
+                                      call is fully stream-ordered (the default).  Memory: the first piped call allocates two
+                                      more sets of pass scratch, ~0.5 GB of address space each (touched as filled).  The kv
+                                      workloads' form of the promise is per call: dint_submit_device_ahead */
 
 /* workloads (dint_config.workload) */
 enum {
@@ -190,7 +192,7 @@ void dint_free_pinned(void *p);
  * CALLER enqueues on other streams (producing d_reqs, consuming d_replies) is the caller's to order --
  * dint_stream_wait / dint_stream_signal do that for the engine's own stream. */
 int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, void *stream);
-/* The same with a LOOK-AHEAD (round 6; store / tatp -- every other workload ignores the announcement): (d_next_reqs, next_n,
+/* The same with a LOOK-AHEAD (round 6; store / tatp / lock_fasst / lock_2pl -- smallbank and log_server ignore the announcement): (d_next_reqs, next_n,
  * d_next_replies) is the batch of the engine's NEXT dint_submit_device[_ahead] call.  The caller promises that (1) that call
  * will be made, with exactly these pointers and this count, before anything else is submitted to the engine, (2) the
  * batch's request bytes are complete in device memory in the order of `stream` -- produced by work enqueued on `stream`
@@ -201,12 +203,15 @@ int dint_submit_device(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d
  * hot keys (k_kv_hot_part) and starts the next call at its resolve kernel: a pass's chain is two launches instead of four.
  * Replies, table state and log ring are exactly those of two plain calls; between the two calls dint_read_log /
  * dint_log_drain already show the announced batch's log records.  A different next submission (or dint_snapshot) fails
- * with DINT_ESTATE after the engine has cleaned its scratch -- the announced batch's log records stay where they are;
- * dint_reset / dint_restore drop the announcement silently.  A dint_submit_device of more requests than one pass takes looks
+ * with DINT_ESTATE after the engine has cleaned its scratch -- the announced batch's log records stay where they are, and
+ * its reply buffer (= its request buffer, when in place) holds what the first stage wrote: undefined for the caller;
+ * dint_reset / dint_restore drop the announcement silently.  lock_fasst / lock_2pl (batches of at most 65,536): the count
+ * stage of the next batch rides in this batch's resolve launch the same way (k_lock_pass).  A dint_submit_device of more requests than one pass takes looks
  * ahead from pass to pass by itself (stream order already has the whole array complete). */
 int dint_submit_device_ahead(dint_engine_t *e, const void *d_reqs, uint32_t n, void *d_replies, const void *d_next_reqs,
                              uint32_t next_n, void *d_next_replies, void *stream);
-/* wait for everything enqueued on the engine's own streams */
+/* wait for everything enqueued on the engine's own streams; replies of dint_submit_async calls from pageable memory that are
+ * still staged in the engine's page-locked buffers reach the caller's buffers here too (as in dint_wait) */
 int dint_sync(dint_engine_t *e);
 /* the engine's own stream (a hipStream_t) */
 void *dint_engine_stream(dint_engine_t *e);

@@ -219,3 +219,49 @@ def test_smallbank_and_lock_tables_ignore_the_announcement():
     _chain(ef, df, [30_000, 20_000])
     ef.sync()
     assert np.concatenate([x.cpu().numpy() for x in df]).tobytes() == orc.FasstOracle(1 << 20).replay(reqf).tobytes()
+
+
+@pytest.mark.parametrize("wl", ["fasst", "tpl"])
+@pytest.mark.parametrize("inplace", [True, False])
+def test_lock_tables_many_passes_with_look_ahead(wl, inplace):
+    """lock_fasst / lock_2pl: the count stage of batch k + 1 rides in the resolve launch of batch k (k_lock_pass; two scratch
+    sets in turn).  60 announced batches of uneven size with hot slots (direct big bins, the dominant-slot path) against the
+    oracle (lock_fasst/udp/server.cc:78-119, lock_2pl/udp/server.cc:70-122); then ONE submit_device of 300,000 requests -- five
+    passes of 65,536 that look ahead at each other; then a broken announcement."""
+    import torch
+
+    n = 400_000
+    if wl == "fasst":
+        req, o = tracegen.fasst_random(n, seed=21, n_hot=6, p_hot=0.5), orc.FasstOracle(1 << 20)
+        eng = _engine(W.FASST, n_slots=1 << 20)
+    else:
+        req, o = tracegen.tpl_random(n, seed=22, n_hot=6, p_hot=0.5), orc.TplOracle(1 << 20)
+        eng = _engine(W.TPL, n_slots=1 << 20)
+    assert eng.pass_max == 65536
+    want = o.replay(req)
+    cuts = [c for c in _cuts(100_000, 60, np.random.default_rng(4))]
+    d_req = [_up(req[a:b]) for a, b in cuts]
+    d_rep = None if inplace else [torch.empty_like(d) for d in d_req]
+    _chain(eng, d_req, [b - a for a, b in cuts], d_rep)
+    big = _up(req[100_000:])
+    eng.submit_device(big, 300_000)  # (passes of 65,536: the slices of one call announce each other)
+    eng.sync()
+    got = np.concatenate([(d_req if inplace else d_rep)[i].cpu().numpy() for i in range(len(cuts))] + [big.cpu().numpy()])
+    assert got.tobytes() == want.tobytes()
+    a, b = eng.read_locks()
+    if wl == "fasst":
+        assert (a == o.locks).all() and (b == o.vers).all()
+    else:
+        assert (a == o.num_ex).all() and (b == o.num_sh).all()
+    assert eng.stats()["batches"] == len(cuts) + 5
+    # a broken announcement: DINT_ESTATE, and the engine goes on from a clean scratch
+    more = tracegen.fasst_random(30_000, seed=23, n_hot=4, p_hot=0.5) if wl == "fasst" else tracegen.tpl_random(30_000, seed=23, n_hot=4, p_hot=0.5)
+    x, y, z = _up(more[:10_000]), _up(more[10_000:20_000]), _up(more[20_000:])
+    eng.submit_device(x, 10_000, None, 0, ahead=(y, 10_000, None))
+    with pytest.raises(_lib.DintError, match="announced"):
+        eng.submit_device(z, 10_000)
+    y = _up(more[10_000:20_000])  # (the announced batch's buffers are undefined after the error: its count stage wrote default reply codes)
+    eng.submit_device(y, 10_000)
+    eng.submit_device(z, 10_000)
+    eng.sync()
+    assert np.concatenate([t.cpu().numpy() for t in (x, y, z)]).tobytes() == o.replay(more).tobytes()
