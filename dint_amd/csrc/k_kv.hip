@@ -96,6 +96,7 @@ static inline bool kv_uses_hot(const dint_kv &kv, int load_mode) {
   return kv.workload != DINT_WL_SMALLBANK && !(kv.force_rounds & 3) && !load_mode && !kv.knobs.no_split;
 }
 bool dint_kv_ahead_ok(const dint_kv &kv, int load_mode) {
+  if (kv.workload == DINT_WL_SMALLBANK) return !load_mode && !kv.knobs.no_ahead && !kv.knobs.no_fuse;  // (the partition beside the resolve stage)
   return kv_uses_hot(kv, load_mode) && !kv.knobs.one_big_kernel && !kv.knobs.no_ahead;
 }
 
@@ -174,7 +175,7 @@ static void launch_kv_dispatch(uint32_t workload, kv_multi_args &M, uint32_t n_e
   switch (workload) {
     case DINT_WL_STORE: launch_kv_passes<DINT_WL_STORE>(M, n_eng, rpt, st, ev, K, part_done, next, next_rpt); break;
     case DINT_WL_TATP: launch_kv_passes<DINT_WL_TATP>(M, n_eng, rpt, st, ev, K, part_done, next, next_rpt); break;
-    default: launch_kv_passes<DINT_WL_SMALLBANK>(M, n_eng, rpt, st, ev, K, part_done, nullptr, 0); break;
+    default: launch_kv_passes<DINT_WL_SMALLBANK>(M, n_eng, rpt, st, ev, K, part_done, next, next_rpt); break;
   }
 }
 

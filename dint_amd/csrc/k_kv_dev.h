@@ -4058,6 +4058,15 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
       else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, P, K.workers, K.part_first);
       one = fused = true;
     }
+  } else {
+    // smallbank with the next batch announced: its partition beside this pass's resolve workgroups (k_kv_pass without workers --
+    // the big subs and the pieces of the hot accounts are k_kv_big's, behind this launch)
+    if (next && !K.no_fuse && n_eng == 1) {
+      const dim3 g(sum_c + next->n_tiles);
+      if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, 0u, 0u);
+      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, 0u, 0u);
+      one = true;
+    }
   }
   if (!one) hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
   if (ev) hipEventRecord(ev[2], st);
