@@ -1477,7 +1477,7 @@ def client_sweep(args, world, rank, dev, transport, kind):
     import gc
 
     rows = []
-    for c in (4096, 32768, 131072, 524288):
+    for c in (4096, 32768, 131072, 524288, 1048576, 2097152):  # (2M clients: ~0.97M requests per shard server and epoch -- one pass still)
         a = copy.copy(args)
         a.clients, a.compact, a.steps, a.warmup, a.per_step = c, True, 6, 2, 8
         a.no_cpu_baseline = a.no_rand64 = a.no_closed_loop = a.no_host_path = True
@@ -1498,9 +1498,11 @@ def other_workloads(args, world, rank, dev, transport):
     import gc
 
     out = {}
-    for wl in ("tatp_nurand", "fasst", "fasst_36m", "2pl", "log", "store", "smallbank"):
+    for wl in ("tatp_nurand", "tatp_1m_clients", "tatp_2m_clients", "fasst", "fasst_36m", "2pl", "log", "store", "smallbank"):
         a = copy.copy(args)
         a.workload, a.compact, a.steps, a.warmup, a.per_step, a.theta = wl, True, 8, 2, (4 if wl in ("store", "smallbank", "tatp_nurand") else 16), None
+        if wl in ("tatp_1m_clients", "tatp_2m_clients"):  # the headline at twice / four times the clients (the r03 sweep was still rising at 524k)
+            a.workload, a.clients, a.steps, a.warmup, a.per_step, a.no_cpu_baseline = "tatp", (1 << 20) if wl == "tatp_1m_clients" else (1 << 21), 4, 1, 4, True
         a.no_rand64 = a.no_closed_loop = a.no_host_path = True
         if wl == "fasst_36m":  # the reference's own table size: 288 MB, HBM-resident -- configs[1]'s 1M slots (8 MB) live in L2
             a.workload, a.slots, a.no_cpu_baseline = "fasst", 36_000_000, True
@@ -1517,6 +1519,7 @@ def other_workloads(args, world, rank, dev, transport):
         cb = r.get("cpu_baseline") or {}
         par = cb.get("oracle_parity") or (cb.get("port_on_bench_config") or {}).get("oracle_parity")
         out[wl] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
+                   "goodput_Mtxn_s": r.get("goodput_Mtxn_s"), "late": r.get("late"),
                    "roofline": {k: r["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "frac")} if r.get("roofline") else None,
                    "kernels_us": r.get("kernels_us"), "latency_us": r.get("latency_us"),
                    "replay_equals_recorded": r.get("replay_equals_recorded"), "abort_rate": r.get("abort_rate"),

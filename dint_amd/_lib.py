@@ -25,7 +25,7 @@ SYMBOLS = [
     "dint_submit_async", "dint_wait", "dint_alloc_pinned", "dint_free_pinned", "dint_engine_stream", "dint_max_pass",
     "dint_stream_wait", "dint_stream_signal", "dint_route_pack", "dint_route_unpack", "dint_submit_segments",
     "dint_log_drain", "dint_refuse", "dint_route_pack_multi", "dint_route_unpack_multi", "dint_bench_access", "dint_selftest",
-    "dint_submit_segments_multi", "dint_submit_device_ahead",
+    "dint_submit_segments_multi", "dint_submit_device_ahead", "dint_submit_segments_multi_ahead",
 ]
 
 
@@ -126,6 +126,7 @@ def load() -> C.CDLL:
         "dint_route_unpack_multi": (C.c_int, [C.POINTER(RouteItem), u32, u64, vp]),
         "dint_submit_segments": (C.c_int, [vp, vp, u32, u32, u64, vp, u64, vp]),
         "dint_submit_segments_multi": (C.c_int, [C.POINTER(SegmentsItem), u32, vp]),
+        "dint_submit_segments_multi_ahead": (C.c_int, [C.POINTER(SegmentsItem), u32, C.POINTER(SegmentsItem), vp]),
         "dint_log_drain": (i64, [vp, vp, u64, C.POINTER(u64)]),
         "dint_refuse": (C.c_int, [u32, vp, u32, vp]),
     }

@@ -106,7 +106,8 @@ struct dint_kv_pass {
   dint_scratch s;
   dint_view view;
 };
-void dint_launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st);
+void dint_launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st, bool part_done = false, const dint_kv_pass *next = nullptr);
+bool dint_kv_multi_ahead_ok(const dint_kv &kv);
 void dint_launch_home_kv(const void *d_req, uint32_t n, const dint_kv &kv, uint8_t *d_home, hipStream_t st);
 // wire message size / field offsets of a kv workload
 struct dint_kv_fmt {

@@ -137,6 +137,8 @@ struct dint_engine {
     void *rep = nullptr;
     uint32_t n = 0;
     int set = 0;  // lock tables: the scratch set (0 = `scratch`, 1 = lp.set[1]) the announced batch's count stage filled
+    uint32_t seg_cap = 0, n_seg = 0;  // a segmented batch (dint_submit_segments_multi_ahead): its geometry
+    const void *cnt = nullptr;
   } ahead;
 
   // snapshot
@@ -365,7 +367,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
              const dint_view &view = dint_flat_view(), bool inputs_ready = false, const dint_kv_ahead *next = nullptr) {
   bool part_done = false;
   if (e->ahead.valid) {  // the pass that was announced, and nothing else
-    if (e->ahead.req != d_req || e->ahead.rep != d_rep || e->ahead.n != n || view.seg_cap || load_mode) {
+    if (e->ahead.req != d_req || e->ahead.rep != d_rep || e->ahead.n != n || view.seg_cap != e->ahead.seg_cap || load_mode) {
       if (int rc = ahead_cancel(e)) return rc;
       return fail(DINT_ESTATE, "the batch announced by dint_submit_device_ahead (%u requests at %p) must be the engine's next "
                                "submission; its log records are appended already", e->ahead.n, e->ahead.req);
@@ -416,6 +418,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
         e->ahead.valid = true;
         e->ahead.req = next->d_req; e->ahead.rep = next->d_rep; e->ahead.n = next->n;
         e->ahead.set = b ^ 1;
+        e->ahead.seg_cap = 0; e->ahead.n_seg = 0; e->ahead.cnt = nullptr;
       }
       break;
     }
@@ -433,6 +436,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
       if (next) {
         e->ahead.valid = true;
         e->ahead.req = next->d_req; e->ahead.rep = next->d_rep; e->ahead.n = next->n;
+        e->ahead.seg_cap = 0; e->ahead.n_seg = 0; e->ahead.cnt = nullptr;
       }
       break;
     default:
@@ -744,6 +748,10 @@ int dint_submit_segments(dint_engine_t *e, void *d_base, uint32_t n_seg, uint32_
 }
 
 int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items, void *stream) {
+  return dint_submit_segments_multi_ahead(items, n_items, nullptr, stream);
+}
+
+int dint_submit_segments_multi_ahead(const dint_segments_item *items, uint32_t n_items, const dint_segments_item *next, void *stream) {
   if (!items || n_items == 0) return fail(DINT_EINVAL, "null argument");
   for (uint32_t k = 0; k < n_items; k++) {
     if (!items[k].engine) return fail(DINT_EINVAL, "null engine");
@@ -764,8 +772,14 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
       if (int rc = dint_submit_segments(items[k].engine, items[k].d_base, items[k].n_seg, items[k].seg_cap, items[k].seg_stride,
                                         items[k].d_cnt, items[k].cnt_stride, st))
         return rc;
-    return 0;
+    return 0;  // (an announcement is dropped: nothing ran ahead)
   }
+  // the announced next step: the same engines, the same geometry, other buffers -- else it is ignored
+  for (uint32_t k = 0; next && k < n_items; k++)
+    if (next[k].engine != items[k].engine || !next[k].d_base || !next[k].d_cnt || next[k].n_seg != items[k].n_seg ||
+        next[k].seg_cap != items[k].seg_cap || next[k].seg_stride != items[k].seg_stride || next[k].cnt_stride != items[k].cnt_stride)
+      next = nullptr;
+  if (next && !dint_kv_multi_ahead_ok(items[0].engine->kv)) next = nullptr;
   // every argument is checked before an engine is locked or a stream ordered: an EINVAL on item k must not leave the
   // engines of items 0 .. k-1 with a new last_stream and a stale ordering event
   for (uint32_t k = 0; k < n_items; k++) {
@@ -779,12 +793,24 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
   std::vector<std::unique_lock<std::mutex>> locks;
   for (dint_engine *e : es) locks.emplace_back(e->mu);  // address order: two calls that share engines cannot deadlock
   HIP_TRY(hipSetDevice(items[0].engine->device));
-  dint_kv_pass pass[DINT_KV_MULTI_MAX];
-  for (uint32_t k = 0; k < n_items; k++)
-    if (items[k].engine->ahead.valid) {
+  dint_kv_pass pass[DINT_KV_MULTI_MAX], npass[DINT_KV_MULTI_MAX];
+  // what ran ahead: all of the engines' partitions (the previous call of this kind announced exactly this step), or none
+  uint32_t n_done = 0;
+  for (uint32_t k = 0; k < n_items; k++) {
+    const dint_engine::Ahead &a = items[k].engine->ahead;
+    if (a.valid && a.req == items[k].d_base && a.n == items[k].n_seg * items[k].seg_cap && a.seg_cap == items[k].seg_cap &&
+        a.n_seg == items[k].n_seg && a.cnt == items[k].d_cnt)
+      n_done++;
+    else if (a.valid)
+      n_done = 0xFFFFu;
+  }
+  if (n_done != 0 && n_done != n_items) {
+    for (uint32_t k = 0; k < n_items; k++)
       if (int rc = ahead_cancel(items[k].engine)) return rc;
-      return fail(DINT_ESTATE, "a batch announced by dint_submit_device_ahead must be the engine's next submission");
-    }
+    return fail(DINT_ESTATE, "a batch announced by dint_submit_device_ahead / dint_submit_segments_multi_ahead must be the engine's next submission");
+  }
+  const bool part_done = n_done == n_items;
+  for (uint32_t k = 0; k < n_items; k++) items[k].engine->ahead.valid = false;
   for (uint32_t k = 0; k < n_items; k++) {
     const dint_segments_item &it = items[k];
     dint_engine *e = it.engine;
@@ -793,8 +819,13 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
     pass[k].d_req = it.d_base; pass[k].d_rep = it.d_base; pass[k].n = it.n_seg * it.seg_cap;
     pass[k].kv = &e->kv; pass[k].log = e->log; pass[k].s = e->scratch;
     pass[k].view = dint_seg_view(it.n_seg, it.seg_cap, it.seg_stride, it.d_cnt, it.cnt_stride);
+    if (next) {
+      npass[k] = pass[k];
+      npass[k].d_req = next[k].d_base; npass[k].d_rep = next[k].d_base;
+      npass[k].view = dint_seg_view(it.n_seg, it.seg_cap, it.seg_stride, next[k].d_cnt, it.cnt_stride);
+    }
   }
-  dint_launch_kv_multi(pass, n_items, st);
+  dint_launch_kv_multi(pass, n_items, st, part_done, next ? npass : nullptr);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(DINT_EHIP, "kernel launch: %s", hipGetErrorString(err));
   for (uint32_t k = 0; k < n_items; k++) {
@@ -802,6 +833,11 @@ int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items
     if (int rc = mark_stream(e, st)) return rc;
     e->batches++;
     e->requests += pass[k].n;
+    if (next) {
+      e->ahead.valid = true;
+      e->ahead.req = next[k].d_base; e->ahead.rep = next[k].d_base; e->ahead.n = pass[k].n;
+      e->ahead.seg_cap = items[k].seg_cap; e->ahead.n_seg = items[k].n_seg; e->ahead.cnt = next[k].d_cnt;
+    }
   }
   return 0;
 }

@@ -154,9 +154,9 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
 extern template int kv_piece_residency<DINT_WL_STORE>(int);
 extern template int kv_piece_residency<DINT_WL_TATP>(int);
 extern template int kv_piece_residency<DINT_WL_SMALLBANK>(int);
-extern template void launch_kv_passes<DINT_WL_STORE>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_pass_args *, uint32_t);
-extern template void launch_kv_passes<DINT_WL_TATP>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_pass_args *, uint32_t);
-extern template void launch_kv_passes<DINT_WL_SMALLBANK>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_pass_args *, uint32_t);
+extern template void launch_kv_passes<DINT_WL_STORE>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_multi_args *, uint32_t);
+extern template void launch_kv_passes<DINT_WL_TATP>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_multi_args *, uint32_t);
+extern template void launch_kv_passes<DINT_WL_SMALLBANK>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool, const kv_multi_args *, uint32_t);
 
 // requests per thread of k_kv_part: longer tiles = fewer, longer runs per (tile, coarse bin), but a pass must still
 // fill the GPU's 256 CUs
@@ -171,7 +171,7 @@ static inline uint32_t kv_pick_rpt_ahead(uint32_t n, const dint_kv_knobs &K) {
 }
 
 static void launch_kv_dispatch(uint32_t workload, kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_t st, hipEvent_t *ev,
-                               const dint_kv_knobs &K, bool part_done = false, const kv_pass_args *next = nullptr, uint32_t next_rpt = 0) {
+                               const dint_kv_knobs &K, bool part_done = false, const kv_multi_args *next = nullptr, uint32_t next_rpt = 0) {
   switch (workload) {
     case DINT_WL_STORE: launch_kv_passes<DINT_WL_STORE>(M, n_eng, rpt, st, ev, K, part_done, next, next_rpt); break;
     case DINT_WL_TATP: launch_kv_passes<DINT_WL_TATP>(M, n_eng, rpt, st, ev, K, part_done, next, next_rpt); break;
@@ -187,7 +187,7 @@ void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &k
   // (a pass whose partition ran ahead was cut into k_kv_hot_part's tiles: n_tiles must say so -- the last tile writes the log tail)
   const uint32_t rpt = kv_pick_rpt(n, kv.knobs), rpt_a = kv_pick_rpt_ahead(n, kv.knobs);
   kv_fill_pass(M.e[0], d_req, d_rep, n, kv, log, s, load_mode, view, part_done ? KVB_T * rpt_a : KV_TB * rpt);
-  kv_pass_args N;
+  kv_multi_args N;
   uint32_t next_rpt = 0;
   if (next && next->n && dint_kv_ahead_ok(kv, load_mode)) {
     // the next pass's view of the scratch: its own sets (by pass number), the next tag
@@ -196,7 +196,7 @@ void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &k
     sn.pass_seq = s.pass_seq + 1 >= 0x3FFFFFFFu ? 1u : s.pass_seq + 1;
     next_rpt = kv_pick_rpt_ahead(next->n, kv.knobs);
     memset(&N, 0, sizeof N);
-    kv_fill_pass(N, next->d_req, next->d_rep, next->n, kv, log, sn, load_mode, next->view, KVB_T * next_rpt);
+    kv_fill_pass(N.e[0], next->d_req, next->d_rep, next->n, kv, log, sn, load_mode, next->view, KVB_T * next_rpt);
   } else {
     next = nullptr;
   }
@@ -207,16 +207,33 @@ void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &k
 // (and a step of the multi-GPU exchange) hands every shard server of the GPU one batch at the same moment; with the
 // engines' kernels side by side in one grid the epoch is one stream, no fork and join over engine streams.  The engines
 // stay independent (own tables, own scratch, own log).
-void dint_launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st) {
+// r06: `next` (or nullptr) = every engine's NEXT pass, announced: their partitions ride in this launch set's k_kv_pass, and that
+// next call comes with part_done = true.
+void dint_launch_kv_multi(const dint_kv_pass *p, uint32_t n_eng, hipStream_t st, bool part_done, const dint_kv_pass *next) {
   if (n_eng == 0) return;
-  kv_multi_args M;
+  kv_multi_args M, N;
   memset(&M, 0, sizeof M);
   uint32_t n_total = 0;
   for (uint32_t k = 0; k < n_eng; k++) n_total += p[k].n;
   const uint32_t rpt = kv_pick_rpt(n_total, p[0].kv->knobs);
   for (uint32_t k = 0; k < n_eng; k++) kv_fill_pass(M.e[k], p[k].d_req, p[k].d_rep, p[k].n, *p[k].kv, p[k].log, p[k].s, 0, p[k].view, KV_TB * rpt);
-  launch_kv_dispatch(p[0].kv->workload, M, n_eng, rpt, st, nullptr, p[0].kv->knobs);
+  uint32_t next_rpt = 0;
+  if (next) {
+    uint32_t nmax = 0;
+    for (uint32_t k = 0; k < n_eng; k++) nmax = std::max(nmax, next[k].n);
+    next_rpt = kv_pick_rpt_ahead(nmax, p[0].kv->knobs);
+    memset(&N, 0, sizeof N);
+    for (uint32_t k = 0; k < n_eng; k++) {
+      dint_scratch sn = next[k].s;  // (the caller's copy of the engine's scratch: the next pass's number and tag)
+      sn.kvs.pass_no = p[k].s.kvs.pass_no + 1;
+      sn.pass_seq = p[k].s.pass_seq + 1 >= 0x3FFFFFFFu ? 1u : p[k].s.pass_seq + 1;
+      kv_fill_pass(N.e[k], next[k].d_req, next[k].d_rep, next[k].n, *next[k].kv, next[k].log, sn, 0, next[k].view, KVB_T * next_rpt);
+    }
+  }
+  launch_kv_dispatch(p[0].kv->workload, M, n_eng, rpt, st, nullptr, p[0].kv->knobs, part_done, next ? &N : nullptr, next_rpt);
 }
+// can the engines of a launch set take an announcement?  (all of one workload: the first decides)
+bool dint_kv_multi_ahead_ok(const dint_kv &kv) { return dint_kv_ahead_ok(kv, 0) && !kv.knobs.no_fuse; }
 
 // ---- home shard of each request (multi-GPU routing): global bucket % shard_count -------------------------
 __global__ void __launch_bounds__(256)

@@ -2356,7 +2356,8 @@ kv_big_bin(uint8_t *rep, uint32_t n, const kv_cut cut, const kv_dev *kv, uint32_
 // path's stretch machinery (kvb_lds); the two never live at the same time and share one buffer.
 #define KVR_LCAP 1024u   // records of a coarse bin's small subs that fit the LDS split (the average bin holds ~512)
 #define KVR_F 64u        // subs per coarse bin = lanes of the wave that lays them out
-#define KVR_NPMAX 32u     // pieces of one hot key at most (a key of up to ~12,000 requests per pass; beyond: kv_big_bin)
+#define KVR_NPMAX 64u     // pieces of one hot key at most (a key of up to ~24,000 requests per pass -- the hottest subscriber of a
+                          // 2M-client tatp pass has 16,000; beyond: the late list.  r05 / early r06: 32)
 struct kvr_lds {
   uint4 rec[KVR_LCAP];         // records of the small subs, sub after sub
   uint32_t hist[KVR_F];        // records per sub
@@ -3917,7 +3918,9 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_hot_part(kv_pass_args H, kv_pas
 // write-back.  The next partition beside this resolve needs its own coarse bins and control words: dint_kv_sets.
 // RPT = 0: no partition role (plain dint_submit_device calls, launch sets of several engines).
 template <int WL, int RPT>
-__global__ void __launch_bounds__(KVB_T, 4) k_kv_pass(kv_multi_args M, uint32_t n_eng, uint32_t sum_c, kv_pass_args P, uint32_t n_work /* workers per engine */,
+__global__ void __launch_bounds__(KVB_T, 4) k_kv_pass(kv_multi_args M, uint32_t n_eng, uint32_t sum_c, kv_multi_args PM /* the engines' NEXT passes */,
+                                                       uint32_t max_tiles /* tiles of the longest of them (0: none announced) */,
+                                                       uint32_t n_work /* workers per engine */,
                                                        uint32_t part_first /* the partition's tiles are placed before the workers */) {
   constexpr size_t L1 = sizeof(kvh_lds) > sizeof(kvr_lds) ? sizeof(kvh_lds) : sizeof(kvr_lds);
   constexpr size_t LB = L1 > sizeof(kv_part_lds<RPT ? RPT : 1, KVB_T>) ? L1 : sizeof(kv_part_lds<RPT ? RPT : 1, KVB_T>);
@@ -3933,7 +3936,7 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_pass(kv_multi_args M, uint32_t 
     return;
   }
   b -= sum_c;
-  const uint32_t nw = n_work * n_eng, nt = RPT != 0 ? P.n_tiles : 0u;
+  const uint32_t nw = n_work * n_eng, nt = RPT != 0 ? max_tiles * n_eng : 0u;
   const bool worker = part_first ? b >= nt : b < nw;
   if (worker) {
     if (part_first) b -= nt;
@@ -3944,8 +3947,11 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_pass(kv_multi_args M, uint32_t 
   }
   if constexpr (RPT != 0) {
     if (!part_first) b -= nw;
-    if (b >= P.n_tiles) return;
-    kv_part_body<WL, RPT, KVB_T>(P, *(kv_part_lds<RPT, KVB_T> *)Lraw, b == 0);
+    if (b >= nt) return;
+    const uint32_t e = b / max_tiles, slot = b - e * max_tiles;  // (tiles draw tickets: only how many blocks an engine gets matters)
+    const kv_pass_args &P = PM.e[e];
+    if (slot >= P.n_tiles) return;
+    kv_part_body<WL, RPT, KVB_T>(P, *(kv_part_lds<RPT, KVB_T> *)Lraw, slot == 0);
   }
 }
 
@@ -4030,7 +4036,7 @@ int kv_piece_residency(int device) {
 // `next` (one engine only): the partition of the engine's next pass, launched with this pass's hot keys (k_kv_hot_part)
 template <int WL>
 void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_t st, hipEvent_t *ev, const dint_kv_knobs &K,
-                      bool part_done, const kv_pass_args *next, uint32_t next_rpt) {
+                      bool part_done, const kv_multi_args *next /* every engine's next pass, or nullptr */, uint32_t next_rpt) {
   uint32_t max_tiles = 0, sum_c = 0;
   for (uint32_t k = 0; k < n_eng; k++) {
     max_tiles = std::max(max_tiles, M.e[k].n_tiles);
@@ -4049,32 +4055,33 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
   bool fused = false, one = false;
   if constexpr (WL != DINT_WL_SMALLBANK) {
     if (hot && !K.no_fuse) {
-      kv_pass_args none;
-      memset(&none, 0, sizeof none);
-      const kv_pass_args &P = next ? *next : none;
-      const dim3 g(sum_c + K.workers * n_eng + P.n_tiles);
-      if (!next) hipLaunchKernelGGL((k_kv_pass<WL, 0>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, P, K.workers, K.part_first);
-      else if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, P, K.workers, K.part_first);
-      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, P, K.workers, K.part_first);
+      uint32_t nmax = 0;
+      for (uint32_t k = 0; next && k < n_eng; k++) nmax = std::max(nmax, next->e[k].n_tiles);
+      const dim3 g(sum_c + K.workers * n_eng + nmax * n_eng);
+      if (!next) hipLaunchKernelGGL((k_kv_pass<WL, 0>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, M, 0u, K.workers, K.part_first);
+      else if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, K.workers, K.part_first);
+      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, K.workers, K.part_first);
       one = fused = true;
     }
   } else {
     // smallbank with the next batch announced: its partition beside this pass's resolve workgroups (k_kv_pass without workers --
     // the big subs and the pieces of the hot accounts are k_kv_big's, behind this launch)
-    if (next && !K.no_fuse && n_eng == 1) {
-      const dim3 g(sum_c + next->n_tiles);
-      if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, 0u, 0u);
-      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, 0u, 0u);
+    if (next && !K.no_fuse) {
+      uint32_t nmax = 0;
+      for (uint32_t k = 0; k < n_eng; k++) nmax = std::max(nmax, next->e[k].n_tiles);
+      const dim3 g(sum_c + nmax * n_eng);
+      if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, 0u, 0u);
+      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, 0u, 0u);
       one = true;
     }
   }
   if (!one) hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
   if (ev) hipEventRecord(ev[2], st);
   if constexpr (WL != DINT_WL_SMALLBANK) {
-    if (hot && next && !one) {
-      const dim3 g(KVB_GRID + next->n_tiles);
-      if (next_rpt == 2) hipLaunchKernelGGL((k_kv_hot_part<WL, 2>), g, dim3(KVB_T), 0, st, M.e[0], *next);
-      else hipLaunchKernelGGL((k_kv_hot_part<WL, 4>), g, dim3(KVB_T), 0, st, M.e[0], *next);
+    if (hot && next && !one && n_eng == 1) {
+      const dim3 g(KVB_GRID + next->e[0].n_tiles);
+      if (next_rpt == 2) hipLaunchKernelGGL((k_kv_hot_part<WL, 2>), g, dim3(KVB_T), 0, st, M.e[0], next->e[0]);
+      else hipLaunchKernelGGL((k_kv_hot_part<WL, 4>), g, dim3(KVB_T), 0, st, M.e[0], next->e[0]);
       fused = true;
     }
   }

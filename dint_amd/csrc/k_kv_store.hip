@@ -2,5 +2,5 @@
 #include "k_kv_dev.h"
 
 template void launch_kv_passes<DINT_WL_STORE>(kv_multi_args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const dint_kv_knobs &, bool,
-                                     const kv_pass_args *, uint32_t);
+                                     const kv_multi_args *, uint32_t);
 template int kv_piece_residency<DINT_WL_STORE>(int);

@@ -53,8 +53,8 @@ static void *run(void *arg) {
   srv.sin_addr.s_addr = htonl(g_host);
   if (fd < 0 || connect(fd, (struct sockaddr *)&srv, sizeof srv) < 0) { perror("client socket"); return NULL; }
   int sz = 4 << 20;
-  setsockopt(fd, SOL_SOCKET, SO_RCVBUF, &sz, sizeof sz);
-  setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &sz, sizeof sz);
+  if (setsockopt(fd, SOL_SOCKET, SO_RCVBUFFORCE, &sz, sizeof sz) < 0) setsockopt(fd, SOL_SOCKET, SO_RCVBUF, &sz, sizeof sz);  /* (SO_RCVBUF alone is clamped to net.core.rmem_max: ~270 datagrams) */
+  if (setsockopt(fd, SOL_SOCKET, SO_SNDBUFFORCE, &sz, sizeof sz) < 0) setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &sz, sizeof sz);
 
   size_t next = (size_t)w->id, stride = (size_t)g_threads; /* thread t replays requests t, t+T, t+2T, ... */
   struct mmsghdr sm[VEC], rm[VEC];

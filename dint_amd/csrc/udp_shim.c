@@ -374,8 +374,8 @@ static void *control_thread(void *p) {
         ok = 0;
         break;
       }
-      setsockopt(dfd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
-      setsockopt(dfd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
+      if (setsockopt(dfd, SOL_SOCKET, SO_RCVBUFFORCE, &buf, sizeof buf) < 0) setsockopt(dfd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);  /* (SO_RCVBUF alone is clamped to net.core.rmem_max: ~270 datagrams) */
+      if (setsockopt(dfd, SOL_SOCKET, SO_SNDBUFFORCE, &buf, sizeof buf) < 0) setsockopt(dfd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
       const uint16_t port = ntohs(da.sin_port);  /* host order: Caladan's netaddr.port is host order (client_caladan.cc:305-308) */
       memcpy(resp + 4 + 2 * i, &port, 2);
       struct epoll_event ev;
@@ -477,8 +477,8 @@ int main(int argc, char **argv) {
       if (w->fd < 0) { perror("socket"); return 1; }
       int one = 1, buf = 64 << 20;
       setsockopt(w->fd, SOL_SOCKET, SO_REUSEPORT, &one, sizeof one);  /* as the reference: lock_fasst/udp/server.cc:57-58 */
-      setsockopt(w->fd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);
-      setsockopt(w->fd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
+      if (setsockopt(w->fd, SOL_SOCKET, SO_RCVBUFFORCE, &buf, sizeof buf) < 0) setsockopt(w->fd, SOL_SOCKET, SO_RCVBUF, &buf, sizeof buf);  /* (SO_RCVBUF alone is clamped to net.core.rmem_max: ~270 datagrams) */
+      if (setsockopt(w->fd, SOL_SOCKET, SO_SNDBUFFORCE, &buf, sizeof buf) < 0) setsockopt(w->fd, SOL_SOCKET, SO_SNDBUF, &buf, sizeof buf);
       if (bind(w->fd, (struct sockaddr *)&addr, sizeof addr) < 0) { perror("bind"); return 1; }
       struct timeval tv = {0, 100000};  /* wake up to notice signals */
       setsockopt(w->fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);

@@ -224,13 +224,20 @@ class Engine:
         return {names[i].decode(): {"avg_us": us[i], "launches": cnt[i]} for i in range(k)}
 
 
-def submit_segments_multi(engines, d_bases, n_seg: int, seg_caps, seg_stride: int, d_cnts, cnt_stride: int, stream: int = 0):
+def submit_segments_multi(engines, d_bases, n_seg: int, seg_caps, seg_stride: int, d_cnts, cnt_stride: int, stream: int = 0, ahead=None):
     """dint_submit_segments_multi: engine k answers its n_seg segments at d_bases[k] in place; the engines' kernels run
-    side by side in ONE set of launches on ONE stream (no fork / join across the engines' streams)"""
+    side by side in ONE set of launches on ONE stream (no fork / join across the engines' streams).
+    `ahead` = (d_bases, d_cnts) of the NEXT call (same engines, same geometry; dint_submit_segments_multi_ahead)."""
     items = (_lib.SegmentsItem * len(engines))()
     for k, e in enumerate(engines):
         items[k] = _lib.SegmentsItem(e._h, _ptr(d_bases[k]), n_seg, seg_caps[k], seg_stride, _ptr(d_cnts[k]), cnt_stride)
-    _lib.check(engines[0]._L.dint_submit_segments_multi(items, len(engines), stream))
+    if ahead is None:
+        _lib.check(engines[0]._L.dint_submit_segments_multi(items, len(engines), stream))
+        return
+    nxt = (_lib.SegmentsItem * len(engines))()
+    for k, e in enumerate(engines):
+        nxt[k] = _lib.SegmentsItem(e._h, _ptr(ahead[0][k]), n_seg, seg_caps[k], seg_stride, _ptr(ahead[1][k]), cnt_stride)
+    _lib.check(engines[0]._L.dint_submit_segments_multi_ahead(items, len(engines), nxt, stream))
 
 
 def route_pack_multi(engines, d_reqs, counts, d_slots, seg_caps, seg_stride: int, d_cnts, cnt_stride: int, d_slot,

@@ -90,12 +90,12 @@ class Router:
         # the backward half of a step (inverse all-to-all + unpack) on a stream of its own: the exchange stream then
         # carries only pack + forward all-to-all, and the two halves of consecutive steps run side by side
         self.bstream = (torch.cuda.Stream() if device == "cuda" and os.environ.get("DINT_BWD_STREAM", "1") != "0" else None)
-        self.ev_unpacked = [None] * 2  # per buffer set: its last unpack has read the send buffer
+        self.NBUF = 3  # exchange buffer sets: step k uses set k % 3 (see run(): the forward exchange runs TWO steps ahead)
+        self.ev_unpacked = [None] * self.NBUF  # per buffer set: its last unpack has read the send buffer
         self.multi = None  # (pack, unpack) of several batches per launch set: the real engines on a GPU
         if device == "cuda" and self.S <= 4:
             from .engine import route_pack_multi, route_unpack_multi
             self.multi = (route_pack_multi, route_unpack_multi)
-        self.NBUF = 2  # exchange buffer sets: step k uses set k % 2 (see run())
         self.d_slot = [[torch.empty(n_max, dtype=torch.int32, device=device) for _ in range(self.S)] for _ in range(self.NBUF)]
         self.send = self.recv = None
         self.max_seen = [0] * self.S
@@ -118,7 +118,7 @@ class Router:
         self.chunk = _align(o, 64)
         if self.device == "cuda":
             torch.cuda.synchronize()
-        self.ev_unpacked = [None] * 2
+        self.ev_unpacked = [None] * self.NBUF
         self.send = [torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device) for _ in range(self.NBUF)]
         self.recv = [torch.zeros(self.world * self.chunk, dtype=torch.uint8, device=self.device) for _ in range(self.NBUF)]
 
@@ -160,16 +160,23 @@ class Router:
         ev.record(self.stream)
         return ev
 
-    def _engines(self, k: int, ev_fwd):
-        """every home engine answers its W segments of step k on its own stream; returns their completion events"""
+    def _engines(self, k: int, ev_fwd, ev_next=None):
+        """every home engine answers its W segments of step k on its own stream; returns their completion events.
+        ev_next: the forward exchange of step k + 1 (buffer set (k + 1) % NBUF) -- its segments are ANNOUNCED to the engines
+        (dint_submit_segments_multi_ahead: their partition stage rides in this step's launch set)"""
         b = k % self.NBUF
         rp = self.recv[b].data_ptr()
         done = []
         if self._one_set():  # all home engines in one set of launches on the first engine's stream
             from .engine import submit_segments_multi
             self.estream[0].wait_event(ev_fwd)
+            ahead = None
+            if ev_next is not None and os.environ.get("DINT_ROUTER_NO_AHEAD", "0") != "1":
+                self.estream[0].wait_event(ev_next)
+                rn = self.recv[(k + 1) % self.NBUF].data_ptr()
+                ahead = ([rn + self.off[s] for s in range(self.S)], [rn + 4 * s for s in range(self.S)])
             submit_segments_multi(self.engines, [rp + self.off[s] for s in range(self.S)], self.world, self.caps, self.chunk,
-                                  [rp + 4 * s for s in range(self.S)], self.chunk, self.estream[0].cuda_stream)
+                                  [rp + 4 * s for s in range(self.S)], self.chunk, self.estream[0].cuda_stream, ahead=ahead)
             ev = torch.cuda.Event()
             ev.record(self.estream[0])
             return [ev]
@@ -215,10 +222,11 @@ class Router:
     def run(self, steps, track: bool = False) -> None:
         """steps: [(d_reqs[S], counts[S], d_reps[S][, d_n[S]])] -- independent batches (a recorded trace).  Asynchronous.
 
-        Software pipeline over two buffer sets: the forward exchange of step k+1 is issued BEFORE the backward
-        exchange of step k, so on the exchange stream (and on RCCL's, which runs collectives in issue order) step
-        k+1's requests travel while the engines work on step k, and step k's replies travel while they work on step
-        k+1.  Every rank issues the same sequence, so the collectives match up."""
+        Software pipeline over three buffer sets (r06; two until r05): the forward exchange runs TWO steps ahead -- that of step
+        k+2 is issued before the backward exchange of step k -- so that when the engines start on step k the segments of step
+        k+1 have arrived and can be announced to them (their partition stage then rides in step k's launch set), step k+2's
+        requests travel while the engines work on step k+1, and step k's replies travel beside.  Every rank issues the same
+        sequence, so the collectives match up."""
         if not steps:
             return
         if self.stream is not None:
@@ -227,16 +235,18 @@ class Router:
                 self.bstream.wait_stream(torch.cuda.current_stream())
         with self._on_stream():
             dn = lambda k: steps[k][3] if len(steps[k]) > 3 else None  # noqa: E731
-            ev = self._forward(0, steps[0][0], steps[0][1], track, dn(0))
-            done = self._engines(0, ev)
-            for k in range(len(steps)):
-                nxt = None
-                if k + 1 < len(steps):
-                    ev = self._forward(k + 1, steps[k + 1][0], steps[k + 1][1], track, dn(k + 1))
-                    nxt = ev
+            n = len(steps)
+            ev = [None] * (n + 2)
+            ev[0] = self._forward(0, steps[0][0], steps[0][1], track, dn(0))
+            if n > 1:
+                ev[1] = self._forward(1, steps[1][0], steps[1][1], track, dn(1))
+            done = self._engines(0, ev[0], ev[1])
+            for k in range(n):
+                if k + 2 < n:
+                    ev[k + 2] = self._forward(k + 2, steps[k + 2][0], steps[k + 2][1], track, dn(k + 2))
                 self._backward(k, done, *steps[k][:3], dn(k))
-                if k + 1 < len(steps):
-                    done = self._engines(k + 1, nxt)
+                if k + 1 < n:
+                    done = self._engines(k + 1, ev[k + 1], ev[k + 2])
 
     def step(self, d_reqs, counts, d_reps, track: bool = False, d_n=None) -> None:
         """one batch per server: d_reqs / d_reps are per server uint8 device tensors (or raw device pointers) of

@@ -324,6 +324,12 @@ typedef struct dint_segments_item {
   uint64_t cnt_stride;
 } dint_segments_item;
 int dint_submit_segments_multi(const dint_segments_item *items, uint32_t n_items, void *stream);
+/* ... with a LOOK-AHEAD (round 6, as dint_submit_device_ahead): next[k] = the segments engine k will be handed by the NEXT call of
+ * this kind -- the same engines in the same order, the same geometry (n_seg, seg_cap, strides), other buffers, complete in
+ * device memory in the order of `stream` (the exchange has delivered them).  The engines' partitions of that step ride in this
+ * step's launch set.  next == NULL, or an announcement that does not fit (other engines, another geometry, a workload without
+ * the one-launch pass): plain dint_submit_segments_multi.  The announced step MUST be the engines' next submission. */
+int dint_submit_segments_multi_ahead(const dint_segments_item *items, uint32_t n_items, const dint_segments_item *next, void *stream);
 /* d_home[i] = home shard (0..shard_count-1) of d_reqs[i], computed on the GPU with the
  * same hash/modulus the engine uses; 0xFF for requests that have no home (bad table). */
 int dint_home_shard(dint_engine_t *e, const void *d_reqs, uint32_t n, uint8_t *d_home, void *stream);
