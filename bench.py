@@ -533,14 +533,18 @@ def bench_lock(args, world, rank, dev, transport, kind):
             mut = float(((ra == 2) | (ra == 5)).mean())
             alg_bytes = BATCH * (20.0 + 8.0 * mut)
         dom = max(tim.items(), key=lambda kv: kv[1]["avg_us"])
+        # r06: with the next batch announced, the engine's "k_lock_resolve" interval is k_lock_pass -- this batch's resolve stage AND
+        # the next batch's count stage in one launch: the whole pass, all its algorithmic bytes
+        fused_lock = ahead and os.environ.get("DINT_LOCK_NO_FUSE") is None and dom[0] == "k_lock_resolve"
+        dom_name = "k_lock_pass" if fused_lock else dom[0]
         achieved = alg_bytes / (dom[1]["avg_us"] * 1e-6) / 1e9
         # a table of a few MB lives in L2 / Infinity Cache: priced against the L2, not against HBM
         in_cache = args.slots * 8 <= 64 << 20
         peak = L2_PEAK_GBS if in_cache else HBM_PEAK_GBS
-        roof = {"bound": "l2" if in_cache else "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": peak,
+        roof = {"bound": "l2" if in_cache else "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": peak,
                 "unit": "GB/s", "frac": round(achieved / peak, 5), "traffic": None,
                 "alg_bytes_per_launch": int(alg_bytes), "kernel_avg_us": round(dom[1]["avg_us"], 3),
-                "from_profile": profile_counters(kind, [dom[0]])}
+                "from_profile": profile_counters(kind, [dom_name])}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
@@ -827,7 +831,9 @@ def bench_store(args, world, rank, dev, transport):
         # for tatp / smallbank; the 53 request bytes of every request are k_kv_part's, which reads them (bench_txn)
         part_b, alg = NB * float(msg), alg_all - NB * float(msg)
         t_part = tim.get("k_kv_part", {"avg_us": 0.0})["avg_us"]
-        us = tim["k_kv_resolve"]["avg_us"] + tim.get("k_kv_hot", {"avg_us": 0.0})["avg_us"] + tim.get("k_kv_big", {"avg_us": 0.0})["avg_us"]
+        z = {"avg_us": 0.0}
+        us = (tim.get("k_kv_resolve", z)["avg_us"] + tim.get("k_kv_pass", z)["avg_us"] + tim.get("k_kv_hot", z)["avg_us"] + tim.get("k_kv_big", z)["avg_us"] +
+              tim.get("k_kv_late", z)["avg_us"])
         ach = alg / (us * 1e-6) / 1e9
         one_launch = os.environ.get("DINT_KV_NO_FUSE", "0") in ("", "0")
         if one_launch:  # r06: k_kv_pass (resolve + hot-key workers + the next batch's partition) + k_kv_late: the whole pass is the priced stage
@@ -837,7 +843,8 @@ def bench_store(args, world, rank, dev, transport):
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": int(alg),
                 "kernel_avg_us": round(us, 3),
-                "from_profile": profile_counters("store", ["k_kv_pass", "k_kv_late", "k_kv_part", "k_kv_resolve", "k_kv_hot", "k_kv_big"])}
+                "from_profile": profile_counters("store", (["k_kv_pass", "k_kv_late"] + ([] if ahead else ["k_kv_part"])) if one_launch else
+                                                 ["k_kv_resolve", "k_kv_hot", "k_kv_hot_part", "k_kv_big"])}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
@@ -1249,8 +1256,9 @@ def bench_txn(args, world, rank, dev, transport, kind):
         part_b = msgb * n_all + sum((b - msgb) * int(hist[c]) for c, b in alg_tab.items() if c in log_types)
         f_big = big_req / max(1, n_tab)
         L = max(1, launches)
-        t_part, t_res = avg.get("k_kv_part", 0.0), avg.get("k_kv_resolve", 0.0)
-        t_big = avg.get("k_kv_hot", 0.0) + avg.get("k_kv_big", 0.0)  # the hot keys: closed forms (k_kv_hot), then what they do not cover
+        # (the engine's timer: {k_kv_part, k_kv_pass, k_kv_late} when a pass is one launch -- store / tatp, r06 --, else r05's four)
+        t_part, t_res = avg.get("k_kv_part", 0.0), avg.get("k_kv_resolve", 0.0) + avg.get("k_kv_pass", 0.0)
+        t_big = avg.get("k_kv_hot", 0.0) + avg.get("k_kv_big", 0.0) + avg.get("k_kv_late", 0.0)  # the hot keys: closed forms (k_kv_hot), then what they do not cover
 
         def priced(name, us, nbytes):
             ach = nbytes / L / max(us, 1e-9) / 1e3  # bytes per launch / us -> GB/s
@@ -1264,6 +1272,10 @@ def bench_txn(args, world, rank, dev, transport, kind):
             # "k_kv_resolve" interval is k_kv_pass, "k_kv_big" is k_kv_late, "k_kv_part" the first pass's partition only (or, without
             # look-ahead, every pass's).  The priced stage is the WHOLE pass: every algorithmic byte over the whole chain.
             stage = priced("k_kv_pass+k_kv_late" + ("" if rp.ahead else "+k_kv_part"), t_part + t_res + t_big, tab_b + part_b)
+        elif rp.ahead and kind == "smallbank":
+            # smallbank, look-ahead replay: k_kv_pass (this pass's resolve workgroups + the next batch's partition) -> k_kv_big (the big
+            # subs; a hot account's row in pieces, kv_sb_item).  The whole pass is the priced stage.
+            stage = priced("k_kv_pass+k_kv_big", t_part + t_res + t_big, tab_b + part_b)
         elif rp.ahead:
             # look-ahead replay, DINT_KV_NO_FUSE: k_kv_resolve -> k_kv_hot_part (the hot keys AND the next batch's partition) -> k_kv_late
             stage = priced("k_kv_resolve+k_kv_hot_part+k_kv_big", t_part + t_res + t_big, tab_b + part_b)
@@ -1273,16 +1285,18 @@ def bench_txn(args, world, rank, dev, transport, kind):
         # the same command live in profiles/ and are quoted under from_profile only for the same kernel sources
         roof = {"bound": "hbm", **stage, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
                 "requests_in_big_bins": round(f_big, 4),
-                "from_profile": profile_counters(kind, ["k_kv_pass", "k_kv_late", "k_kv_resolve", "k_kv_hot_part", "k_kv_hot", "k_kv_big"] +
-                                                 (["k_kv_part"] if rp.ahead or one_launch else []))}
+                # (the kernels of THIS configuration's pass only: the profile also holds the recording's kernels under their own names)
+                "from_profile": profile_counters(kind, (["k_kv_pass", "k_kv_late"] + ([] if rp.ahead else ["k_kv_part"])) if one_launch else
+                                                 (["k_kv_pass", "k_kv_big"] if kind == "smallbank" and rp.ahead else
+                                                  ["k_kv_resolve", "k_kv_hot_part", "k_kv_big"] if rp.ahead else ["k_kv_resolve", "k_kv_hot", "k_kv_big"]))}
         fp = roof["from_profile"]
         if fp and fp.get("traffic_bytes"):
             roof["traffic"] = fp["traffic_bytes"]
             roof["traffic_over_alg"] = round(fp["traffic_bytes"] / max(1.0, stage["alg_bytes_per_launch"]), 3)
         if one_launch:
             roof["kernels"] = [priced("k_kv_part" + (" (first pass only)" if rp.ahead else ""), t_part, 0 if rp.ahead else part_b),
-                               priced("k_kv_pass", t_res + avg.get("k_kv_hot", 0.0), tab_b + (part_b if rp.ahead else 0)),
-                               priced("k_kv_late", avg.get("k_kv_big", 0.0), 0)]
+                               priced("k_kv_pass", t_res, tab_b + (part_b if rp.ahead else 0)),
+                               priced("k_kv_late", t_big, 0)]
         elif rp.ahead:
             roof["kernels"] = [priced("k_kv_part (first pass only)", t_part, 0), priced("k_kv_resolve", t_res, tab_b * (1.0 - f_big)),
                                priced("k_kv_hot_part+k_kv_big", t_big, tab_b * f_big + part_b)]

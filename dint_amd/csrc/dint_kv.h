@@ -91,6 +91,7 @@ struct dint_kv_ahead {
   dint_view view;
 };
 bool dint_kv_ahead_ok(const dint_kv &kv, int load_mode);
+bool dint_kv_one_launch(const dint_kv &kv, int load_mode);
 void dint_launch_kv(const void *d_req, void *d_rep, uint32_t n, const dint_kv &kv, dint_log log, dint_scratch s,
                     int load_mode, hipStream_t st, hipEvent_t *ev, const dint_view &view = dint_flat_view(),
                     bool part_done = false, const dint_kv_ahead *next = nullptr);

@@ -381,6 +381,7 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
   static const char *const lock_names[] = {"k_lock_count", "k_kv_scan_place", "k_lock_resolve"};
   static const char *const log_names[] = {"k_log_append"};
   static const char *const kv_names[] = {"k_kv_part", "k_kv_resolve", "k_kv_hot", "k_kv_big"};
+  static const char *const kv_names_one[] = {"k_kv_part", "k_kv_pass", "k_kv_late"};  // (store / tatp, r06: one launch per pass + the late list's)
   switch (piped ? DINT_WL_COUNT : e->cfg.workload) {
     case DINT_WL_COUNT:
       if (int rc = run_lock_pass_piped(e, d_req, n, d_rep, st, view)) return rc;
@@ -432,7 +433,8 @@ int run_pass(dint_engine *e, const void *d_req, uint32_t n, void *d_rep, hipStre
     case DINT_WL_SMALLBANK:
       if (int rc = next_pass_seq(e, st)) return rc;  // tags what the pieces of a hot key publish in this pass
       if (next && (!n || !next->n || view.seg_cap || next->view.seg_cap || !dint_kv_ahead_ok(e->kv, load_mode))) next = nullptr;
-      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st, timer_events(e, 4, kv_names), view, part_done, next);
+      dint_launch_kv(d_req, d_rep, n, e->kv, e->log, e->scratch, load_mode, st,
+                     dint_kv_one_launch(e->kv, load_mode) ? timer_events(e, 3, kv_names_one) : timer_events(e, 4, kv_names), view, part_done, next);
       if (next) {
         e->ahead.valid = true;
         e->ahead.req = next->d_req; e->ahead.rep = next->d_rep; e->ahead.n = next->n;

@@ -95,6 +95,10 @@ static dint_kv_knobs kv_read_knobs() {
 static inline bool kv_uses_hot(const dint_kv &kv, int load_mode) {
   return kv.workload != DINT_WL_SMALLBANK && !(kv.force_rounds & 3) && !load_mode && !kv.knobs.no_split;
 }
+// a pass of this engine is k_kv_pass (+ k_kv_late): the engine's kernel timer then has three intervals (part, pass, late)
+bool dint_kv_one_launch(const dint_kv &kv, int load_mode) {
+  return kv_uses_hot(kv, load_mode) && !kv.knobs.one_big_kernel && !kv.knobs.no_fuse;
+}
 bool dint_kv_ahead_ok(const dint_kv &kv, int load_mode) {
   if (kv.workload == DINT_WL_SMALLBANK) return !load_mode && !kv.knobs.no_ahead && !kv.knobs.no_fuse;  // (the partition beside the resolve stage)
   return kv_uses_hot(kv, load_mode) && !kv.knobs.one_big_kernel && !kv.knobs.no_ahead;

@@ -3358,6 +3358,9 @@ __device__ __forceinline__ static int kv_hot_item(uint8_t *rep, const kv_cut cut
   if (c_rem == 0) return 0;
   // ---- the remainder: other buckets, or other rows of the hot bucket -- beside the pieces
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (a solo item: the hot row's write-back above, then its bucket's other rows)
+  // (r06 tried the remainder as a SOLO item here -- a second hot key of the sub answered in closed form instead of going to the
+  // late list: late items 50 -> 30 per 600 passes, the kernel 72 -> 224 bytes of scratch per lane, the bench +0.7 % (tatp) / -2 %
+  // (store).  Not kept: k_kv_late does the same off this kernel's register budget.)
   if (c_rem <= KVB_T && kv_rem_chunks<WL>(rep, cut2, kv, d.x, H.rem, c_rem, H, stats, force_rounds, V)) return 0;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // ... this workgroup's own ovf2 stores before kv_big_bin's loads
   *src = 1; *off = d.y; *cnt = c_rem;
@@ -4076,6 +4079,7 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
     }
   }
   if (!one) hipLaunchKernelGGL((k_kv_resolve<WL>), dim3(sum_c), dim3(KVB_T), 0, st, M, n_eng);
+  const bool ev3 = ev && one && WL != DINT_WL_SMALLBANK;  // (store / tatp, one launch: three timed intervals -- part, pass, late -- not four)
   if (ev) hipEventRecord(ev[2], st);
   if constexpr (WL != DINT_WL_SMALLBANK) {
     if (hot && next && !one && n_eng == 1) {
@@ -4086,7 +4090,7 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
     }
   }
   if (hot && !fused) hipLaunchKernelGGL((k_kv_hot<WL>), dim3(KVB_GRID, n_eng), dim3(KVB_T), 0, st, M);
-  if (ev) hipEventRecord(ev[3], st);
+  if (ev && !ev3) hipEventRecord(ev[3], st);
   // (behind k_kv_hot the launch is almost always empty, and k_kv_big's workgroups -- 256 VGPRs x 8 waves -- each wait for a compute
   // unit with nothing on it: 14 .. 19 us per pass beside the other servers' kernels, whether 8 of them or one.  k_kv_late has
   // k_kv_hot's footprint and starts beside anything; DINT_KV_LATE_BIG=1 keeps r05's launch for A/B runs and cross-checks)
@@ -4101,6 +4105,6 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
   } else {
     hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? K.late_grid : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
   }
-  if (ev) hipEventRecord(ev[4], st);
+  if (ev) hipEventRecord(ev3 ? ev[3] : ev[4], st);
 }
 
