@@ -33,6 +33,9 @@ struct dint_kv_sets {
   uint64_t pass_no = 0;                             // passes launched so far (host side)
 };
 
+#define DINT_KV_HOTPUB_WORDS (3u * DINT_KV_BIGQ_MAX)  // hotpub: [i] item i's word; [BIGQ_MAX + 2 i ..] the two words of a smallbank item that is a sub's only piece
+#define DINT_KV_SBX_WORDS 48u  // smallbank: words per work item in dint_kv_sets::sbx (k_kv_dev.h, kv_sb_item)
+
 // scratch shared by every workload: bins of batch records
 struct dint_scratch {
   uint32_t *bin_cnt;   // [DINT_KV_PMAX]   zero between passes (the resolve kernels re-zero their own)
@@ -54,7 +57,7 @@ struct dint_scratch {
   uint4 *kbins = nullptr;          // [C][cap] 16-byte records {key, group / C | idx | payload}
   uint64_t kbins_slots = 0;        // records `kbins` holds: C * cap never exceeds it
   uint4 *bigq = nullptr;           // [DINT_KV_BIGQ_MAX][3] the pass's big subs and hot-key pieces (work items of k_kv_big)
-  unsigned long long *hotpub = nullptr;  // [DINT_KV_BIGQ_MAX] what the pieces of a hot key tell each other (tagged with pass_seq)
+  unsigned long long *hotpub = nullptr;  // [DINT_KV_HOTPUB_WORDS] what the pieces of a hot key tell each other (tagged with pass_seq)
   uint4 *lateq = nullptr;          // [DINT_KV_BIGQ_MAX] what k_kv_hot leaves to k_kv_big {bin, offset, records, 0: in ovf / 1: in ovf2}
   uint32_t pass_seq = 0;           // host side: passes launched so far (never 0 in a launch)
   dint_kv_sets kvs;                // kv workloads: the sets by pass number (the fields above are their set 0 / unused)

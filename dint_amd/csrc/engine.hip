@@ -233,7 +233,7 @@ hipEvent_t *timer_events(dint_engine *e, int n_kernels, const char *const *names
 int next_pass_seq(dint_engine *e, hipStream_t st) {
   e->scratch.kvs.pass_no++;  // (which set of the pass scratch a pass uses: dint_kv_sets)
   if (++e->scratch.pass_seq >= 0x3FFFFFFFu) {
-    if (e->scratch.hotpub) HIP_TRY(hipMemsetAsync(e->scratch.hotpub, 0, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long), st));
+    if (e->scratch.hotpub) HIP_TRY(hipMemsetAsync(e->scratch.hotpub, 0, (size_t)DINT_KV_HOTPUB_WORDS * sizeof(unsigned long long), st));
     if (e->scratch.kvs.bigrdy) HIP_TRY(hipMemsetAsync(e->scratch.kvs.bigrdy, 0, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint32_t), st));
     e->scratch.pass_seq = 1;
   }
@@ -552,7 +552,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
       e->scratch.kbins_slots = (uint64_t)dint_kv_cap_mult() * e->pass_max + 128ull * DINT_KV_CMAX;
       TRY(dev_alloc((void **)&e->scratch.kbins, (size_t)e->scratch.kbins_slots * sizeof(uint4), false));
       TRY(dev_alloc((void **)&e->scratch.bigq, (size_t)DINT_KV_BIGQ_MAX * 3 * sizeof(uint4), false));  // KVQ_W uint4 per work item (k_kv.hip)
-      TRY(dev_alloc((void **)&e->scratch.hotpub, (size_t)DINT_KV_BIGQ_MAX * sizeof(unsigned long long)));
+      TRY(dev_alloc((void **)&e->scratch.hotpub, (size_t)DINT_KV_HOTPUB_WORDS * sizeof(unsigned long long)));
       TRY(dev_alloc((void **)&e->scratch.lateq, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint4), false));
       // the second set of what the partition stage writes (dint_kv_sets): 288 GB of HBM are there to be used
       TRY(dev_alloc((void **)&e->scratch.kvs.bin_cnt[1], DINT_KV_PMAX * sizeof(uint32_t)));
@@ -560,7 +560,7 @@ int dint_engine_create(const dint_config *cfg, dint_engine_t **out) {
       TRY(dev_alloc((void **)&e->scratch.kvs.ovl[1], (size_t)e->pass_max * sizeof(uint4) * 2, false));
       TRY(dev_alloc((void **)&e->scratch.kvs.bigrdy, (size_t)DINT_KV_BIGQ_MAX * sizeof(uint32_t)));
       if (wl == DINT_WL_SMALLBANK)  // what the pieces of a hot account's row tell each other: 40 words per work item (kv_sb_item)
-        TRY(dev_alloc((void **)&e->scratch.kvs.sbx, (size_t)DINT_KV_BIGQ_MAX * 40 * sizeof(uint64_t), false));
+        TRY(dev_alloc((void **)&e->scratch.kvs.sbx, (size_t)DINT_KV_BIGQ_MAX * DINT_KV_SBX_WORDS * sizeof(uint64_t), false));
     } else {
       TRY(dev_alloc((void **)&e->scratch.bins, (size_t)DINT_KV_PMAX * DINT_KV_BINCAP * sizeof(uint64_t), false));
       // lock tables, passes of <= 65,536 requests (k_locks.hip, LK_DIRECT_NMAX): a big bin's records beyond the 64 in place go

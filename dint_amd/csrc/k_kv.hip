@@ -77,7 +77,7 @@ static dint_kv_knobs kv_read_knobs() {
   k.one_big_kernel = kv_env("DINT_KV_ONE_BIG_KERNEL", 0);
   k.no_ahead = kv_env("DINT_KV_NO_AHEAD", 0);
   k.no_fuse = kv_env("DINT_KV_NO_FUSE", 0);
-  k.sb_split_min = kv_env("DINT_KV_SB_SPLIT_MIN", 2048u);
+  k.sb_split_min = kv_env("DINT_KV_SB_SPLIT_MIN", 128u);
   // (never fewer workers than a hot key has pieces + a remainder, + 1: the pieces wait for each other.  An idle worker holds half
   // a compute unit that another shard server's resolve workgroup is waiting for: 320 / 192 / 96 / 48 workers per engine gave
   // 2,320 / 2,650 .. 2,840 / 2,980 .. 3,030 / 2,820 Mtxn/s on the tatp bench stream -- ~160 items per pass)
@@ -145,7 +145,7 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   // smallbank (r06): a hot account's row of at least DINT_KV_SB_SPLIT_MIN requests in pieces, several workgroups of k_kv_big at
   // once (kv_sb_item); never with the closed forms switched off or for LOAD requests
   if (kv.workload == DINT_WL_SMALLBANK && K.sb_split_min && s.kvs.sbx && !(kv.force_rounds & 3) && !load_mode && !K.no_split) {
-    A.split_min = std::max(2u * K.split_target, K.sb_split_min);
+    A.split_min = std::max(8u, K.sb_split_min);
     A.np_max = KSB_NPMAX;
   }
   A.has_log = kv.workload != DINT_WL_STORE;

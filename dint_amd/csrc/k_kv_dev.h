@@ -2403,7 +2403,8 @@ __device__ static inline void kv_list_items(const kv_pass_args &A, uint32_t b, c
   }
   const uint32_t np0 = (bs.y + target - 1) / target;
   // (more than the pieces can hold: k_kv_late's / kv_big_bin's, via the late list; smallbank (np_max = KSB_NPMAX): pieces or nothing)
-  const bool hot = bs.y >= A.split_min && np0 <= A.np_max && (A.np_max == KVR_NPMAX || np0 >= 2);
+  // (smallbank, one piece: a SOLO item of kv_sb_item -- its closed form covers a second key on the row's counter pair)
+  const bool hot = bs.y >= A.split_min && np0 <= A.np_max;
   const uint32_t np = hot ? np0 : 0u;
   const uint32_t nent = bs.y ? (np > 1 ? np + 1 : 1u) : 0u;
   uint32_t tot, at = wave_excl_scan_u32(nent, &tot);
@@ -2415,7 +2416,31 @@ __device__ static inline void kv_list_items(const kv_pass_args &A, uint32_t b, c
   if (nent && !hot) {
     kv_st_agent(A.bigq + KVQ_W * (size_t)at, make_uint4(bin, bs.x, bs.y, KVQ_SUB));
   } else if (nent) {
-    const uint64_t hk = L.ckey[t], hr = L.hrec[t];
+    uint64_t hk = L.ckey[t], hr = L.hrec[t];
+    if (A.np_max != KVR_NPMAX) {
+      // smallbank: WHICH row the pieces are cut around decides whether the sub is answered in closed form.  "Whichever record came
+      // first" is the hot row's nine times out of ten in a sub of thousands; in a sub of 200 .. 1,200 records (a warm row among cold
+      // ones) it was a cold row's often enough that the warm row and a neighbour on its counter pair went to kv_big_bin's rounds
+      // in the remainder: 0.2 .. 1.5 ms, the passes behind the p99 (r06b trace).  Eight records from across the sub vote.
+      using F = Fmt<DINT_WL_SMALLBANK>;
+      const uint32_t sh_g = 16 + A.cut.ibits;
+      uint64_t smp[8];
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) smp[j] = kv_ld_agent(&A.ovf[bs.x + (uint32_t)(((uint64_t)(2 * j + 1) * bs.y) >> 4)]);
+      uint32_t best = 0, bj = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 8; j++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) c += (smp[i] >> sh_g) == (smp[j] >> sh_g) && pay_q(kv_rec_pay(smp[i])) == pay_q(kv_rec_pay(smp[j]));
+        if (c > best) { best = c; bj = j; }
+      }
+      hr = smp[0];
+#pragma unroll
+      for (uint32_t j = 1; j < 8; j++) if (j == bj) hr = smp[j];
+      const uint32_t hidx = (uint32_t)(hr >> 16) & (uint32_t)((1ull << A.cut.ibits) - 1ull);
+      hk = ld_u64(A.rep + dint_view_off(A.V, hidx, F::MSG) + F::KEY);
+    }
     for (uint32_t p = 0; p < nent; p++) {
       const uint32_t kind = np == 1 ? KVQ_SOLO : (p < np ? KVQ_PIECE : KVQ_REM);
       uint4 *q = A.bigq + KVQ_W * (size_t)(at + p);
@@ -3561,13 +3586,20 @@ __global__ void __launch_bounds__(KVB_T, WPS) k_kv_late(kv_multi_args M, uint32_
 //   every piece   answers its requests: grants from the coordinator's masks, version = v0 + writers before me, value = message of
 //                 the last writer before me (else the row) -- the writers before a piece come from the pieces' words;
 //                 the piece with the pass's last COMMIT stores row and version.
-// The serial part of a 35,000-request account is one wave's pass over ~560 chunk masks instead of nine stretches.  ALL OR NOTHING as
-// kv_hot_item: a piece with more than KVB_T requests, a second key behind the hash bits, another key on the hot row's counter pair,
-// an unknown op -- then piece 0 takes the whole sub the old way (kv_big_bin) and its siblings do nothing.
+// The serial part of a 35,000-request account is one wave's pass over ~560 chunk masks instead of nine stretches.
+// ANOTHER KEY ON THE ROW'S COUNTER PAIR (a cold account whose row hashes to the same bucket and lock quadrant -- the lock table is
+// 2/3 full -- with a request or two in this pass): kv_big_bin then runs the hot row's thousands of requests in ROUNDS, 1 .. 4 ms,
+// the passes behind r05's p99.  Here a piece takes every request ON THE PAIR of its index range: the foreign ones' lock ops sit in
+// the masks like the hot row's (the counters see them in request order), their row ops (the GET of a granted ACQUIRE, a COMMIT's
+// SET) are few and are done by the coordinator, one after the other in request order, before anybody else touches the table.
+// ALL OR NOTHING as kv_hot_item: a piece with more than KVB_T requests or more than KSB_FMAX foreign ones, an unknown op -- then
+// piece 0 takes the whole sub the old way (kv_big_bin) and its siblings do nothing.
 // Semantics per op: smallbank/udp/server_shard.cc:121-173 (as kv_do_request).  Nobody stores to the table before the
 // coordinator's word is out, i.e. before every piece has read header and row.
 #define KSB_NPMAX 128u   // pieces of one hot row at most (~49,000 requests; beyond: kv_big_bin)
-#define KSB_WORDS 40u    // words per item in sbx: [4 c + k] op kind k of chunk c (k: AS, AX, RS, RX), [32 + c] the granted lanes of chunk c
+#define KSB_WORDS DINT_KV_SBX_WORDS  // words per item in sbx: [4 c + k] op kind k of chunk c (k: AS, AX, RS, RX), [32 + c] the granted lanes of chunk c,
+                                    // [40 + f] the piece's f-th FOREIGN request (another key on the row's counter pair): valid << 63 | type << 48 | position << 32 | idx
+#define KSB_FMAX 8u      // foreign requests per piece at most (a cold account that shares the hot row's lock slot: a handful per pass)
 struct kvs_lds {
   uint32_t key[KVB_T];            // idx << 9 | slot: sorted = the piece in request order
   uint32_t idx[KVB_T];            // request index at each sorted position
@@ -3576,7 +3608,9 @@ struct kvs_lds {
   unsigned long long pub[KSB_NPMAX + 1];
   uint64_t cm[4][KSB_NPMAX * KVB_W];  // the coordinator: every piece's op masks, chunk after chunk
   uint64_t cg[KSB_NPMAX * KVB_W];     // ... and the grants
-  uint32_t bad, timeout, nhot, nrem, found, link, slot, ver0, table, la, lb, allok;
+  uint64_t cf[KSB_NPMAX * KSB_FMAX];  // ... and the foreign requests of all pieces
+  uint64_t fl[KSB_FMAX];              // a piece's own foreign requests
+  uint32_t bad, timeout, nhot, nrem, found, link, slot, ver0, table, la, lb, allok, nf;
   uint32_t rowv[2];
 };
 template <int WL>
@@ -3593,8 +3627,10 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
   const uint32_t sh_g = 16 + cut2.ibits, idx_mask = (uint32_t)((1ull << cut2.ibits) - 1ull);
   const uint64_t hkey = ((uint64_t)x.y << 32) | x.x, hrec = ((uint64_t)y.y << 32) | y.x;
   const uint32_t hq = pay_q(kv_rec_pay(hrec)), hkh = pay_kh(kv_rec_pay(hrec));
-  const bool do_piece = kind == KVQ_PIECE;
-  unsigned long long *pub = hotpub + first;  // [0, np): the pieces' words; [np]: the coordinator's
+  // (SOLO: the sub's only piece answers the row's counter pair in closed form and hands the sub's other keys to kv_big_bin itself --
+  // nobody else reads its words, which live apart from the item words of the neighbours)
+  const bool solo = kind == KVQ_SOLO, do_piece = kind != KVQ_REM;
+  unsigned long long *pub = solo ? hotpub + DINT_KV_BIGQ_MAX + 2 * (size_t)first : hotpub + first;  // [0, np): the pieces' words; [np]: the coordinator's
   *src = 0; *off = d.y; *cnt = h;
   auto spin_for = [&](unsigned long long *p) -> unsigned long long {  // a word of this pass (siblings hold tickets or draw the next ones)
     unsigned long long w = 0;
@@ -3608,15 +3644,16 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
   };
   __syncthreads();  // the LDS buffer is free
   H.key[t] = 0xFFFFFFFFu;
-  if (t == 0) { H.bad = 0; H.timeout = 0; H.nhot = 0; H.nrem = 0; H.allok = 0; }
+  if (t == 0) { H.bad = 0; H.timeout = 0; H.nhot = 0; H.nrem = 0; H.allok = 0; H.nf = 0; }
+  if (t < KSB_FMAX) H.fl[t] = 0;
   __syncthreads();
-  // ---- one pass over the sub's records: the hot row's requests of my index range are mine; the others are the remainder's
+  // ---- one pass over the sub's records: the requests on the hot row's COUNTER PAIR of my index range are mine; the others are the remainder's
   for (uint32_t k0 = 0; k0 < h; k0 += KVB_T) {
     const uint32_t k = k0 + t;
     const uint64_t r = k < h ? kv_ld_agent(&ovf[d.y + k]) : 0;
     const uint32_t pay = kv_rec_pay(r), ridx = (uint32_t)(r >> 16) & idx_mask, type = pay_type(pay);
-    const bool same_g = k < h && (r >> sh_g) == (hrec >> sh_g), same = same_g && pay_kh(pay) == hkh;
-    if (same_g && !same && pay_q(pay) == hq && type <= 3u) H.bad = 1;  // another key on the hot row's counter pair (every item sees it alike)
+    const bool same = k < h && (r >> sh_g) == (hrec >> sh_g) && pay_q(pay) == hq;  // on the pair: the hot row, or another key of its bucket and quadrant
+    (void)type; (void)hkh;
     if (do_piece) {
       const bool mine = same && kv_piece_of(ridx, np, inv_n) == j;
       const uint64_t mm = __ballot(mine);
@@ -3624,7 +3661,8 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
       if (lane == 0 && mm) at = atomicAdd(&H.nhot, (uint32_t)__popcll(mm));
       at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at) + (uint32_t)__popcll(mm & lanemask_lt());
       if (mine && at < KVB_T) { H.key[at] = (ridx << 9) | at; H.typ[at] = (uint8_t)(type & 0xFFu); }
-    } else {
+    }
+    if (!do_piece || solo) {
       const bool other = k < h && !same;
       const uint64_t mm = __ballot(other);
       uint32_t at = 0;
@@ -3644,7 +3682,7 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
     return 1;
   }
   const uint32_t c = H.nhot;
-  if (t == 0 && c > KVB_T) H.bad = 1;
+  if (t == 0 && c > KVB_T) { H.bad = 1; atomicAdd(&stats->late_items[0], 1ULL); }  // (why a hot row was not answered in pieces: stats, late_items)
   // ---- the row (every piece: the value a read may need) and, piece 0, the counters -- BEFORE anything is published
   kv_tab tb;
   uint64_t bucket = 0;
@@ -3674,15 +3712,22 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
   const bool v = sk != 0xFFFFFFFFu;
   const uint32_t my_idx = sk >> 9, my_type = v ? H.typ[sk & 511u] : 0xFFu;
   uint8_t *msg = rep + dint_view_off(V, v ? my_idx : 0u, F::MSG);
-  if (v && ld_u64(msg + F::KEY) != hkey) H.bad = 1;     // 9 hash bits can collide
-  if (v && !(my_type <= 5u || my_type == 17u)) H.bad = 1;
-  const bool wr = v && (my_type == 4u || my_type == 5u);
+  const bool foreign = v && ld_u64(msg + F::KEY) != hkey;  // another key on the pair: its lock ops count, its row ops are the coordinator's
+  if (v && !(my_type <= 5u || my_type == 17u)) { H.bad = 1; atomicAdd(&stats->late_items[2], 1ULL); }
+  const bool wr = v && !foreign && (my_type == 4u || my_type == 5u);
   {
     const uint64_t b0 = __ballot(v && my_type == 0u), b1 = __ballot(v && my_type == 1u), b2 = __ballot(v && my_type == 2u), b3 = __ballot(v && my_type == 3u);
-    const uint64_t bw = __ballot(wr);
-    if (lane == 0) { H.Mk[0][wave] = b0; H.Mk[1][wave] = b1; H.Mk[2][wave] = b2; H.Mk[3][wave] = b3; H.Mw[wave] = bw; }
+    const uint64_t bw = __ballot(wr), bf = __ballot(foreign);
+    if (lane == 0) { H.Mk[0][wave] = b0; H.Mk[1][wave] = b1; H.Mk[2][wave] = b2; H.Mk[3][wave] = b3; H.Mw[wave] = bw; H.G[wave] = bf; }
   }
   H.idx[t] = my_idx;
+  __syncthreads();
+  if (foreign) {  // the piece's foreign requests in request order (the piece is sorted by index): slot = foreign requests before me
+    uint32_t f = (uint32_t)__popcll(H.G[wave] & lanemask_lt());
+    for (uint32_t w = 0; w < wave; w++) f += (uint32_t)__popcll(H.G[w]);
+    if (f < KSB_FMAX) H.fl[f] = (1ull << 63) | ((uint64_t)my_type << 48) | ((uint64_t)t << 32) | my_idx;
+    else { H.bad = 1; if (f == KSB_FMAX) atomicAdd(&stats->late_items[1], 1ULL); }
+  }
   __syncthreads();
   uint32_t wr_below = 0, wr_tot = 0;
   int lw_below = -1, lw_tot = -1;
@@ -3693,8 +3738,9 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
     if (mwb) lw_below = (int)(w * 64 + 63 - __clzll((long long)mwb));
     if (mw) lw_tot = (int)(w * 64 + 63 - __clzll((long long)mw));
   }
-  // ---- publish: the op masks, then the word
+  // ---- publish: the op masks and the foreign requests, then the word
   if (t < 4 * KVB_W) kv_st_agent(&sbx[(size_t)(first + j) * KSB_WORDS + t], H.Mk[t & 3u][t >> 2]);
+  if (t < KSB_FMAX) kv_st_agent(&sbx[(size_t)(first + j) * KSB_WORDS + 5 * KVB_W + t], H.fl[t]);
   if (wave == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (t == 0) __hip_atomic_store(&pub[j], kvh_word(seq, !H.bad, wr_tot, lw_tot >= 0 ? (int)H.idx[lw_tot] : -1, -1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3712,6 +3758,7 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
         const uint32_t p = w / (4 * KVB_W), r = w % (4 * KVB_W);
         H.cm[r & 3u][p * KVB_W + (r >> 2)] = kv_ld_agent(&sbx[(size_t)(first + p) * KSB_WORDS + r]);
       }
+      for (uint32_t w = t; w < np * KSB_FMAX; w += KVB_T) H.cf[w] = kv_ld_agent(&sbx[(size_t)(first + w / KSB_FMAX) * KSB_WORDS + 5 * KVB_W + (w % KSB_FMAX)]);
       __syncthreads();
       if (wave == 0) {  // lane l holds chunk base + l; all 64 checked at once under the assumption that the mode holds (kv_big_bin)
         uint32_t la = H.la, lb = H.lb;
@@ -3743,6 +3790,45 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
         if (lane == 0 && (la != H.la || lb != H.lb)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * hq) = make_uint2(la, lb);  // (every piece has read the row: their words are in)
       }
       __syncthreads();
+      // the foreign requests of the whole sub, in request order -- piece after piece, and every piece lists its own in order --, one
+      // lane: grants from the walk, row ops with the reference's own chain walk (kv_apply); nobody else has stored to the table yet
+      if (wave == 0) {
+        for (uint32_t base = 0; base < np * KSB_FMAX; base += 64) {
+          const uint64_t fe_l = base + lane < np * KSB_FMAX ? H.cf[base + lane] : 0ull;
+          uint64_t todo = __ballot((fe_l >> 63) != 0);
+          while (todo) {
+            const int fl = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint64_t fe = readlane_u64(fe_l, fl);
+            if (lane != 0) continue;
+            const uint32_t ftype = (uint32_t)(fe >> 48) & 0xFFu, fpos = (uint32_t)(fe >> 32) & 511u, fpiece = (base + (uint32_t)fl) / KSB_FMAX;
+            uint8_t *fm = rep + dint_view_off(V, (uint32_t)(fe & 0xFFFFFu), F::MSG);
+            const uint64_t fkey = ld_u64(fm + F::KEY);
+            const bool granted = (H.cg[fpiece * KVB_W + (fpos >> 6)] >> (fpos & 63u)) & 1ull;
+            uint32_t code, act = KV_ACT_NONE;
+            bool counts = false;
+            switch (ftype) {
+              case 0: code = granted ? 7 : 8; if (granted) { act = KV_ACT_GET; counts = true; } break;
+              case 1: code = granted ? 9 : 10; if (granted) { act = KV_ACT_GET; counts = true; } break;
+              case 2: code = 11; break;
+              case 3: code = 12; break;
+              case 4: code = 13; act = KV_ACT_SET; counts = true; break;
+              case 5: code = 14; act = KV_ACT_SET; counts = true; break;
+              default: code = 18; act = KV_ACT_GET; break;  // 17 WARMUP_READ
+            }
+            if (act != KV_ACT_NONE) {
+              kv_hdr Hf;
+              kv_hdr_load(Hf, ie);
+              const kv_res fr = kv_apply<kv_dev_mem>(tb, bucket, Hf, act, fkey, fm + F::VAL, 0, blockIdx.x);
+              if (act == KV_ACT_GET && fr.ok) st_u32(fm + F::VER, fr.ver);
+              if (!fr.ok && counts) atomicAdd(&stats->missing_keys, 1ULL);
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the next foreign request may read what this one wrote)
+            }
+            fm[F::TYPE] = (uint8_t)code;
+          }
+        }
+      }
+      __syncthreads();
       for (uint32_t w = t; w < nchunk; w += KVB_T) kv_st_agent(&sbx[(size_t)(first + w / KVB_W) * KSB_WORDS + 4 * KVB_W + (w % KVB_W)], H.cg[w]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -3755,13 +3841,21 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
   if (H.timeout) __builtin_trap();
   if (!((H.pub[KSB_NPMAX] >> 33) & 1ull)) {  // not in closed form: piece 0 takes the whole sub (nobody has touched it), the others nothing
     if (j != 0) return 0;
+    if (t == 0) atomicAdd(&stats->late_requests, (unsigned long long)h);
     *src = 0; *off = d.y; *cnt = h;
     return 1;
   }
+  const uint32_t solo_rem = solo ? H.nrem : 0u;  // (SOLO: the sub's other keys, compacted in ovf2, are mine too -- behind the row's)
+  auto done = [&]() -> int {
+    if (!solo_rem) return 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    *src = 1; *off = d.y; *cnt = solo_rem;
+    return 1;
+  };
   if (t < KVB_W) H.G[t] = kv_ld_agent(&sbx[(size_t)(first + j) * KSB_WORDS + 4 * KVB_W + t]);
   if (t < np) H.pub[t] = __hip_atomic_load(&pub[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (c == 0) return 0;
+  if (c == 0) return done();
   uint32_t nw_before = 0, nw_all = 0;
   int lw_before = -1, jw = -1;
   for (uint32_t k = 0; k < np; k++) {
@@ -3776,7 +3870,7 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
   }
   const uint32_t found = H.found, ver0 = H.ver0;
   uint32_t miss = 0;
-  if (v) {
+  if (v && !foreign) {  // (a foreign request has its answer from the coordinator)
     const bool granted = (H.G[wave] >> lane) & 1ull;
     uint32_t code;
     bool get = false;
@@ -3815,7 +3909,7 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
     KV_ST(uint32_t, row + 4, ld_u32(msg + F::VAL + 4));
     KV_ST(uint32_t, &kv_entry_hdr(tb, bucket, H.link)->ver[H.slot], ver0 + nw_all);
   }
-  return 0;
+  return done();
 }
 
 // One workgroup per CU: its 8 waves are 2 per SIMD (the second launch bound is waves per SIMD, not workgroups per CU) at
@@ -4003,8 +4097,9 @@ __global__ void __launch_bounds__(KVB_T, 1) k_kv_big(kv_multi_args M, uint32_t f
     uint32_t src = 0, off = d.y, cnt = d.z;
     uint64_t *ttr = first ? tr : nullptr;
     if (ttr && t == 0) { ttr[0] = __builtin_amdgcn_s_memrealtime(); ttr[2] = d.z; ttr[3] = d.x; ttr[30] = d.w; }
+    const uint64_t t_in = tr ? __builtin_amdgcn_s_memrealtime() : 0ull;  // [31]: the LONGEST item of the workgroup: ticks << 40 | records << 20 | went on to kv_big_bin << 18 | kind word
     int run = 1;
-    if ((d.w & 3u) == KVQ_SOLO)
+    if ((d.w & 3u) == KVQ_SOLO && WL != DINT_WL_SMALLBANK)
       run = kv_solo_item<WL>(A.rep, cut2, &Skv, d, A.ovf, A.ovf2, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
     else if ((d.w & 3u) != KVQ_SUB && WL == DINT_WL_SMALLBANK)
       run = kv_sb_item<WL>(A.rep, cut2, &Skv, d, A.bigq[KVQ_W * (size_t)i + 1], A.bigq[KVQ_W * (size_t)i + 2], A.ovf, A.ovf2, A.hotpub, A.sbx, A.seq,
@@ -4018,6 +4113,10 @@ __global__ void __launch_bounds__(KVB_T, 1) k_kv_big(kv_multi_args M, uint32_t f
       kv_big_bin<WL>(A.rep, A.n, cut2, &Skv, d.x, recs, src || !A.ovf2 ? nullptr : A.ovf2 + off, cnt, A.stats, A.force_flags, A.V, Lraw, Lbm, ttr);
     }
     if (ttr && t == 0) ttr[1] = __builtin_amdgcn_s_memrealtime();
+    if (tr && t == 0) {
+      const uint64_t dt = __builtin_amdgcn_s_memrealtime() - t_in;
+      if (dt > (tr[31] >> 40)) tr[31] = (dt << 40) | ((uint64_t)(d.z & 0xFFFFFu) << 20) | (d.w & 0x3FFFFu) | (run ? 1ull << 18 : 0ull);
+    }
   }
 }
 

@@ -735,7 +735,7 @@ def test_partition_corners(wl, knob, monkeypatch):
 
 # ---------------------------------------------------------------- smallbank: a hot account's row in pieces (r06, kv_sb_item)
 SB_KNOBS = [{}, {"DINT_KV_SB_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "64"}, {"DINT_KV_SB_SPLIT_MIN": "600", "DINT_KV_SPLIT_TARGET": "300"},
-            {"DINT_KV_SB_SPLIT_MIN": "0"}]
+            {"DINT_KV_SB_SPLIT_MIN": "0"}, {"DINT_KV_SB_SPLIT_MIN": "100"}]
 
 
 def _sb_hot(n, p_hot, mix, hot, seed, n_acct):
@@ -754,7 +754,7 @@ def _sb_hot(n, p_hot, mix, hot, seed, n_acct):
     return req
 
 
-@pytest.mark.parametrize("knobs", SB_KNOBS, ids=["default", "t64", "t300", "off"])
+@pytest.mark.parametrize("knobs", SB_KNOBS, ids=["default", "t64", "t300", "off", "solo100"])
 @pytest.mark.parametrize("p_hot,mix,hot", [
     (0.6, {0: 30, 1: 25, 2: 15, 3: 12, 4: 10, 5: 8}, [(0, 7), (1, 7)]),          # the account's savings and checking rows, every op kind
     (0.7, {0: 40, 1: 10, 2: 38, 3: 6, 4: 6}, [(0, 3)]),                           # mostly shared traffic: long FREE stretches
@@ -786,10 +786,13 @@ def test_smallbank_hot_row_in_pieces(p_hot, mix, hot, knobs, monkeypatch):
         assert st["missing_keys"] > 1000
 
 
-@pytest.mark.parametrize("knobs", SB_KNOBS[:2], ids=["default", "t64"])
-def test_smallbank_hot_row_beside_a_key_on_its_counter_pair(knobs, monkeypatch):
-    """two accounts whose rows share a bucket AND a lock quadrant (one counter pair): no closed form -- every piece sees the
-    neighbour's lock ops in the sub's records and says so, piece 0 takes the sub the old way"""
+@pytest.mark.parametrize("share", [0.1, 0.003], ids=["warm-neighbour", "cold-neighbour"])
+@pytest.mark.parametrize("knobs", SB_KNOBS[:2] + SB_KNOBS[4:], ids=["default", "t64", "solo100"])
+def test_smallbank_hot_row_beside_a_key_on_its_counter_pair(knobs, share, monkeypatch):
+    """two accounts whose rows share a bucket AND a lock quadrant (one counter pair).  A COLD neighbour (a handful of requests per
+    piece) rides in the pieces: its lock ops in the masks the coordinator walks, its row ops done by the coordinator in request
+    order (kv_sb_item, r06b) -- nothing falls back.  A WARM one (more than KSB_FMAX requests in a piece) is no closed form: the
+    piece says so and piece 0 takes the sub the old way (stats: late_requests)."""
     import struct
 
     for k, v in knobs.items():
@@ -811,10 +814,14 @@ def test_smallbank_hot_row_beside_a_key_on_its_counter_pair(knobs, monkeypatch):
     for k, n in enumerate((8000, 30_000)):
         req = tracegen.sb_random(n, seed=50 + k, n_acct_touch=n_acct)
         u = rng.random(n)
-        for key, lo, hi in ((pair[0], 0.0, 0.6), (pair[1], 0.6, 0.7)):
+        for key, lo, hi in ((pair[0], 0.0, 0.6), (pair[1], 0.6, 0.6 + share)):
             sel = (u >= lo) & (u < hi)
             req["table"][sel] = 0
             req["key"][sel] = key
             req["type"][sel] = rng.choice(6, int(sel.sum()), p=[0.3, 0.25, 0.15, 0.12, 0.1, 0.08])
         assert eng.submit(req).tobytes() == o.replay(req).tobytes(), k
     _sb_state(eng, o)
+    st = eng.stats()
+    assert st["missing_keys"] == o.errors
+    if share >= 0.1 and "DINT_KV_SB_SPLIT_MIN" not in knobs:
+        assert st["late_requests"] > 0  # (pieces of ~384: ~50 of the neighbour's requests each)
