@@ -77,7 +77,7 @@ static dint_kv_knobs kv_read_knobs() {
   k.one_big_kernel = kv_env("DINT_KV_ONE_BIG_KERNEL", 0);
   k.no_ahead = kv_env("DINT_KV_NO_AHEAD", 0);
   k.no_fuse = kv_env("DINT_KV_NO_FUSE", 0);
-  k.sb_split_min = kv_env("DINT_KV_SB_SPLIT_MIN", 128u);
+  k.sb_split_min = kv_env("DINT_KV_SB_SPLIT_MIN", 65u);
   // (never fewer workers than a hot key has pieces + a remainder, + 1: the pieces wait for each other.  An idle worker holds half
   // a compute unit that another shard server's resolve workgroup is waiting for: 320 / 192 / 96 / 48 workers per engine gave
   // 2,320 / 2,650 .. 2,840 / 2,980 .. 3,030 / 2,820 Mtxn/s on the tatp bench stream -- ~160 items per pass)

@@ -735,7 +735,7 @@ def test_partition_corners(wl, knob, monkeypatch):
 
 # ---------------------------------------------------------------- smallbank: a hot account's row in pieces (r06, kv_sb_item)
 SB_KNOBS = [{}, {"DINT_KV_SB_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "64"}, {"DINT_KV_SB_SPLIT_MIN": "600", "DINT_KV_SPLIT_TARGET": "300"},
-            {"DINT_KV_SB_SPLIT_MIN": "0"}, {"DINT_KV_SB_SPLIT_MIN": "100"}]
+            {"DINT_KV_SB_SPLIT_MIN": "0"}, {"DINT_KV_SB_SPLIT_MIN": "2048"}]
 
 
 def _sb_hot(n, p_hot, mix, hot, seed, n_acct):
@@ -754,7 +754,7 @@ def _sb_hot(n, p_hot, mix, hot, seed, n_acct):
     return req
 
 
-@pytest.mark.parametrize("knobs", SB_KNOBS, ids=["default", "t64", "t300", "off", "solo100"])
+@pytest.mark.parametrize("knobs", SB_KNOBS, ids=["default", "t64", "t300", "off", "r06a"])
 @pytest.mark.parametrize("p_hot,mix,hot", [
     (0.6, {0: 30, 1: 25, 2: 15, 3: 12, 4: 10, 5: 8}, [(0, 7), (1, 7)]),          # the account's savings and checking rows, every op kind
     (0.7, {0: 40, 1: 10, 2: 38, 3: 6, 4: 6}, [(0, 3)]),                           # mostly shared traffic: long FREE stretches
@@ -787,7 +787,7 @@ def test_smallbank_hot_row_in_pieces(p_hot, mix, hot, knobs, monkeypatch):
 
 
 @pytest.mark.parametrize("share", [0.1, 0.003], ids=["warm-neighbour", "cold-neighbour"])
-@pytest.mark.parametrize("knobs", SB_KNOBS[:2] + SB_KNOBS[4:], ids=["default", "t64", "solo100"])
+@pytest.mark.parametrize("knobs", SB_KNOBS[:2] + SB_KNOBS[4:], ids=["default", "t64", "r06a"])
 def test_smallbank_hot_row_beside_a_key_on_its_counter_pair(knobs, share, monkeypatch):
     """two accounts whose rows share a bucket AND a lock quadrant (one counter pair).  A COLD neighbour (a handful of requests per
     piece) rides in the pieces: its lock ops in the masks the coordinator walks, its row ops done by the coordinator in request
@@ -823,5 +823,5 @@ def test_smallbank_hot_row_beside_a_key_on_its_counter_pair(knobs, share, monkey
     _sb_state(eng, o)
     st = eng.stats()
     assert st["missing_keys"] == o.errors
-    if share >= 0.1 and "DINT_KV_SB_SPLIT_MIN" not in knobs:
+    if share >= 0.1 and knobs.get("DINT_KV_SB_SPLIT_MIN") != "200":
         assert st["late_requests"] > 0  # (pieces of ~384: ~50 of the neighbour's requests each)
