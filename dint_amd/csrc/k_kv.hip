@@ -78,6 +78,9 @@ static dint_kv_knobs kv_read_knobs() {
   k.no_ahead = kv_env("DINT_KV_NO_AHEAD", 0);
   k.no_fuse = kv_env("DINT_KV_NO_FUSE", 0);
   k.sb_split_min = kv_env("DINT_KV_SB_SPLIT_MIN", 65u);
+  k.sb_late_grid = std::max(1u, std::min(KVB_GRID, kv_env("DINT_KV_SB_LATE_GRID", 32u)));
+  k.sb_workers = kv_env("DINT_KV_SB_WORKERS", 130u);
+  if (k.sb_workers) k.sb_workers = std::max(k.sb_workers, KSB_NPMAX + 2u);
   // (never fewer workers than a hot key has pieces + a remainder, + 1: the pieces wait for each other.  An idle worker holds half
   // a compute unit that another shard server's resolve workgroup is waiting for: 320 / 192 / 96 / 48 workers per engine gave
   // 2,320 / 2,650 .. 2,840 / 2,980 .. 3,030 / 2,820 Mtxn/s on the tatp bench stream -- ~160 items per pass)

@@ -3606,9 +3606,6 @@ struct kvs_lds {
   uint8_t typ[KVB_T];             // request type by slot
   uint64_t Mk[4][KVB_W], Mw[KVB_W], G[KVB_W];
   unsigned long long pub[KSB_NPMAX + 1];
-  uint64_t cm[4][KSB_NPMAX * KVB_W];  // the coordinator: every piece's op masks, chunk after chunk
-  uint64_t cg[KSB_NPMAX * KVB_W];     // ... and the grants
-  uint64_t cf[KSB_NPMAX * KSB_FMAX];  // ... and the foreign requests of all pieces
   uint64_t fl[KSB_FMAX];              // a piece's own foreign requests
   uint32_t bad, timeout, nhot, nrem, found, link, slot, ver0, table, la, lb, allok, nf;
   uint32_t rowv[2];
@@ -3619,7 +3616,7 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
                                                  uint32_t seq, uint32_t inv_n, dint_dev_stats *__restrict__ stats, const dint_view V, uint8_t *lds_raw,
                                                  uint32_t *src, uint32_t *off, uint32_t *cnt) {
   using F = Fmt<WL>;
-  static_assert(sizeof(kvs_lds) <= sizeof(kvb_lds), "the pieces' LDS lives in kv_big_bin's buffer");
+  static_assert(sizeof(kvs_lds) <= sizeof(kvb_lds) && sizeof(kvs_lds) <= 16384, "the pieces' LDS lives in kv_big_bin's buffer (k_kv_big) or a worker's (k_kv_pass: four workgroups per CU)");
   kvs_lds &H = *(kvs_lds *)lds_raw;
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t kind = d.w & 3u, j = (d.w >> 2) & 255u, np = (d.w >> 10) & 255u;
@@ -3754,18 +3751,15 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
     for (uint32_t k = 0; k < np; k++) all_ok = all_ok && ((H.pub[k] >> 33) & 1ull);
     const uint32_t nchunk = np * KVB_W;
     if (all_ok) {
-      for (uint32_t w = t; w < np * 4 * KVB_W; w += KVB_T) {
-        const uint32_t p = w / (4 * KVB_W), r = w % (4 * KVB_W);
-        H.cm[r & 3u][p * KVB_W + (r >> 2)] = kv_ld_agent(&sbx[(size_t)(first + p) * KSB_WORDS + r]);
-      }
-      for (uint32_t w = t; w < np * KSB_FMAX; w += KVB_T) H.cf[w] = kv_ld_agent(&sbx[(size_t)(first + w / KSB_FMAX) * KSB_WORDS + 5 * KVB_W + (w % KSB_FMAX)]);
-      __syncthreads();
       if (wave == 0) {  // lane l holds chunk base + l; all 64 checked at once under the assumption that the mode holds (kv_big_bin)
         uint32_t la = H.la, lb = H.lb;
         for (uint32_t base = 0; base < nchunk; base += 64) {
           const uint32_t ci = base + lane;
           const bool inr = ci < nchunk;
-          const uint64_t cAS = inr ? H.cm[0][ci] : 0ull, cAX = inr ? H.cm[1][ci] : 0ull, cRS = inr ? H.cm[2][ci] : 0ull, cRX = inr ? H.cm[3][ci] : 0ull;
+          // (the pieces' masks straight from where they were published: no copy in LDS -- 40 KB that kept kv_sb_item out of the light kernels)
+          uint64_t *mine_w = &sbx[(size_t)(first + ci / KVB_W) * KSB_WORDS];
+          const uint64_t *mw = mine_w + 4 * (ci % KVB_W);
+          const uint64_t cAS = inr ? kv_ld_agent(mw) : 0ull, cAX = inr ? kv_ld_agent(mw + 1) : 0ull, cRS = inr ? kv_ld_agent(mw + 2) : 0ull, cRX = inr ? kv_ld_agent(mw + 3) : 0ull;
           const uint32_t nas = (uint32_t)__popcll(cAS), nrs = (uint32_t)__popcll(cRS);
           uint64_t g = 0, pend = __ballot((cAS | cAX | cRS | cRX) != 0);
           while (pend) {
@@ -3785,16 +3779,17 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
             if ((int)lane == f) g |= G;
             pend &= ~(ok | (1ull << f));
           }
-          if (inr) H.cg[ci] = g;
+          if (inr) kv_st_agent(mine_w + 4 * KVB_W + (ci % KVB_W), g);
         }
         if (lane == 0 && (la != H.la || lb != H.lb)) *(uint2 *)(ie + KV_SB_LOCK_OFF + 8 * hq) = make_uint2(la, lb);  // (every piece has read the row: their words are in)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the grants are out: the foreign requests below read them back)
       }
-      __syncthreads();
       // the foreign requests of the whole sub, in request order -- piece after piece, and every piece lists its own in order --, one
       // lane: grants from the walk, row ops with the reference's own chain walk (kv_apply); nobody else has stored to the table yet
       if (wave == 0) {
         for (uint32_t base = 0; base < np * KSB_FMAX; base += 64) {
-          const uint64_t fe_l = base + lane < np * KSB_FMAX ? H.cf[base + lane] : 0ull;
+          const uint32_t fw = base + lane;
+          const uint64_t fe_l = fw < np * KSB_FMAX ? kv_ld_agent(&sbx[(size_t)(first + fw / KSB_FMAX) * KSB_WORDS + 5 * KVB_W + (fw % KSB_FMAX)]) : 0ull;
           uint64_t todo = __ballot((fe_l >> 63) != 0);
           while (todo) {
             const int fl = __ffsll((unsigned long long)todo) - 1;
@@ -3804,7 +3799,7 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
             const uint32_t ftype = (uint32_t)(fe >> 48) & 0xFFu, fpos = (uint32_t)(fe >> 32) & 511u, fpiece = (base + (uint32_t)fl) / KSB_FMAX;
             uint8_t *fm = rep + dint_view_off(V, (uint32_t)(fe & 0xFFFFFu), F::MSG);
             const uint64_t fkey = ld_u64(fm + F::KEY);
-            const bool granted = (H.cg[fpiece * KVB_W + (fpos >> 6)] >> (fpos & 63u)) & 1ull;
+            const bool granted = (kv_ld_agent(&sbx[(size_t)(first + fpiece) * KSB_WORDS + 4 * KVB_W + (fpos >> 6)]) >> (fpos & 63u)) & 1ull;
             uint32_t code, act = KV_ACT_NONE;
             bool counts = false;
             switch (ftype) {
@@ -3828,8 +3823,6 @@ __device__ __forceinline__ static int kv_sb_item(uint8_t *rep, const kv_cut cut2
           }
         }
       }
-      __syncthreads();
-      for (uint32_t w = t; w < nchunk; w += KVB_T) kv_st_agent(&sbx[(size_t)(first + w / KVB_W) * KSB_WORDS + 4 * KVB_W + (w % KVB_W)], H.cg[w]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -3959,6 +3952,24 @@ __device__ __forceinline__ static void kv_hot_role(const kv_pass_args &A, kv_dev
     uint64_t *ttr = first ? tr : nullptr;
     if (ttr && t == 0) { ttr[0] = __builtin_amdgcn_s_memrealtime(); ttr[2] = d.z; ttr[3] = d.x; ttr[30] = d.w; }
     int run = 1;
+    if constexpr (WL == DINT_WL_SMALLBANK) {
+      // smallbank (r06b): the pieces of a sub's row, its coordinator and the foreign requests -- kv_sb_item -- here, beside the
+      // resolve workgroups; what is left of the sub (the other keys: kv_big_bin, 256 VGPRs and an empty compute unit) goes to the
+      // list of the k_kv_big launch behind this kernel.  (That is the normal case, not a late one: the stats are kv_sb_item's.)
+      if ((d.w & 3u) != KVQ_SUB)
+        run = kv_sb_item<WL>(A.rep, cut2, &Skv, d, kv_ld_agent(A.bigq + KVQ_W * (size_t)i + 1), kv_ld_agent(A.bigq + KVQ_W * (size_t)i + 2), A.ovf, A.ovf2,
+                             A.hotpub, A.sbx, A.seq, A.inv_n, A.stats, A.V, Lraw, &src, &off, &cnt);
+      if (run && src == 1 && cnt <= KVB_T) {
+        // a remainder of at most a workgroup's worth (a SOLO sub's other keys: cold rows, a few requests each), compacted in ovf2 by this
+        // workgroup: the light way -- chunks of bucket groups through kv_chunk, as the resolve workgroups do -- instead of an
+        // empty compute unit for kv_big_bin.  (false: a bucket group longer than a chunk -- kv_big_bin's)
+        kvh_lds &Hh = *(kvh_lds *)Lraw;
+        __syncthreads();
+        Hh.rem[t] = t < cnt ? A.ovf2[off + t] : 0ull;
+        if (kv_rem_chunks<WL>(A.rep, cut2, &Skv, d.x, Hh.rem, cnt, Hh, A.stats, A.force_flags & 1, A.V)) run = 0;
+      }
+      if (run && t == 0) A.lateq[atomicAdd(&A.big[5], 1u)] = make_uint4(d.x, off, cnt, src);
+    } else {
     if ((d.w & 3u) == KVQ_SOLO)
       run = kv_solo_item<WL>(A.rep, cut2, &Skv, d, A.ovf, A.ovf2, A.stats, A.force_flags & 1, A.V, Lraw, &src, &off, &cnt, ttr);
     else if ((d.w & 3u) != KVQ_SUB)
@@ -3968,6 +3979,7 @@ __device__ __forceinline__ static void kv_hot_role(const kv_pass_args &A, kv_dev
       A.lateq[atomicAdd(&A.big[5], 1u)] = make_uint4(d.x, off, cnt, src);
       atomicAdd(&A.stats->late_requests, (unsigned long long)cnt);
       atomicAdd(&A.stats->late_items[(d.w & 3u) == KVQ_SUB ? 0 : (d.w & 3u) == KVQ_SOLO ? 1 : 2], 1ULL);
+    }
     }
     if (ttr && t == 0) ttr[1] = __builtin_amdgcn_s_memrealtime();
   }
@@ -4019,7 +4031,8 @@ __global__ void __launch_bounds__(KVB_T, 4) k_kv_pass(kv_multi_args M, uint32_t 
                                                        uint32_t max_tiles /* tiles of the longest of them (0: none announced) */,
                                                        uint32_t n_work /* workers per engine */,
                                                        uint32_t part_first /* the partition's tiles are placed before the workers */) {
-  constexpr size_t L1 = sizeof(kvh_lds) > sizeof(kvr_lds) ? sizeof(kvh_lds) : sizeof(kvr_lds);
+  constexpr size_t LW = sizeof(kvs_lds) > sizeof(kvh_lds) ? sizeof(kvs_lds) : sizeof(kvh_lds);  // a worker's (smallbank: kv_sb_item's, then kv_rem_chunks')
+  constexpr size_t L1 = LW > sizeof(kvr_lds) ? LW : sizeof(kvr_lds);
   constexpr size_t LB = L1 > sizeof(kv_part_lds<RPT ? RPT : 1, KVB_T>) ? L1 : sizeof(kv_part_lds<RPT ? RPT : 1, KVB_T>);
   __shared__ kv_dev Skv;
   __shared__ __attribute__((aligned(16))) uint8_t Lraw[LB];
@@ -4155,6 +4168,7 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
   // smallbank (counters: no closed form across workgroups yet) and DINT_KV_NO_SPLIT / DINT_KV_ONE_BIG_KERNEL: k_kv_big alone
   const bool hot = WL != DINT_WL_SMALLBANK && M.e[0].split_min != 0xFFFFFFFFu && !K.one_big_kernel;  // (smallbank's pieces run in k_kv_big)
   bool fused = false, one = false;
+  uint32_t sb_workers = 0;
   if constexpr (WL != DINT_WL_SMALLBANK) {
     if (hot && !K.no_fuse) {
       uint32_t nmax = 0;
@@ -4168,12 +4182,16 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
   } else {
     // smallbank with the next batch announced: its partition beside this pass's resolve workgroups (k_kv_pass without workers --
     // the big subs and the pieces of the hot accounts are k_kv_big's, behind this launch)
-    if (next && !K.no_fuse) {
+    // (r06b: with workers -- the pieces of the subs' rows beside the resolve workgroups, the remainders in the k_kv_big launch behind;
+    // DINT_KV_SB_WORKERS=0: r06a's k_kv_pass without workers, every item in k_kv_big)
+    sb_workers = !K.no_fuse && !K.one_big_kernel && M.e[0].np_max == KSB_NPMAX ? K.sb_workers : 0u;
+    if ((next || sb_workers) && !K.no_fuse) {
       uint32_t nmax = 0;
-      for (uint32_t k = 0; k < n_eng; k++) nmax = std::max(nmax, next->e[k].n_tiles);
-      const dim3 g(sum_c + nmax * n_eng);
-      if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, 0u, 0u);
-      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, 0u, 0u);
+      for (uint32_t k = 0; next && k < n_eng; k++) nmax = std::max(nmax, next->e[k].n_tiles);
+      const dim3 g(sum_c + sb_workers * n_eng + nmax * n_eng);
+      if (!next) hipLaunchKernelGGL((k_kv_pass<WL, 0>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, M, 0u, sb_workers, 0u);
+      else if (next_rpt == 2) hipLaunchKernelGGL((k_kv_pass<WL, 2>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, sb_workers, K.part_first);
+      else hipLaunchKernelGGL((k_kv_pass<WL, 4>), g, dim3(KVB_T), 0, st, M, n_eng, sum_c, *next, nmax, sb_workers, K.part_first);
       one = true;
     }
   }
@@ -4202,7 +4220,8 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
     }
     else hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? K.late_grid : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
   } else {
-    hipLaunchKernelGGL((k_kv_big<WL>), dim3(hot ? K.late_grid : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, hot ? 1u : 0u);
+    // (behind the workers what is left is a dozen remainders: a SMALL grid -- every workgroup of this kernel waits for an empty compute unit)
+    hipLaunchKernelGGL((k_kv_big<WL>), dim3(sb_workers ? K.sb_late_grid : KVB_GRID, n_eng), dim3(KVB_T), 0, st, M, sb_workers ? 1u : 0u);
   }
   if (ev) hipEventRecord(ev3 ? ev[3] : ev[4], st);
 }
