@@ -40,6 +40,7 @@ struct dint_kv_knobs {
   uint32_t workers = 96;        // DINT_KV_WORKERS: hot-key workers per engine of k_kv_pass
   uint32_t part_first = 0;      // DINT_KV_PART_FIRST: k_kv_pass places the next partition's tiles before (1) / behind (0) the workers
   uint32_t sb_split_min = 65;   // DINT_KV_SB_SPLIT_MIN: smallbank, the smallest big sub whose row is answered in pieces (65: every big sub; 0: never -- r05's kv_big_bin)
+  uint32_t sb_npmax = 128;      // DINT_KV_SB_NPMAX: smallbank, pieces of one row at most (<= KSB_NPMAX; x 384 requests: 49,000 -- a bigger row goes the old way)
   uint32_t sb_workers = 130;    // DINT_KV_SB_WORKERS: smallbank, workers per engine of k_kv_pass (>= KSB_NPMAX + 2: a row's pieces wait for each other; 0: every item in k_kv_big)
   uint32_t sb_late_grid = 32;   // DINT_KV_SB_LATE_GRID: smallbank, workgroups per engine of the k_kv_big launch behind the workers
   uint32_t residency = 0;       // workgroups of the pieces' kernel the device holds at once (kv_piece_residency)

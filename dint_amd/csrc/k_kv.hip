@@ -79,8 +79,9 @@ static dint_kv_knobs kv_read_knobs() {
   k.no_fuse = kv_env("DINT_KV_NO_FUSE", 0);
   k.sb_split_min = kv_env("DINT_KV_SB_SPLIT_MIN", 65u);
   k.sb_late_grid = std::max(1u, std::min(KVB_GRID, kv_env("DINT_KV_SB_LATE_GRID", 32u)));
-  k.sb_workers = kv_env("DINT_KV_SB_WORKERS", 130u);
-  if (k.sb_workers) k.sb_workers = std::max(k.sb_workers, KSB_NPMAX + 2u);
+  k.sb_npmax = std::max(2u, std::min(KSB_NPMAX, kv_env("DINT_KV_SB_NPMAX", 128u)));
+  k.sb_workers = kv_env("DINT_KV_SB_WORKERS", k.sb_npmax + 2u);
+  if (k.sb_workers) k.sb_workers = std::max(k.sb_workers, k.sb_npmax + 2u);  // (a row's pieces wait for each other, its remainder for them)
   // (never fewer workers than a hot key has pieces + a remainder, + 1: the pieces wait for each other.  An idle worker holds half
   // a compute unit that another shard server's resolve workgroup is waiting for: 320 / 192 / 96 / 48 workers per engine gave
   // 2,320 / 2,650 .. 2,840 / 2,980 .. 3,030 / 2,820 Mtxn/s on the tatp bench stream -- ~160 items per pass)
@@ -144,12 +145,14 @@ static void kv_fill_pass(kv_pass_args &A, const void *d_req, void *d_rep, uint32
   A.split_min = kv_uses_hot(kv, load_mode) ? K.split_min : 0xFFFFFFFFu;
   A.split_target = K.split_target;
   A.np_max = KVR_NPMAX;
+  A.sb_pieces = 0;
   A.sbx = s.kvs.sbx;
   // smallbank (r06): a hot account's row of at least DINT_KV_SB_SPLIT_MIN requests in pieces, several workgroups of k_kv_big at
   // once (kv_sb_item); never with the closed forms switched off or for LOAD requests
   if (kv.workload == DINT_WL_SMALLBANK && K.sb_split_min && s.kvs.sbx && !(kv.force_rounds & 3) && !load_mode && !K.no_split) {
     A.split_min = std::max(8u, K.sb_split_min);
-    A.np_max = KSB_NPMAX;
+    A.np_max = K.sb_npmax;
+    A.sb_pieces = 1;
   }
   A.has_log = kv.workload != DINT_WL_STORE;
   A.trace = kv.d_trace;

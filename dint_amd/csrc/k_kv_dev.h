@@ -176,7 +176,8 @@ struct kv_pass_args {
   uint32_t *blk_pub, *blk_pub_z;
   uint32_t *bigrdy;          // [item] listed: tagged with `seq`
   uint64_t *sbx;             // smallbank, [item][KSB_WORDS]: what the pieces of a hot row and their coordinator tell each other (kv_sb_item)
-  uint32_t np_max;           // pieces of one hot key at most: KVR_NPMAX (store / tatp), KSB_NPMAX (smallbank)
+  uint32_t np_max;           // pieces of one hot key at most: KVR_NPMAX (store / tatp), DINT_KV_SB_NPMAX <= KSB_NPMAX (smallbank)
+  uint32_t sb_pieces;        // smallbank with its rows in pieces (kv_sb_item)
   uint32_t pno;              // pass number & 1: which pend set the pass's frees go to, which log tail word its partition reads
   uint4 *ovl;            // overflow list: two uint4 per entry {record, {coarse bin, -, -, -}}
   uint64_t *ovf;         // 8-byte records of the big subs, one range per sub
@@ -2417,7 +2418,7 @@ __device__ static inline void kv_list_items(const kv_pass_args &A, uint32_t b, c
     kv_st_agent(A.bigq + KVQ_W * (size_t)at, make_uint4(bin, bs.x, bs.y, KVQ_SUB));
   } else if (nent) {
     uint64_t hk = L.ckey[t], hr = L.hrec[t];
-    if (A.np_max != KVR_NPMAX) {
+    if (A.sb_pieces) {
       // smallbank: WHICH row the pieces are cut around decides whether the sub is answered in closed form.  "Whichever record came
       // first" is the hot row's nine times out of ten in a sub of thousands; in a sub of 200 .. 1,200 records (a warm row among cold
       // ones) it was a cold row's often enough that the warm row and a neighbour on its counter pair went to kv_big_bin's rounds
@@ -4165,8 +4166,8 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
   if (ev) hipEventRecord(ev[1], st);
   // the hot keys.  store / tatp: workers in the resolve launch (k_kv_pass; DINT_KV_NO_FUSE: k_kv_hot / k_kv_hot_part behind
   // k_kv_resolve, r05 / early r06), then k_kv_late for what the closed forms left -- usually nothing;
-  // smallbank (counters: no closed form across workgroups yet) and DINT_KV_NO_SPLIT / DINT_KV_ONE_BIG_KERNEL: k_kv_big alone
-  const bool hot = WL != DINT_WL_SMALLBANK && M.e[0].split_min != 0xFFFFFFFFu && !K.one_big_kernel;  // (smallbank's pieces run in k_kv_big)
+  // smallbank: workers in the resolve launch too (kv_sb_item), then k_kv_big for the remainders; DINT_KV_NO_SPLIT / DINT_KV_ONE_BIG_KERNEL: k_kv_big alone
+  const bool hot = WL != DINT_WL_SMALLBANK && M.e[0].split_min != 0xFFFFFFFFu && !K.one_big_kernel;  // (store / tatp: k_kv_hot / k_kv_late exist)
   bool fused = false, one = false;
   uint32_t sb_workers = 0;
   if constexpr (WL != DINT_WL_SMALLBANK) {
@@ -4184,7 +4185,7 @@ void launch_kv_passes(kv_multi_args &M, uint32_t n_eng, uint32_t rpt, hipStream_
     // the big subs and the pieces of the hot accounts are k_kv_big's, behind this launch)
     // (r06b: with workers -- the pieces of the subs' rows beside the resolve workgroups, the remainders in the k_kv_big launch behind;
     // DINT_KV_SB_WORKERS=0: r06a's k_kv_pass without workers, every item in k_kv_big)
-    sb_workers = !K.no_fuse && !K.one_big_kernel && M.e[0].np_max == KSB_NPMAX ? K.sb_workers : 0u;
+    sb_workers = !K.no_fuse && !K.one_big_kernel && M.e[0].sb_pieces ? K.sb_workers : 0u;
     if ((next || sb_workers) && !K.no_fuse) {
       uint32_t nmax = 0;
       for (uint32_t k = 0; next && k < n_eng; k++) nmax = std::max(nmax, next->e[k].n_tiles);
