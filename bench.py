@@ -93,8 +93,11 @@ def parse():
     args = ap.parse_args()
     if args.legs in ("gpu", "headline"):
         args.no_cpu_baseline = args.no_cpu_reference = args.no_shim = args.no_as_shipped = True
-    args.no_pass_1m = False
+    args.no_pass_1m = args.no_inputs_ready = False
     if args.legs == "headline":
+        # (lock tables: the DINT_FLAG_INPUTS_READY leg is a side leg like the others -- and under `rocprofv3 --pmc` its two-stream
+        # engine answers wrongly or traps, r06: NOTEBOOK.md; not reproducible without the profiler, HIP_LAUNCH_BLOCKING=1 included)
+        args.no_inputs_ready = True
         args.no_closed_loop = args.no_rand64 = args.no_host_path = args.no_other_workloads = args.no_mixes = args.no_exchange_leg = True
         args.no_pass_1m = True  # (lock tables: the 2^20-request passes would fall into the profile's "last N dispatches")
     return args
@@ -418,7 +421,7 @@ def bench_lock(args, world, rank, dev, transport, kind):
 
     wl, dtype = (wire.Workload.FASST, wire.FASST_MSG) if fasst else (wire.Workload.TPL, wire.TPL_MSG)
     from dint_amd import _lib
-    piped = world == 1 and not args.force_exchange  # the `inputs_ready` leg below (not with an exchange: the routed path submits segments)
+    piped = world == 1 and not args.force_exchange and not args.no_inputs_ready  # the `inputs_ready` leg below (not with an exchange: the routed path submits segments)
     eng = Engine(wl, n_slots=args.slots, device=dev, shard_index=rank, shard_count=world)
     rt = Router([eng], world, rank, transport=None if world > 1 else "self", n_max=BATCH) if (world > 1 or args.force_exchange) else None
 
