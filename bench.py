@@ -95,8 +95,7 @@ def parse():
         args.no_cpu_baseline = args.no_cpu_reference = args.no_shim = args.no_as_shipped = True
     args.no_pass_1m = args.no_inputs_ready = False
     if args.legs == "headline":
-        # (lock tables: the DINT_FLAG_INPUTS_READY leg is a side leg like the others -- and under `rocprofv3 --pmc` its two-stream
-        # engine answers wrongly or traps, r06: NOTEBOOK.md; not reproducible without the profiler, HIP_LAUNCH_BLOCKING=1 included)
+        # (lock tables: the DINT_FLAG_INPUTS_READY leg is a side leg like the others; a profile is of the timed region's kernels)
         args.no_inputs_ready = True
         args.no_closed_loop = args.no_rand64 = args.no_host_path = args.no_other_workloads = args.no_mixes = args.no_exchange_leg = True
         args.no_pass_1m = True  # (lock tables: the 2^20-request passes would fall into the profile's "last N dispatches")

@@ -282,6 +282,11 @@ int lock_pipe_init(dint_engine *e) {
     s.blk_pub_next = s.blk_pub + 1024;
     s.big_next = s.big + (4 + DINT_KV_PMAX);
   }
+  // The zero fills above ran on the NULL stream, which the helper stream and the engine's own (non-blocking) do not wait for: the
+  // first count stage on a new set could find its counters and region names not yet cleared.  Never seen in a plain run (the fills
+  // take microseconds); under `rocprofv3 --pmc`, which serializes every dispatch, it was `k_lock_count`'s trap and wrong replies of
+  // the DINT_FLAG_INPUTS_READY engine (r06, NOTEBOOK.md).
+  HIP_TRY(hipDeviceSynchronize());
   lp.ready = true;
   return 0;
 }
@@ -345,6 +350,7 @@ int ahead_cancel(dint_engine *e) {
     HIP_TRY(hipMemset(ls.bin_cnt, 0, DINT_KV_PMAX * sizeof(uint32_t)));
     HIP_TRY(hipMemset(std::min(ls.big, ls.big_next), 0, 2 * (4 + DINT_KV_PMAX) * sizeof(uint32_t)));
     HIP_TRY(hipMemset(ls.bin_off, 0xFF, DINT_KV_PMAX * sizeof(uint32_t)));
+    HIP_TRY(hipDeviceSynchronize());  // (the fills ran on the null stream: the engine's streams do not wait for it)
     return 0;
   }
   dint_scratch &s = e->scratch;
@@ -360,6 +366,7 @@ int ahead_cancel(dint_engine *e) {
     t[c ^ 1] = t[c]; t[2] = (uint32_t)appended; t[3] = (uint32_t)(appended >> 32);
     HIP_TRY(hipMemcpy(e->log.tail, t, sizeof t, hipMemcpyHostToDevice));
   }
+  HIP_TRY(hipDeviceSynchronize());  // (the fills ran on the null stream: the engine's streams do not wait for it)
   return 0;
 }
 
@@ -1397,6 +1404,7 @@ int dint_kv_trace_read(dint_engine_t *e, uint64_t *out, uint64_t cap) {
   const uint64_t words = std::min<uint64_t>(cap, (uint64_t)DINT_KV_TRACE_WORDS);
   HIP_TRY(hipMemcpy(out, e->kv.d_trace, words * 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(e->kv.d_trace, 0, DINT_KV_TRACE_WORDS * 8));  // the next read sees one launch only
+  HIP_TRY(hipDeviceSynchronize());  // (a fill on the null stream: the engine's streams do not wait for it)
   return (int)DINT_KV_PMAX;
 }
 

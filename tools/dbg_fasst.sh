@@ -1,15 +1,17 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $R
-pf() { python -c "
-import json,sys
+mkdir -p $R/gpurun_out/dbg
+cd /tmp; export TMPDIR=/tmp
+B="python $R/bench.py --workload fasst --steps 12 --warmup 1 --per-step 16 --legs gpu"
+for p in "FETCH_SIZE" "WRITE_SIZE"; do
+  s=$(date +%s)
+  timeout -s INT 90 rocprofv3 --pmc $p --kernel-trace -d /tmp/dbg_$p -o t -- $B > $R/gpurun_out/dbg/$p.out 2> $R/gpurun_out/dbg/$p.err
+  echo "pmc $p: rc $? in $(( $(date +%s) - s )) s"
+  python - <<PY
+import json
 try:
-    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d.get('parity_failures'), (d.get('inputs_ready') or {}).get('replies_equal'), d.get('value'))
-except Exception as e: print('$1 failed', e)"; }
-B="--steps 12 --warmup 1 --per-step 16 --legs headline"
-HIP_LAUNCH_BLOCKING=1 timeout 100 python bench.py --workload fasst $B 2>/dev/null | pf fasst_lb
-HIP_LAUNCH_BLOCKING=1 DINT_LOCK_NO_DIRECT=1 timeout 100 python bench.py --workload fasst $B 2>/dev/null | pf fasst_lb_nodirect
-HIP_LAUNCH_BLOCKING=1 DINT_LOCK_NO_FUSE=1 timeout 100 python bench.py --workload fasst $B 2>/dev/null | pf fasst_lb_nofuse
-HIP_LAUNCH_BLOCKING=1 timeout 100 python bench.py --workload fasst $B --no-ahead 2>/dev/null | pf fasst_lb_noahead
-HIP_LAUNCH_BLOCKING=1 timeout 100 python bench.py --workload 2pl $B 2>/dev/null | pf 2pl_lb
-HIP_LAUNCH_BLOCKING=1 timeout 300 python -m pytest tests/test_gpu_locks.py tests/test_gpu_ahead.py -x -q 2>&1 | tail -4
+    d=json.loads(open("$R/gpurun_out/dbg/$p.out").read().strip().splitlines()[-1]); print(d.get("parity_failures"), (d.get("inputs_ready") or {}).get("replies_equal"), d.get("value"))
+except Exception as e: print("no line", e)
+PY
+  grep -v "simple_timer\|generateRocpd\|tool.cpp" $R/gpurun_out/dbg/$p.err | tail -3 | cut -c1-300
+done
