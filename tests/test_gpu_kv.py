@@ -577,7 +577,8 @@ SPLIT_KNOBS = [{"DINT_KV_SPLIT_MIN": "65", "DINT_KV_SPLIT_TARGET": "16"},    # 1
                {"DINT_KV_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "100"},
                {},                                                          # the defaults: every big sub, ~384 requests per piece
                {"DINT_KV_NO_SPLIT": "1"},                                   # r04: one workgroup per hot key
-               {"DINT_KV_LATE_BIG": "1"}]                                   # r05: what k_kv_hot leaves goes to k_kv_big, not k_kv_late
+               {"DINT_KV_LATE_BIG": "1"},                                   # r05: what k_kv_hot leaves goes to k_kv_big, not k_kv_late
+               {"DINT_KV_NO_FUSE": "1"}]                                    # r05's launches: k_kv_resolve -> k_kv_hot -> k_kv_late
 
 
 @pytest.mark.parametrize("knobs", SPLIT_KNOBS, ids=lambda k: "+".join(f"{a[8:]}={b}" for a, b in k.items()) or "default")
@@ -616,7 +617,7 @@ def test_tatp_hot_key_in_pieces(p_hot, mix, hot_key, knobs, monkeypatch):
         assert st["missing_keys"] > 100  # every COMMIT of the missing hot row is counted (tatp/udp/kvs.h:91)
 
 
-@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3] + SPLIT_KNOBS[4:], ids=["t16", "t100", "default", "late_big"])
+@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3] + SPLIT_KNOBS[4:], ids=["t16", "t100", "default", "late_big", "nofuse"])
 def test_store_hot_key_in_pieces(knobs, monkeypatch):
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
@@ -635,7 +636,7 @@ def test_store_hot_key_in_pieces(knobs, monkeypatch):
     assert _same_rows(eng.dump_rows(0), o.dump())
 
 
-@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3] + SPLIT_KNOBS[4:], ids=["t16", "t100", "default", "late_big"])
+@pytest.mark.parametrize("knobs", SPLIT_KNOBS[:3] + SPLIT_KNOBS[4:], ids=["t16", "t100", "default", "late_big", "nofuse"])
 @pytest.mark.parametrize("same_quadrant", [False, True])
 def test_tatp_hot_key_in_pieces_beside_a_neighbour_in_its_bucket(same_quadrant, knobs, monkeypatch):
     """The sub's other keys (the remainder) are resolved beside the pieces -- unless one of the hot BUCKET uses the hot key's
@@ -735,7 +736,9 @@ def test_partition_corners(wl, knob, monkeypatch):
 
 # ---------------------------------------------------------------- smallbank: a hot account's row in pieces (r06, kv_sb_item)
 SB_KNOBS = [{}, {"DINT_KV_SB_SPLIT_MIN": "200", "DINT_KV_SPLIT_TARGET": "64"}, {"DINT_KV_SB_SPLIT_MIN": "600", "DINT_KV_SPLIT_TARGET": "300"},
-            {"DINT_KV_SB_SPLIT_MIN": "0"}, {"DINT_KV_SB_SPLIT_MIN": "2048"}]
+            {"DINT_KV_SB_SPLIT_MIN": "0"}, {"DINT_KV_SB_SPLIT_MIN": "2048"},
+            {"DINT_KV_SB_WORKERS": "0"},   # r06a: every work item in k_kv_big (pieces included), k_kv_pass without workers
+            {"DINT_KV_NO_FUSE": "1"}]      # r05's launches: k_kv_resolve -> k_kv_big
 
 
 def _sb_hot(n, p_hot, mix, hot, seed, n_acct):
@@ -754,7 +757,7 @@ def _sb_hot(n, p_hot, mix, hot, seed, n_acct):
     return req
 
 
-@pytest.mark.parametrize("knobs", SB_KNOBS, ids=["default", "t64", "t300", "off", "r06a"])
+@pytest.mark.parametrize("knobs", SB_KNOBS, ids=["default", "t64", "t300", "off", "min2048", "big-only", "nofuse"])
 @pytest.mark.parametrize("p_hot,mix,hot", [
     (0.6, {0: 30, 1: 25, 2: 15, 3: 12, 4: 10, 5: 8}, [(0, 7), (1, 7)]),          # the account's savings and checking rows, every op kind
     (0.7, {0: 40, 1: 10, 2: 38, 3: 6, 4: 6}, [(0, 3)]),                           # mostly shared traffic: long FREE stretches
@@ -787,7 +790,7 @@ def test_smallbank_hot_row_in_pieces(p_hot, mix, hot, knobs, monkeypatch):
 
 
 @pytest.mark.parametrize("share", [0.1, 0.003], ids=["warm-neighbour", "cold-neighbour"])
-@pytest.mark.parametrize("knobs", SB_KNOBS[:2] + SB_KNOBS[4:], ids=["default", "t64", "r06a"])
+@pytest.mark.parametrize("knobs", SB_KNOBS[:2] + SB_KNOBS[4:], ids=["default", "t64", "min2048", "big-only", "nofuse"])
 def test_smallbank_hot_row_beside_a_key_on_its_counter_pair(knobs, share, monkeypatch):
     """two accounts whose rows share a bucket AND a lock quadrant (one counter pair).  A COLD neighbour (a handful of requests per
     piece) rides in the pieces: its lock ops in the masks the coordinator walks, its row ops done by the coordinator in request
