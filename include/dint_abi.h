@@ -149,8 +149,11 @@ typedef struct dint_stats {
                               dint_route_unpack with the back-pressure reply of dint_refuse ("not now, send again") */
   uint64_t big_bin_requests; /* kv workloads: requests that were resolved by the big-bin kernel (hot keys) */
   uint64_t late_requests;  /* store / tatp (ABI v4): requests of hot subs that no closed form of k_kv_hot covered and the general
-                              path answered (k_kv_late) -- a diagnostic: they are the slow ones */
-  uint64_t reserved[3];
+                              path answered (k_kv_late) -- a diagnostic: they are the slow ones.  smallbank: requests of subs whose
+                              row the pieces refused (kv_sb_item: more than 512 requests or more than 8 foreign ones in a piece,
+                              an unknown op) and one workgroup answered the old way */
+  uint64_t reserved[3];    /* [0..2] (v4): the late work items by kind -- store / tatp {sub as listed, solo, pieces}; smallbank: why a
+                              row was refused {a piece over 512 requests, over 8 foreign requests, an unknown op} */
 } dint_stats;
 
 typedef struct dint_engine dint_engine_t;
